@@ -1,0 +1,461 @@
+"""Test-side helpers (TEST INFRASTRUCTURE): fixtures, an independent Python JSON ingest, and
+the ctypes loader for the CPU oracle (oracle/liborc.so).
+
+The ingest here is written against the reference's data model, independently of the product's
+C++ parser (csrc/gpv_ingest.cpp), so that the two can be compared word for word:
+  types/common_data.go:11-59,61-127   common_circuit_data.json
+  types/deserialize.go:9-43,45-72     proof_with_public_inputs.json (evals_proofs are 2-tuples)
+  types/deserialize.go:86-89          verifier_only_circuit_data.json
+  plonk/gates/*.go                    gate-id regexes (one per gate file)
+Packed record layout: SURVEY.md Appendix C / include/gpv.h.
+"""
+import ctypes
+import json
+import os
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLDEN = ROOT / "tests" / "golden"
+GL_P = 2**64 - 2**32 + 1
+BN_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+BLOB_MAGIC = 0x0001435650470000
+BLOB_HEADER_WORDS = 32
+
+# gate kinds (include/gpv.h GPV_GATE_*)
+(GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_BASE_SUM, GATE_ARITHMETIC, GATE_ARITHMETIC_EXT, GATE_MUL_EXT,
+ GATE_REDUCING, GATE_REDUCING_EXT, GATE_EXPONENTIATION, GATE_RANDOM_ACCESS, GATE_COSET_INTERPOLATION, GATE_POSEIDON,
+ GATE_POSEIDON_MDS) = range(14)
+
+_PH = r"_phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=(?P<D>[0-9]+)>"
+_GATE_REGEXES = [
+    # (regex, kind, parameter names) -- one per reference gate file
+    (re.compile(r"ArithmeticGate { num_ops: (?P<a>[0-9]+) }"), GATE_ARITHMETIC, "a"),            # arithmetic_gate.go:13
+    (re.compile(r"ArithmeticExtensionGate { num_ops: (?P<a>[0-9]+) }"), GATE_ARITHMETIC_EXT, "a"),  # arithmetic_extension_gate.go:13
+    (re.compile(r"BaseSumGate { num_limbs: (?P<a>[0-9]+) } \+ Base: (?P<b>[0-9]+)"), GATE_BASE_SUM, "ab"),  # base_sum_gate.go:13
+    (re.compile(r"ConstantGate { num_consts: (?P<a>[0-9]+) }"), GATE_CONSTANT, "a"),             # constant_gate.go:13
+    (re.compile(r"CosetInterpolationGate { subgroup_bits: (?P<a>[0-9]+), degree: (?P<b>[0-9]+), "
+                r"barycentric_weights: \[(?P<w>[0-9, ]+)\], _phantom: PhantomData<plonky2_field::goldilocks_field::"
+                r"GoldilocksField> }<D=2>"), GATE_COSET_INTERPOLATION, "ab"),                     # coset_interpolation_gate.go:15
+    (re.compile(r"ExponentiationGate { num_power_bits: (?P<a>[0-9]+), " + _PH), GATE_EXPONENTIATION, "a"),  # exponentiation_gate.go:13
+    (re.compile(r"MulExtensionGate { num_ops: (?P<a>[0-9]+) }"), GATE_MUL_EXT, "a"),             # multiplication_extension_gate.go:13
+    (re.compile(r"NoopGate"), GATE_NOOP, ""),                                                    # noop_gate.go:10
+    (re.compile(r"PoseidonGate.*"), GATE_POSEIDON, ""),                                          # poseidon_gate.go:11
+    (re.compile(r"PoseidonMdsGate.*"), GATE_POSEIDON_MDS, ""),                                   # poseidon_mds_gate.go:11
+    (re.compile(r"PublicInputGate"), GATE_PUBLIC_INPUT, ""),                                     # public_input_gate.go:10
+    (re.compile(r"RandomAccessGate { bits: (?P<a>[0-9]+), num_copies: (?P<b>[0-9]+), num_extra_constants: "
+                r"(?P<c>[0-9]+), " + _PH), GATE_RANDOM_ACCESS, "abc"),                            # random_access_gate.go:13
+    (re.compile(r"ReducingExtensionGate { num_coeffs: (?P<a>[0-9]+) }"), GATE_REDUCING_EXT, "a"),  # reducing_extension_gate.go:13
+    (re.compile(r"ReducingGate { num_coeffs: (?P<a>[0-9]+) }"), GATE_REDUCING, "a"),             # reducing_gate.go:13
+]
+
+
+def parse_gate_id(gate_id):
+    """gates/gates.go:37-54 GateInstanceFromId -> (kind, [p0, p1, p2], weights)."""
+    for rx, kind, names in _GATE_REGEXES:
+        m = rx.search(gate_id)
+        if m is None:
+            continue
+        params = [int(m.group(nm)) for nm in names] + [0] * (3 - len(names))
+        weights = []
+        if kind == GATE_COSET_INTERPOLATION:
+            weights = [int(w.strip()) for w in m.group("w").split(",")]
+        if "D" in rx.groupindex and int(m.group("D")) != 2:
+            raise ValueError("expected D=2")
+        return kind, params, weights
+    raise ValueError("Unknown gate ID %s" % gate_id)
+
+
+class CircuitInfo:
+    """Parsed CommonCircuitData + VerifierOnlyCircuitData and the derived packed layout."""
+
+    def __init__(self, common, verifier_only):
+        cfg = common["config"]
+        fp = common["fri_params"]
+        if fp["hiding"]:
+            raise ValueError("Circuit has hiding enabled, which is not supported")  # common_data.go:121-124
+        self.num_wires = cfg["num_wires"]
+        self.num_routed_wires = cfg["num_routed_wires"]
+        self.num_challenges = cfg["num_challenges"]
+        self.num_constants = common["num_constants"]
+        self.num_partial_products = common["num_partial_products"]
+        self.quotient_degree_factor = common["quotient_degree_factor"]
+        self.num_gate_constraints = common["num_gate_constraints"]
+        self.num_public_inputs = common["num_public_inputs"]
+        self.degree_bits = fp["degree_bits"]
+        self.rate_bits = fp["config"]["rate_bits"]
+        self.cap_height = fp["config"]["cap_height"]
+        self.pow_bits = fp["config"]["proof_of_work_bits"]
+        self.num_query_rounds = fp["config"]["num_query_rounds"]
+        self.arity_bits = list(fp["reduction_arity_bits"])
+        self.k_is = list(common["k_is"])
+        self.gates = [parse_gate_id(g) for g in common["gates"]]
+        self.selector_indices = list(common["selectors_info"]["selector_indices"])
+        self.groups = [(g["start"], g["end"]) for g in common["selectors_info"]["groups"]]
+        self.constants_sigmas_cap = [int(x) % BN_R for x in verifier_only["constants_sigmas_cap"]]
+        self.circuit_digest = int(verifier_only["circuit_digest"]) % BN_R
+
+    # ---- layout
+    @property
+    def lde_bits(self):
+        return self.degree_bits + self.rate_bits
+
+    @property
+    def cap_len(self):
+        return 1 << self.cap_height
+
+    @property
+    def final_poly_len(self):
+        return 1 << (self.degree_bits - sum(self.arity_bits))
+
+    def leaf_len(self, oracle):
+        return [self.num_constants + self.num_routed_wires, self.num_wires,
+                self.num_challenges * (1 + self.num_partial_products),
+                self.num_challenges * self.quotient_degree_factor][oracle]
+
+    @property
+    def n_challenge_words(self):
+        return 3 * self.num_challenges + 4 + 2 * len(self.arity_bits) + 1 + self.num_query_rounds
+
+    def blob(self):
+        hdr = [0] * BLOB_HEADER_WORDS
+        hdr[0] = BLOB_MAGIC
+        hdr[1:14] = [self.num_wires, self.num_routed_wires, self.num_constants, self.num_challenges,
+                     self.num_partial_products, self.quotient_degree_factor, self.num_gate_constraints,
+                     self.num_public_inputs, self.degree_bits, self.rate_bits, self.cap_height, self.pow_bits,
+                     self.num_query_rounds]
+        hdr[14] = len(self.arity_bits)
+        for i, a in enumerate(self.arity_bits):
+            hdr[15 + i] = a
+        hdr[23] = len(self.gates)
+        hdr[24] = len(self.groups)
+        body = []
+
+        def put(words):
+            off = BLOB_HEADER_WORDS + len(body)
+            body.extend(words)
+            return off
+
+        hdr[25] = put(self.k_is)
+        gate_off = put([0] * (8 * len(self.gates)))
+        hdr[26] = gate_off
+        for gi, (kind, params, weights) in enumerate(self.gates):
+            woff = put(weights) if weights else 0
+            rec = [kind] + params + [woff, len(weights), 0, 0]
+            body[gate_off - BLOB_HEADER_WORDS + 8 * gi: gate_off - BLOB_HEADER_WORDS + 8 * gi + 8] = rec
+        hdr[27] = put(self.selector_indices)
+        hdr[28] = put([x for g in self.groups for x in g])
+        hdr[29] = put([w for v in self.constants_sigmas_cap for w in fr_limbs(v)])
+        hdr[30] = put(fr_limbs(self.circuit_digest))
+        hdr[31] = BLOB_HEADER_WORDS + len(body)
+        return np.array(hdr + body, dtype=np.uint64)
+
+
+def fr_limbs(v):
+    return [(v >> (64 * i)) & (2**64 - 1) for i in range(4)]
+
+
+def fr_from_limbs(l):
+    return sum(int(x) << (64 * i) for i, x in enumerate(l))
+
+
+def pack_proof(ci, pj):
+    """proof_with_public_inputs.json (parsed) -> packed record bytes (Appendix C)."""
+    proof = pj["proof"]
+    op = proof["openings"]
+    fp = proof["opening_proof"]
+    gl = []
+
+    def put_ext(lst, n):
+        if len(lst) != n:
+            raise ValueError("shape")
+        for e in lst:
+            if len(e) != 2:
+                raise ValueError("shape")
+            gl.extend(e)
+
+    put_ext(op["constants"], ci.num_constants)
+    put_ext(op["plonk_sigmas"], ci.num_routed_wires)
+    put_ext(op["wires"], ci.num_wires)
+    put_ext(op["plonk_zs"], ci.num_challenges)
+    put_ext(op["plonk_zs_next"], ci.num_challenges)
+    put_ext(op["partial_products"], ci.num_challenges * ci.num_partial_products)
+    put_ext(op["quotient_polys"], ci.num_challenges * ci.quotient_degree_factor)
+    frs = []
+
+    def put_cap(cap):
+        if len(cap) != ci.cap_len:
+            raise ValueError("shape")  # fri_utils.go:175-179
+        frs.extend(int(x) % BN_R for x in cap)
+
+    put_cap(proof["wires_cap"])
+    put_cap(proof["plonk_zs_partial_products_cap"])
+    put_cap(proof["quotient_polys_cap"])
+    if len(fp["commit_phase_merkle_caps"]) != len(ci.arity_bits):
+        raise ValueError("shape")
+    for cap in fp["commit_phase_merkle_caps"]:
+        put_cap(cap)
+    if len(fp["query_round_proofs"]) != ci.num_query_rounds:
+        raise ValueError("shape")  # fri.go:515-517
+    for qr in fp["query_round_proofs"]:
+        eps = qr["initial_trees_proof"]["evals_proofs"]
+        if len(eps) != 4:
+            raise ValueError("shape")  # fri_utils.go:185-187
+        for o, (leaf, mp) in enumerate(eps):
+            if len(leaf) != ci.leaf_len(o) or len(mp["siblings"]) + ci.cap_height != ci.lde_bits:
+                raise ValueError("shape")  # fri_utils.go:199-205
+            gl.extend(leaf)
+            frs.extend(int(x) % BN_R for x in mp["siblings"])
+        if len(qr["steps"]) != len(ci.arity_bits):
+            raise ValueError("shape")  # fri_utils.go:208-210
+        bits = ci.lde_bits
+        for s, st in enumerate(qr["steps"]):
+            bits -= ci.arity_bits[s]
+            if len(st["evals"]) != (1 << ci.arity_bits[s]) or len(st["merkle_proof"]["siblings"]) + ci.cap_height != bits:
+                raise ValueError("shape")  # fri_utils.go:219-225
+            put_ext(st["evals"], 1 << ci.arity_bits[s])
+            frs.extend(int(x) % BN_R for x in st["merkle_proof"]["siblings"])
+    put_ext(fp["final_poly"]["coeffs"], ci.final_poly_len)
+    gl.append(fp["pow_witness"])
+    if len(pj["public_inputs"]) != ci.num_public_inputs:
+        raise ValueError("shape")
+    gl.extend(pj["public_inputs"])
+    for v in gl:
+        if not (0 <= v < 2**64):
+            raise ValueError("not a uint64")
+    words = list(gl)
+    for v in frs:
+        words.extend(fr_limbs(v))
+    return np.array(words, dtype=np.uint64).tobytes()
+
+
+_fixture_cache = {}
+
+
+def load_fixture(name):
+    """-> (CircuitInfo, packed proof bytes, raw json dicts)"""
+    if name not in _fixture_cache:
+        d = GOLDEN / name
+        common = json.loads((d / "common_circuit_data.json").read_text())
+        vo = json.loads((d / "verifier_only_circuit_data.json").read_text())
+        pj = json.loads((d / "proof_with_public_inputs.json").read_text())
+        ci = CircuitInfo(common, vo)
+        _fixture_cache[name] = (ci, pack_proof(ci, pj), (common, vo, pj))
+    return _fixture_cache[name]
+
+
+# ---------------------------------------------------------------- oracle loader
+_orc = None
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", str(ROOT / "oracle")])
+
+
+def oracle():
+    global _orc
+    if _orc is None:
+        so = ROOT / "oracle" / "liborc.so"
+        if not so.exists() or any(p.stat().st_mtime > so.stat().st_mtime
+                                  for p in (ROOT / "oracle").glob("*.[hc]*")):
+            build_oracle()
+        lib = ctypes.CDLL(str(so))
+        lib.orc_circuit_new.restype = ctypes.c_void_p
+        lib.orc_circuit_new.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        lib.orc_circuit_free.argtypes = [ctypes.c_void_p]
+        lib.orc_proof_nbytes.restype = ctypes.c_size_t
+        lib.orc_proof_nbytes.argtypes = [ctypes.c_void_p]
+        lib.orc_n_challenge_words.restype = ctypes.c_size_t
+        lib.orc_n_challenge_words.argtypes = [ctypes.c_void_p]
+        _orc = Oracle(lib)
+    return _orc
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def u64arr(x):
+    return np.ascontiguousarray(np.array(x, dtype=np.uint64))
+
+
+class OracleCircuit:
+    def __init__(self, lib, ci):
+        self.ci = ci
+        self._blob = ci.blob()
+        self.h = lib.orc_circuit_new(_p(self._blob), ctypes.c_size_t(len(self._blob)))
+        assert self.h, "oracle rejected the circuit blob"
+        self.lib = lib
+        self.nbytes = lib.orc_proof_nbytes(ctypes.c_void_p(self.h))
+        self.ncw = lib.orc_n_challenge_words(ctypes.c_void_p(self.h))
+
+    def __del__(self):
+        try:
+            self.lib.orc_circuit_free(ctypes.c_void_p(self.h))
+        except Exception:
+            pass
+
+
+class Oracle:
+    OP_ADD, OP_SUB, OP_MUL, OP_MULADD, OP_INV, OP_REDUCE, OP_DIV = range(7)
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def selftest(self):
+        return self.lib.orc_selftest()
+
+    def gl_op(self, op, a, b=None, c=None):
+        a = u64arr(a)
+        b = None if b is None else u64arr(b)
+        c = None if c is None else u64arr(c)
+        out = np.empty_like(a)
+        assert self.lib.orc_gl_op(op, _p(a), _p(b), _p(c), _p(out), ctypes.c_size_t(a.size)) == 0
+        return out
+
+    def gl2_op(self, op, a, b=None):
+        a = u64arr(a).reshape(-1, 2)
+        b = None if b is None else u64arr(b).reshape(-1, 2)
+        out = np.empty_like(a)
+        ok = np.ones(a.shape[0], dtype=np.uint8)
+        assert self.lib.orc_gl2_op(op, _p(a), _p(b), _p(out), _p(ok), ctypes.c_size_t(a.shape[0])) == 0
+        return out, ok
+
+    def poseidon_gl_permute(self, states):
+        s = u64arr(states).reshape(-1, 12)
+        out = np.empty_like(s)
+        self.lib.orc_poseidon_gl_permute(_p(s), _p(out), ctypes.c_size_t(s.shape[0]))
+        return out
+
+    def poseidon_gl_hash_no_pad(self, inputs):
+        x = u64arr(inputs)
+        x = x.reshape(1, -1) if x.ndim == 1 else x
+        out = np.empty((x.shape[0], 4), dtype=np.uint64)
+        self.lib.orc_poseidon_gl_hash_no_pad(_p(x), ctypes.c_size_t(x.shape[1]), _p(out), ctypes.c_size_t(x.shape[0]))
+        return out
+
+    def poseidon_bn254_permute(self, states):
+        s = u64arr(states).reshape(-1, 4, 4)
+        out = np.empty_like(s)
+        self.lib.orc_poseidon_bn254_permute(_p(s), _p(out), ctypes.c_size_t(s.shape[0]))
+        return out
+
+    def poseidon_bn254_hash_or_noop(self, inputs):
+        x = u64arr(inputs)
+        x = x.reshape(1, -1) if x.ndim == 1 else x
+        out = np.empty((x.shape[0], 4), dtype=np.uint64)
+        self.lib.orc_poseidon_bn254_hash_or_noop(_p(x), ctypes.c_size_t(x.shape[1]), _p(out), ctypes.c_size_t(x.shape[0]))
+        return out
+
+    def poseidon_bn254_two_to_one(self, l, r):
+        l = u64arr(l).reshape(-1, 4)
+        r = u64arr(r).reshape(-1, 4)
+        out = np.empty_like(l)
+        self.lib.orc_poseidon_bn254_two_to_one(_p(l), _p(r), _p(out), ctypes.c_size_t(l.shape[0]))
+        return out
+
+    def poseidon_bn254_to_vec(self, h):
+        h = u64arr(h).reshape(-1, 4)
+        out = np.empty((h.shape[0], 5), dtype=np.uint64)
+        self.lib.orc_poseidon_bn254_to_vec(_p(h), _p(out), ctypes.c_size_t(h.shape[0]))
+        return out
+
+    def circuit(self, ci):
+        return OracleCircuit(self.lib, ci)
+
+    @staticmethod
+    def _proofs(oc, proofs):
+        buf = np.frombuffer(proofs, dtype=np.uint8) if isinstance(proofs, (bytes, bytearray)) else np.ascontiguousarray(proofs).view(np.uint8).reshape(-1)
+        assert buf.size % oc.nbytes == 0
+        return buf, buf.size // oc.nbytes
+
+    def public_inputs_hash(self, oc, proofs):
+        buf, n = self._proofs(oc, proofs)
+        out = np.empty((n, 4), dtype=np.uint64)
+        self.lib.orc_public_inputs_hash(ctypes.c_void_p(oc.h), _p(buf), ctypes.c_size_t(n), _p(out))
+        return out
+
+    def challenges(self, oc, proofs):
+        buf, n = self._proofs(oc, proofs)
+        out = np.empty((n, oc.ncw), dtype=np.uint64)
+        self.lib.orc_challenges(ctypes.c_void_p(oc.h), _p(buf), ctypes.c_size_t(n), _p(out))
+        return out
+
+    def plonk_verify(self, oc, proofs, challenges):
+        buf, n = self._proofs(oc, proofs)
+        ch = u64arr(challenges).reshape(n, oc.ncw)
+        fail = np.empty(n, dtype=np.int32)
+        self.lib.orc_plonk_verify(ctypes.c_void_p(oc.h), _p(buf), _p(ch), ctypes.c_size_t(n), _p(fail))
+        return fail
+
+    def fri_verify(self, oc, proofs, challenges):
+        buf, n = self._proofs(oc, proofs)
+        ch = u64arr(challenges).reshape(n, oc.ncw)
+        fail = np.empty(n, dtype=np.int32)
+        self.lib.orc_fri_verify(ctypes.c_void_p(oc.h), _p(buf), _p(ch), ctypes.c_size_t(n), _p(fail))
+        return fail
+
+    def merkle_chains(self, oc, proofs, challenges):
+        buf, n = self._proofs(oc, proofs)
+        ch = u64arr(challenges).reshape(n, oc.ncw)
+        ok = np.empty((n, oc.ci.num_query_rounds, 4 + len(oc.ci.arity_bits)), dtype=np.uint8)
+        self.lib.orc_merkle_chains(ctypes.c_void_p(oc.h), _p(buf), _p(ch), ctypes.c_size_t(n), _p(ok))
+        return ok
+
+    def verify(self, oc, proofs, n_threads=1):
+        buf, n = self._proofs(oc, proofs)
+        accept = np.empty(n, dtype=np.uint8)
+        fail = np.empty(n, dtype=np.int32)
+        ch = np.empty((n, oc.ncw), dtype=np.uint64)
+        self.lib.orc_verify(ctypes.c_void_p(oc.h), _p(buf), ctypes.c_size_t(n), _p(accept), _p(fail), _p(ch), n_threads)
+        return accept, fail, ch
+
+    def gate_eval_unfiltered(self, kind, params, weights, constants, wires, pi_hash):
+        w = u64arr(weights if len(weights) else [0])
+        cst = u64arr(constants).reshape(-1)
+        wi = u64arr(wires).reshape(-1, 2)
+        ph = u64arr(pi_hash)
+        out = np.empty((512, 2), dtype=np.uint64)
+        n = self.lib.orc_gate_eval_unfiltered(kind, ctypes.c_uint64(params[0]), ctypes.c_uint64(params[1]),
+                                              ctypes.c_uint64(params[2]), _p(w), ctypes.c_size_t(len(weights)),
+                                              _p(cst), _p(wi), ctypes.c_size_t(wi.shape[0]), _p(ph), _p(out),
+                                              ctypes.c_size_t(512))
+        assert n >= 0
+        return out[:n].copy()
+
+    def gate_constraints(self, oc, proofs):
+        buf, n = self._proofs(oc, proofs)
+        out = np.empty((n, oc.ci.num_gate_constraints, 2), dtype=np.uint64)
+        self.lib.orc_gate_constraints(ctypes.c_void_p(oc.h), _p(buf), ctypes.c_size_t(n), _p(out))
+        return out
+
+
+# ---------------------------------------------------------------- synthetic batches
+def splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+    return z ^ (z >> 31)
+
+
+def synthetic_batch(ci, packed, n, seed=1, tamper_every=16):
+    """n copies of one packed proof; proof i is corrupted iff splitmix64(seed+i) % tamper_every == 0 by XOR-ing
+    bit 0 of one word of the query-round section. Returns (uint8 array [n, nbytes], tampered mask)."""
+    rec = np.frombuffer(packed, dtype=np.uint64)
+    batch = np.tile(rec, (n, 1))
+    n_open = 2 * (ci.num_constants + ci.num_routed_wires + ci.num_wires + 2 * ci.num_challenges
+                  + ci.num_challenges * ci.num_partial_products + ci.num_challenges * ci.quotient_degree_factor)
+    qwords = sum(ci.leaf_len(o) for o in range(4)) + sum(2 << a for a in ci.arity_bits)
+    nq = ci.num_query_rounds * qwords
+    tampered = np.zeros(n, dtype=bool)
+    for i in range(n):
+        if tamper_every and splitmix64(seed + i) % tamper_every == 0:
+            w = n_open + splitmix64(seed + i + 1) % nq
+            batch[i, w] ^= np.uint64(1)
+            tampered[i] = True
+    return batch.view(np.uint8).reshape(n, -1), tampered
