@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- Plonky2 proofs verified per second on N MI355X (one process per GPU, RCCL over xGMI).
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path (verifier.VerifierChip.Verify: range checks, Fiat-Shamir transcript, plonk gate
+constraints, 168 Poseidon-BN254 Merkle paths and the FRI folding per proof) over one synthetic batch that is already
+resident in HBM: BASELINE.json config 4's per-GPU shard, 8192 packed `step` proofs per GPU (weak scaling), one in 16
+tampered, followed -- for N > 1 -- by the RCCL all-gather of the packed accept bits. Rank 0 prints ONE JSON line.
+
+The same line carries
+  roofline      -- dominant kernel (k_merkle): algorithmic bytes / launch duration against HBM peak, as the contract asks;
+                   this workload is integer-VALU bound (2 000 32-bit multiply-adds per input byte), so the line also
+                   carries `valu_roofline`: achieved v_mad_u64_u32 rate vs the peak measured on this chip.
+  cpu_baseline  -- the C++ restatement of the reference algorithm (oracle/, kind "port") timed on the host cores on a
+                   bounded sample; the Go reference itself cannot run here (no Go toolchain, gnark not vendored).
+  poseidon_gl   -- the second half of BASELINE's metric: Poseidon-Goldilocks permutations/s at 2^20 states (config 2).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MADS_PER_FR_MUL = 136  # 8x8 product + 8x8 reduction + 8 "m" multiplies (CIOS, 32-bit limbs)
+FR_MULS_PER_PERM = 784  # poseidon/bn254.go: 8 full rounds x 28 + 56 partial rounds x 10
+
+
+def perms_per_proof(ci):
+    """Poseidon-BN254 permutations per proof: per query, per tree ceil(leaf/9) + siblings."""
+    per_q = 0
+    sib = ci.lde_bits - ci.cap_height
+    for o in range(4):
+        per_q += (ci.leaf_len(o) + 8) // 9 + sib
+    bits = sib
+    for a in ci.arity_bits:
+        bits -= a
+        per_q += ((2 << a) + 8) // 9 + bits
+    return per_q * ci.num_query_rounds
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--proofs-per-gpu", type=int, default=8192)
+    ap.add_argument("--fixture", default="step", choices=["step", "decode_block"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-poseidon-gl", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path in the product)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    import gpv_testlib as T
+    gpv = importlib.import_module("gnark-plonky2-verifier_amd")
+    D = importlib.import_module("gnark-plonky2-verifier_amd.distributed")
+
+    ctx = gpv.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    # ---- circuit + synthetic batch: n copies of the packed fixture, 1 in 16 tampered
+    d = T.GOLDEN / args.fixture
+    common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
+    vo = gpv.variables.DeserializeVerifierOnlyCircuitData(gpv.types.ReadVerifierOnlyCircuitData(d / "verifier_only_circuit_data.json"))
+    circuit = gpv.variables.circuit_for(common, vo)
+    proof = gpv.variables.DeserializeProofWithPublicInputs(gpv.types.ReadProofWithPublicInputs(d / "proof_with_public_inputs.json"), circuit)
+    ci, packed, _ = T.load_fixture(args.fixture)
+    assert proof.data.tobytes() == packed
+    n_local = args.proofs_per_gpu
+    n_total = n_local * world
+    lo, hi = D.shard_bounds(n_total, rank, world)
+    assert hi - lo == n_local
+    # build only this rank's block (same generator, global proof index as the seed offset)
+    rec = torch.from_numpy(np.frombuffer(packed, dtype=np.int64).copy()).to(dev)
+    batch = rec.repeat(n_local, 1).contiguous()
+    n_open = 2 * (ci.num_constants + ci.num_routed_wires + ci.num_wires + 2 * ci.num_challenges
+                  + ci.num_challenges * ci.num_partial_products + ci.num_challenges * ci.quotient_degree_factor)
+    qwords = sum(ci.leaf_len(o) for o in range(4)) + sum(2 << a for a in ci.arity_bits)
+    tampered_all = np.zeros(n_total, dtype=bool)
+    rows, cols = [], []
+    for i in range(n_total):
+        if T.splitmix64(1 + i) % 16 == 0:
+            tampered_all[i] = True
+            if lo <= i < hi:
+                rows.append(i - lo)
+                cols.append(n_open + T.splitmix64(2 + i) % (ci.num_query_rounds * qwords))
+    if rows:
+        r = torch.tensor(rows, device=dev)
+        c = torch.tensor(cols, device=dev)
+        batch[r, c] = batch[r, c] ^ 1
+    accept = torch.zeros(n_local, dtype=torch.uint8, device=dev)
+    chip = gpv.verifier.NewVerifierChip(ctx, common)
+
+    def step():
+        chip.VerifyDevice(circuit, batch.data_ptr(), n_local, accept.data_ptr())
+        return D.all_gather_accept(accept, n_total) if world > 1 else accept
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        full = step()
+    barrier()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    merkle_ms, merkle_launches = ctx.timing_get(0)
+    stage_ms = {nm: ctx.timing_get(k)[0] for nm, k in (("merkle", 0), ("transcript", 2), ("plonk", 3), ("fri_query", 4), ("range_check", 5))}
+    ctx.timing_enable(False)
+
+    # ---- correctness of what was timed: accept vector == tamper mask (the oracle agrees on a sample in the tests)
+    got = full.cpu().numpy()
+    expect = (~tampered_all).astype(np.uint8)
+    if not (got == expect).all():
+        raise SystemExit("accept vector mismatch: %d wrong" % int((got != expect).sum()))
+
+    proofs_per_s = n_total * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    line = {
+        "metric": "plonky2_proofs_verified_per_sec",
+        "value": proofs_per_s,
+        "unit": "proofs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32-limb integer (BN254 Fr Montgomery, Goldilocks u64)",
+        "data": "synthetic: %d packed copies of testdata/%s per GPU, 1 in 16 tampered (splitmix64), resident in HBM" % (n_local, args.fixture),
+        "config": {"workload": "verifier.VerifierChip.Verify end-to-end (BASELINE config 4 shard)", "fixture": args.fixture,
+                   "proofs_per_gpu": n_local, "global_batch": n_total, "queries_per_proof": ci.num_query_rounds,
+                   "merkle_chains_per_proof": ci.num_query_rounds * (4 + len(ci.arity_bits)), "parallelism": "proof-sharded x%d" % world,
+                   "collective": "RCCL all_gather of packed accept bits" if world > 1 else "none"},
+    }
+    if rank == 0:
+        nbytes = len(packed)
+        perms = perms_per_proof(ci)
+        alg_bytes = float(nbytes) * n_local  # the packed record is read once per proof
+        achieved = alg_bytes / (merkle_ms * 1e-3) / 1e9 if merkle_ms > 0 else 0.0
+        line["roofline"] = {"bound": "hbm", "kernel": "k_merkle", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": merkle_ms, "launches": merkle_launches,
+                            "algorithmic_bytes_per_launch": alg_bytes,
+                            "note": "integer-VALU bound workload; see valu_roofline"}
+        mad_peak = ctx.microbench(0)
+        mads = float(perms) * FR_MULS_PER_PERM * MADS_PER_FR_MUL * n_local
+        line["valu_roofline"] = {"bound": "valu_int32_mad", "kernel": "k_merkle", "achieved": mads / (merkle_ms * 1e-3) / 1e12 if merkle_ms > 0 else 0.0,
+                                 "peak": mad_peak / 1e12, "unit": "T v_mad_u64_u32 lane-ops/s",
+                                 "frac": (mads / (merkle_ms * 1e-3)) / mad_peak if merkle_ms > 0 else 0.0,
+                                 "algorithmic_mads_per_proof": float(perms) * FR_MULS_PER_PERM * MADS_PER_FR_MUL,
+                                 "bn254_perms_per_proof": perms}
+        line["stage_ms"] = stage_ms
+        if not args.no_poseidon_gl:
+            n_states = 1 << 20
+            rng = np.random.default_rng(0x9E3779B9)
+            st = (rng.integers(0, 2**63, size=(n_states, 12), dtype=np.uint64) * np.uint64(2)) % np.uint64(T.GL_P)
+            tin = torch.from_numpy(st.view(np.int64)).to(dev)
+            tout = torch.empty_like(tin)
+            pchip = gpv.poseidon.NewGoldilocksChip(ctx)
+            pchip.PoseidonDevice(tin.data_ptr(), tout.data_ptr(), n_states)
+            torch.cuda.synchronize()
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            reps = 20
+            for _ in range(reps):
+                pchip.PoseidonDevice(tin.data_ptr(), tout.data_ptr(), n_states)
+            torch.cuda.synchronize()
+            pgl_ms, _ = ctx.timing_get(1)
+            ctx.timing_enable(False)
+            line["poseidon_gl"] = {"metric": "poseidon_goldilocks_perms_per_sec", "value": n_states / (pgl_ms * 1e-3), "states": n_states,
+                                   "launch_ms": pgl_ms, "hbm_GBs": n_states * 192 / (pgl_ms * 1e-3) / 1e9,
+                                   "hbm_frac": n_states * 192 / (pgl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if not args.no_cpu_baseline and world == 1:
+            orc = T.oracle()
+            oc = orc.circuit(ci)
+            cores = os.cpu_count() or 1
+            n_sample = max(cores, int(round(16.0 / 0.11 / 8)) * 8)  # ~16 CPU-seconds at ~0.11 s/proof/core
+            sample = batch[:n_sample].cpu().numpy().view(np.uint8).reshape(n_sample, -1)
+            t1 = time.perf_counter()
+            oacc, _, _ = orc.verify(oc, sample, n_threads=cores)
+            dt = time.perf_counter() - t1
+            assert (oacc == expect[:n_sample]).all()
+            line["cpu_baseline"] = {"value": n_sample / dt, "unit": "proofs/s", "cores": cores, "kind": "port",
+                                    "sample": "first %d proofs of the same batch, C++ restatement of the reference algorithm (oracle/), %d threads" % (n_sample, cores)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

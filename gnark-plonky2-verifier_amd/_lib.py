@@ -1,0 +1,185 @@
+"""ctypes binding of libgpv.so (include/gpv.h). Plain pointers and sizes only -- no torch types cross the ABI.
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C gnark-plonky2-verifier_amd/csrc`. There is no CPU
+fallback anywhere in this package: if the library is missing, or no GPU is usable, calls raise.
+"""
+import ctypes
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libgpv.so"
+
+GPV_OK, GPV_ESHAPE, GPV_ECONFIG, GPV_EDEVICE, GPV_EINVAL, GPV_ENOMEM = 0, -1, -2, -3, -4, -5
+
+# every symbol include/gpv.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "gpv_ctx_create", "gpv_ctx_destroy", "gpv_ctx_set_stream", "gpv_ctx_synchronize", "gpv_last_error_message",
+    "gpv_circuit_from_json", "gpv_circuit_destroy", "gpv_proof_nbytes", "gpv_num_challenge_words",
+    "gpv_num_gate_constraints", "gpv_num_query_rounds", "gpv_num_merkle_trees", "gpv_circuit_describe",
+    "gpv_proof_pack_json",
+    "gpv_gl_op", "gpv_gl2_op", "gpv_poseidon_gl_permute", "gpv_poseidon_gl_permute_dev", "gpv_poseidon_gl_hash_no_pad",
+    "gpv_poseidon_bn254_permute", "gpv_poseidon_bn254_permute_dev", "gpv_poseidon_bn254_hash_or_noop",
+    "gpv_poseidon_bn254_two_to_one", "gpv_poseidon_bn254_to_vec", "gpv_gate_eval_unfiltered",
+    "gpv_public_inputs_hash", "gpv_challenges", "gpv_plonk_verify", "gpv_gate_constraints", "gpv_fri_verify",
+    "gpv_merkle_verify", "gpv_verify", "gpv_verify_detail", "gpv_verify_dev", "gpv_challenges_dev",
+    "gpv_merkle_verify_dev", "gpv_timing_enable", "gpv_timing_reset", "gpv_timing_get", "gpv_microbench",
+]
+
+
+class GpvError(RuntimeError):
+    """A libgpv call failed. `code` is the GPV_E* value; shape/config errors are what the reference panics on."""
+
+    def __init__(self, code, message):
+        super().__init__("libgpv error %d: %s" % (code, message))
+        self.code = code
+
+
+class ShapeError(GpvError):
+    pass
+
+
+class ConfigError(GpvError):
+    pass
+
+
+class DeviceError(GpvError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise DeviceError(GPV_EDEVICE, "%s not built -- run __graft_entry__.build() (hipcc, gfx950)" % LIB_PATH)
+        L = ctypes.CDLL(str(LIB_PATH))
+        vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        L.gpv_ctx_create.argtypes = [ctypes.POINTER(vp), i32]
+        L.gpv_ctx_destroy.argtypes = [vp]
+        L.gpv_ctx_set_stream.argtypes = [vp, vp]
+        L.gpv_ctx_synchronize.argtypes = [vp]
+        L.gpv_last_error_message.argtypes = [vp, ctypes.c_char_p, sz]
+        L.gpv_circuit_from_json.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, ctypes.POINTER(vp)]
+        L.gpv_circuit_destroy.argtypes = [vp]
+        for f in ("gpv_proof_nbytes", "gpv_num_challenge_words", "gpv_num_gate_constraints", "gpv_num_query_rounds",
+                  "gpv_num_merkle_trees"):
+            getattr(L, f).argtypes = [vp]
+            getattr(L, f).restype = sz
+        L.gpv_circuit_describe.argtypes = [vp, vp, sz]
+        L.gpv_circuit_describe.restype = sz
+        L.gpv_proof_pack_json.argtypes = [vp, ctypes.c_char_p, sz, vp]
+        L.gpv_gl_op.argtypes = [vp, i32, vp, vp, vp, vp, sz]
+        L.gpv_gl2_op.argtypes = [vp, i32, vp, vp, vp, vp, sz]
+        L.gpv_poseidon_gl_permute.argtypes = [vp, vp, vp, sz]
+        L.gpv_poseidon_gl_permute_dev.argtypes = [vp, vp, vp, sz]
+        L.gpv_poseidon_gl_hash_no_pad.argtypes = [vp, vp, sz, vp, sz]
+        L.gpv_poseidon_bn254_permute.argtypes = [vp, vp, vp, sz]
+        L.gpv_poseidon_bn254_permute_dev.argtypes = [vp, vp, vp, sz]
+        L.gpv_poseidon_bn254_hash_or_noop.argtypes = [vp, vp, sz, vp, sz]
+        L.gpv_poseidon_bn254_two_to_one.argtypes = [vp, vp, vp, vp, sz]
+        L.gpv_poseidon_bn254_to_vec.argtypes = [vp, vp, vp, sz]
+        L.gpv_gate_eval_unfiltered.argtypes = [vp, i32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, vp, sz, vp, sz,
+                                               vp, sz, vp, vp, sz, ctypes.POINTER(sz), sz]
+        L.gpv_public_inputs_hash.argtypes = [vp, vp, vp, sz, vp]
+        L.gpv_challenges.argtypes = [vp, vp, vp, sz, vp]
+        L.gpv_plonk_verify.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.gpv_gate_constraints.argtypes = [vp, vp, vp, sz, vp]
+        L.gpv_fri_verify.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.gpv_merkle_verify.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.gpv_verify.argtypes = [vp, vp, vp, sz, vp]
+        L.gpv_verify_detail.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+        L.gpv_verify_dev.argtypes = [vp, vp, vp, sz, vp]
+        L.gpv_challenges_dev.argtypes = [vp, vp, vp, sz, vp]
+        L.gpv_merkle_verify_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.gpv_timing_enable.argtypes = [vp, i32]
+        L.gpv_timing_reset.argtypes = [vp]
+        L.gpv_timing_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
+        L.gpv_microbench.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double)]
+        _lib = L
+    return _lib
+
+
+def last_error(ctx_handle=None):
+    buf = ctypes.create_string_buffer(1024)
+    lib().gpv_last_error_message(ctypes.c_void_p(ctx_handle) if ctx_handle else None, buf, 1024)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc, ctx_handle=None):
+    if rc == GPV_OK:
+        return
+    msg = last_error(ctx_handle)
+    cls = {GPV_ESHAPE: ShapeError, GPV_ECONFIG: ConfigError, GPV_EDEVICE: DeviceError}.get(rc, GpvError)
+    raise cls(rc, msg)
+
+
+def ptr(a):
+    """numpy array / None / int (device pointer) -> c_void_p"""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return ctypes.c_void_p(int(a))
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def u64c(x, shape=None):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+    return a if shape is None else a.reshape(shape)
+
+
+class Context:
+    """gpv_ctx: one per process / GPU (the reference's per-api chip registry, goldilocks/base.go:106-118)."""
+
+    def __init__(self, device_id=0):
+        h = ctypes.c_void_p()
+        check(lib().gpv_ctx_create(ctypes.byref(h), device_id))
+        self.h = h.value
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gpv_ctx_destroy(ctypes.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        check(lib().gpv_ctx_set_stream(ctypes.c_void_p(self.h), ctypes.c_void_p(hip_stream) if hip_stream else None), self.h)
+
+    def synchronize(self):
+        check(lib().gpv_ctx_synchronize(ctypes.c_void_p(self.h)), self.h)
+
+    def timing_enable(self, on=True):
+        check(lib().gpv_timing_enable(ctypes.c_void_p(self.h), int(on)), self.h)
+
+    def timing_reset(self):
+        check(lib().gpv_timing_reset(ctypes.c_void_p(self.h)), self.h)
+
+    def timing_get(self, kind):
+        ms = ctypes.c_double()
+        n = ctypes.c_uint64()
+        check(lib().gpv_timing_get(ctypes.c_void_p(self.h), kind, ctypes.byref(ms), ctypes.byref(n)), self.h)
+        return ms.value, n.value
+
+    def microbench(self, which):
+        v = ctypes.c_double()
+        check(lib().gpv_microbench(ctypes.c_void_p(self.h), which, ctypes.byref(v)), self.h)
+        return v.value
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx

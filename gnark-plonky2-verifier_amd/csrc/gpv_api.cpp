@@ -1,0 +1,697 @@
+// libgpv.so -- kernels, launch logic and the C ABI of include/gpv.h.  gfx950 only.
+//
+// Kernel map (what each launch replaces in the reference):
+//   k_range_check        VerifierChip.rangeCheckProof            verifier/verifier.go:84-141 (coalesced HBM stream)
+//   k_transcript         GetPublicInputsHash + GetChallenges     verifier/verifier.go:41-82, challenger/challenger.go
+//   k_plonk              PlonkChip.Verify                        plonk/plonk.go:209-250 + plonk/gates/*
+//   k_merkle             verifyMerkleProofToCapWithCapIndex      fri/fri.go:97-157, :472-483   <- 97 % of the arithmetic
+//   k_fri_query          verifyQueryRound minus the Merkle paths fri/fri.go:386-498, PoW :75-80
+//   k_finalize           "circuit satisfiable" -> accept byte
+// plus primitive kernels that expose the chip-level operators for parity tests and the Poseidon-GL benchmark.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "gpv_host.h"
+#include "gpv_launch.h"
+
+// ================================================================ context
+enum { TK_MERKLE = 0, TK_PGL = 1, TK_TRANSCRIPT = 2, TK_PLONK = 3, TK_FRI = 4, TK_RANGE = 5, TK_PBN = 6, TK_COUNT = 7 };
+
+struct TimingRec {
+  int kind;
+  hipEvent_t start, stop;
+};
+
+struct gpv_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  std::string err;
+  bool timing = false;
+  std::vector<TimingRec> recs;
+  double acc_ms[TK_COUNT] = {0};
+  uint64_t acc_n[TK_COUNT] = {0};
+  // grow-only scratch for the verify pipeline
+  u64* derived = nullptr;
+  size_t derived_words = 0;
+  u32* fail = nullptr;
+  size_t fail_n = 0;
+};
+
+static void ctx_error(gpv_ctx* ctx, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  else gpv_set_global_error("%s", buf);
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      ctx_error(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return GPV_EDEVICE;                                                                       \
+    }                                                                                           \
+  } while (0)
+
+struct Timed {  // brackets one launch with events on the launch stream when timing is enabled
+  gpv_ctx* ctx;
+  TimingRec r;
+  bool on;
+  Timed(gpv_ctx* c, int kind) : ctx(c), on(c->timing) {
+    if (on) {
+      r.kind = kind;
+      if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) { on = false; return; }
+      hipEventRecord(r.start, ctx->stream);
+    }
+  }
+  ~Timed() {
+    if (on) {
+      hipEventRecord(r.stop, ctx->stream);
+      ctx->recs.push_back(r);
+    }
+  }
+};
+
+static int drain_timing(gpv_ctx* ctx) {
+  if (ctx->recs.empty()) return GPV_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->recs) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      ctx->acc_ms[r.kind] += ms;
+      ctx->acc_n[r.kind]++;
+    }
+    hipEventDestroy(r.start);
+    hipEventDestroy(r.stop);
+  }
+  ctx->recs.clear();
+  return GPV_OK;
+}
+
+template <class T>
+struct DevBuf {  // RAII device allocation for the host-pointer entry points
+  T* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+extern "C" int gpv_ctx_create(gpv_ctx** out, int device_id) {
+  if (!out) return GPV_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    gpv_set_global_error("no usable GPU: hipGetDeviceCount -> %s (count %d). libgpv has no CPU fallback.",
+                         hipGetErrorString(e), n);
+    return GPV_EDEVICE;
+  }
+  if (device_id < 0 || device_id >= n) {
+    gpv_set_global_error("device_id %d out of range (0..%d)", device_id, n - 1);
+    return GPV_EINVAL;
+  }
+  gpv_ctx* ctx = new gpv_ctx();
+  ctx->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    gpv_set_global_error("hipSetDevice/hipStreamCreate failed on device %d", device_id);
+    delete ctx;
+    return GPV_EDEVICE;
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return GPV_OK;
+}
+extern "C" int gpv_ctx_destroy(gpv_ctx* ctx) {
+  if (!ctx) return GPV_EINVAL;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  drain_timing(ctx);
+  if (ctx->derived) hipFree(ctx->derived);
+  if (ctx->fail) hipFree(ctx->fail);
+  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return GPV_OK;
+}
+extern "C" int gpv_ctx_set_stream(gpv_ctx* ctx, void* hip_stream) {
+  if (!ctx) return GPV_EINVAL;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return GPV_OK;
+}
+extern "C" int gpv_ctx_synchronize(gpv_ctx* ctx) {
+  if (!ctx) return GPV_EINVAL;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+extern "C" int gpv_last_error_message(gpv_ctx* ctx, char* buf, size_t buf_len) {
+  if (!buf || !buf_len) return GPV_EINVAL;
+  const char* s = ctx ? ctx->err.c_str() : gpv_get_global_error();
+  snprintf(buf, buf_len, "%s", s);
+  return GPV_OK;
+}
+extern "C" int gpv_timing_enable(gpv_ctx* ctx, int on) {
+  if (!ctx) return GPV_EINVAL;
+  ctx->timing = on != 0;
+  return GPV_OK;
+}
+extern "C" int gpv_timing_reset(gpv_ctx* ctx) {
+  if (!ctx) return GPV_EINVAL;
+  int rc = drain_timing(ctx);
+  for (int i = 0; i < TK_COUNT; i++) { ctx->acc_ms[i] = 0; ctx->acc_n[i] = 0; }
+  return rc;
+}
+extern "C" int gpv_timing_get(gpv_ctx* ctx, int kind, double* avg_ms, uint64_t* launches) {
+  if (!ctx || kind < 0 || kind >= TK_COUNT) return GPV_EINVAL;
+  int rc = drain_timing(ctx);
+  if (rc != GPV_OK) return rc;
+  if (avg_ms) *avg_ms = ctx->acc_n[kind] ? ctx->acc_ms[kind] / (double)ctx->acc_n[kind] : 0.0;
+  if (launches) *launches = ctx->acc_n[kind];
+  return GPV_OK;
+}
+
+void gpv_circuit_release_device(gpv_circuit* c) {
+  if (c->dev) {
+    hipFree(c->dev);
+    c->dev = nullptr;
+  }
+}
+static int circuit_on_device(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit** out) {
+  if (!c->dev || c->dev_id != ctx->device) {
+    if (c->dev) hipFree(c->dev);
+    c->dev = nullptr;
+    HIP_TRY(ctx, hipMalloc(&c->dev, sizeof(DevCircuit)));
+    HIP_TRY(ctx, hipMemcpy(c->dev, &c->dc, sizeof(DevCircuit), hipMemcpyHostToDevice));
+    c->dev_id = ctx->device;
+  }
+  *out = (const DevCircuit*)c->dev;
+  return GPV_OK;
+}
+
+
+// ================================================================ primitive kernels
+// ================================================================ protocol kernels
+// ================================================================ launch helpers (device pointers)
+static int ensure_scratch(gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
+  size_t need = n * (c->dc.n_challenge_words + GPV_DERIVED_EXTRA);
+  if (need > ctx->derived_words) {
+    if (ctx->derived) { hipStreamSynchronize(ctx->stream); hipFree(ctx->derived); ctx->derived = nullptr; ctx->derived_words = 0; }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->derived, need * sizeof(u64)));
+    ctx->derived_words = need;
+  }
+  if (n > ctx->fail_n) {
+    if (ctx->fail) { hipStreamSynchronize(ctx->stream); hipFree(ctx->fail); ctx->fail = nullptr; ctx->fail_n = 0; }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->fail, n * sizeof(u32)));
+    ctx->fail_n = n;
+  }
+  return GPV_OK;
+}
+
+static int launch_range_check(gpv_ctx* ctx, const DevCircuit* dcd, const void* proofs, size_t n) {
+  Timed t(ctx, TK_RANGE);
+  gpvk_range_check(ctx->stream, dcd, (const u64*)proofs, n, ctx->fail);
+  return GPV_OK;
+}
+static int launch_transcript(gpv_ctx* ctx, const DevCircuit* dcd, const void* proofs, size_t n) {
+  Timed t(ctx, TK_TRANSCRIPT);
+  gpvk_transcript(ctx->stream, dcd, (const u64*)proofs, n, ctx->derived);
+  return GPV_OK;
+}
+static int launch_plonk(gpv_ctx* ctx, const DevCircuit* dcd, const void* proofs, size_t n) {
+  Timed t(ctx, TK_PLONK);
+  gpvk_plonk(ctx->stream, dcd, (const u64*)proofs,
+                     (const u64*)ctx->derived, n, ctx->fail);
+  return GPV_OK;
+}
+static int launch_merkle(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, uint8_t* ok_dev) {
+  Timed t(ctx, TK_MERKLE);
+  gpvk_merkle(ctx->stream, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->fail, ok_dev);
+  return GPV_OK;
+}
+static int launch_fri_query(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n) {
+  Timed t(ctx, TK_FRI);
+  gpvk_fri_query(ctx->stream, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->fail);
+  return GPV_OK;
+}
+#define CHECK_LAUNCH(ctx) HIP_TRY(ctx, hipGetLastError())
+
+// full pipeline on device-resident proofs; leaves the failure masks in ctx->fail and the derived values in ctx->derived
+static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n) {
+  const DevCircuit* dcd;
+  int rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  rc = ensure_scratch(ctx, c, n);
+  if (rc != GPV_OK) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), ctx->stream));
+  launch_range_check(ctx, dcd, proofs_dev, n);
+  launch_transcript(ctx, dcd, proofs_dev, n);
+  launch_merkle(ctx, c, dcd, proofs_dev, n, nullptr);
+  launch_plonk(ctx, dcd, proofs_dev, n);
+  launch_fri_query(ctx, c, dcd, proofs_dev, n);
+  CHECK_LAUNCH(ctx);
+  return GPV_OK;
+}
+
+// ================================================================ C ABI: primitives
+#define REQUIRE(ctx, cond)                           \
+  do {                                               \
+    if (!(cond)) {                                   \
+      ctx_error(ctx, "invalid argument: %s", #cond); \
+      return GPV_EINVAL;                             \
+    }                                                \
+  } while (0)
+
+extern "C" int gpv_gl_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && a && out);
+  REQUIRE(ctx, op == GPV_OP_ADD || op == GPV_OP_SUB || op == GPV_OP_MUL || op == GPV_OP_MULADD || op == GPV_OP_INV || op == GPV_OP_REDUCE);
+  REQUIRE(ctx, (op == GPV_OP_INV || op == GPV_OP_REDUCE) || b);
+  REQUIRE(ctx, op != GPV_OP_MULADD || c);
+  if (n == 0) return GPV_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf<u64> da, db, dc_, dout;
+  HIP_TRY(ctx, da.alloc(n));
+  HIP_TRY(ctx, db.alloc(n));
+  HIP_TRY(ctx, dc_.alloc(n));
+  HIP_TRY(ctx, dout.alloc(n));
+  HIP_TRY(ctx, hipMemcpyAsync(da.p, a, 8 * n, hipMemcpyHostToDevice, ctx->stream));
+  if (b) HIP_TRY(ctx, hipMemcpyAsync(db.p, b, 8 * n, hipMemcpyHostToDevice, ctx->stream));
+  if (c) HIP_TRY(ctx, hipMemcpyAsync(dc_.p, c, 8 * n, hipMemcpyHostToDevice, ctx->stream));
+  gpvk_gl_op(ctx->stream, op, da.p, db.p, dc_.p, dout.p, n);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+extern "C" int gpv_gl2_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* ok, size_t n) {
+  REQUIRE(ctx, ctx && a && out);
+  REQUIRE(ctx, op == GPV_OP_ADD || op == GPV_OP_SUB || op == GPV_OP_MUL || op == GPV_OP_INV || op == GPV_OP_DIV);
+  REQUIRE(ctx, op == GPV_OP_INV || b);
+  if (n == 0) return GPV_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf<u64> da, db, dout;
+  DevBuf<uint8_t> dok;
+  HIP_TRY(ctx, da.alloc(2 * n));
+  HIP_TRY(ctx, db.alloc(2 * n));
+  HIP_TRY(ctx, dout.alloc(2 * n));
+  HIP_TRY(ctx, dok.alloc(n));
+  HIP_TRY(ctx, hipMemcpyAsync(da.p, a, 16 * n, hipMemcpyHostToDevice, ctx->stream));
+  if (b) HIP_TRY(ctx, hipMemcpyAsync(db.p, b, 16 * n, hipMemcpyHostToDevice, ctx->stream));
+  gpvk_gl2_op(ctx->stream, op, da.p, b ? db.p : (u64*)nullptr, dout.p, dok.p, n);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 16 * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (ok) HIP_TRY(ctx, hipMemcpyAsync(ok, dok.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+
+extern "C" int gpv_poseidon_gl_permute_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && states && out);
+  if (n == 0) return GPV_OK;
+  {
+    Timed t(ctx, TK_PGL);
+    gpvk_poseidon_gl_permute(ctx->stream, states, out, n);
+  }
+  CHECK_LAUNCH(ctx);
+  return GPV_OK;
+}
+extern "C" int gpv_poseidon_bn254_permute_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && states && out);
+  if (n == 0) return GPV_OK;
+  {
+    Timed t(ctx, TK_PBN);
+    gpvk_poseidon_bn254_permute(ctx->stream, states, out, n);
+  }
+  CHECK_LAUNCH(ctx);
+  return GPV_OK;
+}
+
+// generic "copy in, run a _dev style launch, copy out" helper for [n][in_words] -> [n][out_words] maps
+template <class F>
+static int map_host(gpv_ctx* ctx, const uint64_t* in, size_t in_words, uint64_t* out, size_t out_words, size_t n, F launch) {
+  if (n == 0) return GPV_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf<u64> din, dout;
+  HIP_TRY(ctx, din.alloc(in_words * n));
+  HIP_TRY(ctx, dout.alloc(out_words * n));
+  HIP_TRY(ctx, hipMemcpyAsync(din.p, in, 8 * in_words * n, hipMemcpyHostToDevice, ctx->stream));
+  int rc = launch(din.p, dout.p);
+  if (rc != GPV_OK) return rc;
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 8 * out_words * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+
+extern "C" int gpv_poseidon_gl_permute(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && states && out);
+  return map_host(ctx, states, 12, out, 12, n, [&](u64* i, u64* o) { return gpv_poseidon_gl_permute_dev(ctx, i, o, n); });
+}
+extern "C" int gpv_poseidon_gl_hash_no_pad(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && out && (in || len == 0) && len <= 0xFFFFFFFFu);
+  if (len == 0) {  // goldilocks.go:41-68: no input -> no permutation -> zero hash
+    memset(out, 0, 32 * n);
+    return GPV_OK;
+  }
+  return map_host(ctx, in, len, out, 4, n, [&](u64* i, u64* o) {
+    gpvk_poseidon_gl_hash_no_pad(ctx->stream, i, (u32)len, o, n);
+    return GPV_OK;
+  });
+}
+extern "C" int gpv_poseidon_bn254_permute(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && states && out);
+  return map_host(ctx, states, 16, out, 16, n, [&](u64* i, u64* o) { return gpv_poseidon_bn254_permute_dev(ctx, i, o, n); });
+}
+extern "C" int gpv_poseidon_bn254_hash_or_noop(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && out && (in || len == 0) && len <= 0xFFFFFFFFu);
+  if (len == 0) {
+    memset(out, 0, 32 * n);
+    return GPV_OK;
+  }
+  return map_host(ctx, in, len, out, 4, n, [&](u64* i, u64* o) {
+    gpvk_poseidon_bn254_hash_or_noop(ctx->stream, i, (u32)len, o, n);
+    return GPV_OK;
+  });
+}
+extern "C" int gpv_poseidon_bn254_two_to_one(gpv_ctx* ctx, const uint64_t* left, const uint64_t* right, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && left && right && out);
+  if (n == 0) return GPV_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf<u64> dl, dr, dout;
+  HIP_TRY(ctx, dl.alloc(4 * n));
+  HIP_TRY(ctx, dr.alloc(4 * n));
+  HIP_TRY(ctx, dout.alloc(4 * n));
+  HIP_TRY(ctx, hipMemcpyAsync(dl.p, left, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(dr.p, right, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  gpvk_poseidon_bn254_two_to_one(ctx->stream, dl.p, dr.p, dout.p, n);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+extern "C" int gpv_poseidon_bn254_to_vec(gpv_ctx* ctx, const uint64_t* hashes, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && hashes && out);
+  return map_host(ctx, hashes, 4, out, 5, n, [&](u64* i, u64* o) {
+    gpvk_poseidon_bn254_to_vec(ctx->stream, i, o, n);
+    return GPV_OK;
+  });
+}
+
+extern "C" int gpv_gate_eval_unfiltered(gpv_ctx* ctx, int kind, uint64_t p0, uint64_t p1, uint64_t p2, const uint64_t* weights,
+                                        size_t n_weights, const uint64_t* constants, size_t n_constants, const uint64_t* wires,
+                                        size_t n_wires, const uint64_t* pi_hash, uint64_t* out, size_t max_out, size_t* n_out,
+                                        size_t n) {
+  REQUIRE(ctx, ctx && wires && pi_hash && out && (constants || n_constants == 0));
+  REQUIRE(ctx, kind >= 0 && kind <= GPV_GATE_POSEIDON_MDS && p0 <= 0xFFFFFFFFu && p1 <= 0xFFFFFFFFu && p2 <= 0xFFFFFFFFu);
+  DevGate g;
+  memset(&g, 0, sizeof g);
+  g.kind = (u32)kind;
+  g.p0 = (u32)p0;
+  g.p1 = (u32)p1;
+  g.p2 = (u32)p2;
+  g.n_weights = (u32)n_weights;
+  if (kind == GPV_GATE_COSET_INTERPOLATION && (p1 < 2 || p0 > 8 || n_weights != ((size_t)1 << p0))) { ctx_error(ctx, "bad coset gate parameters"); return GPV_ECONFIG; }
+  if (kind == GPV_GATE_RANDOM_ACCESS && p0 > GPV_MAX_RA_BITS) { ctx_error(ctx, "random access bits > %d", GPV_MAX_RA_BITS); return GPV_ECONFIG; }
+  if (n == 0) return GPV_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf<u64> dw, dc_, dwi, dp, dout;
+  HIP_TRY(ctx, dw.alloc(n_weights));
+  HIP_TRY(ctx, dc_.alloc(2 * n_constants * n));
+  HIP_TRY(ctx, dwi.alloc(2 * n_wires * n));
+  HIP_TRY(ctx, dp.alloc(4 * n));
+  HIP_TRY(ctx, dout.alloc(2 * max_out * n));
+  if (n_weights) HIP_TRY(ctx, hipMemcpyAsync(dw.p, weights, 8 * n_weights, hipMemcpyHostToDevice, ctx->stream));
+  if (n_constants) HIP_TRY(ctx, hipMemcpyAsync(dc_.p, constants, 16 * n_constants * n, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(dwi.p, wires, 16 * n_wires * n, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(dp.p, pi_hash, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(dout.p, 0, 16 * max_out * n, ctx->stream));
+  gpvk_gate_eval_unfiltered(ctx->stream, g, dw.p, dc_.p,
+                     (u32)n_constants, dwi.p, (u32)n_wires, dp.p, dout.p, (u32)max_out, n);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 16 * max_out * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_out) {
+    switch (kind) {  // same counts as gate_num_constraints in gpv_ingest.cpp
+      case GPV_GATE_NOOP: *n_out = 0; break;
+      case GPV_GATE_CONSTANT: *n_out = p0; break;
+      case GPV_GATE_PUBLIC_INPUT: *n_out = 4; break;
+      case GPV_GATE_BASE_SUM: *n_out = 1 + p0; break;
+      case GPV_GATE_ARITHMETIC: *n_out = p0; break;
+      case GPV_GATE_ARITHMETIC_EXT: case GPV_GATE_MUL_EXT: case GPV_GATE_REDUCING: case GPV_GATE_REDUCING_EXT: *n_out = 2 * p0; break;
+      case GPV_GATE_EXPONENTIATION: *n_out = p0 + 1; break;
+      case GPV_GATE_RANDOM_ACCESS: *n_out = p1 * (p0 + 2) + p2; break;
+      case GPV_GATE_COSET_INTERPOLATION: *n_out = 4 + 4 * ((((size_t)1 << p0) - 2) / (p1 - 1)); break;
+      case GPV_GATE_POSEIDON: *n_out = 123; break;
+      case GPV_GATE_POSEIDON_MDS: *n_out = 24; break;
+    }
+  }
+  return GPV_OK;
+}
+
+// ================================================================ C ABI: protocol stages
+struct HostBatch {  // uploads a host batch of packed proofs
+  DevBuf<uint8_t> proofs;
+  int upload(gpv_ctx* ctx, const gpv_circuit* c, const void* host, size_t n) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, proofs.alloc(c->dc.proof_nbytes * n));
+    HIP_TRY(ctx, hipMemcpyAsync(proofs.p, host, c->dc.proof_nbytes * n, hipMemcpyHostToDevice, ctx->stream));
+    return GPV_OK;
+  }
+};
+
+static int upload_challenges(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs_dev, const uint64_t* challenges,
+                             size_t n, bool challenges_on_device) {
+  const u32 ncw = c->dc.n_challenge_words;
+  DevBuf<u64> tmp;
+  const u64* src = challenges;
+  if (!challenges_on_device) {
+    HIP_TRY(ctx, tmp.alloc((size_t)ncw * n));
+    HIP_TRY(ctx, hipMemcpyAsync(tmp.p, challenges, 8 * (size_t)ncw * n, hipMemcpyHostToDevice, ctx->stream));
+    src = tmp.p;
+  }
+  gpvk_scatter_challenges(ctx->stream, src, ctx->derived, ncw, n);
+  gpvk_derive_extra(ctx->stream, dcd, (const u64*)proofs_dev, n, ctx->derived);
+  CHECK_LAUNCH(ctx);
+  if (!challenges_on_device) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // tmp is freed on return
+  return GPV_OK;
+}
+
+extern "C" int gpv_challenges_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint64_t* challenges_dev) {
+  REQUIRE(ctx, ctx && c && proofs_dev && challenges_dev);
+  if (n == 0) return GPV_OK;
+  const DevCircuit* dcd;
+  int rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  rc = ensure_scratch(ctx, c, n);
+  if (rc != GPV_OK) return rc;
+  launch_transcript(ctx, dcd, proofs_dev, n);
+  const u32 ncw = c->dc.n_challenge_words;
+  gpvk_gather_challenges(ctx->stream, (const u64*)ctx->derived,
+                     challenges_dev, ncw, n);
+  CHECK_LAUNCH(ctx);
+  return GPV_OK;
+}
+extern "C" int gpv_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* out) {
+  REQUIRE(ctx, ctx && c && proofs && out);
+  if (n == 0) return GPV_OK;
+  HostBatch hb;
+  int rc = hb.upload(ctx, c, proofs, n);
+  if (rc != GPV_OK) return rc;
+  DevBuf<u64> dch;
+  const size_t ncw = c->dc.n_challenge_words;
+  HIP_TRY(ctx, dch.alloc(ncw * n));
+  rc = gpv_challenges_dev(ctx, c, hb.proofs.p, n, dch.p);
+  if (rc != GPV_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out, dch.p, 8 * ncw * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+extern "C" int gpv_public_inputs_hash(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* out) {
+  REQUIRE(ctx, ctx && c && proofs && out);
+  if (n == 0) return GPV_OK;
+  HostBatch hb;
+  int rc = hb.upload(ctx, c, proofs, n);
+  if (rc != GPV_OK) return rc;
+  const DevCircuit* dcd;
+  rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  rc = ensure_scratch(ctx, c, n);
+  if (rc != GPV_OK) return rc;
+  launch_transcript(ctx, dcd, hb.proofs.p, n);
+  DevBuf<u64> dout;
+  HIP_TRY(ctx, dout.alloc(4 * n));
+  gpvk_gather_pih(ctx->stream, (const u64*)ctx->derived, dout.p,
+                     c->dc.n_challenge_words, n);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+
+// shared prologue of the "stage with caller-supplied challenges" entry points
+struct StageSetup {
+  HostBatch hb;
+  const DevCircuit* dcd = nullptr;
+  int run(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n) {
+    int rc = hb.upload(ctx, c, proofs, n);
+    if (rc != GPV_OK) return rc;
+    rc = circuit_on_device(ctx, c, &dcd);
+    if (rc != GPV_OK) return rc;
+    rc = ensure_scratch(ctx, c, n);
+    if (rc != GPV_OK) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), ctx->stream));
+    return upload_challenges(ctx, c, dcd, hb.proofs.p, challenges, n, false);
+  }
+};
+
+extern "C" int gpv_plonk_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n,
+                                uint32_t* fail_mask) {
+  REQUIRE(ctx, ctx && c && proofs && challenges && fail_mask);
+  if (n == 0) return GPV_OK;
+  StageSetup st;
+  int rc = st.run(ctx, c, proofs, challenges, n);
+  if (rc != GPV_OK) return rc;
+  launch_plonk(ctx, st.dcd, st.hb.proofs.p, n);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(fail_mask, ctx->fail, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+extern "C" int gpv_gate_constraints(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* out) {
+  REQUIRE(ctx, ctx && c && proofs && out);
+  if (n == 0) return GPV_OK;
+  HostBatch hb;
+  int rc = hb.upload(ctx, c, proofs, n);
+  if (rc != GPV_OK) return rc;
+  const DevCircuit* dcd;
+  rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  rc = ensure_scratch(ctx, c, n);
+  if (rc != GPV_OK) return rc;
+  launch_transcript(ctx, dcd, hb.proofs.p, n);  // for the public-inputs hash
+  DevBuf<u64> dout;
+  const size_t w = 2 * (size_t)c->dc.num_gate_constraints;
+  HIP_TRY(ctx, dout.alloc(w * n));
+  gpvk_gate_constraints(ctx->stream, dcd,
+                     (const u64*)hb.proofs.p, (const u64*)ctx->derived, n, dout.p);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 8 * w * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+extern "C" int gpv_fri_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n,
+                              uint32_t* fail_mask) {
+  REQUIRE(ctx, ctx && c && proofs && challenges && fail_mask);
+  if (n == 0) return GPV_OK;
+  StageSetup st;
+  int rc = st.run(ctx, c, proofs, challenges, n);
+  if (rc != GPV_OK) return rc;
+  launch_merkle(ctx, c, st.dcd, st.hb.proofs.p, n, nullptr);
+  launch_fri_query(ctx, c, st.dcd, st.hb.proofs.p, n);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(fail_mask, ctx->fail, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+extern "C" int gpv_merkle_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, const uint64_t* challenges_dev, size_t n,
+                                     uint8_t* ok_dev) {
+  REQUIRE(ctx, ctx && c && proofs_dev && challenges_dev && ok_dev);
+  if (n == 0) return GPV_OK;
+  const DevCircuit* dcd;
+  int rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  rc = ensure_scratch(ctx, c, n);
+  if (rc != GPV_OK) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), ctx->stream));
+  const u32 ncw = c->dc.n_challenge_words;
+  gpvk_scatter_challenges(ctx->stream, (const u64*)challenges_dev,
+                     ctx->derived, ncw, n);
+  launch_merkle(ctx, c, dcd, proofs_dev, n, ok_dev);
+  CHECK_LAUNCH(ctx);
+  return GPV_OK;
+}
+extern "C" int gpv_merkle_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n, uint8_t* ok) {
+  REQUIRE(ctx, ctx && c && proofs && challenges && ok);
+  if (n == 0) return GPV_OK;
+  StageSetup st;
+  int rc = st.run(ctx, c, proofs, challenges, n);
+  if (rc != GPV_OK) return rc;
+  DevBuf<uint8_t> dok;
+  const size_t items = n * c->dc.num_queries * c->dc.n_trees;
+  HIP_TRY(ctx, dok.alloc(items));
+  launch_merkle(ctx, c, st.dcd, st.hb.proofs.p, n, dok.p);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(ok, dok.p, items, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+
+extern "C" int gpv_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint8_t* accept_dev) {
+  REQUIRE(ctx, ctx && c && proofs_dev && accept_dev);
+  if (n == 0) return GPV_OK;
+  int rc = verify_pipeline_dev(ctx, c, proofs_dev, n);
+  if (rc != GPV_OK) return rc;
+  gpvk_finalize(ctx->stream, (const u32*)ctx->fail, accept_dev, n);
+  CHECK_LAUNCH(ctx);
+  return GPV_OK;
+}
+extern "C" int gpv_verify_detail(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept, uint32_t* fail_mask,
+                                 uint64_t* challenges) {
+  REQUIRE(ctx, ctx && c && proofs && accept);
+  if (n == 0) return GPV_OK;
+  HostBatch hb;
+  int rc = hb.upload(ctx, c, proofs, n);
+  if (rc != GPV_OK) return rc;
+  DevBuf<uint8_t> dacc;
+  HIP_TRY(ctx, dacc.alloc(n));
+  rc = gpv_verify_dev(ctx, c, hb.proofs.p, n, dacc.p);
+  if (rc != GPV_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(accept, dacc.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  if (fail_mask) HIP_TRY(ctx, hipMemcpyAsync(fail_mask, ctx->fail, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+  DevBuf<u64> dch;
+  if (challenges) {
+    const u32 ncw = c->dc.n_challenge_words;
+    HIP_TRY(ctx, dch.alloc((size_t)ncw * n));
+    gpvk_gather_challenges(ctx->stream, (const u64*)ctx->derived,
+                       dch.p, ncw, n);
+    CHECK_LAUNCH(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(challenges, dch.p, 8 * (size_t)ncw * n, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+extern "C" int gpv_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept) {
+  return gpv_verify_detail(ctx, c, proofs, n, accept, nullptr, nullptr);
+}
+
+// ================================================================ instruction-rate microbenchmark (kernels: gpv_k_prim.hip)
+extern "C" int gpv_microbench(gpv_ctx* ctx, int which, double* lane_ops_per_sec) {
+  REQUIRE(ctx, ctx && lane_ops_per_sec && which >= 0 && which <= 7);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int blocks = 256 * 8, threads = 256, iters = 4096;
+  DevBuf<u64> out;
+  HIP_TRY(ctx, out.alloc((size_t)blocks * threads));
+  hipEvent_t e0, e1;
+  HIP_TRY(ctx, hipEventCreate(&e0));
+  HIP_TRY(ctx, hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; rep++) {
+    hipEventRecord(e0, ctx->stream);
+    gpvk_microbench(ctx->stream, which, out.p, blocks, threads, iters);
+    hipEventRecord(e1, ctx->stream);
+    if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); ctx_error(ctx, "microbench launch failed"); return GPV_EDEVICE; }
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  double ops = (double)blocks * threads * (double)iters * (double)gpvk_microbench_ops_per_iter();
+  *lane_ops_per_sec = ops / (best * 1e-3);
+  return GPV_OK;
+}

@@ -1,0 +1,197 @@
+// FRI verification on the device.
+//
+//   dev_merkle_chain   one lane = one (proof, query, tree) Merkle path to the cap
+//                      replaces verifyMerkleProofToCapWithCapIndex / verifyInitialProof (fri/fri.go:97-157,472-483)
+//   dev_fri_query      one lane = one (proof, query): everything else in verifyQueryRound
+//                      replaces calculateSubgroupX, friCombineInitial, computeEvaluation, interpolate,
+//                      finalPolyEval (fri/fri.go:159-384, 386-498)
+//
+// Work shaping for MI355X. A query's six Merkle paths are 93-99 dependent Poseidon-BN254 permutations (97 % of all
+// arithmetic); they are split into one lane per path and launched per tree class so that every lane of a
+// wave runs the same number of permutations. The field part of a query is folded algebraically so that it needs two
+// base-field inversions per reduction step instead of the reference's 32 extension inversions:
+//   * coset points are x_i = s g^i, so the barycentric weights are w_i = g^i / (16 s^15)   (fri.go:361-381 computes
+//     them with n^2 products and 16 inversions), and l(beta) = prod (beta - x_i) = beta^16 - s^16;
+//   * 1 / (beta - x_i) = conj(beta - x_i) / N_i with N_i in F_p, and all N_i together with 16 s^15 are inverted with one
+//     batched (Montgomery-trick) inversion.
+// The field is exact, so the values are identical to the reference's; a vanishing denominator (beta on the coset) is
+// reported as the same assertion failure (quadratic_extension.go:124-125).
+#pragma once
+#include "gpv_circuit_dev.h"
+#include "gpv_poseidon.cuh"
+
+// ---------------------------------------------------------------- Merkle path (one lane)
+// Returns true iff the path hashes to cap[cap_index].
+GPV_DEV bool dev_merkle_chain(const u64* __restrict__ leaf, u32 leaf_len, const u64* __restrict__ siblings, u32 n_siblings,
+                              u32 index_bits, const u64* __restrict__ cap_entry) {
+  Fr cur = poseidon_bn254_hash_or_noop(leaf, leaf_len);  // fri.go:104
+#pragma unroll 1
+  for (u32 i = 0; i < n_siblings; i++) {
+    Fr sib = fr_from_canonical64(siblings + 4 * i);
+    bool bit = (index_bits >> i) & 1;
+    // bit = 1: hash(sibling, cur); bit = 0: hash(cur, sibling)   (fri.go:105-116)
+    Fr s[4];
+    s[0] = fr_zero();
+    s[1] = fr_zero();
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      s[2].l[k] = bit ? sib.l[k] : cur.l[k];
+      s[3].l[k] = bit ? cur.l[k] : sib.l[k];
+    }
+    poseidon_bn254_permute(s);
+    cur = s[0];
+  }
+  Fr cap = fr_from_canonical64(cap_entry);  // fri.go:135-143
+  return fr_eq(cur, cap);
+}
+
+// ---------------------------------------------------------------- field part of one query round
+GPV_DEV u32 bitrev(u32 x, u32 nbits) { return __brev(x) >> (32 - nbits); }
+
+// batched inversion of N base-field values (all must be non-zero), in place
+template <int N>
+GPV_DEV void gl_batch_inv(u64 v[N]) {
+  u64 pre[N];
+  pre[0] = v[0];
+#pragma unroll
+  for (int i = 1; i < N; i++) pre[i] = gl_mul(pre[i - 1], v[i]);
+  u64 inv = gl_inv(pre[N - 1]);
+#pragma unroll
+  for (int i = N - 1; i > 0; i--) {
+    u64 t = gl_mul(inv, pre[i - 1]);
+    inv = gl_mul(inv, v[i]);
+    v[i] = t;
+  }
+  v[0] = inv;
+}
+
+// computeEvaluation for arity 16 (fri.go:314-384, :261-312). x = current subgroup point, idx4 = index within coset.
+GPV_DEV Ext dev_fri_fold16(u64 x, u32 idx4, const u64* __restrict__ evals, Ext beta, u32* fail) {
+  // g = primitive 16th root of unity, g_inv = g^15 (fri.go:329-331)
+  u64 g = 1753635133440165772ULL;
+#pragma unroll 1
+  for (int i = 0; i < 28; i++) g = gl_sqr(g);
+  u64 g2 = gl_sqr(g), g4 = gl_sqr(g2), g8 = gl_sqr(g4);
+  u64 g_inv = gl_mul(gl_mul(g8, g4), gl_mul(g2, g));
+  // start = g_inv^rev(idx4), coset start s = start * x   (fri.go:344-350)
+  u32 rev = bitrev(idx4, 4);
+  u64 start = 1, gp = g_inv;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    if ((rev >> b) & 1) start = gl_mul(start, gp);
+    gp = gl_sqr(gp);
+  }
+  u64 s = gl_mul(start, x);
+  // norms N_i = (beta0 - x_i)^2 - 7 beta1^2, x_i = s g^i
+  u64 inv[17];
+  u64 xi[16];
+  u64 b1sq7 = gl_mul7(gl_sqr(beta.b));
+  u64 cur = s;
+  bool on_coset = false;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    xi[i] = cur;
+    u64 d0 = gl_sub(beta.a, cur);
+    u64 nrm = gl_sub(gl_sqr(d0), b1sq7);
+    // N_i = 0 iff beta - x_i = 0 (7 is a non-residue): the reference's InverseExtension assertion (fri.go:280-286)
+    if (nrm == 0) { on_coset = true; nrm = 1; }
+    inv[i] = nrm;
+    cur = gl_mul(cur, g);
+  }
+  // 16 s^15 (never zero: s != 0)
+  u64 s2 = gl_sqr(s), s4 = gl_sqr(s2), s8 = gl_sqr(s4), s16 = gl_sqr(s8);
+  u64 s15 = gl_mul(gl_mul(s8, s4), gl_mul(s2, s));
+  inv[16] = gl_mul(s15, 16);
+  gl_batch_inv<17>(inv);
+  if (on_coset) *fail |= 256;  // GPV_FAIL_FRI_INTERP
+  // sum_i y_i g^i conj(beta - x_i) / N_i, with y_i = evals[bitrev4(i)]  (fri.go:337-342)
+  Ext sum = ext_make(0, 0);
+  u64 gi = 1;
+  u64 nb1 = gl_neg(beta.b);
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int r = ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+    Ext y = ext_make(evals[2 * r], evals[2 * r + 1]);
+    Ext q = ext_make(gl_sub(beta.a, xi[i]), nb1);  // conj(beta - x_i)
+    u64 scale = gl_mul(inv[i], gi);
+    sum = ext_add(sum, ext_scalar_mul(ext_mul(y, q), scale));
+    gi = gl_mul(gi, g);
+  }
+  // l(beta) = beta^16 - s^16
+  Ext b2 = ext_sqr(beta), b4 = ext_sqr(b2), b8 = ext_sqr(b4), b16 = ext_sqr(b8);
+  Ext l = ext_make(gl_sub(b16.a, s16), b16.b);
+  return ext_scalar_mul(ext_mul(l, sum), inv[16]);
+}
+
+// verifyQueryRound without the Merkle paths. Returns failure bits.
+GPV_DEV u32 dev_fri_query(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ derived,
+                          u32 q) {
+  u32 fail = 0;
+  const u32 n_log = dc->lde_bits;
+  u64 x_index = gl_canon(derived[dc->ch_queries + q]);          // fri.go:400
+  u32 idx = (u32)(x_index & (((u64)1 << n_log) - 1));           // low n_log bits (fri.go:401)
+  // subgroup point x = 7 * w^bitrev(idx)   (fri.go:187-206)
+  u32 e = bitrev(idx, n_log);
+  u64 x = 1, wp = dc->root_lde;
+#pragma unroll 1
+  for (u32 b = 0; b < n_log; b++) {
+    if ((e >> b) & 1) x = gl_mul(x, wp);
+    wp = gl_sqr(wp);
+  }
+  x = gl_mul(x, 7);
+  // friCombineInitial (fri.go:208-251)
+  const u64* qrec = rec + dc->off_queries + (u64)q * dc->query_words;
+  Ext alpha = ext_make(derived[dc->ch_fri_alpha], derived[dc->ch_fri_alpha + 1]);
+  Ext zeta = ext_make(derived[dc->ch_zeta], derived[dc->ch_zeta + 1]);
+  const u64* extra = derived + dc->n_challenge_words;
+  Ext ro0 = ext_make(extra[4], extra[5]), ro1 = ext_make(extra[6], extra[7]);
+  // zeta batch: all four leaves in oracle order (fri_utils.go:144-152); Horner from the last polynomial
+  Ext red0 = ext_make(0, 0);
+  u32 total = dc->leaf_off[3] + dc->leaf_len[3];  // the four leaves are contiguous in the query block
+#pragma unroll 1
+  for (u32 w = total; w-- > 0;) {
+    Ext t = ext_mul(red0, alpha);
+    red0 = ext_make(gl_add(t.a, qrec[w]), t.b);
+  }
+  // zeta*g batch: the first num_challenges columns of oracle 2 (fri_utils.go:114-121)
+  Ext red1 = ext_make(0, 0);
+  u32 nc = dc->num_challenges;
+#pragma unroll 1
+  for (u32 w = nc; w-- > 0;) {
+    Ext t = ext_mul(red1, alpha);
+    red1 = ext_make(gl_add(t.a, qrec[dc->leaf_off[2] + w]), t.b);
+  }
+  Ext zeta_next = ext_scalar_mul(zeta, dc->root_degree);  // fri.go:46-50
+  Ext d0 = ext_make(gl_sub(x, zeta.a), gl_neg(zeta.b));
+  Ext d1 = ext_make(gl_sub(x, zeta_next.a), gl_neg(zeta_next.b));
+  if (ext_is_zero(d0) || ext_is_zero(d1)) fail |= 64;  // GPV_FAIL_FRI_DENOM (fri.go:241-242)
+  // sum = alpha^nc * (red0 - ro0)/d0 + (red1 - ro1)/d1, one shared inversion
+  Ext dinv = ext_inv(ext_mul(d0, d1));
+  Ext inv0 = ext_mul(dinv, d1), inv1 = ext_mul(dinv, d0);
+  Ext apow = ext_make(1, 0);
+#pragma unroll 1
+  for (u32 i = 0; i < nc; i++) apow = ext_mul(apow, alpha);
+  Ext old_eval = ext_mul(ext_sub(red0, ro0), inv0);
+  old_eval = ext_add(ext_mul(apow, old_eval), ext_mul(ext_sub(red1, ro1), inv1));
+  // reduction steps (fri.go:421-491); arity is 16 (the reference panics otherwise, :431-433)
+#pragma unroll 1
+  for (u32 s = 0; s < dc->num_steps; s++) {
+    const u64* evals = qrec + dc->step_evals_off[s];
+    u32 idx4 = idx & 15;
+    Ext chosen = ext_make(evals[2 * idx4], evals[2 * idx4 + 1]);
+    if (!ext_eq(chosen, old_eval)) fail |= 128;  // GPV_FAIL_FRI_EVAL (fri.go:460-461)
+    Ext beta = ext_make(derived[dc->ch_fri_betas + 2 * s], derived[dc->ch_fri_betas + 2 * s + 1]);
+    old_eval = dev_fri_fold16(x, idx4, evals, beta, &fail);
+    x = gl_sqr(gl_sqr(gl_sqr(gl_sqr(x))));  // fri.go:486-488
+    idx >>= 4;
+  }
+  // final polynomial (fri.go:253-259, :493-497)
+  Ext fin = ext_make(0, 0);
+#pragma unroll 1
+  for (u32 i = dc->final_len; i-- > 0;) {
+    u32 o = dc->off_final + 2 * i;
+    fin = ext_scalar_muladd(fin, x, ext_make(rec[o], rec[o + 1]));
+  }
+  if (!ext_eq(old_eval, fin)) fail |= 512;  // GPV_FAIL_FRI_FINAL
+  return fail;
+}

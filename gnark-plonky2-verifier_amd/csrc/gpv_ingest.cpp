@@ -1,0 +1,644 @@
+// Host-side ingest: the reference's JSON formats -> circuit descriptor and packed proof records.
+//
+//   common_circuit_data.json          types.ReadCommonCircuitData            types/common_data.go:11-127
+//   verifier_only_circuit_data.json   variables.DeserializeVerifierOnlyCircuitData   variables/deserialize.go:149-156
+//   proof_with_public_inputs.json     types.ReadProofWithPublicInputs + variables.DeserializeProofWithPublicInputs
+//                                     types/deserialize.go:9-108, variables/deserialize.go:12-147
+//   gate ids                          gates.GateInstanceFromId and the per-gate regexes   plonk/gates/gates.go:37-54
+//
+// Numbers are parsed as exact integers: Goldilocks words as uint64 (the Go structs use uint64 fields, so a value that
+// does not fit is a decode error there and GPV_ESHAPE here), Fr values from decimal strings of any length, reduced mod r
+// like a gnark witness assignment.
+#include "gpv_host.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------- error text (context-free calls)
+static thread_local std::string g_ingest_error;
+void gpv_set_global_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_ingest_error = buf;
+}
+const char* gpv_get_global_error() { return g_ingest_error.c_str(); }
+
+// ---------------------------------------------------------------- minimal JSON reader
+namespace {
+
+struct JValue;
+typedef std::shared_ptr<JValue> JPtr;
+struct JValue {
+  enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+  bool b = false;
+  std::string text;  // Number: raw digits; String: unescaped contents
+  std::vector<JPtr> arr;
+  std::vector<std::pair<std::string, JPtr>> obj;
+  const JValue* get(const char* key) const {
+    for (auto& kv : obj)
+      if (kv.first == key) return kv.second.get();
+    return nullptr;
+  }
+};
+
+struct JParser {
+  const char* p;
+  const char* end;
+  bool ok = true;
+  std::string err;
+  JParser(const char* s, size_t n) : p(s), end(s + n) {}
+  void fail(const char* what) {
+    if (ok) err = what;
+    ok = false;
+  }
+  void ws() {
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+  }
+  JPtr parse() {
+    JPtr v = value(0);
+    ws();
+    if (ok && p != end) fail("trailing characters");
+    return v;
+  }
+  JPtr value(int depth) {
+    JPtr v = std::make_shared<JValue>();
+    if (depth > 64) { fail("nesting too deep"); return v; }
+    ws();
+    if (p >= end) { fail("unexpected end"); return v; }
+    char c = *p;
+    if (c == '{') {
+      v->kind = JValue::Object;
+      p++;
+      ws();
+      if (p < end && *p == '}') { p++; return v; }
+      while (ok) {
+        ws();
+        if (p >= end || *p != '"') { fail("expected key"); break; }
+        std::string k = str();
+        ws();
+        if (p >= end || *p != ':') { fail("expected ':'"); break; }
+        p++;
+        JPtr child = value(depth + 1);
+        v->obj.emplace_back(k, child);
+        ws();
+        if (p < end && *p == ',') { p++; continue; }
+        if (p < end && *p == '}') { p++; break; }
+        fail("expected ',' or '}'");
+      }
+    } else if (c == '[') {
+      v->kind = JValue::Array;
+      p++;
+      ws();
+      if (p < end && *p == ']') { p++; return v; }
+      while (ok) {
+        v->arr.push_back(value(depth + 1));
+        ws();
+        if (p < end && *p == ',') { p++; continue; }
+        if (p < end && *p == ']') { p++; break; }
+        fail("expected ',' or ']'");
+      }
+    } else if (c == '"') {
+      v->kind = JValue::String;
+      v->text = str();
+    } else if (c == 't' && end - p >= 4 && !strncmp(p, "true", 4)) {
+      v->kind = JValue::Bool; v->b = true; p += 4;
+    } else if (c == 'f' && end - p >= 5 && !strncmp(p, "false", 5)) {
+      v->kind = JValue::Bool; v->b = false; p += 5;
+    } else if (c == 'n' && end - p >= 4 && !strncmp(p, "null", 4)) {
+      v->kind = JValue::Null; p += 4;
+    } else if (c == '-' || (c >= '0' && c <= '9')) {
+      v->kind = JValue::Number;
+      const char* s = p;
+      if (*p == '-') p++;
+      while (p < end && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) p++;
+      v->text.assign(s, p - s);
+    } else {
+      fail("unexpected character");
+    }
+    return v;
+  }
+  std::string str() {
+    std::string out;
+    p++;  // opening quote
+    while (p < end && *p != '"') {
+      if (*p == '\\') {
+        p++;
+        if (p >= end) break;
+        switch (*p) {
+          case 'n': out += '\n'; break;
+          case 't': out += '\t'; break;
+          case 'r': out += '\r'; break;
+          case 'b': out += '\b'; break;
+          case 'f': out += '\f'; break;
+          case 'u':  // only needed for completeness; gate ids are ASCII
+            if (end - p >= 5) { out += '?'; p += 4; }
+            break;
+          default: out += *p;
+        }
+        p++;
+      } else {
+        out += *p++;
+      }
+    }
+    if (p >= end) fail("unterminated string");
+    else p++;
+    return out;
+  }
+};
+
+bool parse_u64(const std::string& t, uint64_t* out) {
+  if (t.empty() || t.size() > 20) return false;
+  unsigned __int128 v = 0;
+  for (char c : t) {
+    if (c < '0' || c > '9') return false;
+    v = v * 10 + (unsigned)(c - '0');
+  }
+  if (v >> 64) return false;
+  *out = (uint64_t)v;
+  return true;
+}
+bool j_u64(const JValue* v, uint64_t* out) { return v && v->kind == JValue::Number && parse_u64(v->text, out); }
+bool j_u32(const JValue* v, uint32_t* out) {
+  uint64_t x;
+  if (!j_u64(v, &x) || x > 0xFFFFFFFFull) return false;
+  *out = (uint32_t)x;
+  return true;
+}
+
+// decimal string -> value mod r, 4 x u64 little-endian
+const uint64_t FR_MOD64[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+bool geq_mod(const uint64_t a[5]) {
+  if (a[4]) return true;
+  for (int i = 3; i >= 0; i--) {
+    if (a[i] > FR_MOD64[i]) return true;
+    if (a[i] < FR_MOD64[i]) return false;
+  }
+  return true;
+}
+void sub_mod(uint64_t a[5]) {
+  unsigned __int128 borrow = 0;
+  for (int i = 0; i < 5; i++) {
+    unsigned __int128 d = (unsigned __int128)a[i] - (i < 4 ? FR_MOD64[i] : 0) - (uint64_t)borrow;
+    a[i] = (uint64_t)d;
+    borrow = (d >> 64) & 1;
+  }
+}
+bool parse_fr_decimal(const std::string& t, uint64_t out[4]) {
+  if (t.empty()) return false;
+  uint64_t acc[5] = {0, 0, 0, 0, 0};
+  for (char c : t) {
+    if (c < '0' || c > '9') return false;
+    unsigned __int128 carry = (unsigned)(c - '0');
+    for (int i = 0; i < 5; i++) {
+      carry += (unsigned __int128)acc[i] * 10;
+      acc[i] = (uint64_t)carry;
+      carry >>= 64;
+    }
+    while (geq_mod(acc)) sub_mod(acc);  // acc < 10 r + 9 before: at most 10 rounds
+  }
+  memcpy(out, acc, 32);
+  return true;
+}
+bool j_fr(const JValue* v, uint64_t out[4]) { return v && v->kind == JValue::String && parse_fr_decimal(v->text, out); }
+
+// ---- gate-id parsing (the reference matches regexes; ids are generated by plonky2's Debug formatting)
+// Consumes `lit` at position *pos of s.
+bool eat(const std::string& s, size_t* pos, const char* lit) {
+  size_t n = strlen(lit);
+  if (s.compare(*pos, n, lit) != 0) return false;
+  *pos += n;
+  return true;
+}
+bool eat_u64(const std::string& s, size_t* pos, uint64_t* out) {
+  size_t b = *pos;
+  while (*pos < s.size() && s[*pos] >= '0' && s[*pos] <= '9') (*pos)++;
+  return *pos > b && parse_u64(s.substr(b, *pos - b), out);
+}
+const char* PHANTOM = "_phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=";
+
+// returns GPV_OK / GPV_ECONFIG
+int parse_gate_id(const std::string& id, uint32_t* kind, uint64_t p[3], std::vector<uint64_t>* weights) {
+  p[0] = p[1] = p[2] = 0;
+  weights->clear();
+  size_t pos;
+  uint64_t d;
+  // the reference uses unanchored regexes (FindStringSubmatch): search for the pattern start
+  auto find = [&](const char* head) -> bool {
+    size_t f = id.find(head);
+    if (f == std::string::npos) return false;
+    pos = f + strlen(head);
+    return true;
+  };
+  if (find("ArithmeticGate { num_ops: ") && eat_u64(id, &pos, &p[0]) && eat(id, &pos, " }")) { *kind = GPV_GATE_ARITHMETIC; return GPV_OK; }
+  if (find("ArithmeticExtensionGate { num_ops: ") && eat_u64(id, &pos, &p[0]) && eat(id, &pos, " }")) { *kind = GPV_GATE_ARITHMETIC_EXT; return GPV_OK; }
+  if (find("BaseSumGate { num_limbs: ") && eat_u64(id, &pos, &p[0]) && eat(id, &pos, " } + Base: ") && eat_u64(id, &pos, &p[1])) { *kind = GPV_GATE_BASE_SUM; return GPV_OK; }
+  if (find("ConstantGate { num_consts: ") && eat_u64(id, &pos, &p[0]) && eat(id, &pos, " }")) { *kind = GPV_GATE_CONSTANT; return GPV_OK; }
+  if (find("CosetInterpolationGate { subgroup_bits: ") && eat_u64(id, &pos, &p[0]) && eat(id, &pos, ", degree: ") &&
+      eat_u64(id, &pos, &p[1]) && eat(id, &pos, ", barycentric_weights: [")) {
+    for (;;) {
+      uint64_t w;
+      while (pos < id.size() && id[pos] == ' ') pos++;
+      if (!eat_u64(id, &pos, &w)) return GPV_ECONFIG;
+      weights->push_back(w);
+      if (eat(id, &pos, ",")) continue;
+      break;
+    }
+    if (!eat(id, &pos, "], ") || !eat(id, &pos, PHANTOM) || !eat(id, &pos, "2>")) return GPV_ECONFIG;
+    if (p[1] < 2) return GPV_ECONFIG;  // coset_interpolation_gate.go:35-37
+    *kind = GPV_GATE_COSET_INTERPOLATION;
+    return GPV_OK;
+  }
+  if (find("ExponentiationGate { num_power_bits: ") && eat_u64(id, &pos, &p[0]) && eat(id, &pos, ", ") && eat(id, &pos, PHANTOM) &&
+      eat_u64(id, &pos, &d) && eat(id, &pos, ">")) {
+    if (d != 2) return GPV_ECONFIG;  // exponentiation_gate.go:37-39
+    *kind = GPV_GATE_EXPONENTIATION;
+    return GPV_OK;
+  }
+  if (find("MulExtensionGate { num_ops: ") && eat_u64(id, &pos, &p[0]) && eat(id, &pos, " }")) { *kind = GPV_GATE_MUL_EXT; return GPV_OK; }
+  if (find("RandomAccessGate { bits: ") && eat_u64(id, &pos, &p[0]) && eat(id, &pos, ", num_copies: ") && eat_u64(id, &pos, &p[1]) &&
+      eat(id, &pos, ", num_extra_constants: ") && eat_u64(id, &pos, &p[2]) && eat(id, &pos, ", ") && eat(id, &pos, PHANTOM) &&
+      eat_u64(id, &pos, &d) && eat(id, &pos, ">")) {
+    if (d != 2) return GPV_ECONFIG;  // random_access_gate.go:52-54
+    *kind = GPV_GATE_RANDOM_ACCESS;
+    return GPV_OK;
+  }
+  if (find("ReducingExtensionGate { num_coeffs: ") && eat_u64(id, &pos, &p[0]) && eat(id, &pos, " }")) { *kind = GPV_GATE_REDUCING_EXT; return GPV_OK; }
+  if (find("ReducingGate { num_coeffs: ") && eat_u64(id, &pos, &p[0]) && eat(id, &pos, " }")) { *kind = GPV_GATE_REDUCING; return GPV_OK; }
+  if (id.find("PoseidonMdsGate") != std::string::npos) { *kind = GPV_GATE_POSEIDON_MDS; return GPV_OK; }
+  if (id.find("PoseidonGate") != std::string::npos) { *kind = GPV_GATE_POSEIDON; return GPV_OK; }
+  if (id.find("PublicInputGate") != std::string::npos) { *kind = GPV_GATE_PUBLIC_INPUT; return GPV_OK; }
+  if (id.find("NoopGate") != std::string::npos) { *kind = GPV_GATE_NOOP; return GPV_OK; }
+  return GPV_ECONFIG;  // gates.go:53 panics "Unknown gate ID"
+}
+
+uint64_t gl_mul_host(uint64_t a, uint64_t b) {
+  const unsigned __int128 P = 0xFFFFFFFF00000001ULL;
+  return (uint64_t)(((unsigned __int128)a * b) % P);
+}
+uint64_t primitive_root_of_unity(unsigned n_log) {  // goldilocks/base.go:445-454
+  uint64_t r = 1753635133440165772ULL;
+  for (unsigned i = 0; i < 32 - n_log; i++) r = gl_mul_host(r, r);
+  return r;
+}
+
+uint32_t gate_num_constraints(const DevGate& g) {
+  switch (g.kind) {
+    case GPV_GATE_NOOP: return 0;
+    case GPV_GATE_CONSTANT: return g.p0;
+    case GPV_GATE_PUBLIC_INPUT: return 4;
+    case GPV_GATE_BASE_SUM: return 1 + g.p0;
+    case GPV_GATE_ARITHMETIC: return g.p0;
+    case GPV_GATE_ARITHMETIC_EXT: return 2 * g.p0;
+    case GPV_GATE_MUL_EXT: return 2 * g.p0;
+    case GPV_GATE_REDUCING: return 2 * g.p0;
+    case GPV_GATE_REDUCING_EXT: return 2 * g.p0;
+    case GPV_GATE_EXPONENTIATION: return g.p0 + 1;
+    case GPV_GATE_RANDOM_ACCESS: return g.p1 * (g.p0 + 2) + g.p2;
+    case GPV_GATE_COSET_INTERPOLATION: return 2 + 4 * (((1u << g.p0) - 2) / (g.p1 - 1)) + 2;
+    case GPV_GATE_POSEIDON: return 123;
+    case GPV_GATE_POSEIDON_MDS: return 24;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- layout
+static int finish_layout(DevCircuit& c) {
+  c.lde_bits = c.degree_bits + c.rate_bits;
+  uint32_t total_arity = 0;
+  for (uint32_t s = 0; s < c.num_steps; s++) total_arity += c.arity_bits[s];
+  if (total_arity > c.degree_bits) return GPV_ECONFIG;
+  c.final_len = 1u << (c.degree_bits - total_arity);
+  uint32_t w = 0;
+  c.off_constants = w; w += 2 * c.num_constants;
+  c.off_sigmas = w; w += 2 * c.num_routed;
+  c.off_wires = w; w += 2 * c.num_wires;
+  c.off_zs = w; w += 2 * c.num_challenges;
+  c.off_zs_next = w; w += 2 * c.num_challenges;
+  c.off_pp = w; w += 2 * c.num_challenges * c.num_pp;
+  c.off_quot = w; w += 2 * c.num_challenges * c.qdf;
+  c.off_queries = w;
+  c.leaf_len[0] = c.num_constants + c.num_routed;                 // fri_utils.go:60-72 numPreprocessedPolys
+  c.leaf_len[1] = c.num_wires;
+  c.leaf_len[2] = c.num_challenges * (1 + c.num_pp);               // :74-76
+  c.leaf_len[3] = c.num_challenges * c.qdf;                        // :78-80
+  uint32_t qw = 0;
+  for (int o = 0; o < 4; o++) { c.leaf_off[o] = qw; qw += c.leaf_len[o]; }
+  for (uint32_t s = 0; s < c.num_steps; s++) { c.step_evals_off[s] = qw; qw += 2u << c.arity_bits[s]; }
+  c.query_words = qw;
+  w += c.num_queries * qw;
+  c.off_final = w; w += 2 * c.final_len;
+  c.off_pow = w; w += 1;
+  c.off_pi = w; w += c.num_pi;
+  c.n_gl_words = w;
+  uint32_t cap_len = 1u << c.cap_height;
+  c.fr_wires_cap = 0;
+  c.fr_zs_pp_cap = cap_len;
+  c.fr_quot_cap = 2 * cap_len;
+  c.fr_commit_caps = 3 * cap_len;
+  c.fr_queries = (3 + c.num_steps) * cap_len;
+  if (c.lde_bits < c.cap_height + total_arity) return GPV_ECONFIG;
+  c.init_siblings = c.lde_bits - c.cap_height;
+  uint32_t qf = 4 * c.init_siblings, bits = c.init_siblings;
+  for (uint32_t s = 0; s < c.num_steps; s++) {
+    bits -= c.arity_bits[s];
+    c.step_siblings[s] = bits;
+    c.step_sib_off[s] = qf;
+    qf += bits;
+  }
+  c.query_frs = qf;
+  c.n_fr = c.fr_queries + c.num_queries * qf;
+  c.n_trees = 4 + c.num_steps;
+  c.proof_nbytes = 8ull * c.n_gl_words + 32ull * c.n_fr;
+  uint32_t k = 0;
+  c.ch_betas = k; k += c.num_challenges;
+  c.ch_gammas = k; k += c.num_challenges;
+  c.ch_alphas = k; k += c.num_challenges;
+  c.ch_zeta = k; k += 2;
+  c.ch_fri_alpha = k; k += 2;
+  c.ch_fri_betas = k; k += 2 * c.num_steps;
+  c.ch_pow = k; k += 1;
+  c.ch_queries = k; k += c.num_queries;
+  c.n_challenge_words = k;
+  c.root_degree = primitive_root_of_unity(c.degree_bits);
+  c.root_lde = primitive_root_of_unity(c.lde_bits);
+  return GPV_OK;
+}
+
+extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len, const char* verifier_only_json,
+                                     size_t verifier_only_len, gpv_circuit** out) {
+  if (!common_json || !verifier_only_json || !out) return GPV_EINVAL;
+  *out = nullptr;
+  JParser pc(common_json, common_len);
+  JPtr common = pc.parse();
+  if (!pc.ok) { gpv_set_global_error("common_circuit_data: %s", pc.err.c_str()); return GPV_ESHAPE; }
+  JParser pv(verifier_only_json, verifier_only_len);
+  JPtr vo = pv.parse();
+  if (!pv.ok) { gpv_set_global_error("verifier_only_circuit_data: %s", pv.err.c_str()); return GPV_ESHAPE; }
+
+  std::unique_ptr<gpv_circuit> circ(new gpv_circuit());
+  DevCircuit& c = circ->dc;
+  memset(&c, 0, sizeof c);
+  const JValue* cfg = common->get("config");
+  const JValue* fp = common->get("fri_params");
+  const JValue* fpc = fp ? fp->get("config") : nullptr;
+  if (!cfg || !fp || !fpc) { gpv_set_global_error("missing config / fri_params"); return GPV_ESHAPE; }
+  bool good = j_u32(cfg->get("num_wires"), &c.num_wires) && j_u32(cfg->get("num_routed_wires"), &c.num_routed) &&
+              j_u32(cfg->get("num_challenges"), &c.num_challenges) && j_u32(common->get("num_constants"), &c.num_constants) &&
+              j_u32(common->get("num_partial_products"), &c.num_pp) && j_u32(common->get("quotient_degree_factor"), &c.qdf) &&
+              j_u32(common->get("num_gate_constraints"), &c.num_gate_constraints) &&
+              j_u32(common->get("num_public_inputs"), &c.num_pi) && j_u32(fp->get("degree_bits"), &c.degree_bits) &&
+              j_u32(fpc->get("rate_bits"), &c.rate_bits) && j_u32(fpc->get("cap_height"), &c.cap_height) &&
+              j_u32(fpc->get("proof_of_work_bits"), &c.pow_bits) && j_u32(fpc->get("num_query_rounds"), &c.num_queries);
+  if (!good) { gpv_set_global_error("common_circuit_data: missing or malformed scalar field"); return GPV_ESHAPE; }
+  const JValue* hiding = fp->get("hiding");
+  if (hiding && hiding->kind == JValue::Bool && hiding->b) {  // common_data.go:121-124
+    gpv_set_global_error("Circuit has hiding enabled, which is not supported");
+    return GPV_ECONFIG;
+  }
+  const JValue* rab = fp->get("reduction_arity_bits");
+  if (!rab || rab->kind != JValue::Array || rab->arr.size() > GPV_MAX_STEPS) { gpv_set_global_error("reduction_arity_bits"); return GPV_ESHAPE; }
+  c.num_steps = (uint32_t)rab->arr.size();
+  for (uint32_t s = 0; s < c.num_steps; s++) {
+    if (!j_u32(rab->arr[s].get(), &c.arity_bits[s])) return GPV_ESHAPE;
+    if (c.arity_bits[s] != 4) {  // fri.go:431-433 "assuming arity bits is 4"
+      gpv_set_global_error("reduction arity bits %u != 4 is not supported", c.arity_bits[s]);
+      return GPV_ECONFIG;
+    }
+  }
+  if (c.cap_height != 4) {  // fri.go:118-126
+    gpv_set_global_error("cap_height %u != 4 is not supported", c.cap_height);
+    return GPV_ECONFIG;
+  }
+  if (c.num_challenges < 1 || c.num_challenges > GPV_MAX_CHALLENGES || c.num_routed > GPV_MAX_ROUTED || c.num_routed > c.num_wires ||
+      c.qdf == 0 || c.num_routed != c.qdf * (c.num_pp + 1) || c.degree_bits + c.rate_bits > 32 || c.pow_bits > 63 || c.num_queries == 0) {
+    gpv_set_global_error("unsupported circuit dimensions");
+    return GPV_ECONFIG;
+  }
+  const JValue* kis = common->get("k_is");
+  if (!kis || kis->kind != JValue::Array || kis->arr.size() < c.num_routed) { gpv_set_global_error("k_is"); return GPV_ESHAPE; }
+  for (uint32_t i = 0; i < c.num_routed; i++)
+    if (!j_u64(kis->arr[i].get(), &c.k_is[i])) return GPV_ESHAPE;
+  const JValue* gates = common->get("gates");
+  const JValue* si = common->get("selectors_info");
+  const JValue* sidx = si ? si->get("selector_indices") : nullptr;
+  const JValue* groups = si ? si->get("groups") : nullptr;
+  if (!gates || gates->kind != JValue::Array || !sidx || sidx->kind != JValue::Array || !groups || groups->kind != JValue::Array ||
+      sidx->arr.size() != gates->arr.size()) {
+    gpv_set_global_error("gates / selectors_info");
+    return GPV_ESHAPE;
+  }
+  if (gates->arr.size() > GPV_MAX_GATES || groups->arr.size() > GPV_MAX_GROUPS || groups->arr.empty()) return GPV_ECONFIG;
+  c.n_gates = (uint32_t)gates->arr.size();
+  c.n_groups = (uint32_t)groups->arr.size();
+  if (c.n_groups > c.num_constants) return GPV_ESHAPE;
+  uint32_t wused = 0;
+  for (uint32_t g = 0; g < c.n_gates; g++) {
+    const JValue* gid = gates->arr[g].get();
+    if (gid->kind != JValue::String) return GPV_ESHAPE;
+    uint32_t kind;
+    uint64_t p[3];
+    std::vector<uint64_t> weights;
+    if (parse_gate_id(gid->text, &kind, p, &weights) != GPV_OK) {
+      gpv_set_global_error("Unknown gate ID %s", gid->text.c_str());
+      return GPV_ECONFIG;
+    }
+    DevGate& dg = c.gates[g];
+    dg.kind = kind;
+    if (p[0] > 0xFFFFFFFFull || p[1] > 0xFFFFFFFFull || p[2] > 0xFFFFFFFFull) return GPV_ECONFIG;
+    dg.p0 = (uint32_t)p[0]; dg.p1 = (uint32_t)p[1]; dg.p2 = (uint32_t)p[2];
+    dg.weights_off = wused;
+    dg.n_weights = (uint32_t)weights.size();
+    if (wused + weights.size() > GPV_MAX_WEIGHTS) return GPV_ECONFIG;
+    for (uint64_t wv : weights) c.weights[wused++] = wv;
+    if (kind == GPV_GATE_COSET_INTERPOLATION && (dg.p0 > 8 || weights.size() != (1ull << dg.p0))) return GPV_ECONFIG;
+    if (kind == GPV_GATE_RANDOM_ACCESS && dg.p0 > GPV_MAX_RA_BITS) return GPV_ECONFIG;
+    if (kind == GPV_GATE_BASE_SUM && dg.p1 > 256) return GPV_ECONFIG;
+    dg.n_constraints = gate_num_constraints(dg);
+    if (dg.n_constraints > c.num_gate_constraints) {  // evaluate_gates.go:97-99
+      gpv_set_global_error("num_constraints() gave too low of a number");
+      return GPV_ESHAPE;
+    }
+    if (!j_u32(sidx->arr[g].get(), &c.selector_index[g]) || c.selector_index[g] >= c.n_groups) return GPV_ESHAPE;
+  }
+  for (uint32_t g = 0; g < c.n_groups; g++) {
+    const JValue* gr = groups->arr[g].get();
+    if (!j_u32(gr->get("start"), &c.group_start[g]) || !j_u32(gr->get("end"), &c.group_end[g])) return GPV_ESHAPE;
+  }
+  const JValue* cap = vo->get("constants_sigmas_cap");
+  if (!cap || cap->kind != JValue::Array || cap->arr.size() != 16) { gpv_set_global_error("constants_sigmas_cap"); return GPV_ESHAPE; }
+  for (int i = 0; i < 16; i++)
+    if (!j_fr(cap->arr[i].get(), c.sigmas_cap[i])) return GPV_ESHAPE;
+  if (!j_fr(vo->get("circuit_digest"), c.digest)) { gpv_set_global_error("circuit_digest"); return GPV_ESHAPE; }
+  int rc = finish_layout(c);
+  if (rc != GPV_OK) return rc;
+  *out = circ.release();
+  return GPV_OK;
+}
+
+extern "C" int gpv_circuit_destroy(gpv_circuit* c) {
+  if (!c) return GPV_EINVAL;
+  gpv_circuit_release_device(c);
+  delete c;
+  return GPV_OK;
+}
+extern "C" size_t gpv_proof_nbytes(const gpv_circuit* c) { return c ? (size_t)c->dc.proof_nbytes : 0; }
+extern "C" size_t gpv_num_challenge_words(const gpv_circuit* c) { return c ? c->dc.n_challenge_words : 0; }
+extern "C" size_t gpv_num_gate_constraints(const gpv_circuit* c) { return c ? c->dc.num_gate_constraints : 0; }
+extern "C" size_t gpv_num_query_rounds(const gpv_circuit* c) { return c ? c->dc.num_queries : 0; }
+extern "C" size_t gpv_num_merkle_trees(const gpv_circuit* c) { return c ? c->dc.n_trees : 0; }
+
+// circuit blob: 32-word header + sections (same format the tests build independently, tests/gpv_testlib.py)
+extern "C" size_t gpv_circuit_describe(const gpv_circuit* circ, uint64_t* blob, size_t cap) {
+  if (!circ) return 0;
+  const DevCircuit& c = circ->dc;
+  std::vector<uint64_t> b(32, 0);
+  b[0] = 0x0001435650470000ULL;
+  b[1] = c.num_wires; b[2] = c.num_routed; b[3] = c.num_constants; b[4] = c.num_challenges; b[5] = c.num_pp; b[6] = c.qdf;
+  b[7] = c.num_gate_constraints; b[8] = c.num_pi; b[9] = c.degree_bits; b[10] = c.rate_bits; b[11] = c.cap_height;
+  b[12] = c.pow_bits; b[13] = c.num_queries; b[14] = c.num_steps;
+  for (uint32_t s = 0; s < c.num_steps; s++) b[15 + s] = c.arity_bits[s];
+  b[23] = c.n_gates; b[24] = c.n_groups;
+  b[25] = b.size();
+  for (uint32_t i = 0; i < c.num_routed; i++) b.push_back(c.k_is[i]);
+  size_t gate_off = b.size();
+  b[26] = gate_off;
+  b.resize(b.size() + 8 * c.n_gates, 0);
+  for (uint32_t g = 0; g < c.n_gates; g++) {
+    const DevGate& dg = c.gates[g];
+    size_t woff = 0;
+    if (dg.n_weights) {
+      woff = b.size();
+      for (uint32_t i = 0; i < dg.n_weights; i++) b.push_back(c.weights[dg.weights_off + i]);
+    }
+    uint64_t* e = &b[gate_off + 8 * g];
+    e[0] = dg.kind; e[1] = dg.p0; e[2] = dg.p1; e[3] = dg.p2; e[4] = woff; e[5] = dg.n_weights;
+  }
+  b[27] = b.size();
+  for (uint32_t g = 0; g < c.n_gates; g++) b.push_back(c.selector_index[g]);
+  b[28] = b.size();
+  for (uint32_t g = 0; g < c.n_groups; g++) { b.push_back(c.group_start[g]); b.push_back(c.group_end[g]); }
+  b[29] = b.size();
+  for (int i = 0; i < 16; i++)
+    for (int k = 0; k < 4; k++) b.push_back(c.sigmas_cap[i][k]);
+  b[30] = b.size();
+  for (int k = 0; k < 4; k++) b.push_back(c.digest[k]);
+  b[31] = b.size();
+  if (blob) memcpy(blob, b.data(), 8 * (b.size() < cap ? b.size() : cap));
+  return b.size();
+}
+
+// ---------------------------------------------------------------- proof packing
+namespace {
+struct Packer {
+  uint64_t* gl;
+  uint64_t* fr;
+  bool ok = true;
+  const char* why = "";
+  void fail(const char* w) { if (ok) why = w; ok = false; }
+  void put_u64(const JValue* v) {
+    uint64_t x = 0;
+    if (!j_u64(v, &x)) fail("expected a uint64");
+    *gl++ = x;
+  }
+  void put_ext_list(const JValue* v, size_t n) {
+    if (!v || v->kind != JValue::Array || v->arr.size() != n) { fail("extension array of the wrong length"); gl += 2 * n; return; }
+    for (auto& e : v->arr) {
+      if (e->kind != JValue::Array || e->arr.size() != 2) { fail("extension element must have 2 limbs"); gl += 2; continue; }
+      put_u64(e->arr[0].get());
+      put_u64(e->arr[1].get());
+    }
+  }
+  void put_u64_list(const JValue* v, size_t n) {
+    if (!v || v->kind != JValue::Array || v->arr.size() != n) { fail("array of the wrong length"); gl += n; return; }
+    for (auto& e : v->arr) put_u64(e.get());
+  }
+  void put_fr_list(const JValue* v, size_t n) {
+    if (!v || v->kind != JValue::Array || v->arr.size() != n) { fail("hash array of the wrong length"); fr += 4 * n; return; }
+    for (auto& e : v->arr) {
+      if (!j_fr(e.get(), fr)) fail("expected a decimal string");
+      fr += 4;
+    }
+  }
+};
+}  // namespace
+
+extern "C" int gpv_proof_pack_json(const gpv_circuit* circ, const char* proof_json, size_t proof_len, void* out_packed) {
+  if (!circ || !proof_json || !out_packed) return GPV_EINVAL;
+  const DevCircuit& c = circ->dc;
+  JParser pp(proof_json, proof_len);
+  JPtr root = pp.parse();
+  if (!pp.ok) { gpv_set_global_error("proof_with_public_inputs: %s", pp.err.c_str()); return GPV_ESHAPE; }
+  const JValue* proof = root->get("proof");
+  const JValue* op = proof ? proof->get("openings") : nullptr;
+  const JValue* fp = proof ? proof->get("opening_proof") : nullptr;
+  if (!proof || !op || !fp) { gpv_set_global_error("missing proof / openings / opening_proof"); return GPV_ESHAPE; }
+  memset(out_packed, 0, c.proof_nbytes);
+  Packer pk;
+  pk.gl = (uint64_t*)out_packed;
+  pk.fr = pk.gl + c.n_gl_words;
+  uint64_t* gl_end = pk.fr;
+  const uint32_t nc = c.num_challenges, cap_len = 1u << c.cap_height;
+  // openings (types/deserialize.go:14-22)
+  pk.put_ext_list(op->get("constants"), c.num_constants);
+  pk.put_ext_list(op->get("plonk_sigmas"), c.num_routed);
+  pk.put_ext_list(op->get("wires"), c.num_wires);
+  pk.put_ext_list(op->get("plonk_zs"), nc);
+  pk.put_ext_list(op->get("plonk_zs_next"), nc);
+  pk.put_ext_list(op->get("partial_products"), nc * c.num_pp);
+  pk.put_ext_list(op->get("quotient_polys"), nc * c.qdf);
+  // caps (:10-13, :24)
+  pk.put_fr_list(proof->get("wires_cap"), cap_len);
+  pk.put_fr_list(proof->get("plonk_zs_partial_products_cap"), cap_len);
+  pk.put_fr_list(proof->get("quotient_polys_cap"), cap_len);
+  const JValue* ccaps = fp->get("commit_phase_merkle_caps");
+  if (!ccaps || ccaps->kind != JValue::Array || ccaps->arr.size() != c.num_steps) { gpv_set_global_error("commit_phase_merkle_caps"); return GPV_ESHAPE; }
+  for (auto& cp : ccaps->arr) pk.put_fr_list(cp.get(), cap_len);  // fri_utils.go:175-179
+  const JValue* qrs = fp->get("query_round_proofs");
+  if (!qrs || qrs->kind != JValue::Array || qrs->arr.size() != c.num_queries) {  // fri.go:515-517
+    gpv_set_global_error("Number of query rounds does not match config.");
+    return GPV_ESHAPE;
+  }
+  for (auto& qr : qrs->arr) {
+    const JValue* itp = qr->get("initial_trees_proof");
+    const JValue* eps = itp ? itp->get("evals_proofs") : nullptr;
+    if (!eps || eps->kind != JValue::Array || eps->arr.size() != 4) {  // fri_utils.go:185-187
+      gpv_set_global_error("eval proofs length is not equal to instance oracles length");
+      return GPV_ESHAPE;
+    }
+    for (int o = 0; o < 4; o++) {
+      const JValue* ep = eps->arr[o].get();  // 2-tuple [leaf, {"siblings": [...]}]  (types/deserialize.go:45-72)
+      if (ep->kind != JValue::Array || ep->arr.size() != 2) { gpv_set_global_error("evals_proofs entry must be a 2-tuple"); return GPV_ESHAPE; }
+      pk.put_u64_list(ep->arr[0].get(), c.leaf_len[o]);                         // fri_utils.go:199-201
+      pk.put_fr_list(ep->arr[1]->get("siblings"), c.init_siblings);             // :203-205
+    }
+    const JValue* steps = qr->get("steps");
+    if (!steps || steps->kind != JValue::Array || steps->arr.size() != c.num_steps) {  // fri_utils.go:208-210
+      gpv_set_global_error("length of steps != params.reduction_arity_bits");
+      return GPV_ESHAPE;
+    }
+    for (uint32_t s = 0; s < c.num_steps; s++) {
+      const JValue* st = steps->arr[s].get();
+      pk.put_ext_list(st->get("evals"), 1u << c.arity_bits[s]);                 // :219-221
+      const JValue* mp = st->get("merkle_proof");
+      pk.put_fr_list(mp ? mp->get("siblings") : nullptr, c.step_siblings[s]);   // :223-225
+    }
+  }
+  const JValue* fpoly = fp->get("final_poly");
+  pk.put_ext_list(fpoly ? fpoly->get("coeffs") : nullptr, c.final_len);         // fri_utils.go:226-228
+  pk.put_u64(fp->get("pow_witness"));
+  pk.put_u64_list(root->get("public_inputs"), c.num_pi);
+  if (!pk.ok) { gpv_set_global_error("proof shape: %s", pk.why); return GPV_ESHAPE; }
+  if (pk.gl != gl_end || pk.fr != gl_end + 4 * c.n_fr) { gpv_set_global_error("internal layout mismatch"); return GPV_ESHAPE; }
+  return GPV_OK;
+}

@@ -1,0 +1,123 @@
+// Poseidon-BN254 kernels: the chip-level operators of poseidon/bn254.go and the Merkle-path kernel that carries 97 % of
+// the verification arithmetic (fri/fri.go:97-157, :472-483).
+#include "../../include/gpv.h"
+#include "gpv_launch.h"
+#include "gpv_fri.cuh"
+#include "gpv_transcript.cuh"
+
+__global__ __launch_bounds__(64) void k_poseidon_bn254_permute(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr s[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) s[k] = fr_from_canonical64(in + 16 * i + 4 * k);
+  poseidon_bn254_permute(s);
+#pragma unroll
+  for (int k = 0; k < 4; k++) fr_to_canonical64(s[k], out + 16 * i + 4 * k);
+}
+__global__ __launch_bounds__(64) void k_poseidon_bn254_hash_or_noop(const u64* __restrict__ in, u32 len, u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr h = poseidon_bn254_hash_or_noop(in + (size_t)len * i, len);
+  fr_to_canonical64(h, out + 4 * i);
+}
+__global__ __launch_bounds__(64) void k_poseidon_bn254_two_to_one(const u64* __restrict__ l, const u64* __restrict__ r, u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr h = poseidon_bn254_two_to_one(fr_from_canonical64(l + 4 * i), fr_from_canonical64(r + 4 * i));
+  fr_to_canonical64(h, out + 4 * i);
+}
+__global__ void k_poseidon_bn254_to_vec(const u64* __restrict__ h, u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 c[4] = {h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]};
+  DevChallenger::fr64_reduce(c);
+  u64 v[5];
+  fr_canonical_to_vec(c, v);
+#pragma unroll
+  for (int k = 0; k < 5; k++) out[5 * i + k] = v[k];
+}
+
+struct MerkleOrder {
+  u32 cls[4 + GPV_MAX_STEPS];  // tree classes, most expensive first
+};
+// One lane per (proof, query, tree). blockIdx.y picks the tree class, so every lane of a wave hashes a leaf of the same
+// length and climbs the same number of levels.
+#define GPV_MERKLE_BLOCK 64
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                             const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                             u32* __restrict__ fail, uint8_t* __restrict__ ok_out) {
+  size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nq = dc->num_queries;
+  if (item >= n * nq) return;
+  size_t p = item / nq;
+  u32 q = (u32)(item - p * nq);
+  u32 tree = order.cls[blockIdx.y];
+  const u64* rec = proofs + p * (dc->proof_nbytes / 8);
+  const u64* frs = rec + dc->n_gl_words;
+  const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
+  const u32 n_log = dc->lde_bits;
+  u64 x_index = gl_canon(d[dc->ch_queries + q]);
+  u32 idx = (u32)(x_index & (((u64)1 << n_log) - 1));
+  u32 cap_index = idx >> (n_log - dc->cap_height);  // fri.go:402, reused for every step (:477-483)
+  const u64* qrec = rec + dc->off_queries + (size_t)q * dc->query_words;
+  const u64* qfr = frs + 4 * ((size_t)dc->fr_queries + (size_t)q * dc->query_frs);
+  const u64 *leaf, *sib, *cap;
+  u32 leaf_len, n_sib, bits;
+  if (tree < 4) {
+    leaf = qrec + dc->leaf_off[tree];
+    leaf_len = dc->leaf_len[tree];
+    sib = qfr + 4 * (size_t)(tree * dc->init_siblings);
+    n_sib = dc->init_siblings;
+    bits = idx;
+    cap = tree == 0 ? &dc->sigmas_cap[0][0] : frs + 4 * (size_t)((tree - 1) << dc->cap_height);
+  } else {
+    u32 s = tree - 4;
+    u32 shift = 0;
+    for (u32 k = 0; k <= s; k++) shift += dc->arity_bits[k];
+    leaf = qrec + dc->step_evals_off[s];
+    leaf_len = 2u << dc->arity_bits[s];
+    sib = qfr + 4 * (size_t)dc->step_sib_off[s];
+    n_sib = dc->step_siblings[s];
+    bits = idx >> shift;
+    cap = frs + 4 * (size_t)(dc->fr_commit_caps + (s << dc->cap_height));
+  }
+  bool ok = dev_merkle_chain(leaf, leaf_len, sib, n_sib, bits, cap + 4 * cap_index);
+  if (ok_out) ok_out[item * dc->n_trees + tree] = ok;
+  if (!ok) atomicOr(&fail[p], tree < 4 ? (u32)GPV_FAIL_MERKLE_INITIAL : (u32)GPV_FAIL_MERKLE_STEP);
+}
+static MerkleOrder merkle_order(const DevCircuit& c) {
+  // cost of a chain = ceil(leaf_len / 9) + siblings permutations; sort classes by descending cost
+  MerkleOrder o;
+  u32 cost[4 + GPV_MAX_STEPS];
+  for (u32 t = 0; t < c.n_trees; t++) {
+    u32 len = t < 4 ? c.leaf_len[t] : (2u << c.arity_bits[t - 4]);
+    u32 sib = t < 4 ? c.init_siblings : c.step_siblings[t - 4];
+    cost[t] = (len <= 3 ? 0 : (len + 8) / 9) + sib;
+    o.cls[t] = t;
+  }
+  for (u32 i = 0; i < c.n_trees; i++)
+    for (u32 j = i + 1; j < c.n_trees; j++)
+      if (cost[o.cls[j]] > cost[o.cls[i]]) { u32 t = o.cls[i]; o.cls[i] = o.cls[j]; o.cls[j] = t; }
+  return o;
+}
+
+
+void gpvk_poseidon_bn254_permute(hipStream_t st, const u64* in, u64* out, size_t n) {
+  hipLaunchKernelGGL(k_poseidon_bn254_permute, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, out, n);
+}
+void gpvk_poseidon_bn254_hash_or_noop(hipStream_t st, const u64* in, u32 len, u64* out, size_t n) {
+  hipLaunchKernelGGL(k_poseidon_bn254_hash_or_noop, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
+}
+void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, u64* out, size_t n) {
+  hipLaunchKernelGGL(k_poseidon_bn254_two_to_one, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, l, r, out, n);
+}
+void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n) {
+  hipLaunchKernelGGL(k_poseidon_bn254_to_vec, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, h, out, n);
+}
+void gpvk_merkle(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, u32* fail,
+                 uint8_t* ok_out) {
+  size_t items = n * hc.num_queries;
+  hipLaunchKernelGGL(k_merkle, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
+                     derived, n, merkle_order(hc), fail, ok_out);
+}

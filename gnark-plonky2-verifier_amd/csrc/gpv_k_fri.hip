@@ -1,0 +1,25 @@
+// FRI query kernel: everything in verifyQueryRound except the Merkle paths (fri/fri.go:386-498) plus the PoW check.
+#include "../../include/gpv.h"
+#include "gpv_launch.h"
+#include "gpv_fri.cuh"
+
+__global__ __launch_bounds__(64) void k_fri_query(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                  const u64* __restrict__ derived, size_t n, u32* __restrict__ fail) {
+  size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nq = dc->num_queries;
+  if (item >= n * nq) return;
+  size_t p = item / nq;
+  u32 q = (u32)(item - p * nq);
+  const u64* rec = proofs + p * (dc->proof_nbytes / 8);
+  const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
+  u32 f = dev_fri_query(dc, rec, d, q);
+  // proof of work (fri.go:75-80): pow_response < 2^(64 - pow_bits)
+  if (q == 0 && dc->pow_bits && (d[dc->ch_pow] >> (64 - dc->pow_bits)) != 0) f |= GPV_FAIL_POW;
+  if (f) atomicOr(&fail[p], f);
+}
+
+void gpvk_fri_query(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
+                    u32* fail) {
+  size_t items = n * hc.num_queries;
+  hipLaunchKernelGGL(k_fri_query, dim3(gpvk_blocks_for(items, 64)), dim3(64), 0, st, dcd, proofs, derived, n, fail);
+}

@@ -1,0 +1,80 @@
+// Plonk kernels: the vanishing-polynomial check per proof and the gate-evaluation entry points used for parity tests.
+#include "../../include/gpv.h"
+#include "gpv_launch.h"
+#include "gpv_plonk.cuh"
+
+#define GPV_PLONK_BLOCK 64
+#define GPV_PLONK_LDS_PER_LANE (2 << (GPV_MAX_RA_BITS - 1))  // u64 words: 2^(bits-1) extension elements
+
+__global__ __launch_bounds__(GPV_PLONK_BLOCK) void k_gate_eval_unfiltered(DevGate g, const u64* __restrict__ weights,
+                                                                          const u64* __restrict__ constants, u32 n_constants,
+                                                                          const u64* __restrict__ wires, u32 n_wires,
+                                                                          const u64* __restrict__ pih, u64* __restrict__ out,
+                                                                          u32 max_out, size_t n) {
+  __shared__ u64 lds[GPV_PLONK_BLOCK * GPV_PLONK_LDS_PER_LANE];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  GateVars v;
+  v.constants = constants + 2 * (size_t)n_constants * i;
+  v.wires = wires + 2 * (size_t)n_wires * i;
+#pragma unroll
+  for (int k = 0; k < 4; k++) v.pih[k] = pih[4 * i + k];
+  StoreSink sink;
+  sink.out = out + 2 * (size_t)max_out * i;
+  sink.k = 0;
+  sink.cap = max_out;
+  g.weights_off = 0;
+  gate_eval_unfiltered(g, v, weights, lds + threadIdx.x, GPV_PLONK_BLOCK, sink);
+}
+
+__global__ __launch_bounds__(GPV_PLONK_BLOCK) void k_plonk(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                           const u64* __restrict__ derived, size_t n, u32* __restrict__ fail) {
+  __shared__ u64 lds[GPV_PLONK_BLOCK * GPV_PLONK_LDS_PER_LANE];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64* rec = proofs + i * (dc->proof_nbytes / 8);
+  u32 f = dev_plonk_verify(dc, rec, derived + i * (dc->n_challenge_words + GPV_DERIVED_EXTRA), lds + threadIdx.x, GPV_PLONK_BLOCK);
+  if (f) atomicOr(&fail[i], f);
+}
+// EvaluateGateConstraints with materialised slots (parity/debug path; the verify path streams them, gpv_plonk.cuh)
+__global__ __launch_bounds__(GPV_PLONK_BLOCK) void k_gate_constraints(const DevCircuit* __restrict__ dc,
+                                                                      const u64* __restrict__ proofs,
+                                                                      const u64* __restrict__ derived, size_t n,
+                                                                      u64* __restrict__ out) {
+  __shared__ u64 lds[GPV_PLONK_BLOCK * GPV_PLONK_LDS_PER_LANE];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64* rec = proofs + i * (dc->proof_nbytes / 8);
+  const u64* extra = derived + i * (dc->n_challenge_words + GPV_DERIVED_EXTRA) + dc->n_challenge_words;
+  u64* o = out + 2 * (size_t)dc->num_gate_constraints * i;
+  for (u32 k = 0; k < 2 * dc->num_gate_constraints; k++) o[k] = 0;
+  GateVars v;
+  v.constants = rec + dc->off_constants + 2 * dc->n_groups;
+  v.wires = rec + dc->off_wires;
+#pragma unroll
+  for (int k = 0; k < 4; k++) v.pih[k] = extra[k];
+#pragma unroll 1
+  for (u32 gi = 0; gi < dc->n_gates; gi++) {
+    u32 sel = dc->selector_index[gi];
+    FilteredAccSink sink;
+    sink.out = o;
+    sink.filter = gate_filter(dc, gi, ext_make(rec[dc->off_constants + 2 * sel], rec[dc->off_constants + 2 * sel + 1]));
+    sink.k = 0;
+    sink.cap = dc->num_gate_constraints;
+    gate_eval_unfiltered(dc->gates[gi], v, dc->weights, lds + threadIdx.x, GPV_PLONK_BLOCK, sink);
+  }
+}
+
+
+void gpvk_gate_eval_unfiltered(hipStream_t st, DevGate g, const u64* weights, const u64* constants, u32 n_constants, const u64* wires,
+                               u32 n_wires, const u64* pih, u64* out, u32 max_out, size_t n) {
+  hipLaunchKernelGGL(k_gate_eval_unfiltered, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, g, weights, constants,
+                     n_constants, wires, n_wires, pih, out, max_out, n);
+}
+void gpvk_plonk(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u32* fail) {
+  hipLaunchKernelGGL(k_plonk, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, dcd, proofs, derived, n, fail);
+}
+void gpvk_gate_constraints(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u64* out) {
+  hipLaunchKernelGGL(k_gate_constraints, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, dcd, proofs, derived, n,
+                     out);
+}

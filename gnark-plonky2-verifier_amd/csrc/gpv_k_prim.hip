@@ -1,0 +1,146 @@
+// Primitive kernels: chip-level Goldilocks operators, the batched Poseidon-Goldilocks permutation (BASELINE config 2)
+// and the instruction-rate microbenchmark that defines the VALU-integer roof.
+#include "../../include/gpv.h"
+#include "gpv_launch.h"
+#include "gpv_poseidon.cuh"
+
+__global__ void k_gl_op(int op, const u64* __restrict__ a, const u64* __restrict__ b, const u64* __restrict__ c,
+                        u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 r = 0;
+  switch (op) {
+    case GPV_OP_ADD: r = gl_add(a[i], b[i]); break;
+    case GPV_OP_SUB: r = gl_sub(a[i], b[i]); break;
+    case GPV_OP_MUL: r = gl_mul(a[i], b[i]); break;
+    case GPV_OP_MULADD: r = gl_muladd(a[i], b[i], c[i]); break;
+    case GPV_OP_INV: r = gl_inv(a[i]); break;
+    case GPV_OP_REDUCE: r = gl_canon(a[i]); break;
+  }
+  out[i] = r;
+}
+__global__ void k_gl2_op(int op, const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out,
+                         uint8_t* __restrict__ ok, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Ext x = ext_make(a[2 * i], a[2 * i + 1]);
+  Ext y = b ? ext_make(b[2 * i], b[2 * i + 1]) : ext_make(0, 0);
+  Ext r = ext_make(0, 0);
+  bool good = true;
+  switch (op) {
+    case GPV_OP_ADD: r = ext_add(x, y); break;
+    case GPV_OP_SUB: r = ext_sub(x, y); break;
+    case GPV_OP_MUL: r = ext_mul(x, y); break;
+    case GPV_OP_INV: good = !ext_is_zero(x); r = ext_inv(x); break;
+    case GPV_OP_DIV: good = !ext_is_zero(y); r = ext_mul(x, ext_inv(y)); break;
+  }
+  out[2 * i] = r.a;
+  out[2 * i + 1] = r.b;
+  if (ok) ok[i] = good;
+}
+
+// GoldilocksChip.Poseidon over a batch: one lane per state, 96 B in / 96 B out as 6 x 16-byte accesses.
+__global__ __launch_bounds__(256) void k_poseidon_gl_permute(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ulonglong2* src = (const ulonglong2*)(in + 12 * i);
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    ulonglong2 v = src[k];
+    s[2 * k] = v.x;
+    s[2 * k + 1] = v.y;
+  }
+  poseidon_gl_permute(s);
+  ulonglong2* dst = (ulonglong2*)(out + 12 * i);
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    ulonglong2 v;
+    v.x = s[2 * k];
+    v.y = s[2 * k + 1];
+    dst[k] = v;
+  }
+}
+__global__ void k_poseidon_gl_hash_no_pad(const u64* __restrict__ in, u32 len, u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = 0;
+  const u64* x = in + (size_t)len * i;
+#pragma unroll 1
+  for (u32 j = 0; j < len; j += 8) {
+#pragma unroll
+    for (u32 k = 0; k < 8; k++)
+      if (j + k < len) s[k] = gl_canon(x[j + k]);
+    poseidon_gl_permute(s);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[4 * i + k] = s[k];
+}
+
+// ================================================================ instruction-rate microbenchmark
+// Eight independent dependency chains per lane, enough waves to fill every SIMD: measures issue rate, not latency.
+#define MB_CHAINS 8
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_microbench(u64* out, int iters) {
+  u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 977u;
+  u64 acc64[MB_CHAINS];
+  u32 acc32[MB_CHAINS];
+  double accd[MB_CHAINS];
+#pragma unroll
+  for (int k = 0; k < MB_CHAINS; k++) {
+    acc64[k] = ((u64)a << 32) + b + k;
+    acc32[k] = a + k;
+    accd[k] = 1.0 + 1e-9 * (double)(a + k);
+  }
+  double da = 1.0000001, db = 1e-12 * (double)b;
+#pragma unroll 1
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {
+#pragma unroll
+      for (int k = 0; k < MB_CHAINS; k++) {
+        if (WHICH == 0) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc64[k]) : "v"(a), "v"(b) : "vcc");
+        if (WHICH == 1) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(acc32[k]) : "v"(a));
+        if (WHICH == 2) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(acc32[k]) : "v"(a));
+        if (WHICH == 3) asm volatile("v_fma_f64 %0, %1, %0, %2" : "+v"(accd[k]) : "v"(da), "v"(db));
+        if (WHICH == 4) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(acc32[k]) : "v"(a) : "vcc");
+        if (WHICH == 5) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc32[k]) : "v"(a), "v"(b));
+        if (WHICH == 6) asm volatile("v_add_u32 %0, %0, %1" : "+v"(acc32[k]) : "v"(a));
+        if (WHICH == 7) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc64[k]) : "v"(acc64[(k + 1) % MB_CHAINS]));
+      }
+    }
+  }
+  u64 r = 0;
+#pragma unroll
+  for (int k = 0; k < MB_CHAINS; k++) r ^= acc64[k] ^ acc32[k] ^ (u64)__double_as_longlong(accd[k]);
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+
+void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n) {
+  hipLaunchKernelGGL(k_gl_op, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, c, out, n);
+}
+void gpvk_gl2_op(hipStream_t st, int op, const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n) {
+  hipLaunchKernelGGL(k_gl2_op, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, out, ok, n);
+}
+void gpvk_poseidon_gl_permute(hipStream_t st, const u64* in, u64* out, size_t n) {
+  hipLaunchKernelGGL(k_poseidon_gl_permute, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
+}
+void gpvk_poseidon_gl_hash_no_pad(hipStream_t st, const u64* in, u32 len, u64* out, size_t n) {
+  hipLaunchKernelGGL(k_poseidon_gl_hash_no_pad, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
+}
+int gpvk_microbench_ops_per_iter() { return 4 * MB_CHAINS; }
+void gpvk_microbench(hipStream_t st, int which, u64* out, int blocks, int threads, int iters) {
+  switch (which) {
+    case 0: hipLaunchKernelGGL(k_microbench<0>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 1: hipLaunchKernelGGL(k_microbench<1>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 2: hipLaunchKernelGGL(k_microbench<2>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 3: hipLaunchKernelGGL(k_microbench<3>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 4: hipLaunchKernelGGL(k_microbench<4>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 5: hipLaunchKernelGGL(k_microbench<5>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 6: hipLaunchKernelGGL(k_microbench<6>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 7: hipLaunchKernelGGL(k_microbench<7>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+  }
+}

@@ -1,0 +1,97 @@
+// Range check (the one HBM-streaming kernel), Fiat-Shamir transcript, and the small glue kernels of the pipeline.
+#include "../../include/gpv.h"
+#include "gpv_launch.h"
+#include "gpv_transcript.cuh"
+
+// Canonical-form check of every Goldilocks word except the public inputs: one coalesced pass over the batch.
+__global__ __launch_bounds__(256) void k_range_check(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+                                                     u32* __restrict__ fail) {
+  const u32 words = dc->off_pi;
+  const size_t stride_words = dc->proof_nbytes / 8;
+  const size_t total = (size_t)words * n;
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
+    size_t p = w / words;
+    u32 k = (u32)(w - p * words);
+    u64 x = proofs[p * stride_words + k];
+    if (x >= GLP) atomicOr(&fail[p], (u32)GPV_FAIL_RANGE);
+  }
+}
+__global__ __launch_bounds__(64) void k_transcript(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+                                                   u64* __restrict__ derived) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64* rec = proofs + i * (dc->proof_nbytes / 8);
+  dev_transcript(dc, rec, derived + i * (dc->n_challenge_words + GPV_DERIVED_EXTRA));
+}
+// challenges supplied by the caller: fill in the public-inputs hash and the reduced openings only
+__global__ __launch_bounds__(64) void k_derive_extra(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+                                                     u64* __restrict__ derived) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64* rec = proofs + i * (dc->proof_nbytes / 8);
+  u64* d = derived + i * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
+  u64* extra = d + dc->n_challenge_words;
+  u64 pih[4];
+  dev_public_inputs_hash(dc, rec, pih);
+#pragma unroll
+  for (int k = 0; k < 4; k++) extra[k] = pih[k];
+  Ext fri_alpha = ext_make(d[dc->ch_fri_alpha], d[dc->ch_fri_alpha + 1]);
+  OpeningRanges orr = opening_ranges(dc);
+  Ext sum = ext_make(0, 0);
+#pragma unroll 1
+  for (u32 w = orr.b1; w > orr.b0; w -= 2) sum = ext_muladd(sum, fri_alpha, ext_make(rec[w - 2], rec[w - 1]));
+#pragma unroll 1
+  for (u32 w = orr.a1; w > orr.a0; w -= 2) sum = ext_muladd(sum, fri_alpha, ext_make(rec[w - 2], rec[w - 1]));
+  extra[4] = sum.a;
+  extra[5] = sum.b;
+  sum = ext_make(0, 0);
+#pragma unroll 1
+  for (u32 w = orr.c1; w > orr.c0; w -= 2) sum = ext_muladd(sum, fri_alpha, ext_make(rec[w - 2], rec[w - 1]));
+  extra[6] = sum.a;
+  extra[7] = sum.b;
+}
+__global__ void k_finalize(const u32* __restrict__ fail, uint8_t* __restrict__ accept, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) accept[i] = fail[i] == 0;
+}
+__global__ void k_scatter_challenges(const u64* __restrict__ ch, u64* __restrict__ derived, u32 ncw, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * ncw) return;
+  size_t p = i / ncw;
+  derived[p * (ncw + GPV_DERIVED_EXTRA) + (i - p * ncw)] = ch[i];
+}
+__global__ void k_gather_challenges(const u64* __restrict__ derived, u64* __restrict__ ch, u32 ncw, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * ncw) return;
+  size_t p = i / ncw;
+  ch[i] = derived[p * (ncw + GPV_DERIVED_EXTRA) + (i - p * ncw)];
+}
+__global__ void k_gather_pih(const u64* __restrict__ derived, u64* __restrict__ out, u32 ncw, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 4) return;
+  size_t p = i / 4;
+  out[i] = derived[p * (ncw + GPV_DERIVED_EXTRA) + ncw + (i & 3)];
+}
+
+
+void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u32* fail) {
+  hipLaunchKernelGGL(k_range_check, dim3(2048), dim3(256), 0, st, dcd, proofs, n, fail);
+}
+void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived) {
+  hipLaunchKernelGGL(k_transcript, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
+}
+void gpvk_derive_extra(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived) {
+  hipLaunchKernelGGL(k_derive_extra, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
+}
+void gpvk_finalize(hipStream_t st, const u32* fail, uint8_t* accept, size_t n) {
+  hipLaunchKernelGGL(k_finalize, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, fail, accept, n);
+}
+void gpvk_scatter_challenges(hipStream_t st, const u64* ch, u64* derived, u32 ncw, size_t n) {
+  hipLaunchKernelGGL(k_scatter_challenges, dim3(gpvk_blocks_for((size_t)ncw * n, 256)), dim3(256), 0, st, ch, derived, ncw, n);
+}
+void gpvk_gather_challenges(hipStream_t st, const u64* derived, u64* ch, u32 ncw, size_t n) {
+  hipLaunchKernelGGL(k_gather_challenges, dim3(gpvk_blocks_for((size_t)ncw * n, 256)), dim3(256), 0, st, derived, ch, ncw, n);
+}
+void gpvk_gather_pih(hipStream_t st, const u64* derived, u64* out, u32 ncw, size_t n) {
+  hipLaunchKernelGGL(k_gather_pih, dim3(gpvk_blocks_for(4 * n, 256)), dim3(256), 0, st, derived, out, ncw, n);
+}

@@ -1,0 +1,44 @@
+// Internal launch interface between the host layer (gpv_api.cpp) and the kernel translation units.
+// Each gpv_k_*.hip file is compiled separately for gfx950 (parallel build, smaller code objects).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gpv_circuit_dev.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// gpv_k_prim.hip
+void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n);
+void gpvk_gl2_op(hipStream_t st, int op, const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n);
+void gpvk_poseidon_gl_permute(hipStream_t st, const u64* in, u64* out, size_t n);
+void gpvk_poseidon_gl_hash_no_pad(hipStream_t st, const u64* in, u32 len, u64* out, size_t n);
+void gpvk_microbench(hipStream_t st, int which, u64* out, int blocks, int threads, int iters);
+int gpvk_microbench_ops_per_iter();
+// gpv_k_bn254.hip
+void gpvk_poseidon_bn254_permute(hipStream_t st, const u64* in, u64* out, size_t n);
+void gpvk_poseidon_bn254_hash_or_noop(hipStream_t st, const u64* in, u32 len, u64* out, size_t n);
+void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, u64* out, size_t n);
+void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n);
+void gpvk_merkle(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
+                 u32* fail, uint8_t* ok_out);
+// gpv_k_transcript.hip
+void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u32* fail);
+void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);
+void gpvk_derive_extra(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);
+void gpvk_finalize(hipStream_t st, const u32* fail, uint8_t* accept, size_t n);
+void gpvk_scatter_challenges(hipStream_t st, const u64* ch, u64* derived, u32 ncw, size_t n);
+void gpvk_gather_challenges(hipStream_t st, const u64* derived, u64* ch, u32 ncw, size_t n);
+void gpvk_gather_pih(hipStream_t st, const u64* derived, u64* out, u32 ncw, size_t n);
+// gpv_k_plonk.hip
+void gpvk_gate_eval_unfiltered(hipStream_t st, DevGate g, const u64* weights, const u64* constants, u32 n_constants, const u64* wires,
+                               u32 n_wires, const u64* pih, u64* out, u32 max_out, size_t n);
+void gpvk_plonk(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u32* fail);
+void gpvk_gate_constraints(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u64* out);
+// gpv_k_fri.hip
+void gpvk_fri_query(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
+                    u32* fail);
+
+static inline unsigned gpvk_blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }

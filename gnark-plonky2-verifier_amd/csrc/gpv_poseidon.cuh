@@ -1,0 +1,245 @@
+// Device Poseidon permutations, one lane per state.
+//
+//   Poseidon-Goldilocks (width 12, 4 + 22 + 4 rounds, x^7)   replaces poseidon/goldilocks.go:30-37,92-331
+//   Poseidon-BN254 (t = 4, 4 + 56 + 4 rounds, x^5)           replaces poseidon/bn254.go:39-45,130-208
+//
+// Why one lane per state: the work inside a state is a strictly serial chain of rounds; the batch (proofs x queries
+// x trees, or 2^20 states) supplies the parallelism. With the whole state in VGPRs there is no cross-lane traffic,
+// the MDS circulant (entries <= 41) folds into shift/add immediates, and every table access has a wave-uniform index,
+// so round constants are fetched by the scalar unit (s_load) and fed to v_mad_u64_u32 as SGPR operands.
+#pragma once
+#include "gpv_field.cuh"
+
+#define GPV_TABLE_U64(name, n) static __constant__ u64 name[n]
+#define GPV_TABLE_U32(name, n) static __constant__ u32 name[n]
+#include "poseidon_tables.inc"
+
+// ================================================================ Poseidon-Goldilocks
+// x^7 (goldilocks.go:138-145): 4 multiplications
+GPV_DEV u64 pgl_sbox(u64 x) {
+  u64 x2 = gl_sqr(x);
+  u64 x3 = gl_mul(x, x2);
+  u64 x6 = gl_sqr(x3);
+  return gl_mul(x, x6);
+}
+
+// MDS layer (goldilocks.go:172-216): row r = sum_i v[(i+r) mod 12] * CIRC[i] + v[r] * DIAG[r], DIAG = [8, 0, ...].
+// The coefficients are < 2^6, so each 64-bit word is split into 32-bit halves and the two half-sums (< 2^42 each)
+// are recombined with a single reduction: lo + hi * 2^32.
+GPV_DEV void pgl_mds(u64 s[12]) {
+  constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
+  }
+#pragma unroll
+  for (int r = 0; r < 12; r++) {
+    u64 sl = 0, sh = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      sl += (u64)lo[(i + r) % 12] * C[i];
+      sh += (u64)hi[(i + r) % 12] * C[i];
+    }
+    if (r == 0) {
+      sl += (u64)lo[0] * 8;
+      sh += (u64)hi[0] * 8;
+    }
+    // value = sl + sh * 2^32  (< 2^75): as 128-bit (hi:lo)
+    u64 l = sl + (sh << 32);
+    u64 h = (sh >> 32) + (l < sl);
+    s[r] = gl_reduce128(l, h);
+  }
+}
+
+GPV_DEV void pgl_full_round(u64 s[12], int round) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = pgl_sbox(gl_add(s[i], PGL_ARC[12 * round + i]));
+  pgl_mds(s);
+}
+
+// goldilocks.go:251-275
+GPV_DEV void pgl_partial_init(u64 s[12]) {
+  u64 r[12];
+  r[0] = s[0];
+#pragma unroll
+  for (int d = 1; d < 12; d++) {
+    // sum of 11 products < 11 * 2^128: accumulate as 128-bit with explicit carry count
+    u64 lo = 0, hi = 0, ov = 0;
+#pragma unroll
+    for (int k = 1; k < 12; k++) {
+      u64 m = PGL_INIT[(k - 1) * 11 + (d - 1)];
+      u64 pl = s[k] * m, ph = __umul64hi(s[k], m);
+      lo += pl;
+      u64 c = lo < pl;
+      hi += ph;
+      ov += hi < ph;
+      hi += c;
+      ov += hi < c;
+    }
+    // value = lo + hi 2^64 + ov 2^128, and 2^128 = 2^32 * 2^96 = -2^32 (mod p); ov < 11 so ov << 32 is canonical
+    r[d] = gl_sub(gl_reduce128(lo, hi), ov << 32);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = r[i];
+}
+
+// goldilocks.go:300-331
+GPV_DEV void pgl_partial_round(u64 s[12], int r) {
+  u64 s0 = gl_add(pgl_sbox(s[0]), PGL_PRC[r]);
+  // d = s0 * 25 + sum_{i>=1} s[i] * W_HAT[r][i-1]
+  u64 lo = s0 * 25, hi = __umul64hi(s0, 25), ov = 0;
+#pragma unroll
+  for (int i = 1; i < 12; i++) {
+    u64 m = PGL_WHAT[r * 11 + i - 1];
+    u64 pl = s[i] * m, ph = __umul64hi(s[i], m);
+    lo += pl;
+    u64 c = lo < pl;
+    hi += ph;
+    ov += hi < ph;
+    hi += c;
+    ov += hi < c;
+  }
+  u64 d = gl_sub(gl_reduce128(lo, hi), ov << 32);  // 2^128 = -2^32 (mod p)
+#pragma unroll
+  for (int i = 1; i < 12; i++) s[i] = gl_muladd(s0, PGL_VS[r * 11 + i - 1], s[i]);
+  s[0] = d;
+}
+
+// goldilocks.go:30-37. Canonical in, canonical out.
+GPV_DEV void poseidon_gl_permute(u64 s[12]) {
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) pgl_full_round(s, r);
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PGL_FIRST[i]);
+  pgl_partial_init(s);
+#pragma unroll 1
+  for (int r = 0; r < 22; r++) pgl_partial_round(s, r);
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) pgl_full_round(s, 26 + r);
+}
+
+// ================================================================ Poseidon-BN254
+// Code-size discipline: one inlined fr_mul is ~3.5 KB of ISA, so the round bodies are written as short rolled loops
+// over a ROTATING state (s0,s1,s2,s3) <- (s1,s2,s3,f(s0)); four trips return the state to its original order. The
+// rotation is 8 v_mov per trip next to ~1300 multiplier instructions, every register index stays static (no scratch),
+// and the whole permutation stays inside the instruction cache (partial round ~36 KB, full round ~25 KB).
+GPV_DEV Fr pbn_load(const u32* tab, int idx) {  // tab in Montgomery form, idx wave-uniform -> scalar loads
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = tab[8 * idx + i];
+  return r;
+}
+GPV_DEV Fr pbn_exp5(const Fr& x) {  // bn254.go:181-185
+  Fr x2 = fr_sqr(x);
+  Fr x4 = fr_sqr(x2);
+  return fr_mul(x4, x);
+}
+struct PbnState {
+  Fr s0, s1, s2, s3;
+};
+// s_k <- s_k^5 + C[it + k] for k = 0..3  (exp5state then ark, bn254.go:136-143); it < 0: no constants
+GPV_DEV void pbn_sbox_ark(PbnState& st, int it) {
+#pragma unroll 1
+  for (int k = 0; k < 4; k++) {
+    Fr t = pbn_exp5(st.s0);
+    if (it >= 0) t = fr_add(t, pbn_load(PBN_C, it + k));
+    st.s0 = st.s1;
+    st.s1 = st.s2;
+    st.s2 = st.s3;
+    st.s3 = t;
+  }
+}
+// mix (bn254.go:194-208): out_i = sum_j m[j][i] s_j; tab holds the transposed matrix, tab[4 i + j] = m[j][i]
+GPV_DEV void pbn_mix(PbnState& st, const u32* tab) {
+  Fr r0 = fr_zero(), r1 = fr_zero(), r2 = fr_zero(), r3 = fr_zero();
+#pragma unroll 1
+  for (int i = 0; i < 4; i++) {
+    Fr acc = fr_mul(pbn_load(tab, 4 * i), st.s0);
+    acc = fr_add(acc, fr_mul(pbn_load(tab, 4 * i + 1), st.s1));
+    acc = fr_add(acc, fr_mul(pbn_load(tab, 4 * i + 2), st.s2));
+    acc = fr_add(acc, fr_mul(pbn_load(tab, 4 * i + 3), st.s3));
+    r0 = r1;
+    r1 = r2;
+    r2 = r3;
+    r3 = acc;
+  }
+  st.s0 = r0;
+  st.s1 = r1;
+  st.s2 = r2;
+  st.s3 = r3;
+}
+// bn254.go:39-45, state in Montgomery form
+GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
+  PbnState st;
+  st.s0 = fr_add(s[0], pbn_load(PBN_C, 0));  // ark(0)
+  st.s1 = fr_add(s[1], pbn_load(PBN_C, 1));
+  st.s2 = fr_add(s[2], pbn_load(PBN_C, 2));
+  st.s3 = fr_add(s[3], pbn_load(PBN_C, 3));
+  // first half of the full rounds (bn254.go:130-150, isFirst): 3 x {x^5, ark, mix M}, then x^5, ark(16), mix P
+#pragma unroll 1
+  for (int i = 0; i < 4; i++) {
+    pbn_sbox_ark(st, (i + 1) * 4);
+    pbn_mix(st, i < 3 ? PBN_MT : PBN_PT);
+  }
+  // 56 partial rounds (bn254.go:152-169)
+#pragma unroll 1
+  for (int i = 0; i < 56; i++) {
+    Fr t = fr_add(pbn_exp5(st.s0), pbn_load(PBN_C, 20 + i));
+    Fr n0 = fr_mul(pbn_load(PBN_S, 7 * i), t);
+    n0 = fr_add(n0, fr_mul(pbn_load(PBN_S, 7 * i + 1), st.s1));
+    n0 = fr_add(n0, fr_mul(pbn_load(PBN_S, 7 * i + 2), st.s2));
+    n0 = fr_add(n0, fr_mul(pbn_load(PBN_S, 7 * i + 3), st.s3));
+    st.s1 = fr_add(st.s1, fr_mul(t, pbn_load(PBN_S, 7 * i + 4)));
+    st.s2 = fr_add(st.s2, fr_mul(t, pbn_load(PBN_S, 7 * i + 5)));
+    st.s3 = fr_add(st.s3, fr_mul(t, pbn_load(PBN_S, 7 * i + 6)));
+    st.s0 = n0;
+  }
+  // second half (bn254.go:130-150, !isFirst): 3 x {x^5, ark, mix M}, then x^5, mix M
+#pragma unroll 1
+  for (int i = 0; i < 4; i++) {
+    pbn_sbox_ark(st, i < 3 ? 20 + 56 + 4 * i : -1);
+    pbn_mix(st, PBN_MT);
+  }
+  s[0] = st.s0;
+  s[1] = st.s1;
+  s[2] = st.s2;
+  s[3] = st.s3;
+}
+// TwoToOne (bn254.go:96-104)
+GPV_DEV Fr poseidon_bn254_two_to_one(const Fr& l, const Fr& r) {
+  Fr s[4] = {fr_zero(), fr_zero(), l, r};
+  poseidon_bn254_permute(s);
+  return s[0];
+}
+// HashOrNoop / HashNoPad over a leaf of Goldilocks words (bn254.go:47-94); `leaf` may be strided
+GPV_DEV Fr poseidon_bn254_hash_or_noop(const u64* leaf, u32 len) {
+  if (len <= 3) {
+    u64 x0 = len > 0 ? leaf[0] : 0, x1 = len > 1 ? leaf[1] : 0, x2 = len > 2 ? leaf[2] : 0;
+    return fr_pack_gl(x0, x1, x2);
+  }
+  Fr s[4] = {fr_zero(), fr_zero(), fr_zero(), fr_zero()};
+#pragma unroll 1
+  for (u32 i = 0; i < len; i += 9) {
+#pragma unroll
+    for (u32 k = 0; k < 3; k++) {
+      u32 j = i + 3 * k;
+      if (j < len) {
+        u64 x0 = leaf[j], x1 = j + 1 < len ? leaf[j + 1] : 0, x2 = j + 2 < len ? leaf[j + 2] : 0;
+        s[k + 1] = fr_pack_gl(x0, x1, x2);
+      }
+    }
+    poseidon_bn254_permute(s);
+  }
+  return s[0];
+}
+// ToVec (bn254.go:106-120): canonical value -> 5 words of 56,56,56,56,30 bits
+GPV_DEV void fr_canonical_to_vec(const u64 c[4], u64 out[5]) {
+  const u64 mask = ((u64)1 << 56) - 1;
+  out[0] = c[0] & mask;
+  out[1] = ((c[0] >> 56) | (c[1] << 8)) & mask;
+  out[2] = ((c[1] >> 48) | (c[2] << 16)) & mask;
+  out[3] = ((c[2] >> 40) | (c[3] << 24)) & mask;
+  out[4] = (c[3] >> 32) & (((u64)1 << 30) - 1);
+}

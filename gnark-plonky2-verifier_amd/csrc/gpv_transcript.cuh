@@ -1,0 +1,200 @@
+// Fiat-Shamir transcript on the device: one lane runs one proof's duplex sponge.
+//
+// Replaces challenger.Chip (challenger/challenger.go:14-166), VerifierChip.GetPublicInputsHash / GetChallenges
+// (verifier/verifier.go:41-82) and fri.Chip.fromOpeningsAndAlpha (fri/fri.go:82-95).
+//
+// The sponge state (12 words) stays in VGPRs. The reference buffers up to 8 observed elements and overwrites
+// state[0..k) at the next duplexing (challenger.go:146-166); nothing reads the state between an observe and that
+// duplexing, so elements are written into the state as they arrive. A dynamically indexed register array would be
+// demoted to scratch memory, so position-dependent reads/writes are select chains over the 8 rate lanes.
+#pragma once
+#include "gpv_circuit_dev.h"
+#include "gpv_poseidon.cuh"
+
+// The transcript calls the permutation from ~10 sites (every observe/challenge may trigger a duplexing); a real call
+// keeps the kernel at one copy of the ~30 KB permutation body. ~130 calls per proof: the call overhead is noise.
+struct PglState {
+  u64 s[12];
+};
+__device__ __noinline__ PglState poseidon_gl_permute_call(PglState st) {
+  poseidon_gl_permute(st.s);
+  return st;
+}
+
+struct DevChallenger {
+  u64 s[12];
+  u32 n_in;   // elements observed since the last duplexing
+  u32 n_out;  // challenges still available in s[0..n_out)
+
+  GPV_DEV void init() {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    n_in = 0;
+    n_out = 0;
+  }
+  GPV_DEV void duplex() {
+    PglState st;
+#pragma unroll
+    for (int i = 0; i < 12; i++) st.s[i] = s[i];
+    st = poseidon_gl_permute_call(st);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = st.s[i];
+    n_in = 0;
+    n_out = 8;
+  }
+  GPV_DEV void observe(u64 v) {  // challenger.go:42-49
+    v = gl_canon(v);             // Reduce at duplexing time (challenger.go:154-156)
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = (n_in == (u32)i) ? v : s[i];
+    n_in++;
+    n_out = 0;
+    if (n_in == 8) duplex();
+  }
+  GPV_DEV u64 challenge() {  // challenger.go:89-98: pop from the end of the output buffer
+    if (n_in != 0 || n_out == 0) duplex();
+    u64 r = s[0];
+#pragma unroll
+    for (int i = 1; i < 8; i++) r = (n_out - 1 == (u32)i) ? s[i] : r;
+    n_out--;
+    return r;
+  }
+  // ObserveBN254Hash (challenger.go:62-65): canonical Fr -> 5 words (bn254.go:106-120)
+  GPV_DEV void observe_fr(const u64* canon) {
+    u64 c[4] = {canon[0], canon[1], canon[2], canon[3]};
+    fr64_reduce(c);
+    u64 v[5];
+    fr_canonical_to_vec(c, v);
+#pragma unroll
+    for (int i = 0; i < 5; i++) observe(v[i]);
+  }
+  // a 256-bit value taken mod r (gnark reduces witnesses mod r); 2^256 / r < 6
+  GPV_DEV static void fr64_reduce(u64 c[4]) {
+    const u64 n[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    for (int k = 0; k < 5; k++) {
+      u64 d[4];
+      u64 borrow = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        u64 x = c[i] - n[i];
+        u64 b1 = c[i] < n[i];
+        u64 y = x - borrow;
+        u64 b2 = x < borrow;
+        d[i] = y;
+        borrow = b1 | b2;
+      }
+      if (borrow) break;
+#pragma unroll
+      for (int i = 0; i < 4; i++) c[i] = d[i];
+    }
+  }
+  GPV_DEV void observe_cap(const u64* cap, u32 n) {  // challenger.go:67-71
+#pragma unroll 1
+    for (u32 i = 0; i < n; i++) observe_fr(cap + 4 * i);
+  }
+};
+
+// HashNoPad of the public inputs (goldilocks.go:72-86 via verifier.go:41-43)
+GPV_DEV void dev_public_inputs_hash(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, u64 out[4]) {
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = 0;
+  const u64* pi = rec + dc->off_pi;
+  u32 n = dc->num_pi;
+#pragma unroll 1
+  for (u32 i = 0; i < n; i += 8) {
+#pragma unroll
+    for (u32 j = 0; j < 8; j++)
+      if (i + j < n) s[j] = gl_canon(pi[i + j]);
+    PglState st;
+#pragma unroll
+    for (int k = 0; k < 12; k++) st.s[k] = s[k];
+    st = poseidon_gl_permute_call(st);
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = st.s[k];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = s[i];
+}
+
+// The opening batches in FRI order (fri.go:63-73): zeta batch = constants | sigmas | wires | zs | partial products |
+// quotient polys; zeta*g batch = zs_next. Sections are contiguous in the record except that zs_next sits between zs
+// and the partial products, hence the three ranges.
+struct OpeningRanges {
+  u32 a0, a1;  // constants .. zs (words)
+  u32 b0, b1;  // partial products .. quotient polys
+  u32 c0, c1;  // zs_next
+};
+GPV_DEV OpeningRanges opening_ranges(const DevCircuit* dc) {
+  OpeningRanges r;
+  r.a0 = dc->off_constants;
+  r.a1 = dc->off_zs_next;
+  r.b0 = dc->off_pp;
+  r.b1 = dc->off_queries;
+  r.c0 = dc->off_zs_next;
+  r.c1 = dc->off_pp;
+  return r;
+}
+
+// One proof: public-inputs hash, all challenges, and the two alpha-reduced openings.
+// derived: [n_challenge_words | pi_hash[4] | reduced zeta batch[2] | reduced zeta*g batch[2]]
+GPV_DEV void dev_transcript(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, u64* __restrict__ derived) {
+  const u64* frs = rec + dc->n_gl_words;
+  u64 pih[4];
+  dev_public_inputs_hash(dc, rec, pih);
+  DevChallenger ch;
+  ch.init();
+  ch.observe_fr(dc->digest);                                   // verifier.go:56
+#pragma unroll
+  for (int i = 0; i < 4; i++) ch.observe(pih[i]);              // :57
+  const u32 cap_len = 1u << dc->cap_height;
+  ch.observe_cap(frs + 4 * dc->fr_wires_cap, cap_len);         // :58
+  const u32 nc = dc->num_challenges;
+  for (u32 i = 0; i < nc; i++) derived[dc->ch_betas + i] = ch.challenge();   // :59
+  for (u32 i = 0; i < nc; i++) derived[dc->ch_gammas + i] = ch.challenge();  // :60
+  ch.observe_cap(frs + 4 * dc->fr_zs_pp_cap, cap_len);         // :62
+  for (u32 i = 0; i < nc; i++) derived[dc->ch_alphas + i] = ch.challenge();  // :63
+  ch.observe_cap(frs + 4 * dc->fr_quot_cap, cap_len);          // :65
+  derived[dc->ch_zeta] = ch.challenge();                        // :66, challenger.go:108-111
+  derived[dc->ch_zeta + 1] = ch.challenge();
+  OpeningRanges orr = opening_ranges(dc);                       // :68, challenger.go:83-87
+#pragma unroll 1
+  for (u32 w = orr.a0; w < orr.a1; w++) ch.observe(rec[w]);
+#pragma unroll 1
+  for (u32 w = orr.b0; w < orr.b1; w++) ch.observe(rec[w]);
+#pragma unroll 1
+  for (u32 w = orr.c0; w < orr.c1; w++) ch.observe(rec[w]);
+  // GetFriChallenges (challenger.go:117-144)
+  Ext fri_alpha;
+  fri_alpha.a = ch.challenge();
+  fri_alpha.b = ch.challenge();
+  derived[dc->ch_fri_alpha] = fri_alpha.a;
+  derived[dc->ch_fri_alpha + 1] = fri_alpha.b;
+#pragma unroll 1
+  for (u32 s = 0; s < dc->num_steps; s++) {
+    ch.observe_cap(frs + 4 * (dc->fr_commit_caps + s * cap_len), cap_len);
+    derived[dc->ch_fri_betas + 2 * s] = ch.challenge();
+    derived[dc->ch_fri_betas + 2 * s + 1] = ch.challenge();
+  }
+#pragma unroll 1
+  for (u32 w = 0; w < 2 * dc->final_len; w++) ch.observe(rec[dc->off_final + w]);
+  ch.observe(rec[dc->off_pow]);
+  derived[dc->ch_pow] = ch.challenge();
+#pragma unroll 1
+  for (u32 q = 0; q < dc->num_queries; q++) derived[dc->ch_queries + q] = ch.challenge();
+  // pi hash + reduced openings (fri.go:82-95): Horner from the last element of each batch
+  u64* extra = derived + dc->n_challenge_words;
+#pragma unroll
+  for (int i = 0; i < 4; i++) extra[i] = pih[i];
+  Ext sum = ext_make(0, 0);
+#pragma unroll 1
+  for (u32 w = orr.b1; w > orr.b0; w -= 2) sum = ext_muladd(sum, fri_alpha, ext_make(rec[w - 2], rec[w - 1]));
+#pragma unroll 1
+  for (u32 w = orr.a1; w > orr.a0; w -= 2) sum = ext_muladd(sum, fri_alpha, ext_make(rec[w - 2], rec[w - 1]));
+  extra[4] = sum.a;
+  extra[5] = sum.b;
+  sum = ext_make(0, 0);
+#pragma unroll 1
+  for (u32 w = orr.c1; w > orr.c0; w -= 2) sum = ext_muladd(sum, fri_alpha, ext_make(rec[w - 2], rec[w - 1]));
+  extra[6] = sum.a;
+  extra[7] = sum.b;
+}

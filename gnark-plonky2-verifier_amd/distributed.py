@@ -1,0 +1,52 @@
+"""Multi-GPU sharding of a proof batch: one process per GPU, torch.distributed (backend "nccl" == RCCL on ROCm).
+
+Proofs are independent, so the batch is split into contiguous blocks; the only exchange is an all-gather of
+the per-proof accept bits (packed 8 per byte: 1 KiB per rank at 65 536 proofs) so that every rank holds the verdict for
+the whole batch. No other data-path collective exists or is needed.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_total, rank, world_size):
+    """Contiguous block [lo, hi) of proof indices owned by `rank`; sizes differ by at most one."""
+    base, rem = divmod(n_total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_accept_bits(accept_u8):
+    """uint8 {0,1} [m] -> uint8 [(m + 7) // 8], bit i of byte j = accept[8 j + i]."""
+    m = accept_u8.numel()
+    pad = (-m) % 8
+    a = accept_u8.to(torch.uint8)
+    if pad:
+        a = torch.cat([a, torch.zeros(pad, dtype=torch.uint8, device=a.device)])
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=a.device)
+    return (a.view(-1, 8).to(torch.int32) * w).sum(dim=1).to(torch.uint8)
+
+
+def unpack_accept_bits(packed_u8, m):
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=packed_u8.device)
+    bits = (packed_u8.to(torch.int32).view(-1, 1) & w) != 0
+    return bits.view(-1)[:m].to(torch.uint8)
+
+
+def all_gather_accept(accept_local, n_total, group=None):
+    """accept_local: uint8 tensor of this rank's block (on the GPU for RCCL, CPU for gloo). Returns uint8 [n_total] on
+    the same device, identical on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return accept_local.clone()
+    max_block = (n_total + world - 1) // world
+    nbytes = (max_block + 7) // 8
+    mine = torch.zeros(nbytes, dtype=torch.uint8, device=accept_local.device)
+    p = pack_accept_bits(accept_local)
+    mine[: p.numel()] = p
+    gathered = torch.empty(world * nbytes, dtype=torch.uint8, device=accept_local.device)
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    out = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        out.append(unpack_accept_bits(gathered[r * nbytes:(r + 1) * nbytes], hi - lo))
+    return torch.cat(out)

@@ -1,0 +1,50 @@
+"""Mirror of verifier.VerifierChip (verifier/verifier.go:14-39, :41-82, :143-170)."""
+import numpy as np
+
+from . import _lib
+from .challenger import ProofChallenges
+from .variables import ProofBatch, circuit_for
+
+
+class VerifierChip:
+    def __init__(self, api=None, commonCircuitData=None):
+        self.ctx = api or _lib.default_context()
+        self.commonData = commonCircuitData
+
+    def circuit(self, verifierData):
+        return circuit_for(self.commonData, verifierData)
+
+    def GetPublicInputsHash(self, proofs):  # verifier.go:41 -- [n][4]
+        c = proofs.circuit
+        out = np.empty((proofs.n, 4), dtype=np.uint64)
+        _lib.check(_lib.lib().gpv_public_inputs_hash(self.ctx.h, c.h, _lib.ptr(proofs.data), proofs.n, _lib.ptr(out)), self.ctx.h)
+        return out
+
+    def GetChallenges(self, proofs):  # verifier.go:45
+        c = proofs.circuit
+        out = np.empty((proofs.n, c.num_challenge_words), dtype=np.uint64)
+        _lib.check(_lib.lib().gpv_challenges(self.ctx.h, c.h, _lib.ptr(proofs.data), proofs.n, _lib.ptr(out)), self.ctx.h)
+        return ProofChallenges(c, out)
+
+    def Verify(self, proofs, verifierData=None, detail=False):
+        """verifier.go:143. The reference's Verify returns nothing -- "accepted" means its gnark circuit is satisfiable.
+        Here: accept[n] (uint8). With detail=True also the failure mask [n] and the ProofChallenges."""
+        assert isinstance(proofs, ProofBatch)
+        c = proofs.circuit
+        accept = np.empty(proofs.n, dtype=np.uint8)
+        if not detail:
+            _lib.check(_lib.lib().gpv_verify(self.ctx.h, c.h, _lib.ptr(proofs.data), proofs.n, _lib.ptr(accept)), self.ctx.h)
+            return accept
+        mask = np.empty(proofs.n, dtype=np.uint32)
+        ch = np.empty((proofs.n, c.num_challenge_words), dtype=np.uint64)
+        _lib.check(_lib.lib().gpv_verify_detail(self.ctx.h, c.h, _lib.ptr(proofs.data), proofs.n, _lib.ptr(accept), _lib.ptr(mask),
+                                                _lib.ptr(ch)), self.ctx.h)
+        return accept, mask, ProofChallenges(c, ch)
+
+    def VerifyDevice(self, circuit, proofs_dev_ptr, n, accept_dev_ptr):
+        """Device-resident batch (torch tensors' data_ptr()); asynchronous on the context's stream."""
+        _lib.check(_lib.lib().gpv_verify_dev(self.ctx.h, circuit.h, _lib.ptr(proofs_dev_ptr), n, _lib.ptr(accept_dev_ptr)), self.ctx.h)
+
+
+def NewVerifierChip(api=None, commonCircuitData=None):  # verifier.go:24
+    return VerifierChip(api, commonCircuitData)

@@ -1,0 +1,189 @@
+/* gpv.h -- C ABI of the MI355X batch Plonky2-verification engine (libgpv.so).
+ *
+ * The reference (succinctlabs/gnark-plonky2-verifier) has no FFI boundary of its own: its
+ * "operator API" is the Go chip surface
+ *     goldilocks.Chip            goldilocks/base.go:96-104, :162-313; quadratic_extension.go:31-235
+ *     poseidon.GoldilocksChip    poseidon/goldilocks.go:18-86
+ *     poseidon.BN254Chip         poseidon/bn254.go:23-120
+ *     challenger.Chip            challenger/challenger.go:14-144
+ *     fri.Chip                   fri/fri.go:17-61, :500-548
+ *     plonk.PlonkChip            plonk/plonk.go:12-53, :209-250
+ *     verifier.VerifierChip      verifier/verifier.go:14-39, :143-170
+ * Every entry point below names the reference function(s) it stands in for. A thin cgo shim
+ * (bindings/go) binds exactly these symbols behind those Go packages.
+ *
+ * Conventions
+ *   - Little-endian. A Goldilocks element is one uint64_t (canonical, < p = 2^64 - 2^32 + 1, unless
+ *     stated). An extension element is uint64_t[2]. A BN254 scalar (Fr) is uint64_t[4], little-endian
+ *     limbs, canonical (< r) at the boundary; values >= r are taken mod r like a gnark witness.
+ *   - Batch first: every call processes n independent items.
+ *   - Return value: GPV_OK or a negative error. Errors never alias "proof rejected": a rejected
+ *     proof is accept[i] == 0 with GPV_OK. GPV_ESHAPE is what the reference panics on
+ *     (fri/fri_utils.go:167-228, fri/fri.go:119-126,515-531), GPV_ECONFIG an unsupported circuit
+ *     (types/common_data.go:121-124, gates/gates.go:53, fri/fri.go:431-433).
+ *   - Pointers of plain entry points are caller-owned HOST memory; the call returns when results are
+ *     in host memory. *_dev entry points take DEVICE pointers on the context's GPU, enqueue on the
+ *     context's stream and return without synchronising.
+ *   - There is no CPU fallback: without a usable GPU gpv_ctx_create fails with GPV_EDEVICE.
+ */
+#ifndef GPV_H
+#define GPV_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  GPV_OK = 0,
+  GPV_ESHAPE = -1,  /* proof / circuit data of the wrong shape (the reference panics)       */
+  GPV_ECONFIG = -2, /* unsupported configuration (hiding, unknown gate, arity != 4, cap != 4) */
+  GPV_EDEVICE = -3, /* HIP failure or no GPU                                                  */
+  GPV_EINVAL = -4,  /* bad argument                                                           */
+  GPV_ENOMEM = -5
+};
+
+/* gate kinds, in the order of the reference's registry (plonk/gates/gates.go:20-35) */
+enum {
+  GPV_GATE_NOOP = 0,                 /* noop_gate.go                                  */
+  GPV_GATE_CONSTANT = 1,             /* constant_gate.go: p0 = num_consts             */
+  GPV_GATE_PUBLIC_INPUT = 2,         /* public_input_gate.go                          */
+  GPV_GATE_BASE_SUM = 3,             /* base_sum_gate.go: p0 = num_limbs, p1 = base   */
+  GPV_GATE_ARITHMETIC = 4,           /* arithmetic_gate.go: p0 = num_ops              */
+  GPV_GATE_ARITHMETIC_EXT = 5,       /* arithmetic_extension_gate.go: p0 = num_ops    */
+  GPV_GATE_MUL_EXT = 6,              /* multiplication_extension_gate.go: p0 = num_ops */
+  GPV_GATE_REDUCING = 7,             /* reducing_gate.go: p0 = num_coeffs             */
+  GPV_GATE_REDUCING_EXT = 8,         /* reducing_extension_gate.go: p0 = num_coeffs   */
+  GPV_GATE_EXPONENTIATION = 9,       /* exponentiation_gate.go: p0 = num_power_bits   */
+  GPV_GATE_RANDOM_ACCESS = 10,       /* random_access_gate.go: p0 = bits, p1 = num_copies, p2 = num_extra_constants */
+  GPV_GATE_COSET_INTERPOLATION = 11, /* coset_interpolation_gate.go: p0 = subgroup_bits, p1 = degree, weights */
+  GPV_GATE_POSEIDON = 12,            /* poseidon_gate.go                              */
+  GPV_GATE_POSEIDON_MDS = 13         /* poseidon_mds_gate.go                          */
+};
+
+/* field ops for gpv_gl_op / gpv_gl2_op */
+enum { GPV_OP_ADD = 0, GPV_OP_SUB = 1, GPV_OP_MUL = 2, GPV_OP_MULADD = 3, GPV_OP_INV = 4, GPV_OP_REDUCE = 5, GPV_OP_DIV = 6 };
+
+/* bits of the per-proof diagnostic mask returned by gpv_verify_detail (accept == (mask == 0)) */
+enum {
+  GPV_FAIL_RANGE = 1 << 0,          /* verifier/verifier.go:84-141                   */
+  GPV_FAIL_POW = 1 << 1,            /* fri/fri.go:75-80                              */
+  GPV_FAIL_PLONK_L0 = 1 << 2,       /* plonk/plonk.go:75-80                          */
+  GPV_FAIL_PLONK_VANISH = 1 << 3,   /* plonk/plonk.go:248                            */
+  GPV_FAIL_MERKLE_INITIAL = 1 << 4, /* fri/fri.go:143 via :146-157                   */
+  GPV_FAIL_MERKLE_STEP = 1 << 5,    /* fri/fri.go:143 via :477-483                   */
+  GPV_FAIL_FRI_DENOM = 1 << 6,      /* fri/fri.go:241-242                            */
+  GPV_FAIL_FRI_EVAL = 1 << 7,       /* fri/fri.go:460-461                            */
+  GPV_FAIL_FRI_INTERP = 1 << 8,     /* fri/fri.go:378-379, :280-286                  */
+  GPV_FAIL_FRI_FINAL = 1 << 9       /* fri/fri.go:496-497                            */
+};
+
+/* ------------------------------------------------------------------ context */
+typedef struct gpv_ctx gpv_ctx; /* one per process: device, stream, scratch (gl.New(api), base.go:112) */
+int gpv_ctx_create(gpv_ctx** out, int device_id);
+int gpv_ctx_destroy(gpv_ctx* ctx);
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own. */
+int gpv_ctx_set_stream(gpv_ctx* ctx, void* hip_stream);
+int gpv_ctx_synchronize(gpv_ctx* ctx);
+/* Copies the last error text of this context (or of context-free calls when ctx == NULL). */
+int gpv_last_error_message(gpv_ctx* ctx, char* buf, size_t buf_len);
+
+/* ------------------------------------------------------------------ circuit + ingest (host only, no GPU needed) */
+typedef struct gpv_circuit gpv_circuit; /* CommonCircuitData + VerifierOnlyCircuitData, immutable */
+/* types.ReadCommonCircuitData (types/common_data.go:61-127) + variables.DeserializeVerifierOnlyCircuitData
+ * (variables/deserialize.go:149-156); gate ids parsed like gates.GateInstanceFromId (gates/gates.go:37-54). */
+int gpv_circuit_from_json(const char* common_json, size_t common_len, const char* verifier_only_json,
+                          size_t verifier_only_len, gpv_circuit** out);
+int gpv_circuit_destroy(gpv_circuit* c);
+size_t gpv_proof_nbytes(const gpv_circuit* c);         /* packed record size: 127256 / 133416 for the fixtures */
+size_t gpv_num_challenge_words(const gpv_circuit* c);  /* 43 for the fixtures */
+size_t gpv_num_gate_constraints(const gpv_circuit* c);
+size_t gpv_num_query_rounds(const gpv_circuit* c);
+size_t gpv_num_merkle_trees(const gpv_circuit* c);     /* per query: 4 initial + one per reduction step */
+/* Flat description ("circuit blob", layout in DESIGN.md) -- lets a caller inspect what was parsed.
+ * Returns the number of words needed; writes at most cap words. */
+size_t gpv_circuit_describe(const gpv_circuit* c, uint64_t* blob, size_t cap);
+/* types.ReadProofWithPublicInputs + variables.DeserializeProofWithPublicInputs
+ * (types/deserialize.go:92-108, variables/deserialize.go:114-147) into one packed record of
+ * gpv_proof_nbytes(c) bytes; shape checks of fri/fri_utils.go:167-228 -> GPV_ESHAPE. */
+int gpv_proof_pack_json(const gpv_circuit* c, const char* proof_json, size_t proof_len, void* out_packed);
+
+/* ------------------------------------------------------------------ field / hash primitives */
+/* goldilocks.Chip Add/Sub/Mul/MulAdd/Inverse/Reduce (goldilocks/base.go:162-313). b, c may be NULL when unused. */
+int gpv_gl_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n);
+/* Add/Sub/Mul/Inverse/DivExtension (goldilocks/quadratic_extension.go:31-140), [n][2]; ok[i] = 0 where the
+ * reference's "operand != 0" assertion (:124-125) fails. ok may be NULL. */
+int gpv_gl2_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* ok, size_t n);
+/* GoldilocksChip.Poseidon (poseidon/goldilocks.go:30-37): states [n][12] -> out [n][12] */
+int gpv_poseidon_gl_permute(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
+int gpv_poseidon_gl_permute_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
+/* GoldilocksChip.HashNoPad (poseidon/goldilocks.go:72-86): in [n][len] -> out [n][4] */
+int gpv_poseidon_gl_hash_no_pad(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n);
+/* BN254Chip.Poseidon (poseidon/bn254.go:39-45): states [n][4][4] -> out [n][4][4] */
+int gpv_poseidon_bn254_permute(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
+int gpv_poseidon_bn254_permute_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
+/* BN254Chip.HashOrNoop (poseidon/bn254.go:79-94; HashNoPad :47-77 when len > 3): in [n][len] -> out [n][4] */
+int gpv_poseidon_bn254_hash_or_noop(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n);
+/* BN254Chip.TwoToOne (poseidon/bn254.go:96-104): [n][4] x [n][4] -> [n][4] */
+int gpv_poseidon_bn254_two_to_one(gpv_ctx* ctx, const uint64_t* left, const uint64_t* right, uint64_t* out, size_t n);
+/* BN254Chip.ToVec (poseidon/bn254.go:106-120): [n][4] -> [n][5] */
+int gpv_poseidon_bn254_to_vec(gpv_ctx* ctx, const uint64_t* hashes, uint64_t* out, size_t n);
+
+/* gates.Gate.EvalUnfiltered (plonk/gates/gates.go:11-18) on n independent variable sets:
+ * constants [n][n_constants][2] (selector prefix already stripped, vars.go:26-28), wires [n][n_wires][2],
+ * pi_hash [n][4]; out [n][max_out][2]. *n_out receives the constraint count of the gate. */
+int gpv_gate_eval_unfiltered(gpv_ctx* ctx, int kind, uint64_t p0, uint64_t p1, uint64_t p2, const uint64_t* weights,
+                             size_t n_weights, const uint64_t* constants, size_t n_constants, const uint64_t* wires,
+                             size_t n_wires, const uint64_t* pi_hash, uint64_t* out, size_t max_out, size_t* n_out,
+                             size_t n);
+
+/* ------------------------------------------------------------------ protocol stages (n packed proofs of one circuit) */
+/* VerifierChip.GetPublicInputsHash (verifier/verifier.go:41-43): out [n][4] */
+int gpv_public_inputs_hash(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* out);
+/* VerifierChip.GetChallenges (verifier/verifier.go:45-82, challenger/challenger.go:117-144).
+ * out [n][gpv_num_challenge_words]: betas | gammas | alphas | zeta[2] | fri_alpha[2] | fri_betas[steps][2] |
+ * fri_pow_response | fri_query_indices[num_query_rounds] */
+int gpv_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* out);
+/* PlonkChip.Verify (plonk/plonk.go:209-250) with the given challenges: mask [n] (0 = all assertions hold) */
+int gpv_plonk_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n,
+                     uint32_t* fail_mask);
+/* EvaluateGatesChip.EvaluateGateConstraints (plonk/gates/evaluate_gates.go:77-105): out [n][num_gate_constraints][2] */
+int gpv_gate_constraints(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* out);
+/* fri.Chip.VerifyFriProof (fri/fri.go:500-548) with the given challenges */
+int gpv_fri_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n,
+                   uint32_t* fail_mask);
+/* verifyMerkleProofToCapWithCapIndex (fri/fri.go:97-144) for every (proof, query, tree):
+ * ok [n][num_query_rounds][gpv_num_merkle_trees] */
+int gpv_merkle_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n,
+                      uint8_t* ok);
+/* VerifierChip.Verify (verifier/verifier.go:143-170) per proof: accept[i] = 1 iff the reference circuit would be
+ * satisfiable for proof i. */
+int gpv_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept);
+/* Same, plus the diagnostic mask and the derived challenges (either may be NULL). */
+int gpv_verify_detail(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept,
+                      uint32_t* fail_mask, uint64_t* challenges);
+/* Device-resident batch: proofs_dev [n][nbytes] and accept_dev [n] are device pointers; enqueued on the context's
+ * stream, no host synchronisation (the caller owns ordering, e.g. torch stream semantics). */
+int gpv_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint8_t* accept_dev);
+/* Merkle paths only (BASELINE config 5), device-resident: challenges_dev as produced by gpv_challenges_dev */
+int gpv_challenges_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint64_t* challenges_dev);
+int gpv_merkle_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, const uint64_t* challenges_dev,
+                          size_t n, uint8_t* ok_dev);
+
+/* ------------------------------------------------------------------ measurement helpers */
+/* Average duration (ms) of the named kernel class over the launches since the last reset, measured with HIP events on
+ * the stream the kernels were launched on. kind: 0 = merkle, 1 = poseidon_gl_permute, 2 = transcript, 3 = plonk,
+ * 4 = fri_query, 5 = range_check, 6 = poseidon_bn254_permute. Timing is off by default (no event overhead). */
+int gpv_timing_enable(gpv_ctx* ctx, int on);
+int gpv_timing_reset(gpv_ctx* ctx);
+int gpv_timing_get(gpv_ctx* ctx, int kind, double* avg_ms, uint64_t* launches);
+/* Integer-multiply issue-rate microbenchmark (the roof that binds this workload):
+ * which: 0 = v_mad_u64_u32, 1 = v_mul_lo_u32, 2 = v_mul_hi_u32, 3 = v_fma_f64, 4 = v_add_co_u32 chain, 5 = v_mad_u32_u24.
+ * Returns lane-operations per second over the whole chip. */
+int gpv_microbench(gpv_ctx* ctx, int which, double* lane_ops_per_sec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPV_H */

@@ -1,0 +1,326 @@
+"""GPU parity tests: every operator of the hot path, through the C ABI (libgpv.so via the Python mirror), against
+the CPU oracle on the same inputs and against the reference's own known-answer vectors. Bit-exact (integer work).
+
+Run on an MI355X:  python -m pytest tests -m gpu -x -q
+"""
+import importlib
+import json
+
+import numpy as np
+import pytest
+
+import gpv_testlib as T
+from test_oracle_kat import (DECODE_BLOCK_CHALLENGES, PBN_KATS, PGL_ZERO_OUT, STEP_CHALLENGES, _named)
+
+pytestmark = pytest.mark.gpu
+P = T.GL_P
+R = T.BN_R
+
+
+@pytest.fixture(scope="module")
+def gpv():
+    return importlib.import_module("gnark-plonky2-verifier_amd")
+
+
+@pytest.fixture(scope="module")
+def api(gpv):
+    return gpv.default_context()  # raises DeviceError without a GPU -- there is no fallback
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return T.oracle()
+
+
+def rand_gl(rng, shape):
+    x = rng.integers(0, 2**63, size=shape, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=shape, dtype=np.uint64)
+    return x % np.uint64(P)
+
+
+def rand_fr(rng, n):
+    vals = [int.from_bytes(rng.bytes(32), "little") % R for _ in range(n)]
+    return np.array([T.fr_limbs(v) for v in vals], dtype=np.uint64)
+
+
+EDGE = np.array([0, 1, 2, P - 1, P - 2, 2**32, 2**32 - 1, 2**63, 0xFFFFFFFF00000000, 7], dtype=np.uint64)
+
+
+# ---------------------------------------------------------------- goldilocks.Chip
+def test_gl_base_ops(gpv, api, orc):
+    rng = np.random.default_rng(1)
+    a = np.concatenate([np.repeat(EDGE, len(EDGE)), rand_gl(rng, 5000)])
+    b = np.concatenate([np.tile(EDGE, len(EDGE)), rand_gl(rng, 5000)])
+    c = np.concatenate([np.tile(EDGE[::-1], len(EDGE)), rand_gl(rng, 5000)])
+    gl = gpv.goldilocks.New(api)
+    assert (gl.Add(a, b) == orc.gl_op(orc.OP_ADD, a, b)).all()
+    assert (gl.Sub(a, b) == orc.gl_op(orc.OP_SUB, a, b)).all()
+    assert (gl.Mul(a, b) == orc.gl_op(orc.OP_MUL, a, b)).all()
+    assert (gl.MulAdd(a, b, c) == orc.gl_op(orc.OP_MULADD, a, b, c)).all()
+    inv, has = gl.Inverse(a)
+    assert (inv == orc.gl_op(orc.OP_INV, a)).all()
+    assert (has == (a != 0)).all()
+    nz = a != 0
+    assert (gl.Mul(inv[nz], a[nz]) == 1).all()
+    # goldilocks/base_test.go:97-116
+    assert gl.MulAdd([1], [2], [3])[0] == 5
+    assert gl.MulAdd([2**63], [2**63], [3])[0] == 18446744068340842500
+    # goldilocks/base_test.go:26-44
+    assert gl.RangeCheck([0, 1, P - 1, P]).tolist() == [True, True, True, False]
+    x = np.array([P, P + 5, 2**64 - 1, 3], dtype=np.uint64)
+    assert gl.Reduce(x).tolist() == [0, 5, 2**32 - 2, 3]
+
+
+def test_gl_extension_ops(gpv, api, orc):
+    rng = np.random.default_rng(2)
+    a = rand_gl(rng, (3000, 2))
+    b = rand_gl(rng, (3000, 2))
+    a[:4] = [[0, 0], [1, 0], [0, 1], [P - 1, P - 1]]
+    b[:4] = [[5, 6], [0, 0], [P - 1, 0], [P - 1, P - 1]]
+    gl = gpv.goldilocks.New(api)
+    assert (gl.AddExtension(a, b) == orc.gl2_op(orc.OP_ADD, a, b)[0]).all()
+    assert (gl.SubExtension(a, b) == orc.gl2_op(orc.OP_SUB, a, b)[0]).all()
+    assert (gl.MulExtension(a, b) == orc.gl2_op(orc.OP_MUL, a, b)[0]).all()
+    inv, ok = gl.InverseExtension(a)
+    oinv, ook = orc.gl2_op(orc.OP_INV, a)
+    assert (ok == ook).all() and ok[0] == 0
+    assert (inv[ok == 1] == oinv[ok == 1]).all()
+    q, ok = gl.DivExtension(a, b)
+    oq, ook = orc.gl2_op(orc.OP_DIV, a, b)
+    assert (ok == ook).all() and (q[ok == 1] == oq[ok == 1]).all()
+    # goldilocks/quadratic_extension_test.go:25-51, :68-94
+    assert gl.MulExtension([[4994088319481652598, 16489566008211790727]], [[3797605683985595697, 13424401189265534004]]).tolist() == \
+        [[15052319864161058789, 16841416332519902625]]
+    assert gl.DivExtension([[4994088319481652598, 16489566008211790727]], [[7166004739148609569, 14655965871663555016]])[0].tolist() == \
+        [[15052319864161058789, 16841416332519902625]]
+
+
+# ---------------------------------------------------------------- poseidon.GoldilocksChip
+def test_poseidon_gl_permute(gpv, api, orc):
+    rng = np.random.default_rng(3)
+    states = rand_gl(rng, (20000, 12))
+    states[0] = 0
+    states[1] = P - 1
+    chip = gpv.poseidon.NewGoldilocksChip(api)
+    out = chip.Poseidon(states)
+    assert out[0].tolist() == PGL_ZERO_OUT  # poseidon/goldilocks_test.go:37-59
+    assert (out == orc.poseidon_gl_permute(states)).all()
+
+
+def test_poseidon_gl_hash_no_pad(gpv, api, orc):
+    chip = gpv.poseidon.NewGoldilocksChip(api)
+    # poseidon/public_inputs_hash_test.go:43-60
+    assert chip.HashNoPad([0, 1, 3736710860384812976])[0].tolist() == \
+        [8416658900775745054, 12574228347150446423, 9629056739760131473, 3119289788404190010]
+    rng = np.random.default_rng(4)
+    for ln in (1, 7, 8, 9, 16, 36, 100):
+        x = rand_gl(rng, (50, ln))
+        x[0] = 2**64 - 1  # non-canonical inputs are reduced first (goldilocks.go:76-78)
+        assert (chip.HashNoPad(x) == orc.poseidon_gl_hash_no_pad(x)).all(), ln
+
+
+# ---------------------------------------------------------------- poseidon.BN254Chip
+def test_poseidon_bn254_permute(gpv, api, orc):
+    chip = gpv.poseidon.NewBN254Chip(api)
+    for inp, exp in PBN_KATS:  # poseidon/bn254_test.go:31-97
+        out = chip.Poseidon([[T.fr_limbs(int(x)) for x in inp]])[0]
+        assert [T.fr_from_limbs(l) for l in out] == [int(x) for x in exp]
+    rng = np.random.default_rng(5)
+    states = rand_fr(rng, 4 * 3000).reshape(3000, 4, 4)
+    states[0] = 0
+    states[1, :] = T.fr_limbs(R - 1)
+    states[2, 0] = [2**64 - 1] * 4  # >= r: taken mod r
+    assert (chip.Poseidon(states) == orc.poseidon_bn254_permute(states)).all()
+
+
+def test_poseidon_bn254_hashes(gpv, api, orc):
+    chip = gpv.poseidon.NewBN254Chip(api)
+    rng = np.random.default_rng(6)
+    for ln in (1, 2, 3, 4, 8, 9, 10, 16, 20, 32, 85, 86, 136):
+        x = rand_gl(rng, (40, ln))
+        assert (chip.HashOrNoop(x) == orc.poseidon_bn254_hash_or_noop(x)).all(), ln
+    l, r = rand_fr(rng, 500), rand_fr(rng, 500)
+    assert (chip.TwoToOne(l, r) == orc.poseidon_bn254_two_to_one(l, r)).all()
+    h = rand_fr(rng, 500)
+    h[0] = T.fr_limbs(R - 1)
+    assert (chip.ToVec(h) == orc.poseidon_bn254_to_vec(h)).all()
+
+
+# ---------------------------------------------------------------- gates (plonk/gates/gates_test.go:712-768)
+def test_gate_kats(gpv, api, orc):
+    kat = json.loads((T.GOLDEN / "gates_kat.json").read_text())
+    consts = kat["local_constants"][kat["num_selectors_stripped"]:] + [[0, 0]] * 2
+    rng = np.random.default_rng(7)
+    for g in kat["gates"]:
+        gate = gpv.plonk.Gate(g["kind"], *g["params"], weights=g["weights"])
+        out = gate.EvalUnfiltered(consts, kat["local_wires"], kat["public_inputs_hash"], api)
+        assert out[0].tolist() == g["expected"], g["id"]
+        # random variable sets, batch of 33, against the oracle
+        wires = rand_gl(rng, (33, 136, 2))
+        cst = rand_gl(rng, (33, 4, 2))
+        ph = rand_gl(rng, (33, 4))
+        got = gate.EvalUnfiltered(cst, wires, ph, api)
+        for i in (0, 17, 32):
+            exp = orc.gate_eval_unfiltered(g["kind"], g["params"], g["weights"], cst[i], wires[i], ph[i])
+            assert (got[i] == exp).all(), g["id"]
+
+
+def test_gates_without_reference_kat(gpv, api, orc):
+    # Noop, Constant and Exponentiation have no vector in gates_test.go: oracle parity only
+    rng = np.random.default_rng(8)
+    wires = rand_gl(rng, (10, 136, 2))
+    cst = rand_gl(rng, (10, 4, 2))
+    ph = rand_gl(rng, (10, 4))
+    for kind, params in ((0, [0, 0, 0]), (1, [2, 0, 0]), (9, [67, 0, 0]), (10, [2, 13, 2]), (3, [32, 2, 0])):
+        got = gpv.plonk.Gate(kind, *params).EvalUnfiltered(cst, wires, ph, api)
+        for i in range(10):
+            exp = orc.gate_eval_unfiltered(kind, params, [], cst[i], wires[i], ph[i])
+            assert got[i].shape == exp.shape and (got[i] == exp).all(), kind
+
+
+# ---------------------------------------------------------------- protocol stages on the fixtures
+def _load(gpv, name):
+    d = T.GOLDEN / name
+    common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
+    vo = gpv.variables.DeserializeVerifierOnlyCircuitData(gpv.types.ReadVerifierOnlyCircuitData(d / "verifier_only_circuit_data.json"))
+    circuit = gpv.variables.circuit_for(common, vo)
+    proofs = gpv.variables.DeserializeProofWithPublicInputs(gpv.types.ReadProofWithPublicInputs(d / "proof_with_public_inputs.json"), circuit)
+    return common, vo, circuit, proofs
+
+
+@pytest.mark.parametrize("name,expect", [("decode_block", DECODE_BLOCK_CHALLENGES), ("step", STEP_CHALLENGES)])
+def test_challenges(gpv, api, orc, name, expect):
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    chip = gpv.verifier.NewVerifierChip(api, common)
+    ch = chip.GetChallenges(proofs)
+    assert _named(ci, ch.flat[0]) == expect  # fri/fri_test.go:37-67 for decode_block
+    assert (ch.flat == orc.challenges(oc, packed)).all()
+    assert (chip.GetPublicInputsHash(proofs) == orc.public_inputs_hash(oc, packed)).all()
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_plonk_and_gate_constraints(gpv, api, orc, name):  # plonk/plonk_test.go:21-66
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    ch = orc.challenges(oc, packed)
+    plonk = gpv.plonk.NewPlonkChip(api, common)
+    assert plonk.Verify(proofs, ch).tolist() == [0]
+    assert (plonk.EvaluateGateConstraints(proofs) == orc.gate_constraints(oc, packed)).all()
+    # wrong challenges / tampered openings must fail exactly where the oracle fails
+    rec = np.frombuffer(packed, dtype=np.uint64)
+    batch = np.tile(rec, (6, 1))
+    for i, w in enumerate([0, 11, 171, 440, 500]):
+        batch[i, w] ^= np.uint64(1)
+    pb = gpv.variables.ProofBatch(circuit, batch.tobytes())
+    chs = np.tile(ch, (6, 1))
+    chs[5, 2 * ci.num_challenges] ^= np.uint64(1)  # alpha
+    assert plonk.Verify(pb, chs).tolist() == orc.plonk_verify(oc, batch.tobytes(), chs).tolist()
+    assert (plonk.EvaluateGateConstraints(pb) == orc.gate_constraints(oc, batch.tobytes())).all()
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_merkle_and_fri(gpv, api, orc, name):  # fri/fri_test.go:106-133
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    ch = orc.challenges(oc, packed)
+    fri = gpv.fri.NewChip(api, common)
+    assert fri.VerifyMerkleProofsToCap(proofs, ch).all()
+    assert fri.VerifyFriProof(proofs, ch).tolist() == [0]
+    # tamper: leaves, step evals, final poly, pow witness, siblings, caps, and a query index
+    rec = np.frombuffer(packed, dtype=np.uint64)
+    n_gl = (len(packed) - 0) // 8
+    rng = np.random.default_rng(9)
+    words = [600, 700, 900, 1200, 5000, 9000] + rng.integers(520, len(rec), 18).tolist()
+    batch = np.tile(rec, (len(words) + 1, 1))
+    for i, w in enumerate(words):
+        batch[i, w] ^= np.uint64(1)
+    chs = np.tile(ch, (len(words) + 1, 1))
+    chs[len(words), -1] ^= np.uint64(4)  # last query index: different leaf => Merkle + consistency failures
+    pb = gpv.variables.ProofBatch(circuit, batch.tobytes())
+    assert (fri.VerifyMerkleProofsToCap(pb, chs) == orc.merkle_chains(oc, batch.tobytes(), chs)).all()
+    got = fri.VerifyFriProof(pb, chs)
+    exp = orc.fri_verify(oc, batch.tobytes(), chs)
+    assert ((got == 0) == (exp == 0)).all()
+    assert got.tolist() == [int(x) for x in exp]
+    assert n_gl > 0
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_verify_end_to_end(gpv, api, orc, name):  # verifier/verifier_test.go:13-41
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    chip = gpv.verifier.NewVerifierChip(api, common)
+    assert chip.Verify(proofs, vo).tolist() == [1]
+    batch, tampered = T.synthetic_batch(ci, packed, 96, seed=11, tamper_every=4)
+    # a few more corruption sites: openings, public inputs / final poly, Fr section, non-canonical words
+    rec_words = batch.view(np.uint64).reshape(96, -1)
+    rec_words[1, 3] ^= np.uint64(1)
+    rec_words[2, rec_words.shape[1] - 5] ^= np.uint64(1 << 40)
+    rec_words[3, 7] = np.uint64(P)          # range check (verifier.go:84-141)
+    rec_words[5, 100] = np.uint64(2**64 - 1)
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    accept, mask, ch = chip.Verify(pb, vo, detail=True)
+    oacc, ofail, och = orc.verify(oc, batch, n_threads=8)
+    assert accept.tolist() == oacc.tolist()
+    assert (accept == 0).sum() >= tampered.sum()
+    assert (ch.flat == och).all()
+    clean = (ofail & 1) == 0  # with a non-canonical word the remaining diagnostics are unspecified
+    assert mask[clean].tolist() == [int(x) for x in ofail[clean]]
+    assert ((mask[~clean] & 1) == 1).all()
+
+
+def test_verify_device_resident(gpv, api, orc):
+    """gpv_verify_dev on torch-owned HBM buffers and torch's stream (the bench path)."""
+    torch = pytest.importorskip("torch")
+    common, vo, circuit, proofs = _load(gpv, "decode_block")
+    ci, packed, _ = T.load_fixture("decode_block")
+    batch, tampered = T.synthetic_batch(ci, packed, 256, seed=3, tamper_every=8)
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(batch.copy()).to(dev)
+    acc = torch.zeros(256, dtype=torch.uint8, device=dev)
+    api.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        gpv.verifier.NewVerifierChip(api, common).VerifyDevice(circuit, t.data_ptr(), 256, acc.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        api.set_stream(None)
+    assert (acc.cpu().numpy() == 0).tolist() == tampered.tolist()
+
+
+def test_poseidon_gl_full_size_properties(gpv, api, orc):
+    """BASELINE config 2 at full size (2^20 states): spot-check against the oracle and a checksum-of-checksums
+    invariance under batch permutation (size-independent property)."""
+    torch = pytest.importorskip("torch")
+    n = 1 << 20
+    rng = np.random.default_rng(12)
+    states = rand_gl(rng, (n, 12))
+    states[0] = 0
+    states[1] = P - 1
+    dev = torch.device("cuda:0")
+    chip = gpv.poseidon.NewGoldilocksChip(api)
+    tin = torch.from_numpy(states.view(np.int64)).to(dev)
+    tout = torch.empty_like(tin)
+    chip.PoseidonDevice(tin.data_ptr(), tout.data_ptr(), n)
+    api.synchronize()
+    out = tout.cpu().numpy().view(np.uint64)
+    assert out[0].tolist() == PGL_ZERO_OUT
+    idx = rng.integers(0, n, 4096)
+    assert (out[idx] == orc.poseidon_gl_permute(states[idx])).all()
+    perm = rng.permutation(n)
+    tin2 = torch.from_numpy(states[perm].view(np.int64)).to(dev)
+    chip.PoseidonDevice(tin2.data_ptr(), tout.data_ptr(), n)
+    api.synchronize()
+    out2 = tout.cpu().numpy().view(np.uint64)
+    assert (out2 == out[perm]).all()
+
+
+def test_microbench_reports(gpv, api):
+    names = ["v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_fma_f64", "v_add_co_u32", "v_mad_u32_u24", "v_add_u32",
+             "v_lshl_add_u64"]
+    rates = {nm: api.microbench(i) for i, nm in enumerate(names)}
+    print("\nlane-ops/s:", {k: "%.3e" % v for k, v in rates.items()})
+    assert all(v > 1e11 for v in rates.values())
