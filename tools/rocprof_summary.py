@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd database (the default output of ROCm 7.2's rocprofv3) as text.
+
+  python tools/rocprof_summary.py gpurun_out/prof_r1/stats/r1_results.db            # kernel-trace --stats summary
+  python tools/rocprof_summary.py gpurun_out/prof_r1/pmc_fetch/r1_results.db --pmc  # per-kernel PMC counters
+
+The outputs committed under profiles/ are produced with this script from the databases the GPU runs leave in
+gpurun_out/ (scratch).
+"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    pmc = "--pmc" in sys.argv
+    if not pmc:
+        rows = db.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc").fetchall()
+        print("%-72s %6s %14s %14s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+        for name, calls, total, avg, pct in rows:
+            short = name.split("(")[0][-72:]
+            print("%-72s %6d %14.3f %14.3f %7.2f" % (short, calls, total, avg, pct))
+        regs = db.execute("select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
+                          "max(grid_x), max(grid_y), max(workgroup_x) from kernels group by name").fetchall()
+        print()
+        print("%-40s %5s %5s %5s %7s %8s %10s %6s %5s" % ("kernel", "vgpr", "agpr", "sgpr", "lds", "scratch", "grid_x", "grid_y", "wg"))
+        for r in regs:
+            if r[0].startswith("k_") or "gpv" in r[0]:
+                print("%-40s %5d %5d %5d %7d %8d %10d %6d %5d" % ((r[0].split("(")[0][:40],) + tuple(r[1:])))
+    else:
+        rows = db.execute("select name, counter_name, count(*), sum(counter_value), avg(counter_value), avg(duration) from pmc_events "
+                          "group by name, counter_name order by 4 desc").fetchall()
+        print("%-56s %-12s %6s %18s %18s %14s" % ("kernel", "counter", "n", "sum", "avg_per_dispatch", "avg_dur_us"))
+        for name, ctr, n, total, avg, dur in rows:
+            print("%-56s %-12s %6d %18.3f %18.3f %14.3f" % (str(name).split("(")[0][-56:], ctr, n, total, avg, dur / 1e3))
+
+
+if __name__ == "__main__":
+    main()
