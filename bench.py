@@ -173,8 +173,17 @@ def main():
         perms = perms_per_proof(ci)
         alg_bytes = float(nbytes) * n_local  # the packed record is read once per proof
         achieved = alg_bytes / (merkle_ms * 1e-3) / 1e9 if merkle_ms > 0 else 0.0
+        # HBM traffic per launch from the PMC passes of the same command (separate rocprofv3 --pmc runs, FETCH_SIZE x2 on
+        # gfx950), recorded in profiles/traffic.json; only reported when it was measured on this exact configuration
+        traffic = None
+        try:
+            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())["k_merkle"]
+            if tj["fixture"] == args.fixture and tj["proofs_per_gpu"] == n_local:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         line["roofline"] = {"bound": "hbm", "kernel": "k_merkle", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": merkle_ms, "launches": merkle_launches,
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": merkle_ms, "launches": merkle_launches,
                             "algorithmic_bytes_per_launch": alg_bytes,
                             "note": "integer-VALU bound workload; see valu_roofline"}
         mad_peak = ctx.microbench(0)
@@ -208,8 +217,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             orc = T.oracle()
             oc = orc.circuit(ci)
-            cores = os.cpu_count() or 1
-            n_sample = max(cores, int(round(16.0 / 0.11 / 8)) * 8)  # ~16 CPU-seconds at ~0.11 s/proof/core
+            # throughput of the port peaks at ~32 threads on the GPU box's host (profiles/r01a_cpu_scaling.txt)
+            cores = min(os.cpu_count() or 1, 32)
+            n_sample = 8 * cores  # ~20 CPU-seconds at ~0.09 s/proof/core
             sample = batch[:n_sample].cpu().numpy().view(np.uint8).reshape(n_sample, -1)
             t1 = time.perf_counter()
             oacc, _, _ = orc.verify(oc, sample, n_threads=cores)

@@ -1,0 +1,213 @@
+// gpv.hpp -- header-only C++ mirror of the reference's Go package surface over the C ABI (include/gpv.h).
+//
+//   goldilocks::Chip              goldilocks/base.go:96-313, quadratic_extension.go:31-235
+//   poseidon::GoldilocksChip      poseidon/goldilocks.go:18-86
+//   poseidon::BN254Chip           poseidon/bn254.go:23-120
+//   fri::Chip                     fri/fri.go:17-61, :500-548
+//   plonk::PlonkChip              plonk/plonk.go:12-53, :209-250
+//   verifier::VerifierChip        verifier/verifier.go:14-39, :143-170
+//
+// Same names and argument meaning as the Go methods, batch-first (std::vector in, std::vector out). Error behaviour:
+// what the reference panics on throws gpv::Error (code GPV_ESHAPE / GPV_ECONFIG); a rejected proof is accept == 0.
+// The reference is compiled code without a toolchain in this image (Go), hence this C++ host layer; the cgo shim a
+// maintainer would add is in bindings/go (uncompiled).
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/gpv.h"
+
+namespace gpv {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error("libgpv error " + std::to_string(c) + ": " + m), code(c) {}
+};
+inline void check(int rc, gpv_ctx* ctx = nullptr) {
+  if (rc == GPV_OK) return;
+  char buf[1024];
+  gpv_last_error_message(ctx, buf, sizeof buf);
+  throw Error(rc, buf);
+}
+
+// frontend.API's place in the constructors: the device context (one per process / GPU)
+class Api {
+ public:
+  explicit Api(int device = 0) { check(gpv_ctx_create(&h_, device)); }
+  ~Api() { if (h_) gpv_ctx_destroy(h_); }
+  Api(const Api&) = delete;
+  Api& operator=(const Api&) = delete;
+  gpv_ctx* h() const { return h_; }
+ private:
+  gpv_ctx* h_ = nullptr;
+};
+
+// types.CommonCircuitData + variables.VerifierOnlyCircuitData
+class Circuit {
+ public:
+  Circuit(const std::string& common_json, const std::string& verifier_only_json) {
+    check(gpv_circuit_from_json(common_json.data(), common_json.size(), verifier_only_json.data(), verifier_only_json.size(), &h_));
+  }
+  ~Circuit() { if (h_) gpv_circuit_destroy(h_); }
+  Circuit(const Circuit&) = delete;
+  Circuit& operator=(const Circuit&) = delete;
+  gpv_circuit* h() const { return h_; }
+  size_t proof_nbytes() const { return gpv_proof_nbytes(h_); }
+  size_t num_challenge_words() const { return gpv_num_challenge_words(h_); }
+  // variables.DeserializeProofWithPublicInputs(types.ReadProofWithPublicInputs(...)): one packed record
+  std::vector<uint8_t> pack_proof(const std::string& proof_json) const {
+    std::vector<uint8_t> out(proof_nbytes());
+    check(gpv_proof_pack_json(h_, proof_json.data(), proof_json.size(), out.data()));
+    return out;
+  }
+ private:
+  gpv_circuit* h_ = nullptr;
+};
+
+}  // namespace gpv
+
+namespace goldilocks {
+typedef std::vector<uint64_t> Vars;  // n canonical Goldilocks elements (gl.Variable x n)
+class Chip {
+ public:
+  explicit Chip(gpv::Api& api) : api_(api) {}
+  Vars Add(const Vars& a, const Vars& b) { return op(GPV_OP_ADD, a, &b, nullptr); }                    // base.go:162
+  Vars Sub(const Vars& a, const Vars& b) { return op(GPV_OP_SUB, a, &b, nullptr); }                    // base.go:174
+  Vars Mul(const Vars& a, const Vars& b) { return op(GPV_OP_MUL, a, &b, nullptr); }                    // base.go:184
+  Vars MulAdd(const Vars& a, const Vars& b, const Vars& c) { return op(GPV_OP_MULADD, a, &b, &c); }     // base.go:196
+  Vars Reduce(const Vars& x) { return op(GPV_OP_REDUCE, x, nullptr, nullptr); }                         // base.go:246
+  Vars Inverse(const Vars& x) { return op(GPV_OP_INV, x, nullptr, nullptr); }                           // base.go:297
+  // extension elements are consecutive pairs
+  Vars MulExtension(const Vars& a, const Vars& b) { return op2(GPV_OP_MUL, a, &b); }                    // quadratic_extension.go:59
+  Vars AddExtension(const Vars& a, const Vars& b) { return op2(GPV_OP_ADD, a, &b); }                    // :31
+  Vars SubExtension(const Vars& a, const Vars& b) { return op2(GPV_OP_SUB, a, &b); }                    // :45
+  Vars DivExtension(const Vars& a, const Vars& b) { return op2(GPV_OP_DIV, a, &b); }                    // :137
+ private:
+  Vars op(int o, const Vars& a, const Vars* b, const Vars* c) {
+    Vars out(a.size());
+    gpv::check(gpv_gl_op(api_.h(), o, a.data(), b ? b->data() : nullptr, c ? c->data() : nullptr, out.data(), a.size()), api_.h());
+    return out;
+  }
+  Vars op2(int o, const Vars& a, const Vars* b) {
+    Vars out(a.size());
+    gpv::check(gpv_gl2_op(api_.h(), o, a.data(), b ? b->data() : nullptr, out.data(), nullptr, a.size() / 2), api_.h());
+    return out;
+  }
+  gpv::Api& api_;
+};
+inline Chip New(gpv::Api& api) { return Chip(api); }  // base.go:112
+}  // namespace goldilocks
+
+namespace poseidon {
+typedef std::vector<uint64_t> Words;
+class GoldilocksChip {
+ public:
+  explicit GoldilocksChip(gpv::Api& api) : api_(api) {}
+  Words Poseidon(const Words& states) {  // goldilocks.go:30, n x 12
+    Words out(states.size());
+    gpv::check(gpv_poseidon_gl_permute(api_.h(), states.data(), out.data(), states.size() / 12), api_.h());
+    return out;
+  }
+  Words HashNoPad(const Words& in, size_t len) {  // goldilocks.go:72, n x len -> n x 4
+    size_t n = len ? in.size() / len : 0;
+    Words out(4 * n);
+    gpv::check(gpv_poseidon_gl_hash_no_pad(api_.h(), in.data(), len, out.data(), n), api_.h());
+    return out;
+  }
+ private:
+  gpv::Api& api_;
+};
+class BN254Chip {
+ public:
+  explicit BN254Chip(gpv::Api& api) : api_(api) {}
+  Words Poseidon(const Words& states) {  // bn254.go:39, n x 4 x 4 limbs
+    Words out(states.size());
+    gpv::check(gpv_poseidon_bn254_permute(api_.h(), states.data(), out.data(), states.size() / 16), api_.h());
+    return out;
+  }
+  Words HashOrNoop(const Words& in, size_t len) {  // bn254.go:79
+    size_t n = len ? in.size() / len : 0;
+    Words out(4 * n);
+    gpv::check(gpv_poseidon_bn254_hash_or_noop(api_.h(), in.data(), len, out.data(), n), api_.h());
+    return out;
+  }
+  Words TwoToOne(const Words& l, const Words& r) {  // bn254.go:96
+    Words out(l.size());
+    gpv::check(gpv_poseidon_bn254_two_to_one(api_.h(), l.data(), r.data(), out.data(), l.size() / 4), api_.h());
+    return out;
+  }
+  Words ToVec(const Words& h) {  // bn254.go:106
+    Words out(h.size() / 4 * 5);
+    gpv::check(gpv_poseidon_bn254_to_vec(api_.h(), h.data(), out.data(), h.size() / 4), api_.h());
+    return out;
+  }
+ private:
+  gpv::Api& api_;
+};
+inline GoldilocksChip NewGoldilocksChip(gpv::Api& api) { return GoldilocksChip(api); }  // goldilocks.go:23
+inline BN254Chip NewBN254Chip(gpv::Api& api) { return BN254Chip(api); }                 // bn254.go:31
+}  // namespace poseidon
+
+namespace fri {
+class Chip {
+ public:
+  Chip(gpv::Api& api, const gpv::Circuit& c) : api_(api), c_(c) {}
+  // VerifyFriProof (fri.go:500): failure mask per proof (0 == all FRI assertions hold)
+  std::vector<uint32_t> VerifyFriProof(const std::vector<uint8_t>& proofs, const std::vector<uint64_t>& challenges) {
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint32_t> mask(n);
+    gpv::check(gpv_fri_verify(api_.h(), c_.h(), proofs.data(), challenges.data(), n, mask.data()), api_.h());
+    return mask;
+  }
+ private:
+  gpv::Api& api_;
+  const gpv::Circuit& c_;
+};
+}  // namespace fri
+
+namespace plonk {
+class PlonkChip {
+ public:
+  PlonkChip(gpv::Api& api, const gpv::Circuit& c) : api_(api), c_(c) {}
+  std::vector<uint32_t> Verify(const std::vector<uint8_t>& proofs, const std::vector<uint64_t>& challenges) {  // plonk.go:209
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint32_t> mask(n);
+    gpv::check(gpv_plonk_verify(api_.h(), c_.h(), proofs.data(), challenges.data(), n, mask.data()), api_.h());
+    return mask;
+  }
+ private:
+  gpv::Api& api_;
+  const gpv::Circuit& c_;
+};
+}  // namespace plonk
+
+namespace verifier {
+class VerifierChip {
+ public:
+  VerifierChip(gpv::Api& api, const gpv::Circuit& c) : api_(api), c_(c) {}  // NewVerifierChip, verifier.go:24
+  std::vector<uint64_t> GetPublicInputsHash(const std::vector<uint8_t>& proofs) {  // verifier.go:41
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint64_t> out(4 * n);
+    gpv::check(gpv_public_inputs_hash(api_.h(), c_.h(), proofs.data(), n, out.data()), api_.h());
+    return out;
+  }
+  std::vector<uint64_t> GetChallenges(const std::vector<uint8_t>& proofs) {  // verifier.go:45
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint64_t> out(n * c_.num_challenge_words());
+    gpv::check(gpv_challenges(api_.h(), c_.h(), proofs.data(), n, out.data()), api_.h());
+    return out;
+  }
+  // Verify (verifier.go:143): accept[i] == 1 iff the reference's circuit is satisfiable for proof i
+  std::vector<uint8_t> Verify(const std::vector<uint8_t>& proofs) {
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint8_t> accept(n);
+    gpv::check(gpv_verify(api_.h(), c_.h(), proofs.data(), n, accept.data()), api_.h());
+    return accept;
+  }
+ private:
+  gpv::Api& api_;
+  const gpv::Circuit& c_;
+};
+}  // namespace verifier

@@ -1,0 +1,59 @@
+// C++ host-mirror test: reads like verifier/verifier_test.go:13-41 and poseidon/goldilocks_test.go:37-59, through
+// gnark-plonky2-verifier_amd/host/gpv.hpp -> include/gpv.h -> libgpv.so. Built and run by tests/test_host_mirror_cpp.py.
+//   usage: host_mirror_test <fixture dir> [--no-gpu]
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+
+#include "../../gnark-plonky2-verifier_amd/host/gpv.hpp"
+
+static std::string slurp(const std::string& p) {
+  std::ifstream f(p);
+  if (!f) { fprintf(stderr, "cannot open %s\n", p.c_str()); exit(2); }
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+#define EXPECT(c) do { if (!(c)) { fprintf(stderr, "FAILED: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  std::string dir = argv[1];
+  bool no_gpu = argc > 2 && std::string(argv[2]) == "--no-gpu";
+  gpv::Circuit circuit(slurp(dir + "/common_circuit_data.json"), slurp(dir + "/verifier_only_circuit_data.json"));
+  std::vector<uint8_t> proof = circuit.pack_proof(slurp(dir + "/proof_with_public_inputs.json"));
+  EXPECT(proof.size() == circuit.proof_nbytes());
+  // malformed proof -> the reference panics -> gpv::Error(GPV_ESHAPE)
+  try {
+    circuit.pack_proof("{\"proof\": {}}");
+    EXPECT(false);
+  } catch (const gpv::Error& e) { EXPECT(e.code == GPV_ESHAPE); }
+  if (no_gpu) {
+    try {
+      gpv::Api api(0);
+      EXPECT(false);  // a GPU must not appear out of nowhere
+    } catch (const gpv::Error& e) { EXPECT(e.code == GPV_EDEVICE); }
+    printf("host mirror (no gpu) ok\n");
+    return 0;
+  }
+  gpv::Api api(0);
+  // poseidon/goldilocks_test.go:37-59
+  poseidon::GoldilocksChip pgl = poseidon::NewGoldilocksChip(api);
+  poseidon::Words out = pgl.Poseidon(poseidon::Words(12, 0));
+  EXPECT(out[0] == 4330397376401421145ULL && out[11] == 1698615465718385111ULL);
+  // goldilocks/base_test.go:97-116
+  goldilocks::Chip gl = goldilocks::New(api);
+  EXPECT(gl.MulAdd({1ULL << 63}, {1ULL << 63}, {3})[0] == 18446744068340842500ULL);
+  // verifier/verifier_test.go:13-41 (+ a tampered copy)
+  verifier::VerifierChip chip(api, circuit);
+  std::vector<uint8_t> batch = proof;
+  batch.insert(batch.end(), proof.begin(), proof.end());
+  batch[proof.size() + 8 * 700] ^= 1;
+  std::vector<uint8_t> accept = chip.Verify(batch);
+  EXPECT(accept.size() == 2 && accept[0] == 1 && accept[1] == 0);
+  std::vector<uint64_t> ch = chip.GetChallenges(proof);
+  EXPECT(fri::Chip(api, circuit).VerifyFriProof(proof, ch)[0] == 0);
+  EXPECT(plonk::PlonkChip(api, circuit).Verify(proof, ch)[0] == 0);
+  printf("host mirror ok\n");
+  return 0;
+}
