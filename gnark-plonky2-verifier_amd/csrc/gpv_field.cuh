@@ -3,12 +3,10 @@
 //   Goldilocks p = 2^64 - 2^32 + 1          replaces goldilocks.Chip base ops, goldilocks/base.go:162-313
 //   F_p[X]/(X^2 - 7)                        replaces goldilocks/quadratic_extension.go:31-235
 //   extension algebra (pairs)               replaces goldilocks/quadratic_extension_algebra.go:28-125
-//   BN254 scalar field Fr                   replaces the gnark frontend.API Add/Mul/MulAcc calls of poseidon/bn254.go
+//   (BN254 scalar field Fr: gpv_fr.cuh)
 //
 // Design notes (MI355X): there is no 64-bit integer multiplier on CDNA4; a 64x64->128 product is four
 // v_mad_u64_u32 and the 128->64 Goldilocks reduction is add/sub/compare only (2^64 = 2^32 - 1, 2^96 = -1 mod p).
-// Fr uses 8 x 32-bit limbs in Montgomery form (R = 2^256) so that the whole state of a Poseidon-BN254 permutation
-// (4 x 8 limbs) lives in VGPRs and every round constant arrives through the scalar unit (wave-uniform index).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -123,142 +121,3 @@ GPV_DEV ExtAlg alg_mul(ExtAlg x, ExtAlg y) {  // quadratic_extension_algebra.go:
   return alg_make(p0, p1);
 }
 GPV_DEV ExtAlg alg_scalar_mul(Ext s, ExtAlg x) { return alg_make(ext_mul(s, x.a), ext_mul(s, x.b)); }
-
-// ================================================================ BN254 scalar field, 8 x 32-bit limbs, Montgomery
-struct Fr {
-  u32 l[8];
-};
-// modulus r, -r^-1 mod 2^32, R^2 mod r  (values checked in tests against Python integers)
-#define FR_N0 0xf0000001u
-#define FR_N1 0x43e1f593u
-#define FR_N2 0x79b97091u
-#define FR_N3 0x2833e848u
-#define FR_N4 0x8181585du
-#define FR_N5 0xb85045b6u
-#define FR_N6 0xe131a029u
-#define FR_N7 0x30644e72u
-#define FR_NINV 0xefffffffu
-#define FR_R2_INIT {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u}
-
-GPV_DEV Fr fr_zero() {
-  Fr r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.l[i] = 0;
-  return r;
-}
-GPV_DEV bool fr_eq(const Fr& a, const Fr& b) {
-  u32 d = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) d |= a.l[i] ^ b.l[i];
-  return d == 0;
-}
-// r = a - n if a >= n else a   (a < 2n)
-GPV_DEV void fr_cond_sub(u32 t[8]) {
-  const u32 n[8] = {FR_N0, FR_N1, FR_N2, FR_N3, FR_N4, FR_N5, FR_N6, FR_N7};
-  u32 d[8];
-  u64 borrow = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    u64 x = (u64)t[i] - n[i] - borrow;
-    d[i] = (u32)x;
-    borrow = (x >> 32) & 1;
-  }
-  if (!borrow) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) t[i] = d[i];
-  }
-}
-GPV_DEV Fr fr_add(const Fr& a, const Fr& b) {
-  Fr r;
-  u64 c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (u64)a.l[i] + b.l[i];
-    r.l[i] = (u32)c;
-    c >>= 32;
-  }
-  fr_cond_sub(r.l);  // a + b < 2r < 2^255
-  return r;
-}
-// Montgomery product a*b/R mod r. CIOS over 32-bit limbs; since r < 2^254 the running value stays below 2r and
-// fits 8 limbs + 1 carry word ("no extra limb" variant), one conditional subtraction at the end.
-GPV_DEV Fr fr_mul(const Fr& a, const Fr& b) {
-  const u32 n[8] = {FR_N0, FR_N1, FR_N2, FR_N3, FR_N4, FR_N5, FR_N6, FR_N7};
-  u32 t[9];
-#pragma unroll
-  for (int i = 0; i < 9; i++) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    u64 c = 0;
-    u32 bi = b.l[i];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      c += (u64)a.l[j] * bi + t[j];
-      t[j] = (u32)c;
-      c >>= 32;
-    }
-    u64 top = (u64)t[8] + c;  // < 2^33
-    u32 m = t[0] * FR_NINV;
-    c = (u64)m * n[0] + t[0];
-    c >>= 32;
-#pragma unroll
-    for (int j = 1; j < 8; j++) {
-      c += (u64)m * n[j] + t[j];
-      t[j - 1] = (u32)c;
-      c >>= 32;
-    }
-    top += c;
-    t[7] = (u32)top;
-    t[8] = (u32)(top >> 32);
-  }
-  Fr r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.l[i] = t[i];
-  // value < 2r < 2^255 so t[8] == 0 here
-  fr_cond_sub(r.l);
-  return r;
-}
-GPV_DEV Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
-// canonical 8 x u32 (any 256-bit value, taken mod r like a gnark witness) -> Montgomery
-GPV_DEV Fr fr_from_canonical(const u32 x[8]) {
-  Fr a;
-#pragma unroll
-  for (int i = 0; i < 8; i++) a.l[i] = x[i];
-  // 2^256 / r < 6: at most 5 subtractions
-  for (int k = 0; k < 5; k++) fr_cond_sub(a.l);
-  const Fr r2 = {FR_R2_INIT};
-  return fr_mul(a, r2);
-}
-GPV_DEV Fr fr_from_canonical64(const u64* x) {  // 4 x u64 little-endian
-  u32 l[8];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    u64 w = x[i];
-    l[2 * i] = (u32)w;
-    l[2 * i + 1] = (u32)(w >> 32);
-  }
-  return fr_from_canonical(l);
-}
-GPV_DEV void fr_to_canonical(const Fr& a, u32 out[8]) {
-  Fr one = fr_zero();
-  one.l[0] = 1;
-  Fr r = fr_mul(a, one);
-#pragma unroll
-  for (int i = 0; i < 8; i++) out[i] = r.l[i];
-}
-GPV_DEV void fr_to_canonical64(const Fr& a, u64* out) {
-  u32 l[8];
-  fr_to_canonical(a, l);
-#pragma unroll
-  for (int i = 0; i < 4; i++) out[i] = (u64)l[2 * i] | ((u64)l[2 * i + 1] << 32);
-}
-// pack <= 3 Goldilocks words, value = sum x_k 2^(64k) < 2^192 < r  (bn254.go:60-68,82-88) -> Montgomery
-GPV_DEV Fr fr_pack_gl(u64 x0, u64 x1, u64 x2) {
-  Fr a;
-  a.l[0] = (u32)x0; a.l[1] = (u32)(x0 >> 32);
-  a.l[2] = (u32)x1; a.l[3] = (u32)(x1 >> 32);
-  a.l[4] = (u32)x2; a.l[5] = (u32)(x2 >> 32);
-  a.l[6] = 0; a.l[7] = 0;
-  const Fr r2 = {FR_R2_INIT};
-  return fr_mul(a, r2);
-}

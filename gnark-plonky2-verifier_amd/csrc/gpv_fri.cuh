@@ -34,15 +34,18 @@ GPV_DEV bool dev_merkle_chain(const u64* __restrict__ leaf, u32 leaf_len, const 
     s[0] = fr_zero();
     s[1] = fr_zero();
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < FR_LIMBS; k++) {
       s[2].l[k] = bit ? sib.l[k] : cur.l[k];
       s[3].l[k] = bit ? cur.l[k] : sib.l[k];
     }
     poseidon_bn254_permute(s);
     cur = s[0];
   }
-  Fr cap = fr_from_canonical64(cap_entry);  // fri.go:135-143
-  return fr_eq(cur, cap);
+  // compare canonical representatives (fri.go:135-143); the digest inside the chain is only reduced up to multiples of r
+  u64 got[4], want[4] = {cap_entry[0], cap_entry[1], cap_entry[2], cap_entry[3]};
+  fr_to_canonical64(cur, got);
+  fr_words_reduce(want);
+  return ((got[0] ^ want[0]) | (got[1] ^ want[1]) | (got[2] ^ want[2]) | (got[3] ^ want[3])) == 0;
 }
 
 // ---------------------------------------------------------------- field part of one query round

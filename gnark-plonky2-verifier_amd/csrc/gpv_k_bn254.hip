@@ -31,7 +31,7 @@ __global__ void k_poseidon_bn254_to_vec(const u64* __restrict__ h, u64* __restri
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64 c[4] = {h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]};
-  DevChallenger::fr64_reduce(c);
+  fr_words_reduce(c);
   u64 v[5];
   fr_canonical_to_vec(c, v);
 #pragma unroll

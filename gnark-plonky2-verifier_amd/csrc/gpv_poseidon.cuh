@@ -8,11 +8,7 @@
 // the MDS circulant (entries <= 41) folds into shift/add immediates, and every table access has a wave-uniform index,
 // so round constants are fetched by the scalar unit (s_load) and fed to v_mad_u64_u32 as SGPR operands.
 #pragma once
-#include "gpv_field.cuh"
-
-#define GPV_TABLE_U64(name, n) static __constant__ u64 name[n]
-#define GPV_TABLE_U32(name, n) static __constant__ u32 name[n]
-#include "poseidon_tables.inc"
+#include "gpv_fr.cuh"
 
 // ================================================================ Poseidon-Goldilocks
 // x^7 (goldilocks.go:138-145): 4 multiplications
@@ -121,20 +117,26 @@ GPV_DEV void poseidon_gl_permute(u64 s[12]) {
 }
 
 // ================================================================ Poseidon-BN254
-// Code-size discipline: one inlined fr_mul is ~3.5 KB of ISA, so the round bodies are written as short rolled loops
-// over a ROTATING state (s0,s1,s2,s3) <- (s1,s2,s3,f(s0)); four trips return the state to its original order. The
-// rotation is 8 v_mov per trip next to ~1300 multiplier instructions, every register index stays static (no scratch),
-// and the whole permutation stays inside the instruction cache (partial round ~36 KB, full round ~25 KB).
-GPV_DEV Fr pbn_load(const u32* tab, int idx) {  // tab in Montgomery form, idx wave-uniform -> scalar loads
-  Fr r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.l[i] = tab[8 * idx + i];
-  return r;
-}
-GPV_DEV Fr pbn_exp5(const Fr& x) {  // bn254.go:181-185
+// State elements are Montgomery residues in the redundant radix-2^29 form of gpv_fr.cuh (values < ~10 r, never
+// canonical inside the permutation). Fusions relative to the reference's op-by-op form (bn254.go:130-208):
+//   * x^5 + round constant: the constant enters the column accumulators of the last multiplication (C * R) -- free;
+//   * mix row out_i = sum_j m[j][i] s_j: four products in one set of columns, ONE Montgomery reduction;
+//   * partial round: new s_0 likewise (4 products, 1 reduction); s_k += s_0 * S is a multiply with addend.
+// Per permutation: 264 single multiplications/squarings + 88 four-product rows instead of 784 full multiplications.
+// Code-size discipline: the round bodies are short rolled loops over a ROTATING state (s0,s1,s2,s3) <- (s1,s2,s3,f(s0));
+// four trips return the state to its original order, every register index stays static (no scratch) and the loops stay
+// inside the instruction cache.
+GPV_DEV Fr pbn_load(const u32* tab, int idx) { return fr_load(tab, idx); }
+// x^5 (+ c)  (bn254.go:181-185): two squarings and one multiplication
+GPV_DEV Fr pbn_exp5(const Fr& x) {
   Fr x2 = fr_sqr(x);
   Fr x4 = fr_sqr(x2);
   return fr_mul(x4, x);
+}
+GPV_DEV Fr pbn_exp5_add(const Fr& x, const Fr& c) {
+  Fr x2 = fr_sqr(x);
+  Fr x4 = fr_sqr(x2);
+  return fr_mul_add(x4, x, c);
 }
 struct PbnState {
   Fr s0, s1, s2, s3;
@@ -143,23 +145,29 @@ struct PbnState {
 GPV_DEV void pbn_sbox_ark(PbnState& st, int it) {
 #pragma unroll 1
   for (int k = 0; k < 4; k++) {
-    Fr t = pbn_exp5(st.s0);
-    if (it >= 0) t = fr_add(t, pbn_load(PBN_C, it + k));
+    Fr t = it >= 0 ? pbn_exp5_add(st.s0, pbn_load(PBN_C, it + k)) : pbn_exp5(st.s0);
     st.s0 = st.s1;
     st.s1 = st.s2;
     st.s2 = st.s3;
     st.s3 = t;
   }
 }
+// sum_j tab[base + j] * s_j, one reduction. Inputs normalised and < 2.2 r, table entries < r: result < 1.1 r.
+GPV_DEV Fr pbn_dot4(const u32* tab, int base, const Fr& a0, const Fr& a1, const Fr& a2, const Fr& a3) {
+  FrCols c;
+  frc_zero(c);
+  frc_mac(c, a0, pbn_load(tab, base));
+  frc_mac(c, a1, pbn_load(tab, base + 1));
+  frc_mac(c, a2, pbn_load(tab, base + 2));
+  frc_mac(c, a3, pbn_load(tab, base + 3));
+  return frc_reduce(c);
+}
 // mix (bn254.go:194-208): out_i = sum_j m[j][i] s_j; tab holds the transposed matrix, tab[4 i + j] = m[j][i]
 GPV_DEV void pbn_mix(PbnState& st, const u32* tab) {
   Fr r0 = fr_zero(), r1 = fr_zero(), r2 = fr_zero(), r3 = fr_zero();
 #pragma unroll 1
   for (int i = 0; i < 4; i++) {
-    Fr acc = fr_mul(pbn_load(tab, 4 * i), st.s0);
-    acc = fr_add(acc, fr_mul(pbn_load(tab, 4 * i + 1), st.s1));
-    acc = fr_add(acc, fr_mul(pbn_load(tab, 4 * i + 2), st.s2));
-    acc = fr_add(acc, fr_mul(pbn_load(tab, 4 * i + 3), st.s3));
+    Fr acc = pbn_dot4(tab, 4 * i, st.s0, st.s1, st.s2, st.s3);
     r0 = r1;
     r1 = r2;
     r2 = r3;
@@ -170,31 +178,35 @@ GPV_DEV void pbn_mix(PbnState& st, const u32* tab) {
   st.s2 = r2;
   st.s3 = r3;
 }
-// bn254.go:39-45, state in Montgomery form
+// bn254.go:39-45, state in Montgomery form (each element normalised, < 2.2 r on entry)
 GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
   PbnState st;
-  st.s0 = fr_add(s[0], pbn_load(PBN_C, 0));  // ark(0)
-  st.s1 = fr_add(s[1], pbn_load(PBN_C, 1));
-  st.s2 = fr_add(s[2], pbn_load(PBN_C, 2));
-  st.s3 = fr_add(s[3], pbn_load(PBN_C, 3));
+  // ark(0): lazy limb-wise sums (< 2^30 per limb) feed the first squaring directly
+  st.s0 = fr_add_lazy(s[0], pbn_load(PBN_C, 0));
+  st.s1 = fr_add_lazy(s[1], pbn_load(PBN_C, 1));
+  st.s2 = fr_add_lazy(s[2], pbn_load(PBN_C, 2));
+  st.s3 = fr_add_lazy(s[3], pbn_load(PBN_C, 3));
   // first half of the full rounds (bn254.go:130-150, isFirst): 3 x {x^5, ark, mix M}, then x^5, ark(16), mix P
 #pragma unroll 1
   for (int i = 0; i < 4; i++) {
     pbn_sbox_ark(st, (i + 1) * 4);
     pbn_mix(st, i < 3 ? PBN_MT : PBN_PT);
   }
-  // 56 partial rounds (bn254.go:152-169)
+  // 56 partial rounds (bn254.go:152-169). s_1..s_3 grow by < 1.1 r per round; they are shrunk every 8 rounds so that
+  // every operand stays below 10 r.
 #pragma unroll 1
   for (int i = 0; i < 56; i++) {
-    Fr t = fr_add(pbn_exp5(st.s0), pbn_load(PBN_C, 20 + i));
-    Fr n0 = fr_mul(pbn_load(PBN_S, 7 * i), t);
-    n0 = fr_add(n0, fr_mul(pbn_load(PBN_S, 7 * i + 1), st.s1));
-    n0 = fr_add(n0, fr_mul(pbn_load(PBN_S, 7 * i + 2), st.s2));
-    n0 = fr_add(n0, fr_mul(pbn_load(PBN_S, 7 * i + 3), st.s3));
-    st.s1 = fr_add(st.s1, fr_mul(t, pbn_load(PBN_S, 7 * i + 4)));
-    st.s2 = fr_add(st.s2, fr_mul(t, pbn_load(PBN_S, 7 * i + 5)));
-    st.s3 = fr_add(st.s3, fr_mul(t, pbn_load(PBN_S, 7 * i + 6)));
+    Fr t = pbn_exp5_add(st.s0, pbn_load(PBN_C, 20 + i));
+    Fr n0 = pbn_dot4(PBN_S, 7 * i, t, st.s1, st.s2, st.s3);
+    st.s1 = fr_mul_add(t, pbn_load(PBN_S, 7 * i + 4), st.s1);
+    st.s2 = fr_mul_add(t, pbn_load(PBN_S, 7 * i + 5), st.s2);
+    st.s3 = fr_mul_add(t, pbn_load(PBN_S, 7 * i + 6), st.s3);
     st.s0 = n0;
+    if ((i & 7) == 7) {
+      st.s1 = fr_shrink(st.s1);
+      st.s2 = fr_shrink(st.s2);
+      st.s3 = fr_shrink(st.s3);
+    }
   }
   // second half (bn254.go:130-150, !isFirst): 3 x {x^5, ark, mix M}, then x^5, mix M
 #pragma unroll 1

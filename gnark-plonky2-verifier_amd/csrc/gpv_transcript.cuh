@@ -61,31 +61,11 @@ struct DevChallenger {
   // ObserveBN254Hash (challenger.go:62-65): canonical Fr -> 5 words (bn254.go:106-120)
   GPV_DEV void observe_fr(const u64* canon) {
     u64 c[4] = {canon[0], canon[1], canon[2], canon[3]};
-    fr64_reduce(c);
+    fr_words_reduce(c);
     u64 v[5];
     fr_canonical_to_vec(c, v);
 #pragma unroll
     for (int i = 0; i < 5; i++) observe(v[i]);
-  }
-  // a 256-bit value taken mod r (gnark reduces witnesses mod r); 2^256 / r < 6
-  GPV_DEV static void fr64_reduce(u64 c[4]) {
-    const u64 n[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
-    for (int k = 0; k < 5; k++) {
-      u64 d[4];
-      u64 borrow = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        u64 x = c[i] - n[i];
-        u64 b1 = c[i] < n[i];
-        u64 y = x - borrow;
-        u64 b2 = x < borrow;
-        d[i] = y;
-        borrow = b1 | b2;
-      }
-      if (borrow) break;
-#pragma unroll
-      for (int i = 0; i < 4; i++) c[i] = d[i];
-    }
   }
   GPV_DEV void observe_cap(const u64* cap, u32 n) {  // challenger.go:67-71
 #pragma unroll 1
