@@ -38,16 +38,19 @@ FR_MULS_PER_PERM = 784  # poseidon/bn254.go: 8 full rounds x 28 + 56 partial rou
 
 
 def perms_per_proof(ci):
-    """Poseidon-BN254 permutations per proof: per query, per tree ceil(leaf/9) + siblings."""
-    per_q = 0
+    """Poseidon-BN254 permutations per proof as (leaf-digest perms, climb perms): per query and tree
+    ceil(leaf/9) for the leaf digest (k_merkle_leaves) and one per sibling for the climb (k_merkle_climb)."""
+    leaf = climb = 0
     sib = ci.lde_bits - ci.cap_height
     for o in range(4):
-        per_q += (ci.leaf_len(o) + 8) // 9 + sib
+        leaf += (ci.leaf_len(o) + 8) // 9
+        climb += sib
     bits = sib
     for a in ci.arity_bits:
         bits -= a
-        per_q += ((2 << a) + 8) // 9 + bits
-    return per_q * ci.num_query_rounds
+        leaf += ((2 << a) + 8) // 9
+        climb += bits
+    return leaf * ci.num_query_rounds, climb * ci.num_query_rounds
 
 
 def main():
@@ -139,7 +142,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     merkle_ms, merkle_launches = ctx.timing_get(0)
-    stage_ms = {nm: ctx.timing_get(k)[0] for nm, k in (("merkle", 0), ("transcript", 2), ("plonk", 3), ("fri_query", 4), ("range_check", 5))}
+    leaves_ms, _ = ctx.timing_get(7)
+    stage_ms = {nm: ctx.timing_get(k)[0] for nm, k in (("merkle_climb", 0), ("merkle_leaves", 7), ("transcript", 2), ("plonk", 3),
+                                                        ("fri_query", 4), ("range_check", 5))}
     ctx.timing_enable(False)
 
     # ---- correctness of what was timed: accept vector == tamper mask (the oracle agrees on a sample in the tests)
@@ -169,30 +174,36 @@ def main():
                    "collective": "RCCL all_gather of packed accept bits" if world > 1 else "none"},
     }
     if rank == 0:
-        nbytes = len(packed)
-        perms = perms_per_proof(ci)
-        alg_bytes = float(nbytes) * n_local  # the packed record is read once per proof
+        leaf_perms, climb_perms = perms_per_proof(ci)
+        perms = climb_perms
+        # dominant kernel = k_merkle_climb. Its algorithmic bytes per proof: every sibling and cap entry it consumes (the Fr
+        # section of the record, 32 B each) + the leaf digests it reads back (36 B per chain) + the 28 query indices.
+        n_chains = ci.num_query_rounds * (4 + len(ci.arity_bits))
+        n_fr = (3 + len(ci.arity_bits)) * ci.cap_len + climb_perms  # caps + one Fr per sibling
+        alg_bytes_per_proof = 32.0 * n_fr + 36.0 * n_chains + 8.0 * ci.num_query_rounds
+        alg_bytes = alg_bytes_per_proof * n_local
         achieved = alg_bytes / (merkle_ms * 1e-3) / 1e9 if merkle_ms > 0 else 0.0
         # HBM traffic per launch from the PMC passes of the same command (separate rocprofv3 --pmc runs, FETCH_SIZE x2 on
         # gfx950), recorded in profiles/traffic.json; only reported when it was measured on this exact configuration
         traffic = None
         try:
-            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())["k_merkle"]
+            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())["k_merkle_climb"]
             if tj["fixture"] == args.fixture and tj["proofs_per_gpu"] == n_local:
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
-        line["roofline"] = {"bound": "hbm", "kernel": "k_merkle", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        line["roofline"] = {"bound": "hbm", "kernel": "k_merkle_climb", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": merkle_ms, "launches": merkle_launches,
-                            "algorithmic_bytes_per_launch": alg_bytes,
+                            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_proof": alg_bytes_per_proof,
                             "note": "integer-VALU bound workload; see valu_roofline"}
         mad_peak = ctx.microbench(0)
         mads = float(perms) * FR_MULS_PER_PERM * MADS_PER_FR_MUL * n_local
-        line["valu_roofline"] = {"bound": "valu_int32_mad", "kernel": "k_merkle", "achieved": mads / (merkle_ms * 1e-3) / 1e12 if merkle_ms > 0 else 0.0,
+        line["valu_roofline"] = {"bound": "valu_int32_mad", "kernel": "k_merkle_climb", "achieved": mads / (merkle_ms * 1e-3) / 1e12 if merkle_ms > 0 else 0.0,
                                  "peak": mad_peak / 1e12, "unit": "T v_mad_u64_u32 lane-ops/s",
                                  "frac": (mads / (merkle_ms * 1e-3)) / mad_peak if merkle_ms > 0 else 0.0,
                                  "algorithmic_mads_per_proof": float(perms) * FR_MULS_PER_PERM * MADS_PER_FR_MUL,
-                                 "bn254_perms_per_proof": perms}
+                                 "bn254_perms_per_proof": perms, "bn254_leaf_perms_per_proof": leaf_perms,
+                                 "k_merkle_leaves_frac": (float(leaf_perms) * FR_MULS_PER_PERM * MADS_PER_FR_MUL * n_local / (leaves_ms * 1e-3)) / mad_peak if leaves_ms > 0 else 0.0}
         line["stage_ms"] = stage_ms
         if not args.no_poseidon_gl:
             n_states = 1 << 20

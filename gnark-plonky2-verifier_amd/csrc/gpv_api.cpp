@@ -20,7 +20,7 @@
 #include "gpv_launch.h"
 
 // ================================================================ context
-enum { TK_MERKLE = 0, TK_PGL = 1, TK_TRANSCRIPT = 2, TK_PLONK = 3, TK_FRI = 4, TK_RANGE = 5, TK_PBN = 6, TK_COUNT = 7 };
+enum { TK_MERKLE = 0, TK_PGL = 1, TK_TRANSCRIPT = 2, TK_PLONK = 3, TK_FRI = 4, TK_RANGE = 5, TK_PBN = 6, TK_LEAVES = 7, TK_COUNT = 8 };
 
 struct TimingRec {
   int kind;
@@ -31,6 +31,11 @@ struct gpv_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
+  // side stream + events: the latency-bound transcript (and plonk / FRI field work) overlaps the Merkle leaf hashing
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_transcript = nullptr, ev_side_done = nullptr;
+  u32* digests = nullptr;
+  size_t digest_words = 0;
   std::string err;
   bool timing = false;
   std::vector<TimingRec> recs;
@@ -66,16 +71,17 @@ struct Timed {  // brackets one launch with events on the launch stream when tim
   gpv_ctx* ctx;
   TimingRec r;
   bool on;
-  Timed(gpv_ctx* c, int kind) : ctx(c), on(c->timing) {
+  hipStream_t st;
+  Timed(gpv_ctx* c, int kind, hipStream_t stream = nullptr) : ctx(c), on(c->timing), st(stream ? stream : c->stream) {
     if (on) {
       r.kind = kind;
       if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) { on = false; return; }
-      hipEventRecord(r.start, ctx->stream);
+      hipEventRecord(r.start, st);
     }
   }
   ~Timed() {
     if (on) {
-      hipEventRecord(r.stop, ctx->stream);
+      hipEventRecord(r.stop, st);
       ctx->recs.push_back(r);
     }
   }
@@ -126,6 +132,17 @@ extern "C" int gpv_ctx_create(gpv_ctx** out, int device_id) {
     return GPV_EDEVICE;
   }
   ctx->stream = ctx->own_stream;
+  // the side stream carries short, latency-bound kernels: highest priority so they are not starved by the Merkle grids
+  int prio_lo = 0, prio_hi = 0;
+  hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_transcript, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_side_done, hipEventDisableTiming) != hipSuccess) {
+    gpv_set_global_error("side stream / event creation failed on device %d", device_id);
+    delete ctx;
+    return GPV_EDEVICE;
+  }
   *out = ctx;
   return GPV_OK;
 }
@@ -136,6 +153,11 @@ extern "C" int gpv_ctx_destroy(gpv_ctx* ctx) {
   drain_timing(ctx);
   if (ctx->derived) hipFree(ctx->derived);
   if (ctx->fail) hipFree(ctx->fail);
+  if (ctx->digests) hipFree(ctx->digests);
+  if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
+  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_transcript) hipEventDestroy(ctx->ev_transcript);
+  if (ctx->ev_side_done) hipEventDestroy(ctx->ev_side_done);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return GPV_OK;
@@ -210,50 +232,74 @@ static int ensure_scratch(gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->fail, n * sizeof(u32)));
     ctx->fail_n = n;
   }
+  size_t dw = gpvk_merkle_digest_words(c->dc, n);
+  if (dw > ctx->digest_words) {
+    if (ctx->digests) { hipStreamSynchronize(ctx->stream); hipFree(ctx->digests); ctx->digests = nullptr; ctx->digest_words = 0; }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->digests, dw * sizeof(u32)));
+    ctx->digest_words = dw;
+  }
   return GPV_OK;
 }
 
-static int launch_range_check(gpv_ctx* ctx, const DevCircuit* dcd, const void* proofs, size_t n) {
-  Timed t(ctx, TK_RANGE);
-  gpvk_range_check(ctx->stream, dcd, (const u64*)proofs, n, ctx->fail);
-  return GPV_OK;
+static void launch_range_check(gpv_ctx* ctx, hipStream_t st, const DevCircuit* dcd, const void* proofs, size_t n) {
+  Timed t(ctx, TK_RANGE, st);
+  gpvk_range_check(st, dcd, (const u64*)proofs, n, ctx->fail);
 }
-static int launch_transcript(gpv_ctx* ctx, const DevCircuit* dcd, const void* proofs, size_t n) {
-  Timed t(ctx, TK_TRANSCRIPT);
-  gpvk_transcript(ctx->stream, dcd, (const u64*)proofs, n, ctx->derived);
-  return GPV_OK;
+static void launch_transcript(gpv_ctx* ctx, hipStream_t st, const DevCircuit* dcd, const void* proofs, size_t n) {
+  Timed t(ctx, TK_TRANSCRIPT, st);
+  gpvk_transcript(st, dcd, (const u64*)proofs, n, ctx->derived);
 }
-static int launch_plonk(gpv_ctx* ctx, const DevCircuit* dcd, const void* proofs, size_t n) {
-  Timed t(ctx, TK_PLONK);
-  gpvk_plonk(ctx->stream, dcd, (const u64*)proofs,
-                     (const u64*)ctx->derived, n, ctx->fail);
-  return GPV_OK;
+static void launch_plonk(gpv_ctx* ctx, hipStream_t st, const DevCircuit* dcd, const void* proofs, size_t n) {
+  Timed t(ctx, TK_PLONK, st);
+  gpvk_plonk(st, dcd, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->fail);
 }
-static int launch_merkle(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, uint8_t* ok_dev) {
-  Timed t(ctx, TK_MERKLE);
-  gpvk_merkle(ctx->stream, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->fail, ok_dev);
-  return GPV_OK;
+static void launch_merkle_leaves(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n) {
+  Timed t(ctx, TK_LEAVES, st);
+  gpvk_merkle_leaves(st, dcd, c->dc, (const u64*)proofs, n, ctx->digests);
 }
-static int launch_fri_query(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n) {
-  Timed t(ctx, TK_FRI);
-  gpvk_fri_query(ctx->stream, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->fail);
-  return GPV_OK;
+static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n,
+                                uint8_t* ok_dev) {
+  Timed t(ctx, TK_MERKLE, st);
+  gpvk_merkle_climb(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, ctx->fail, ok_dev);
+}
+// both Merkle phases back to back on one stream (entry points with caller-supplied challenges)
+static void launch_merkle(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, uint8_t* ok_dev) {
+  launch_merkle_leaves(ctx, ctx->stream, c, dcd, proofs, n);
+  launch_merkle_climb(ctx, ctx->stream, c, dcd, proofs, n, ok_dev);
+}
+static void launch_fri_query(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n) {
+  Timed t(ctx, TK_FRI, st);
+  gpvk_fri_query(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->fail);
 }
 #define CHECK_LAUNCH(ctx) HIP_TRY(ctx, hipGetLastError())
 
-// full pipeline on device-resident proofs; leaves the failure masks in ctx->fail and the derived values in ctx->derived
+// Full pipeline on device-resident proofs; leaves the failure masks in ctx->fail and the derived values in ctx->derived.
+//
+//   main stream : memset(fail) -> range check -> [fork] -> Merkle leaf digests ------------> [wait T] -> Merkle climb -> [join]
+//   side stream :                              [wait fork] -> transcript -> [T] -> plonk -> FRI queries -> [done]
+//
+// The leaf digests (39 % of the Poseidon-BN254 work) need only the proof bytes, so the latency-bound transcript (one lane
+// per proof, ~130 dependent permutations) and the small field kernels run underneath them instead of in front of them.
 static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n) {
   const DevCircuit* dcd;
   int rc = circuit_on_device(ctx, c, &dcd);
   if (rc != GPV_OK) return rc;
   rc = ensure_scratch(ctx, c, n);
   if (rc != GPV_OK) return rc;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), ctx->stream));
-  launch_range_check(ctx, dcd, proofs_dev, n);
-  launch_transcript(ctx, dcd, proofs_dev, n);
-  launch_merkle(ctx, c, dcd, proofs_dev, n, nullptr);
-  launch_plonk(ctx, dcd, proofs_dev, n);
-  launch_fri_query(ctx, c, dcd, proofs_dev, n);
+  hipStream_t main_st = ctx->stream, side = ctx->side;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), main_st));
+  launch_range_check(ctx, main_st, dcd, proofs_dev, n);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_st));
+  HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
+  launch_transcript(ctx, side, dcd, proofs_dev, n);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_transcript, side));
+  launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n);
+  launch_plonk(ctx, side, dcd, proofs_dev, n);
+  launch_fri_query(ctx, side, c, dcd, proofs_dev, n);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));
+  HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_transcript, 0));
+  launch_merkle_climb(ctx, main_st, c, dcd, proofs_dev, n, nullptr);
+  HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_side_done, 0));
   CHECK_LAUNCH(ctx);
   return GPV_OK;
 }
@@ -489,7 +535,7 @@ extern "C" int gpv_challenges_dev(gpv_ctx* ctx, const gpv_circuit* c, const void
   if (rc != GPV_OK) return rc;
   rc = ensure_scratch(ctx, c, n);
   if (rc != GPV_OK) return rc;
-  launch_transcript(ctx, dcd, proofs_dev, n);
+  launch_transcript(ctx, ctx->stream, dcd, proofs_dev, n);
   const u32 ncw = c->dc.n_challenge_words;
   gpvk_gather_challenges(ctx->stream, (const u64*)ctx->derived,
                      challenges_dev, ncw, n);
@@ -522,7 +568,7 @@ extern "C" int gpv_public_inputs_hash(gpv_ctx* ctx, const gpv_circuit* c, const 
   if (rc != GPV_OK) return rc;
   rc = ensure_scratch(ctx, c, n);
   if (rc != GPV_OK) return rc;
-  launch_transcript(ctx, dcd, hb.proofs.p, n);
+  launch_transcript(ctx, ctx->stream, dcd, hb.proofs.p, n);
   DevBuf<u64> dout;
   HIP_TRY(ctx, dout.alloc(4 * n));
   gpvk_gather_pih(ctx->stream, (const u64*)ctx->derived, dout.p,
@@ -556,7 +602,7 @@ extern "C" int gpv_plonk_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* 
   StageSetup st;
   int rc = st.run(ctx, c, proofs, challenges, n);
   if (rc != GPV_OK) return rc;
-  launch_plonk(ctx, st.dcd, st.hb.proofs.p, n);
+  launch_plonk(ctx, ctx->stream, st.dcd, st.hb.proofs.p, n);
   CHECK_LAUNCH(ctx);
   HIP_TRY(ctx, hipMemcpyAsync(fail_mask, ctx->fail, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -573,7 +619,7 @@ extern "C" int gpv_gate_constraints(gpv_ctx* ctx, const gpv_circuit* c, const vo
   if (rc != GPV_OK) return rc;
   rc = ensure_scratch(ctx, c, n);
   if (rc != GPV_OK) return rc;
-  launch_transcript(ctx, dcd, hb.proofs.p, n);  // for the public-inputs hash
+  launch_transcript(ctx, ctx->stream, dcd, hb.proofs.p, n);  // for the public-inputs hash
   DevBuf<u64> dout;
   const size_t w = 2 * (size_t)c->dc.num_gate_constraints;
   HIP_TRY(ctx, dout.alloc(w * n));
@@ -592,7 +638,7 @@ extern "C" int gpv_fri_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* pr
   int rc = st.run(ctx, c, proofs, challenges, n);
   if (rc != GPV_OK) return rc;
   launch_merkle(ctx, c, st.dcd, st.hb.proofs.p, n, nullptr);
-  launch_fri_query(ctx, c, st.dcd, st.hb.proofs.p, n);
+  launch_fri_query(ctx, ctx->stream, c, st.dcd, st.hb.proofs.p, n);
   CHECK_LAUNCH(ctx);
   HIP_TRY(ctx, hipMemcpyAsync(fail_mask, ctx->fail, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -1,6 +1,6 @@
 // FRI verification on the device.
 //
-//   dev_merkle_chain   one lane = one (proof, query, tree) Merkle path to the cap
+//   dev_merkle_leaf / dev_merkle_climb   one lane = one (proof, query, tree) Merkle path to the cap
 //                      replaces verifyMerkleProofToCapWithCapIndex / verifyInitialProof (fri/fri.go:97-157,472-483)
 //   dev_fri_query      one lane = one (proof, query): everything else in verifyQueryRound
 //                      replaces calculateSubgroupX, friCombineInitial, computeEvaluation, interpolate,
@@ -20,11 +20,15 @@
 #include "gpv_circuit_dev.h"
 #include "gpv_poseidon.cuh"
 
-// ---------------------------------------------------------------- Merkle path (one lane)
-// Returns true iff the path hashes to cap[cap_index].
-GPV_DEV bool dev_merkle_chain(const u64* __restrict__ leaf, u32 leaf_len, const u64* __restrict__ siblings, u32 n_siblings,
-                              u32 index_bits, const u64* __restrict__ cap_entry) {
-  Fr cur = poseidon_bn254_hash_or_noop(leaf, leaf_len);  // fri.go:104
+// ---------------------------------------------------------------- Merkle path (one lane), in two phases
+// Phase 1 (leaf digest) needs only the proof bytes; phase 2 (climb + cap comparison) needs the query index from the
+// Fiat-Shamir transcript. Splitting them lets the latency-bound transcript kernel run concurrently with phase 1.
+GPV_DEV Fr dev_merkle_leaf(const u64* __restrict__ leaf, u32 leaf_len) {
+  return poseidon_bn254_hash_or_noop(leaf, leaf_len);  // fri.go:104
+}
+// Returns true iff the path from `cur` hashes to the cap entry.
+GPV_DEV bool dev_merkle_climb(Fr cur, const u64* __restrict__ siblings, u32 n_siblings, u32 index_bits,
+                              const u64* __restrict__ cap_entry) {
 #pragma unroll 1
   for (u32 i = 0; i < n_siblings; i++) {
     Fr sib = fr_from_canonical64(siblings + 4 * i);

@@ -42,14 +42,42 @@ struct MerkleOrder {
   u32 cls[4 + GPV_MAX_STEPS];  // tree classes, most expensive first
 };
 // One lane per (proof, query, tree). blockIdx.y picks the tree class, so every lane of a wave hashes a leaf of the same
-// length and climbs the same number of levels.
+// length / climbs the same number of levels. Leaf digests travel between the two phases as 9 x u32 redundant limbs,
+// laid out [tree][item][9].
 #define GPV_MERKLE_BLOCK 64
-__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                             const u64* __restrict__ derived, size_t n, MerkleOrder order,
-                                                             u32* __restrict__ fail, uint8_t* __restrict__ ok_out) {
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_leaves(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                    size_t n, MerkleOrder order, u32* __restrict__ digests) {
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries;
-  if (item >= n * nq) return;
+  const size_t items = n * nq;
+  if (item >= items) return;
+  size_t p = item / nq;
+  u32 q = (u32)(item - p * nq);
+  u32 tree = order.cls[blockIdx.y];
+  const u64* rec = proofs + p * (dc->proof_nbytes / 8);
+  const u64* qrec = rec + dc->off_queries + (size_t)q * dc->query_words;
+  const u64* leaf;
+  u32 leaf_len;
+  if (tree < 4) {
+    leaf = qrec + dc->leaf_off[tree];
+    leaf_len = dc->leaf_len[tree];
+  } else {
+    leaf = qrec + dc->step_evals_off[tree - 4];
+    leaf_len = 2u << dc->arity_bits[tree - 4];
+  }
+  Fr d = dev_merkle_leaf(leaf, leaf_len);
+  u32* o = digests + ((size_t)tree * items + item) * FR_LIMBS;
+#pragma unroll
+  for (int k = 0; k < FR_LIMBS; k++) o[k] = d.l[k];
+}
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                   const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                                   const u32* __restrict__ digests, u32* __restrict__ fail,
+                                                                   uint8_t* __restrict__ ok_out) {
+  size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nq = dc->num_queries;
+  const size_t items = n * nq;
+  if (item >= items) return;
   size_t p = item / nq;
   u32 q = (u32)(item - p * nq);
   u32 tree = order.cls[blockIdx.y];
@@ -60,13 +88,10 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle(const DevCircuit* _
   u64 x_index = gl_canon(d[dc->ch_queries + q]);
   u32 idx = (u32)(x_index & (((u64)1 << n_log) - 1));
   u32 cap_index = idx >> (n_log - dc->cap_height);  // fri.go:402, reused for every step (:477-483)
-  const u64* qrec = rec + dc->off_queries + (size_t)q * dc->query_words;
   const u64* qfr = frs + 4 * ((size_t)dc->fr_queries + (size_t)q * dc->query_frs);
-  const u64 *leaf, *sib, *cap;
-  u32 leaf_len, n_sib, bits;
+  const u64 *sib, *cap;
+  u32 n_sib, bits;
   if (tree < 4) {
-    leaf = qrec + dc->leaf_off[tree];
-    leaf_len = dc->leaf_len[tree];
     sib = qfr + 4 * (size_t)(tree * dc->init_siblings);
     n_sib = dc->init_siblings;
     bits = idx;
@@ -75,25 +100,28 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle(const DevCircuit* _
     u32 s = tree - 4;
     u32 shift = 0;
     for (u32 k = 0; k <= s; k++) shift += dc->arity_bits[k];
-    leaf = qrec + dc->step_evals_off[s];
-    leaf_len = 2u << dc->arity_bits[s];
     sib = qfr + 4 * (size_t)dc->step_sib_off[s];
     n_sib = dc->step_siblings[s];
     bits = idx >> shift;
     cap = frs + 4 * (size_t)(dc->fr_commit_caps + (s << dc->cap_height));
   }
-  bool ok = dev_merkle_chain(leaf, leaf_len, sib, n_sib, bits, cap + 4 * cap_index);
+  Fr cur;
+  const u32* din = digests + ((size_t)tree * items + item) * FR_LIMBS;
+#pragma unroll
+  for (int k = 0; k < FR_LIMBS; k++) cur.l[k] = din[k];
+  bool ok = dev_merkle_climb(cur, sib, n_sib, bits, cap + 4 * cap_index);
   if (ok_out) ok_out[item * dc->n_trees + tree] = ok;
   if (!ok) atomicOr(&fail[p], tree < 4 ? (u32)GPV_FAIL_MERKLE_INITIAL : (u32)GPV_FAIL_MERKLE_STEP);
 }
-static MerkleOrder merkle_order(const DevCircuit& c) {
-  // cost of a chain = ceil(leaf_len / 9) + siblings permutations; sort classes by descending cost
+static MerkleOrder merkle_order(const DevCircuit& c, bool leaves) {
+  // cost of a phase-1 chain = ceil(leaf_len / 9) permutations, of a phase-2 chain = number of siblings;
+  // classes are launched most expensive first so that the short ones fill the tail
   MerkleOrder o;
   u32 cost[4 + GPV_MAX_STEPS];
   for (u32 t = 0; t < c.n_trees; t++) {
     u32 len = t < 4 ? c.leaf_len[t] : (2u << c.arity_bits[t - 4]);
     u32 sib = t < 4 ? c.init_siblings : c.step_siblings[t - 4];
-    cost[t] = (len <= 3 ? 0 : (len + 8) / 9) + sib;
+    cost[t] = leaves ? (len <= 3 ? 0 : (len + 8) / 9) : sib;
     o.cls[t] = t;
   }
   for (u32 i = 0; i < c.n_trees; i++)
@@ -101,7 +129,6 @@ static MerkleOrder merkle_order(const DevCircuit& c) {
       if (cost[o.cls[j]] > cost[o.cls[i]]) { u32 t = o.cls[i]; o.cls[i] = o.cls[j]; o.cls[j] = t; }
   return o;
 }
-
 
 void gpvk_poseidon_bn254_permute(hipStream_t st, const u64* in, u64* out, size_t n) {
   hipLaunchKernelGGL(k_poseidon_bn254_permute, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, out, n);
@@ -115,9 +142,15 @@ void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, 
 void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n) {
   hipLaunchKernelGGL(k_poseidon_bn254_to_vec, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, h, out, n);
 }
-void gpvk_merkle(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, u32* fail,
-                 uint8_t* ok_out) {
+size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n) { return n * hc.num_queries * hc.n_trees * FR_LIMBS; }
+void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests) {
   size_t items = n * hc.num_queries;
-  hipLaunchKernelGGL(k_merkle, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
-                     derived, n, merkle_order(hc), fail, ok_out);
+  hipLaunchKernelGGL(k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd,
+                     proofs, n, merkle_order(hc, true), digests);
+}
+void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
+                       const u32* digests, u32* fail, uint8_t* ok_out) {
+  size_t items = n * hc.num_queries;
+  hipLaunchKernelGGL(k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd,
+                     proofs, derived, n, merkle_order(hc, false), digests, fail, ok_out);
 }

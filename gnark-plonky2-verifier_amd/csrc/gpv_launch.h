@@ -22,8 +22,10 @@ void gpvk_poseidon_bn254_permute(hipStream_t st, const u64* in, u64* out, size_t
 void gpvk_poseidon_bn254_hash_or_noop(hipStream_t st, const u64* in, u32 len, u64* out, size_t n);
 void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, u64* out, size_t n);
 void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n);
-void gpvk_merkle(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                 u32* fail, uint8_t* ok_out);
+size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n);  // u32 words of leaf-digest scratch for n proofs
+void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests);
+void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
+                       const u32* digests, u32* fail, uint8_t* ok_out);
 // gpv_k_transcript.hip
 void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u32* fail);
 void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);

@@ -173,8 +173,9 @@ int gpv_merkle_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs
 
 /* ------------------------------------------------------------------ measurement helpers */
 /* Average duration (ms) of the named kernel class over the launches since the last reset, measured with HIP events on
- * the stream the kernels were launched on. kind: 0 = merkle, 1 = poseidon_gl_permute, 2 = transcript, 3 = plonk,
- * 4 = fri_query, 5 = range_check, 6 = poseidon_bn254_permute. Timing is off by default (no event overhead). */
+ * the stream each kernel was launched on. kind: 0 = merkle climb (k_merkle_climb), 1 = poseidon_gl_permute,
+ * 2 = transcript, 3 = plonk, 4 = fri_query, 5 = range_check, 6 = poseidon_bn254_permute, 7 = merkle leaf digests
+ * (k_merkle_leaves). Timing is off by default (no event overhead). */
 int gpv_timing_enable(gpv_ctx* ctx, int on);
 int gpv_timing_reset(gpv_ctx* ctx);
 int gpv_timing_get(gpv_ctx* ctx, int kind, double* avg_ms, uint64_t* launches);
