@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--fixture", default="step", choices=["step", "decode_block"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-poseidon-gl", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the accept all-gather even at world size 1 (test hook)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -73,10 +74,13 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU path in the product)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     import gpv_testlib as T
     gpv = importlib.import_module("gnark-plonky2-verifier_amd")
     D = importlib.import_module("gnark-plonky2-verifier_amd.distributed")
@@ -120,10 +124,10 @@ def main():
 
     def step():
         chip.VerifyDevice(circuit, batch.data_ptr(), n_local, accept.data_ptr())
-        return D.all_gather_accept(accept, n_total) if world > 1 else accept
+        return D.all_gather_accept(accept, n_total, force=args.force_dist) if use_dist else accept
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -137,7 +141,7 @@ def main():
         full = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -171,7 +175,7 @@ def main():
         "config": {"workload": "verifier.VerifierChip.Verify end-to-end (BASELINE config 4 shard)", "fixture": args.fixture,
                    "proofs_per_gpu": n_local, "global_batch": n_total, "queries_per_proof": ci.num_query_rounds,
                    "merkle_chains_per_proof": ci.num_query_rounds * (4 + len(ci.arity_bits)), "parallelism": "proof-sharded x%d" % world,
-                   "collective": "RCCL all_gather of packed accept bits" if world > 1 else "none"},
+                   "collective": "RCCL all_gather of packed accept bits" if use_dist else "none"},
     }
     if rank == 0:
         leaf_perms, climb_perms = perms_per_proof(ci)
@@ -238,10 +242,17 @@ def main():
             assert (oacc == expect[:n_sample]).all()
             line["cpu_baseline"] = {"value": n_sample / dt, "unit": "proofs/s", "cores": cores, "kind": "port",
                                     "sample": "first %d proofs of the same batch, C++ restatement of the reference algorithm (oracle/), %d threads" % (n_sample, cores)}
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; flush it first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -56,6 +56,13 @@ def lib():
     if _lib is None:
         if not LIB_PATH.exists():
             raise DeviceError(GPV_EDEVICE, "%s not built -- run __graft_entry__.build() (hipcc, gfx950)" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if libgpv pulled in the system copy first,
+        # torch would later fail with "No HIP GPUs are available". Loading torch first makes both share torch's runtime.
+        # (C/C++/Go hosts without torch simply use the system ROCm runtime.)
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = ctypes.CDLL(str(LIB_PATH))
         vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
         L.gpv_ctx_create.argtypes = [ctypes.POINTER(vp), i32]

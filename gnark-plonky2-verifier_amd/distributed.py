@@ -32,11 +32,11 @@ def unpack_accept_bits(packed_u8, m):
     return bits.view(-1)[:m].to(torch.uint8)
 
 
-def all_gather_accept(accept_local, n_total, group=None):
+def all_gather_accept(accept_local, n_total, group=None, force=False):
     """accept_local: uint8 tensor of this rank's block (on the GPU for RCCL, CPU for gloo). Returns uint8 [n_total] on
     the same device, identical on every rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not force:
         return accept_local.clone()
     max_block = (n_total + world - 1) // world
     nbytes = (max_block + 7) // 8

@@ -324,3 +324,58 @@ def test_microbench_reports(gpv, api):
     rates = {nm: api.microbench(i) for i, nm in enumerate(names)}
     print("\nlane-ops/s:", {k: "%.3e" % v for k, v in rates.items()})
     assert all(v > 1e11 for v in rates.values())
+
+
+# ---------------------------------------------------------------- full-size configurations (BASELINE.json configs 3 and 5)
+def test_fri_full_size_config3(gpv, api, orc):
+    """fri.VerifyFriProof, 28 queries x 4096 `step` proofs (114 688 query rounds): the accept vector must equal the tamper
+    mask (size-independent property) and a 48-proof sample must match the oracle's failure masks bit for bit."""
+    common, vo, circuit, proofs = _load(gpv, "step")
+    ci, packed, _ = T.load_fixture("step")
+    oc = orc.circuit(ci)
+    n = 4096
+    batch, tampered = T.synthetic_batch(ci, packed, n, seed=7, tamper_every=16)
+    ch1 = orc.challenges(oc, packed)
+    chs = np.tile(ch1, (n, 1))
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    mask = gpv.fri.NewChip(api, common).VerifyFriProof(pb, chs)
+    assert ((mask != 0) == tampered).all()
+    idx = np.concatenate([np.nonzero(tampered)[0][:24], np.nonzero(~tampered)[0][:24]])
+    exp = orc.fri_verify(oc, batch[idx], chs[idx])
+    assert mask[idx].tolist() == [int(x) for x in exp]
+
+
+def test_merkle_full_size_config5(gpv, api, orc):
+    """Poseidon-BN254 Merkle paths only, 4096 `decode_block` proofs x 168 chains (688 128 chains, 10.7 M permutations)."""
+    common, vo, circuit, proofs = _load(gpv, "decode_block")
+    ci, packed, _ = T.load_fixture("decode_block")
+    oc = orc.circuit(ci)
+    n = 4096
+    batch, tampered = T.synthetic_batch(ci, packed, n, seed=9, tamper_every=16)
+    ch1 = orc.challenges(oc, packed)
+    chs = np.tile(ch1, (n, 1))
+    ok = gpv.fri.NewChip(api, common).VerifyMerkleProofsToCap(gpv.variables.ProofBatch(circuit, batch), chs)
+    assert ok.shape == (n, 28, 6)
+    bad = ~ok.reshape(n, -1).all(axis=1)
+    assert (bad == tampered).all()          # every flipped bit of a query section sits in exactly one leaf
+    assert (ok.reshape(n, -1).sum(axis=1)[tampered] == 167).all()
+    idx = np.nonzero(tampered)[0][:16]
+    assert (ok[idx] == orc.merkle_chains(oc, batch[idx], chs[idx])).all()
+
+
+def test_bench_collective_path_single_rank():
+    """bench.py's multi-GPU code path (RCCL init, barrier, packed-bit all_gather, max-reduce of the time) on one rank."""
+    import json as _json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(T.ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--proofs-per-gpu",
+                          "512", "--force-dist", "--no-cpu-baseline", "--no-poseidon-gl"], capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    json_lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(json_lines) == 1, out.stdout + out.stderr
+    line = _json.loads(json_lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["collective"].startswith("RCCL")
