@@ -111,8 +111,8 @@ GPV_DEV Fr frc_reduce(FrCols& c) {
 }
 
 // ---------------------------------------------------------------- composite operations
-// a * b / R (mod r). Operands: normalised or lazy sums of two normalised values; value bound a*b < 2^7 r R keeps the result
-// below 2 r, which every caller satisfies (operands stay below ~10 r).
+// a * b / R (mod r). Operands: normalised or lazy sums of two normalised values, any value < 2^261; the result is
+// < a*b/R + r (e.g. < 2 r when a*b < 168 r^2).
 GPV_DEV Fr fr_mul(const Fr& a, const Fr& b) {
   FrCols c;
   frc_zero(c);

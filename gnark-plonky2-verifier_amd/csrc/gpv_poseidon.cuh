@@ -192,8 +192,10 @@ GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
     pbn_sbox_ark(st, (i + 1) * 4);
     pbn_mix(st, i < 3 ? PBN_MT : PBN_PT);
   }
-  // 56 partial rounds (bn254.go:152-169). s_1..s_3 grow by < 1.1 r per round; they are shrunk every 8 rounds so that
-  // every operand stays below 10 r.
+  // 56 partial rounds (bn254.go:152-169). s_1..s_3 are never reduced below their running bound: each round adds
+  // < 1.02 r (t < 2.2 r times a table entry < r, divided by R, plus the reduction's own < r), so after 56 rounds they are
+  // < 60 r < 2^260 -- representable (R = 2^261 = 168.9 r), limbs normalised by every reduction, and the four-product rows
+  // stay below (2.2 + 3*60) r^2 / R + r < 2.1 r. The next S-box brings them back under 1.3 r.
 #pragma unroll 1
   for (int i = 0; i < 56; i++) {
     Fr t = pbn_exp5_add(st.s0, pbn_load(PBN_C, 20 + i));
@@ -202,11 +204,6 @@ GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
     st.s2 = fr_mul_add(t, pbn_load(PBN_S, 7 * i + 5), st.s2);
     st.s3 = fr_mul_add(t, pbn_load(PBN_S, 7 * i + 6), st.s3);
     st.s0 = n0;
-    if ((i & 7) == 7) {
-      st.s1 = fr_shrink(st.s1);
-      st.s2 = fr_shrink(st.s2);
-      st.s3 = fr_shrink(st.s3);
-    }
   }
   // second half (bn254.go:130-150, !isFirst): 3 x {x^5, ark, mix M}, then x^5, mix M
 #pragma unroll 1
