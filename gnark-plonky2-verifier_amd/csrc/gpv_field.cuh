@@ -50,6 +50,31 @@ GPV_DEV u64 gl_muladd(u64 a, u64 b, u64 c) {
   return gl_reduce128(s, hi);
 }
 GPV_DEV u64 gl_sqr(u64 a) { return gl_mul(a, a); }
+
+// ---- non-canonical ("any u64 representative") variants for long multiplication chains.
+// A 128 -> 64 reduction whose result is only required to be SOME u64 congruent to the input skips the final
+// compare/subtract, and a product accepts any u64 operands; callers canonicalise once at the end (gl_canon).
+// V = lo + hl*(2^32-1) - hh lies in (-2^32, 2^65); with wrapping arithmetic the result is (V mod 2^64) + (c - b)(2^32-1)
+// where c / b flag the wrap of the addition / subtraction: at most one of the two corrections applies.
+GPV_DEV u64 gl_reduce128_nc(u64 lo, u64 hi) {
+  u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+  u64 r1 = (u64)hl * (u32)GLEPS + lo;
+  bool c = r1 < lo;
+  u64 r2 = r1 - hh;
+  bool b = r1 < hh;
+  u64 d = c == b ? 0 : (c ? GLEPS : (0 - GLEPS));
+  return r2 + d;
+}
+// a * b for any u64 operands -> any-u64 result (explicit 32x32 products: the compiler emits 4 v_mad_u64_u32 + glue)
+GPV_DEV u64 gl_mul_nc(u64 a, u64 b) {
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 p00 = (u64)a0 * b0;
+  u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+  u64 p10 = (u64)a1 * b0 + (u32)p01;
+  u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+  u64 lo = (p10 << 32) | (u32)p00;
+  return gl_reduce128_nc(lo, p11);
+}
 GPV_DEV u64 gl_sqr_n(u64 a, int n) {
   for (int i = 0; i < n; i++) a = gl_sqr(a);
   return a;

@@ -11,14 +11,8 @@
 #include "gpv_fr.cuh"
 
 // ================================================================ Poseidon-Goldilocks
-// x^7 (goldilocks.go:138-145): 4 multiplications
-GPV_DEV u64 pgl_sbox(u64 x) {
-  u64 x2 = gl_sqr(x);
-  u64 x3 = gl_mul(x, x2);
-  u64 x6 = gl_sqr(x3);
-  return gl_mul(x, x6);
-}
-
+// The two canonical-form layers below serve the extension-field PoseidonGate / PoseidonMdsGate evaluators (gpv_plonk.cuh),
+// which must follow the reference's fast-round structure because the gate constrains its intermediate wires.
 // MDS layer (goldilocks.go:172-216): row r = sum_i v[(i+r) mod 12] * CIRC[i] + v[r] * DIAG[r], DIAG = [8, 0, ...].
 // The coefficients are < 2^6, so each 64-bit word is split into 32-bit halves and the two half-sums (< 2^42 each)
 // are recombined with a single reduction: lo + hi * 2^32.
@@ -49,12 +43,6 @@ GPV_DEV void pgl_mds(u64 s[12]) {
   }
 }
 
-GPV_DEV void pgl_full_round(u64 s[12], int round) {
-#pragma unroll
-  for (int i = 0; i < 12; i++) s[i] = pgl_sbox(gl_add(s[i], PGL_ARC[12 * round + i]));
-  pgl_mds(s);
-}
-
 // goldilocks.go:251-275
 GPV_DEV void pgl_partial_init(u64 s[12]) {
   u64 r[12];
@@ -81,39 +69,80 @@ GPV_DEV void pgl_partial_init(u64 s[12]) {
   for (int i = 0; i < 12; i++) s[i] = r[i];
 }
 
-// goldilocks.go:300-331
-GPV_DEV void pgl_partial_round(u64 s[12], int r) {
-  u64 s0 = gl_add(pgl_sbox(s[0]), PGL_PRC[r]);
-  // d = s0 * 25 + sum_{i>=1} s[i] * W_HAT[r][i-1]
-  u64 lo = s0 * 25, hi = __umul64hi(s0, 25), ov = 0;
-#pragma unroll
-  for (int i = 1; i < 12; i++) {
-    u64 m = PGL_WHAT[r * 11 + i - 1];
-    u64 pl = s[i] * m, ph = __umul64hi(s[i], m);
-    lo += pl;
-    u64 c = lo < pl;
-    hi += ph;
-    ov += hi < ph;
-    hi += c;
-    ov += hi < c;
-  }
-  u64 d = gl_sub(gl_reduce128(lo, hi), ov << 32);  // 2^128 = -2^32 (mod p)
-#pragma unroll
-  for (int i = 1; i < 12; i++) s[i] = gl_muladd(s0, PGL_VS[r * 11 + i - 1], s[i]);
-  s[0] = d;
+// ---- the permutation used everywhere except inside PoseidonGate
+// goldilocks.go:30-37 evaluates the 22 partial rounds in plonky2's "fast" form (pgl_partial_init above and
+// W_HATS / VS rounds: 22 full 64-bit multiplications per round, each with its own 128 -> 64 reduction). That form exists to save
+// multiplications on a CPU. On gfx950 the textbook form of the SAME permutation is cheaper: a partial round is
+// "add 12 round constants, x^7 on lane 0, full MDS", and an MDS row with coefficients < 2^6 is 26 multiply-adds that
+// reduce ONCE (measured: 690 vs 892 + 155 instructions per partial round). Both forms give identical outputs -- the fast
+// tables are derived from these round constants -- which the parity tests confirm against the oracle's fast form.
+// Intermediates are non-canonical u64 representatives; the next round's constants ride inside the MDS row sums.
+GPV_DEV u64 pgl_sbox_nc(u64 x) {
+  u64 x2 = gl_mul_nc(x, x);
+  u64 x3 = gl_mul_nc(x, x2);
+  u64 x6 = gl_mul_nc(x3, x3);
+  return gl_mul_nc(x, x6);
 }
-
+template <bool ADD_RC>
+GPV_DEV void pgl_mds_nc(u64 s[12], const u64* rc) {
+  constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
+  }
+#pragma unroll
+  for (int r = 0; r < 12; r++) {
+    u64 sl = 0, sh = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      sl += (u64)lo[(i + r) % 12] * C[i];
+      sh += (u64)hi[(i + r) % 12] * C[i];
+    }
+    if (r == 0) {
+      sl += (u64)lo[0] * 8;
+      sh += (u64)hi[0] * 8;
+    }
+    u64 l = sl + (sh << 32);
+    u64 h = (sh >> 32) + (l < sl);
+    if (ADD_RC) {
+      u64 l2 = l + rc[r];
+      h += l2 < l;
+      l = l2;
+    }
+    s[r] = gl_reduce128_nc(l, h);
+  }
+}
 // goldilocks.go:30-37. Canonical in, canonical out.
 GPV_DEV void poseidon_gl_permute(u64 s[12]) {
-#pragma unroll 1
-  for (int r = 0; r < 4; r++) pgl_full_round(s, r);
 #pragma unroll
-  for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PGL_FIRST[i]);
-  pgl_partial_init(s);
+  for (int i = 0; i < 12; i++) {  // first round constants; canonical + canonical < 2^65: one wrap correction
+    u64 a = s[i], t = a + PGL_ARC[i];
+    s[i] = t < a ? t + GLEPS : t;
+  }
 #pragma unroll 1
-  for (int r = 0; r < 22; r++) pgl_partial_round(s, r);
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = pgl_sbox_nc(s[i]);
+    pgl_mds_nc<true>(s, PGL_ARC + 12 * (r + 1));
+  }
 #pragma unroll 1
-  for (int r = 0; r < 4; r++) pgl_full_round(s, 26 + r);
+  for (int r = 4; r < 26; r++) {
+    s[0] = pgl_sbox_nc(s[0]);
+    pgl_mds_nc<true>(s, PGL_ARC + 12 * (r + 1));
+  }
+#pragma unroll 1
+  for (int r = 26; r < 29; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = pgl_sbox_nc(s[i]);
+    pgl_mds_nc<true>(s, PGL_ARC + 12 * (r + 1));
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = pgl_sbox_nc(s[i]);
+  pgl_mds_nc<false>(s, nullptr);
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
 
 // ================================================================ Poseidon-BN254
