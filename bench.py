@@ -33,6 +33,10 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# v_mad_u64_u32 issues on half of the SIMD-32 lanes per clock (measured: half the v_add_u32 rate, profiles/r01a_microbench.txt):
+# 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz (max clock, MI355X_MICROARCH.md). The in-run microbenchmark is reported next to it;
+# it is DVFS-sensitive (a pure multiply stream throttles harder than the kernel does), so it is not used as the denominator.
+MAD_PEAK_MODEL = 256 * 4 * 16 * 2.4e9
 MADS_PER_FR_MUL = 136  # 8x8 product + 8x8 reduction + 8 "m" multiplies (CIOS, 32-bit limbs)
 FR_MULS_PER_PERM = 784  # poseidon/bn254.go: 8 full rounds x 28 + 56 partial rounds x 10
 
@@ -200,11 +204,13 @@ def main():
                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": merkle_ms, "launches": merkle_launches,
                             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_proof": alg_bytes_per_proof,
                             "note": "integer-VALU bound workload; see valu_roofline"}
-        mad_peak = ctx.microbench(0)
+        mad_measured = max(ctx.microbench(0) for _ in range(3))
+        mad_peak = MAD_PEAK_MODEL
         mads = float(perms) * FR_MULS_PER_PERM * MADS_PER_FR_MUL * n_local
         line["valu_roofline"] = {"bound": "valu_int32_mad", "kernel": "k_merkle_climb", "achieved": mads / (merkle_ms * 1e-3) / 1e12 if merkle_ms > 0 else 0.0,
                                  "peak": mad_peak / 1e12, "unit": "T v_mad_u64_u32 lane-ops/s",
                                  "frac": (mads / (merkle_ms * 1e-3)) / mad_peak if merkle_ms > 0 else 0.0,
+                                 "peak_definition": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz", "peak_microbench_this_run": mad_measured / 1e12,
                                  "algorithmic_mads_per_proof": float(perms) * FR_MULS_PER_PERM * MADS_PER_FR_MUL,
                                  "bn254_perms_per_proof": perms, "bn254_leaf_perms_per_proof": leaf_perms,
                                  "k_merkle_leaves_frac": (float(leaf_perms) * FR_MULS_PER_PERM * MADS_PER_FR_MUL * n_local / (leaves_ms * 1e-3)) / mad_peak if leaves_ms > 0 else 0.0}
