@@ -151,7 +151,8 @@ GPV_DEV void poseidon_gl_permute(u64 s[12]) {
 //   * x^5 + round constant: the constant enters the column accumulators of the last multiplication (C * R) -- free;
 //   * mix row out_i = sum_j m[j][i] s_j: four products in one set of columns, ONE Montgomery reduction;
 //   * partial round: new s_0 likewise (4 products, 1 reduction); s_k += s_0 * S is a multiply with addend.
-// Per permutation: 264 single multiplications/squarings + 88 four-product rows instead of 784 full multiplications.
+// Per permutation: 264 single multiplications/squarings, 60 four-product rows, 28 five-product rows and 84 two-product
+// updates: 436 Montgomery reductions instead of 784.
 // Code-size discipline: the round bodies are short rolled loops over a ROTATING state (s0,s1,s2,s3) <- (s1,s2,s3,f(s0));
 // four trips return the state to its original order, every register index stays static (no scratch) and the loops stay
 // inside the instruction cache.
@@ -221,18 +222,50 @@ GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
     pbn_sbox_ark(st, (i + 1) * 4);
     pbn_mix(st, i < 3 ? PBN_MT : PBN_PT);
   }
-  // 56 partial rounds (bn254.go:152-169). s_1..s_3 are never reduced below their running bound: each round adds
-  // < 1.02 r (t < 2.2 r times a table entry < r, divided by R, plus the reduction's own < r), so after 56 rounds they are
-  // < 60 r < 2^260 -- representable (R = 2^261 = 168.9 r), limbs normalised by every reduction, and the four-product rows
-  // stay below (2.2 + 3*60) r^2 / R + r < 2.1 r. The next S-box brings them back under 1.3 r.
+  // 56 partial rounds (bn254.go:152-169), evaluated two at a time. The reference updates s_k += t * S[7i+3+k] every round
+  // (three Montgomery reductions); here rounds A = 2w and B = 2w + 1 share them: round B's row uses the window's base
+  // values b_k and the precomputed cross constant X_w = sum_k S[7B+k] S[7A+3+k] (tools/gen_constants.py), and
+  // b_k <- b_k + t_A S[7A+3+k] + t_B S[7B+3+k] is reduced once. 11 instead of 14 reductions per two rounds, exact in F_r.
+  // Bounds: s_1..s_3 are never reduced below their running bound -- each round adds < 1.02 r, so after 56 rounds they are
+  // < 60 r < 2^260 (R = 2^261 = 168.9 r); limbs are normalised by every reduction; the 5-product row stays below
+  // (2 * 2.2 + 3 * 60) r^2 / R + r < 2.1 r and its columns below 45 * 2^58 + 9 * 2^58 < 2^63.8.
 #pragma unroll 1
-  for (int i = 0; i < 56; i++) {
-    Fr t = pbn_exp5_add(st.s0, pbn_load(PBN_C, 20 + i));
-    Fr n0 = pbn_dot4(PBN_S, 7 * i, t, st.s1, st.s2, st.s3);
-    st.s1 = fr_mul_add(t, pbn_load(PBN_S, 7 * i + 4), st.s1);
-    st.s2 = fr_mul_add(t, pbn_load(PBN_S, 7 * i + 5), st.s2);
-    st.s3 = fr_mul_add(t, pbn_load(PBN_S, 7 * i + 6), st.s3);
-    st.s0 = n0;
+  for (int w = 0; w < 28; w++) {
+    const int a = 2 * w, b = 2 * w + 1;
+    Fr ta = pbn_exp5_add(st.s0, pbn_load(PBN_C, 20 + a));
+    Fr s0a = pbn_dot4(PBN_S, 7 * a, ta, st.s1, st.s2, st.s3);
+    Fr tb = pbn_exp5_add(s0a, pbn_load(PBN_C, 20 + b));
+    {
+      FrCols c;
+      frc_zero(c);
+      frc_mac(c, tb, pbn_load(PBN_S, 7 * b));
+      frc_mac(c, st.s1, pbn_load(PBN_S, 7 * b + 1));
+      frc_mac(c, st.s2, pbn_load(PBN_S, 7 * b + 2));
+      frc_mac(c, st.s3, pbn_load(PBN_S, 7 * b + 3));
+      frc_mac(c, ta, pbn_load(PBN_X, w));
+      st.s0 = frc_reduce(c);
+    }
+    {
+      FrCols c;
+      frc_init_addend(c, st.s1);
+      frc_mac(c, ta, pbn_load(PBN_S, 7 * a + 4));
+      frc_mac(c, tb, pbn_load(PBN_S, 7 * b + 4));
+      st.s1 = frc_reduce(c);
+    }
+    {
+      FrCols c;
+      frc_init_addend(c, st.s2);
+      frc_mac(c, ta, pbn_load(PBN_S, 7 * a + 5));
+      frc_mac(c, tb, pbn_load(PBN_S, 7 * b + 5));
+      st.s2 = frc_reduce(c);
+    }
+    {
+      FrCols c;
+      frc_init_addend(c, st.s3);
+      frc_mac(c, ta, pbn_load(PBN_S, 7 * a + 6));
+      frc_mac(c, tb, pbn_load(PBN_S, 7 * b + 6));
+      st.s3 = frc_reduce(c);
+    }
   }
   // second half (bn254.go:130-150, !isFirst): 3 x {x^5, ark, mix M}, then x^5, mix M
 #pragma unroll 1
