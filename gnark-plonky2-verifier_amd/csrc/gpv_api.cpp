@@ -1,10 +1,12 @@
-// libgpv.so -- kernels, launch logic and the C ABI of include/gpv.h.  gfx950 only.
+// libgpv.so -- host side of the C ABI of include/gpv.h: contexts, scratch, stream orchestration, entry points.
+// The kernels live in the gpv_k_*.hip translation units (launch interface: gpv_launch.h). gfx950 only.
 //
 // Kernel map (what each launch replaces in the reference):
 //   k_range_check        VerifierChip.rangeCheckProof            verifier/verifier.go:84-141 (coalesced HBM stream)
 //   k_transcript         GetPublicInputsHash + GetChallenges     verifier/verifier.go:41-82, challenger/challenger.go
 //   k_plonk              PlonkChip.Verify                        plonk/plonk.go:209-250 + plonk/gates/*
-//   k_merkle             verifyMerkleProofToCapWithCapIndex      fri/fri.go:97-157, :472-483   <- 97 % of the arithmetic
+//   k_merkle_leaves      HashOrNoop of every Merkle leaf         fri/fri.go:104, poseidon/bn254.go:47-94
+//   k_merkle_climb       sibling paths + cap comparison          fri/fri.go:105-157, :472-483   <- dominant kernel
 //   k_fri_query          verifyQueryRound minus the Merkle paths fri/fri.go:386-498, PoW :75-80
 //   k_finalize           "circuit satisfiable" -> accept byte
 // plus primitive kernels that expose the chip-level operators for parity tests and the Poseidon-GL benchmark.

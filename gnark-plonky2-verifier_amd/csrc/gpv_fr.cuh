@@ -132,12 +132,6 @@ GPV_DEV Fr fr_mul_add(const Fr& a, const Fr& b, const Fr& x) {
   frc_mac(c, a, b);
   return frc_reduce(c);
 }
-// bring a value of any size below ~1.1 r (multiply by the Montgomery one)
-GPV_DEV Fr fr_shrink(const Fr& a) {
-  const Fr one = {FR29_ONE_INIT};
-  return fr_mul(a, one);
-}
-
 // ---------------------------------------------------------------- conversions
 // 256-bit little-endian words -> 9 limbs (no reduction: any value < 2^256 < 6 r is a legal operand)
 GPV_DEV Fr fr_limbs_from_words(const u64 x[4]) {

@@ -379,3 +379,87 @@ def test_bench_collective_path_single_rank():
     assert len(json_lines) == 1, out.stdout + out.stderr
     line = _json.loads(json_lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["collective"].startswith("RCCL")
+
+
+# ---------------------------------------------------------------- differential tests on random records
+def _random_records(ci, nbytes, n, rng, canonical=True):
+    """n packed records of random field elements (not valid proofs): every stage runs on arbitrary data."""
+    n_words = nbytes // 8
+    n_fr = (nbytes - 8 * _n_gl_words(ci)) // 32
+    recs = np.zeros((n, n_words), dtype=np.uint64)
+    g = _n_gl_words(ci)
+    recs[:, :g] = rand_gl(rng, (n, g))
+    frs = rand_fr(rng, n * n_fr).reshape(n, n_fr * 4)
+    recs[:, g:] = frs
+    return recs
+
+
+def _n_gl_words(ci):
+    n_open = 2 * (ci.num_constants + ci.num_routed_wires + ci.num_wires + 2 * ci.num_challenges
+                  + ci.num_challenges * ci.num_partial_products + ci.num_challenges * ci.quotient_degree_factor)
+    qwords = sum(ci.leaf_len(o) for o in range(4)) + sum(2 << a for a in ci.arity_bits)
+    return n_open + ci.num_query_rounds * qwords + 2 * ci.final_poly_len + 1 + ci.num_public_inputs
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_random_records_differential(gpv, api, orc, name):
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    assert 8 * _n_gl_words(ci) + 32 * ((len(packed) - 8 * _n_gl_words(ci)) // 32) == len(packed)
+    rng = np.random.default_rng(2024)
+    n = 48
+    recs = _random_records(ci, len(packed), n, rng)
+    # keep the selector constants of a few records equal to real gate rows so that filters are exercised with 0 and non-0
+    recs[:8, 0] = np.arange(8, dtype=np.uint64)
+    recs[:8, 1] = 0
+    # public inputs are not range-checked: feed non-canonical ones (reduced before hashing, goldilocks.go:76-78)
+    if ci.num_public_inputs:
+        recs[1, _n_gl_words(ci) - 1] = np.uint64(2**64 - 1)
+    pb = gpv.variables.ProofBatch(circuit, recs.tobytes())
+    chip = gpv.verifier.NewVerifierChip(api, common)
+    accept, mask, ch = chip.Verify(pb, vo, detail=True)
+    oacc, ofail, och = orc.verify(oc, recs.tobytes(), n_threads=8)
+    assert (ch.flat == och).all()
+    assert accept.tolist() == oacc.tolist() and accept.sum() == 0
+    assert mask.tolist() == [int(x) for x in ofail]
+    assert (chip.GetPublicInputsHash(pb) == orc.public_inputs_hash(oc, recs.tobytes())).all()
+    plonk = gpv.plonk.NewPlonkChip(api, common)
+    assert (plonk.EvaluateGateConstraints(pb) == orc.gate_constraints(oc, recs.tobytes())).all()
+    # stage entry points with arbitrary (random) challenges
+    rch = rand_gl(rng, och.shape)
+    assert plonk.Verify(pb, rch).tolist() == [int(x) for x in orc.plonk_verify(oc, recs.tobytes(), rch)]
+    fri = gpv.fri.NewChip(api, common)
+    assert fri.VerifyFriProof(pb, rch).tolist() == [int(x) for x in orc.fri_verify(oc, recs.tobytes(), rch)]
+    assert (fri.VerifyMerkleProofsToCap(pb, rch) == orc.merkle_chains(oc, recs.tobytes(), rch)).all()
+
+
+def test_circuit_variant_differential(gpv, api, orc):
+    """A different circuit shape (gate list without PoseidonMdsGate/CosetInterpolationGate, 3 selector groups re-cut,
+    20 query rounds, pow bits 10): ingest, layout and every kernel must follow the circuit description, not the fixtures."""
+    _, _, (common, vo, pj) = T.load_fixture("step")
+    var = json.loads(json.dumps(common))
+    gates = [g for g in var["gates"] if "PoseidonMdsGate" not in g and "CosetInterpolationGate" not in g]
+    var["gates"] = gates
+    var["selectors_info"] = {"selector_indices": [0] * 5 + [1] * 4 + [2] * (len(gates) - 9),
+                             "groups": [{"start": 0, "end": 5}, {"start": 5, "end": 9}, {"start": 9, "end": len(gates)}]}
+    var["num_constants"] = 5
+    var["config"]["fri_config"]["num_query_rounds"] = var["fri_params"]["config"]["num_query_rounds"] = 20
+    var["config"]["fri_config"]["proof_of_work_bits"] = var["fri_params"]["config"]["proof_of_work_bits"] = 10
+    var["num_public_inputs"] = 5
+    ci = T.CircuitInfo(var, vo)
+    circuit = gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(var)), gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)))
+    assert (circuit.describe() == ci.blob()).all()
+    oc = orc.circuit(ci)
+    assert circuit.proof_nbytes == oc.nbytes
+    rng = np.random.default_rng(77)
+    n = 24
+    recs = _random_records(ci, oc.nbytes, n, rng)
+    recs[:12, 0] = np.arange(12, dtype=np.uint64)
+    recs[:12, 1] = 0
+    pb = gpv.variables.ProofBatch(circuit, recs.tobytes())
+    accept, mask, ch = gpv.verifier.NewVerifierChip(api, gpv.types.CommonCircuitData(json.dumps(var))).Verify(pb, None, detail=True)
+    oacc, ofail, och = orc.verify(oc, recs.tobytes(), n_threads=8)
+    assert (ch.flat == och).all()
+    assert mask.tolist() == [int(x) for x in ofail] and accept.tolist() == oacc.tolist()
+    assert (gpv.plonk.NewPlonkChip(api).EvaluateGateConstraints(pb) == orc.gate_constraints(oc, recs.tobytes())).all()
