@@ -15,11 +15,12 @@ GPV_OK, GPV_ESHAPE, GPV_ECONFIG, GPV_EDEVICE, GPV_EINVAL, GPV_ENOMEM = 0, -1, -2
 
 # every symbol include/gpv.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "gpv_ctx_create", "gpv_ctx_destroy", "gpv_ctx_set_stream", "gpv_ctx_synchronize", "gpv_last_error_message",
+    "gpv_ctx_create", "gpv_ctx_destroy", "gpv_ctx_set_stream", "gpv_ctx_set_option", "gpv_ctx_synchronize", "gpv_last_error_message",
     "gpv_circuit_from_json", "gpv_circuit_destroy", "gpv_proof_nbytes", "gpv_num_challenge_words",
     "gpv_num_gate_constraints", "gpv_num_query_rounds", "gpv_num_merkle_trees", "gpv_circuit_describe",
     "gpv_proof_pack_json",
-    "gpv_gl_op", "gpv_gl2_op", "gpv_poseidon_gl_permute", "gpv_poseidon_gl_permute_dev", "gpv_poseidon_gl_hash_no_pad",
+    "gpv_gl_op", "gpv_gl2_op", "gpv_poseidon_gl_permute", "gpv_poseidon_gl_permute_dev", "gpv_poseidon_gl_permute_coop",
+    "gpv_poseidon_gl_permute_coop_dev", "gpv_poseidon_gl_hash_no_pad",
     "gpv_poseidon_bn254_permute", "gpv_poseidon_bn254_permute_dev", "gpv_poseidon_bn254_hash_or_noop",
     "gpv_poseidon_bn254_two_to_one", "gpv_poseidon_bn254_to_vec", "gpv_gate_eval_unfiltered",
     "gpv_public_inputs_hash", "gpv_challenges", "gpv_plonk_verify", "gpv_gate_constraints", "gpv_fri_verify",
@@ -69,6 +70,9 @@ def lib():
         L.gpv_ctx_destroy.argtypes = [vp]
         L.gpv_ctx_set_stream.argtypes = [vp, vp]
         L.gpv_ctx_synchronize.argtypes = [vp]
+        L.gpv_ctx_set_option.argtypes = [vp, i32, i32]
+        L.gpv_poseidon_gl_permute_coop.argtypes = [vp, vp, vp, sz]
+        L.gpv_poseidon_gl_permute_coop_dev.argtypes = [vp, vp, vp, sz]
         L.gpv_last_error_message.argtypes = [vp, ctypes.c_char_p, sz]
         L.gpv_circuit_from_json.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, ctypes.POINTER(vp)]
         L.gpv_circuit_destroy.argtypes = [vp]
@@ -160,6 +164,9 @@ class Context:
 
     def set_stream(self, hip_stream):
         check(lib().gpv_ctx_set_stream(ctypes.c_void_p(self.h), ctypes.c_void_p(hip_stream) if hip_stream else None), self.h)
+
+    def set_option(self, option, value):
+        check(lib().gpv_ctx_set_option(ctypes.c_void_p(self.h), option, value), self.h)
 
     def synchronize(self):
         check(lib().gpv_ctx_synchronize(ctypes.c_void_p(self.h)), self.h)

@@ -38,6 +38,7 @@ struct gpv_ctx {
   hipEvent_t ev_fork = nullptr, ev_transcript = nullptr, ev_side_done = nullptr;
   u32* digests = nullptr;
   size_t digest_words = 0;
+  int transcript_variant = 0;  // GPV_OPT_TRANSCRIPT_VARIANT
   std::string err;
   bool timing = false;
   std::vector<TimingRec> recs;
@@ -169,6 +170,15 @@ extern "C" int gpv_ctx_set_stream(gpv_ctx* ctx, void* hip_stream) {
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   return GPV_OK;
 }
+extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
+  if (!ctx) return GPV_EINVAL;
+  if (option == GPV_OPT_TRANSCRIPT_VARIANT && value >= 0 && value <= 2) {
+    ctx->transcript_variant = value;
+    return GPV_OK;
+  }
+  ctx->err = "unknown option or value";
+  return GPV_EINVAL;
+}
 extern "C" int gpv_ctx_synchronize(gpv_ctx* ctx) {
   if (!ctx) return GPV_EINVAL;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -247,9 +257,17 @@ static void launch_range_check(gpv_ctx* ctx, hipStream_t st, const DevCircuit* d
   Timed t(ctx, TK_RANGE, st);
   gpvk_range_check(st, dcd, (const u64*)proofs, n, ctx->fail);
 }
+// One lane per proof costs the least total work and hides under the leaf hashing for large batches; below
+// GPV_TRANSCRIPT_COOP_BELOW proofs its ~10 ms latency is exposed and the 16-lane cooperative kernel wins
+// (profiles/r01e_batch_sweep.txt, r01f_transcript_variants.txt).
+#define GPV_TRANSCRIPT_COOP_BELOW 4096
 static void launch_transcript(gpv_ctx* ctx, hipStream_t st, const DevCircuit* dcd, const void* proofs, size_t n) {
   Timed t(ctx, TK_TRANSCRIPT, st);
-  gpvk_transcript(st, dcd, (const u64*)proofs, n, ctx->derived);
+  bool coop = ctx->transcript_variant == 2 || (ctx->transcript_variant == 0 && n < GPV_TRANSCRIPT_COOP_BELOW);
+  if (coop)
+    gpvk_transcript_coop(st, dcd, (const u64*)proofs, n, ctx->derived);
+  else
+    gpvk_transcript(st, dcd, (const u64*)proofs, n, ctx->derived);
 }
 static void launch_plonk(gpv_ctx* ctx, hipStream_t st, const DevCircuit* dcd, const void* proofs, size_t n) {
   Timed t(ctx, TK_PLONK, st);
@@ -368,6 +386,16 @@ extern "C" int gpv_poseidon_gl_permute_dev(gpv_ctx* ctx, const uint64_t* states,
   CHECK_LAUNCH(ctx);
   return GPV_OK;
 }
+extern "C" int gpv_poseidon_gl_permute_coop_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && states && out);
+  if (n == 0) return GPV_OK;
+  {
+    Timed t(ctx, TK_PGL);
+    gpvk_poseidon_gl_permute_coop(ctx->stream, states, out, n);
+  }
+  CHECK_LAUNCH(ctx);
+  return GPV_OK;
+}
 extern "C" int gpv_poseidon_bn254_permute_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && states && out);
   if (n == 0) return GPV_OK;
@@ -399,6 +427,10 @@ static int map_host(gpv_ctx* ctx, const uint64_t* in, size_t in_words, uint64_t*
 extern "C" int gpv_poseidon_gl_permute(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && states && out);
   return map_host(ctx, states, 12, out, 12, n, [&](u64* i, u64* o) { return gpv_poseidon_gl_permute_dev(ctx, i, o, n); });
+}
+extern "C" int gpv_poseidon_gl_permute_coop(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && states && out);
+  return map_host(ctx, states, 12, out, 12, n, [&](u64* i, u64* o) { return gpv_poseidon_gl_permute_coop_dev(ctx, i, o, n); });
 }
 extern "C" int gpv_poseidon_gl_hash_no_pad(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && out && (in || len == 0) && len <= 0xFFFFFFFFu);

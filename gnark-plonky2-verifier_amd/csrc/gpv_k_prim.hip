@@ -2,7 +2,7 @@
 // and the instruction-rate microbenchmark that defines the VALU-integer roof.
 #include "../../include/gpv.h"
 #include "gpv_launch.h"
-#include "gpv_poseidon.cuh"
+#include "gpv_poseidon_coop.cuh"
 
 __global__ void k_gl_op(int op, const u64* __restrict__ a, const u64* __restrict__ b, const u64* __restrict__ c,
                         u64* __restrict__ out, size_t n) {
@@ -60,6 +60,17 @@ __global__ __launch_bounds__(256) void k_poseidon_gl_permute(const u64* __restri
     v.y = s[2 * k + 1];
     dst[k] = v;
   }
+}
+// Cooperative variant: 16 lanes per state (gpv_poseidon_coop.cuh); the group's 12 words are one coalesced 96-byte access.
+__global__ __launch_bounds__(256) void k_poseidon_gl_permute_coop(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+  __shared__ u64 lds_rc[360];
+  pgl_coop_stage_constants(lds_rc);
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PGL_COOP_LANES;
+  if (i >= n) return;
+  PglCoop c = pgl_coop_init(lds_rc);
+  u64 x = c.g < 12 ? in[12 * i + c.g] : 0;
+  x = pgl_coop_permute(c, x);
+  if (c.g < 12) out[12 * i + c.g] = x;
 }
 __global__ void k_poseidon_gl_hash_no_pad(const u64* __restrict__ in, u32 len, u64* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,6 +138,9 @@ void gpvk_gl2_op(hipStream_t st, int op, const u64* a, const u64* b, u64* out, u
 }
 void gpvk_poseidon_gl_permute(hipStream_t st, const u64* in, u64* out, size_t n) {
   hipLaunchKernelGGL(k_poseidon_gl_permute, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
+}
+void gpvk_poseidon_gl_permute_coop(hipStream_t st, const u64* in, u64* out, size_t n) {
+  hipLaunchKernelGGL(k_poseidon_gl_permute_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 256)), dim3(256), 0, st, in, out, n);
 }
 void gpvk_poseidon_gl_hash_no_pad(hipStream_t st, const u64* in, u32 len, u64* out, size_t n) {
   hipLaunchKernelGGL(k_poseidon_gl_hash_no_pad, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);

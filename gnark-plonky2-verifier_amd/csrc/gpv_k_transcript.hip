@@ -23,6 +23,16 @@ __global__ __launch_bounds__(64) void k_transcript(const DevCircuit* __restrict_
   const u64* rec = proofs + i * (dc->proof_nbytes / 8);
   dev_transcript(dc, rec, derived + i * (dc->n_challenge_words + GPV_DERIVED_EXTRA));
 }
+// cooperative variant: one 16-lane group per proof, four proofs per wave; round constants staged in LDS
+__global__ __launch_bounds__(64) void k_transcript_coop(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+                                                        u64* __restrict__ derived) {
+  __shared__ u64 lds_rc[360];
+  pgl_coop_stage_constants(lds_rc);
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PGL_COOP_LANES;
+  if (i >= n) return;  // whole 16-lane groups leave together; the others only exchange data inside their own group
+  const u64* rec = proofs + i * (dc->proof_nbytes / 8);
+  dev_transcript_coop(dc, rec, derived + i * (dc->n_challenge_words + GPV_DERIVED_EXTRA), lds_rc);
+}
 // challenges supplied by the caller: fill in the public-inputs hash and the reduced openings only
 __global__ __launch_bounds__(64) void k_derive_extra(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
                                                      u64* __restrict__ derived) {
@@ -79,6 +89,9 @@ void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, 
 }
 void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived) {
   hipLaunchKernelGGL(k_transcript, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
+}
+void gpvk_transcript_coop(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived) {
+  hipLaunchKernelGGL(k_transcript_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
 }
 void gpvk_derive_extra(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived) {
   hipLaunchKernelGGL(k_derive_extra, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived);

@@ -14,6 +14,7 @@ typedef uint64_t u64;
 void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n);
 void gpvk_gl2_op(hipStream_t st, int op, const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n);
 void gpvk_poseidon_gl_permute(hipStream_t st, const u64* in, u64* out, size_t n);
+void gpvk_poseidon_gl_permute_coop(hipStream_t st, const u64* in, u64* out, size_t n);  // 16 lanes per state
 void gpvk_poseidon_gl_hash_no_pad(hipStream_t st, const u64* in, u32 len, u64* out, size_t n);
 void gpvk_microbench(hipStream_t st, int which, u64* out, int blocks, int threads, int iters);
 int gpvk_microbench_ops_per_iter();
@@ -29,6 +30,7 @@ void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& 
 // gpv_k_transcript.hip
 void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u32* fail);
 void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);
+void gpvk_transcript_coop(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);  // 16 lanes per proof
 void gpvk_derive_extra(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);
 void gpvk_finalize(hipStream_t st, const u32* fail, uint8_t* accept, size_t n);
 void gpvk_scatter_challenges(hipStream_t st, const u64* ch, u64* derived, u32 ncw, size_t n);

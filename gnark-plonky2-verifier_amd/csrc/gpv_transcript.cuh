@@ -178,3 +178,118 @@ GPV_DEV void dev_transcript(const DevCircuit* __restrict__ dc, const u64* __rest
   extra[6] = sum.a;
   extra[7] = sum.b;
 }
+
+// ================================================================ cooperative variant (16 lanes per proof)
+// Same values as dev_transcript, ~5x lower latency: used when the batch is too small for the Merkle leaf hashing to hide
+// the one-lane-per-proof transcript (profiles/r01e_batch_sweep.txt). All 16 lanes of a group execute this function with
+// the same arguments; lane 0 of the group writes the results.
+#include "gpv_poseidon_coop.cuh"
+
+GPV_DEV void dev_transcript_coop(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, u64* __restrict__ derived,
+                                 const u64* lds_rc) {
+  const u64* frs = rec + dc->n_gl_words;
+  CoopChallenger ch;
+  ch.init(lds_rc);
+  const bool writer = ch.c.g == 0;
+  // public-inputs hash (goldilocks.go:72-86): overwrite-mode sponge, lane j absorbs input j of each 8-word chunk
+  u64 pih[4];
+  {
+    const u64* pi = rec + dc->off_pi;
+    u32 n = dc->num_pi;
+    u64 x = 0;
+#pragma unroll 1
+    for (u32 i = 0; i < n; i += 8) {
+      u32 j = i + (u32)ch.c.g;
+      if (ch.c.g < 8 && j < n) x = gl_canon(pi[j]);
+      x = pgl_coop_permute(ch.c, x);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) pih[k] = pgl_coop_word(ch.c, x, k);
+  }
+  ch.observe_fr(dc->digest);
+#pragma unroll
+  for (int i = 0; i < 4; i++) ch.observe(pih[i]);
+  const u32 cap_len = 1u << dc->cap_height;
+  ch.observe_cap(frs + 4 * dc->fr_wires_cap, cap_len);
+  const u32 nc = dc->num_challenges;
+  for (u32 i = 0; i < nc; i++) { u64 v = ch.challenge(); if (writer) derived[dc->ch_betas + i] = v; }
+  for (u32 i = 0; i < nc; i++) { u64 v = ch.challenge(); if (writer) derived[dc->ch_gammas + i] = v; }
+  ch.observe_cap(frs + 4 * dc->fr_zs_pp_cap, cap_len);
+  for (u32 i = 0; i < nc; i++) { u64 v = ch.challenge(); if (writer) derived[dc->ch_alphas + i] = v; }
+  ch.observe_cap(frs + 4 * dc->fr_quot_cap, cap_len);
+  {
+    u64 z0 = ch.challenge(), z1 = ch.challenge();
+    if (writer) { derived[dc->ch_zeta] = z0; derived[dc->ch_zeta + 1] = z1; }
+  }
+  OpeningRanges orr = opening_ranges(dc);
+#pragma unroll 1
+  for (u32 w = orr.a0; w < orr.a1; w++) ch.observe(rec[w]);
+#pragma unroll 1
+  for (u32 w = orr.b0; w < orr.b1; w++) ch.observe(rec[w]);
+#pragma unroll 1
+  for (u32 w = orr.c0; w < orr.c1; w++) ch.observe(rec[w]);
+  Ext fri_alpha;
+  fri_alpha.a = ch.challenge();
+  fri_alpha.b = ch.challenge();
+  if (writer) { derived[dc->ch_fri_alpha] = fri_alpha.a; derived[dc->ch_fri_alpha + 1] = fri_alpha.b; }
+#pragma unroll 1
+  for (u32 s = 0; s < dc->num_steps; s++) {
+    ch.observe_cap(frs + 4 * (dc->fr_commit_caps + s * cap_len), cap_len);
+    u64 b0 = ch.challenge(), b1 = ch.challenge();
+    if (writer) { derived[dc->ch_fri_betas + 2 * s] = b0; derived[dc->ch_fri_betas + 2 * s + 1] = b1; }
+  }
+#pragma unroll 1
+  for (u32 w = 0; w < 2 * dc->final_len; w++) ch.observe(rec[dc->off_final + w]);
+  ch.observe(rec[dc->off_pow]);
+  { u64 v = ch.challenge(); if (writer) derived[dc->ch_pow] = v; }
+#pragma unroll 1
+  for (u32 q = 0; q < dc->num_queries; q++) { u64 v = ch.challenge(); if (writer) derived[dc->ch_queries + q] = v; }
+  // public-inputs hash + alpha-reduced openings (fri.go:82-95): the Horner chains are split over the 16 lanes.
+  // Lane j takes the terms with index = j (mod 16): partial_j = sum_m v[j + 16 m] (alpha^16)^m, total = sum_j alpha^j partial_j.
+  u64* extra = derived + dc->n_challenge_words;
+  if (writer) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) extra[i] = pih[i];
+  }
+  Ext a2 = ext_sqr(fri_alpha), a4 = ext_sqr(a2), a8 = ext_sqr(a4), a16 = ext_sqr(a8);
+  // alpha^g by square-and-multiply over the 4 bits of g
+  Ext apow = ext_make(1, 0);
+  if (ch.c.g & 1) apow = ext_mul(apow, fri_alpha);
+  if (ch.c.g & 2) apow = ext_mul(apow, a2);
+  if (ch.c.g & 4) apow = ext_mul(apow, a4);
+  if (ch.c.g & 8) apow = ext_mul(apow, a8);
+  // batch 0 = ranges a then b (fri.go:63-73); term index t counts extension elements
+  const u32 na = (orr.a1 - orr.a0) / 2, nb = (orr.b1 - orr.b0) / 2, n0 = na + nb;
+  Ext part = ext_make(0, 0);
+  {
+    // highest index of this lane's residue class, then step down by 16
+    int t = (int)n0 - 1 - (int)(((n0 - 1) - (u32)ch.c.g) & 15u);
+    if ((u32)ch.c.g > n0 - 1) t = -1;
+#pragma unroll 1
+    for (; t >= 0; t -= 16) {
+      u32 w = (u32)t < na ? orr.a0 + 2 * (u32)t : orr.b0 + 2 * ((u32)t - na);
+      part = ext_muladd(part, a16, ext_make(rec[w], rec[w + 1]));
+    }
+  }
+  Ext contrib = ext_mul(part, apow);
+  // batch 1 = range c (num_challenges elements, <= 4): lane j < nc contributes v_j alpha^j
+  const u32 n1 = (orr.c1 - orr.c0) / 2;
+  Ext contrib1 = ext_make(0, 0);
+  if ((u32)ch.c.g < n1) contrib1 = ext_mul(ext_make(rec[orr.c0 + 2 * ch.c.g], rec[orr.c0 + 2 * ch.c.g + 1]), apow);
+  // sum the 16 contributions (butterfly within the group)
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    int lane = (int)(threadIdx.x & 63);
+    int src = ((lane ^ off)) << 2;
+    Ext o0 = ext_make(pgl_coop_shfl(contrib.a, src), pgl_coop_shfl(contrib.b, src));
+    Ext o1 = ext_make(pgl_coop_shfl(contrib1.a, src), pgl_coop_shfl(contrib1.b, src));
+    contrib = ext_add(contrib, o0);
+    contrib1 = ext_add(contrib1, o1);
+  }
+  if (writer) {
+    extra[4] = contrib.a;
+    extra[5] = contrib.b;
+    extra[6] = contrib1.a;
+    extra[7] = contrib1.b;
+  }
+}

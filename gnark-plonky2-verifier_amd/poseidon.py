@@ -12,15 +12,18 @@ class GoldilocksChip:
     def __init__(self, api=None):
         self.ctx = api or _lib.default_context()
 
-    def Poseidon(self, states):  # goldilocks.go:30 -- [n][12] -> [n][12]
+    def Poseidon(self, states, cooperative=False):  # goldilocks.go:30 -- [n][12] -> [n][12]
+        """cooperative=True runs the 16-lanes-per-state kernel (low latency); default is one lane per state (throughput)."""
         s = _lib.u64c(states).reshape(-1, 12)
         out = np.empty_like(s)
-        _lib.check(_lib.lib().gpv_poseidon_gl_permute(self.ctx.h, _lib.ptr(s), _lib.ptr(out), s.shape[0]), self.ctx.h)
+        fn = _lib.lib().gpv_poseidon_gl_permute_coop if cooperative else _lib.lib().gpv_poseidon_gl_permute
+        _lib.check(fn(self.ctx.h, _lib.ptr(s), _lib.ptr(out), s.shape[0]), self.ctx.h)
         return out
 
-    def PoseidonDevice(self, states_dev_ptr, out_dev_ptr, n):
+    def PoseidonDevice(self, states_dev_ptr, out_dev_ptr, n, cooperative=False):
         """Device-resident batch (e.g. torch tensors' data_ptr()); enqueued on the context's stream."""
-        _lib.check(_lib.lib().gpv_poseidon_gl_permute_dev(self.ctx.h, _lib.ptr(states_dev_ptr), _lib.ptr(out_dev_ptr), n), self.ctx.h)
+        fn = _lib.lib().gpv_poseidon_gl_permute_coop_dev if cooperative else _lib.lib().gpv_poseidon_gl_permute_dev
+        _lib.check(fn(self.ctx.h, _lib.ptr(states_dev_ptr), _lib.ptr(out_dev_ptr), n), self.ctx.h)
 
     def HashNoPad(self, inputs):  # goldilocks.go:72 -- [n][len] -> [n][4]
         x = _lib.u64c(inputs)

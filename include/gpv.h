@@ -86,6 +86,11 @@ int gpv_ctx_destroy(gpv_ctx* ctx);
 /* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own. */
 int gpv_ctx_set_stream(gpv_ctx* ctx, void* hip_stream);
 int gpv_ctx_synchronize(gpv_ctx* ctx);
+/* Tuning knobs. GPV_OPT_TRANSCRIPT_VARIANT: 0 = automatic (by batch size), 1 = one lane per proof (least total work; its
+ * latency hides under the Merkle leaf hashing for batches >= ~4000 proofs), 2 = cooperative, 16 lanes per proof (about
+ * 5x lower latency, 3x the work). Both produce identical challenges. */
+enum { GPV_OPT_TRANSCRIPT_VARIANT = 1 };
+int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value);
 /* Copies the last error text of this context (or of context-free calls when ctx == NULL). */
 int gpv_last_error_message(gpv_ctx* ctx, char* buf, size_t buf_len);
 
@@ -118,6 +123,10 @@ int gpv_gl2_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint6
 /* GoldilocksChip.Poseidon (poseidon/goldilocks.go:30-37): states [n][12] -> out [n][12] */
 int gpv_poseidon_gl_permute(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
 int gpv_poseidon_gl_permute_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
+/* Same permutation, sub-wave cooperative kernel (16 lanes per state, cross-lane MDS, constants staged in LDS): the
+ * low-latency variant used inside the transcript for small batches; one lane per state above is the throughput variant. */
+int gpv_poseidon_gl_permute_coop(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
+int gpv_poseidon_gl_permute_coop_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
 /* GoldilocksChip.HashNoPad (poseidon/goldilocks.go:72-86): in [n][len] -> out [n][4] */
 int gpv_poseidon_gl_hash_no_pad(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n);
 /* BN254Chip.Poseidon (poseidon/bn254.go:39-45): states [n][4][4] -> out [n][4][4] */

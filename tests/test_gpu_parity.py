@@ -106,6 +106,42 @@ def test_poseidon_gl_permute(gpv, api, orc):
     assert (out == orc.poseidon_gl_permute(states)).all()
 
 
+def test_poseidon_gl_cooperative_variant(gpv, api, orc):
+    """The 16-lanes-per-state kernel (north-star sketch) computes the same permutation."""
+    rng = np.random.default_rng(31)
+    for n in (1, 3, 4, 5, 63, 64, 65, 4099):  # partial groups / partial waves / partial blocks
+        states = rand_gl(rng, (n, 12))
+        states[0] = 0
+        out = gpv.poseidon.NewGoldilocksChip(api).Poseidon(states, cooperative=True)
+        assert (out == orc.poseidon_gl_permute(states)).all(), n
+    assert out[0].tolist() == PGL_ZERO_OUT
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_transcript_variants_agree(gpv, api, orc, name, variant):
+    """One lane per proof (1) and 16 lanes per proof (2) derive identical challenges, hashes and reduced openings."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    rng = np.random.default_rng(5 + variant)
+    recs = _random_records(ci, len(packed), 37, rng)  # 37: partial wave, partial group count
+    recs[0] = np.frombuffer(packed, dtype=np.uint64)
+    pb = gpv.variables.ProofBatch(circuit, recs.tobytes())
+    api.set_option(1, variant)
+    try:
+        chip = gpv.verifier.NewVerifierChip(api, common)
+        accept, mask, ch = chip.Verify(pb, vo, detail=True)
+        pih = chip.GetPublicInputsHash(pb)
+    finally:
+        api.set_option(1, 0)
+    oacc, ofail, och = orc.verify(oc, recs.tobytes(), n_threads=8)
+    assert (ch.flat == och).all()
+    assert (pih == orc.public_inputs_hash(oc, recs.tobytes())).all()
+    assert accept.tolist() == oacc.tolist() and accept[0] == 1
+    assert mask.tolist() == [int(x) for x in ofail]  # the reduced openings feed the FRI checks
+
+
 def test_poseidon_gl_hash_no_pad(gpv, api, orc):
     chip = gpv.poseidon.NewGoldilocksChip(api)
     # poseidon/public_inputs_hash_test.go:43-60
