@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "gpv_ctx_create", "gpv_ctx_destroy", "gpv_ctx_set_stream", "gpv_ctx_set_option", "gpv_ctx_synchronize", "gpv_last_error_message",
     "gpv_circuit_from_json", "gpv_circuit_destroy", "gpv_proof_nbytes", "gpv_num_challenge_words",
     "gpv_num_gate_constraints", "gpv_num_query_rounds", "gpv_num_merkle_trees", "gpv_circuit_describe",
-    "gpv_proof_pack_json",
+    "gpv_proof_pack_json", "gpv_proof_pack_json_batch",
     "gpv_gl_op", "gpv_gl2_op", "gpv_poseidon_gl_permute", "gpv_poseidon_gl_permute_dev", "gpv_poseidon_gl_permute_coop",
     "gpv_poseidon_gl_permute_coop_dev", "gpv_poseidon_gl_hash_no_pad",
     "gpv_poseidon_bn254_permute", "gpv_poseidon_bn254_permute_dev", "gpv_poseidon_bn254_hash_or_noop",
@@ -83,6 +83,7 @@ def lib():
         L.gpv_circuit_describe.argtypes = [vp, vp, sz]
         L.gpv_circuit_describe.restype = sz
         L.gpv_proof_pack_json.argtypes = [vp, ctypes.c_char_p, sz, vp]
+        L.gpv_proof_pack_json_batch.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), sz, vp, i32]
         L.gpv_gl_op.argtypes = [vp, i32, vp, vp, vp, vp, sz]
         L.gpv_gl2_op.argtypes = [vp, i32, vp, vp, vp, vp, sz]
         L.gpv_poseidon_gl_permute.argtypes = [vp, vp, vp, sz]

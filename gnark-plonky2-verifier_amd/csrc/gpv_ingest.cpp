@@ -15,8 +15,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <deque>
 #include <map>
 #include <memory>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -33,29 +36,42 @@ void gpv_set_global_error(const char* fmt, ...) {
 const char* gpv_get_global_error() { return g_ingest_error.c_str(); }
 
 // ---------------------------------------------------------------- minimal JSON reader
+// Arena DOM: nodes live in one vector, children are linked by index, numbers and strings are views into the source text
+// (no per-node allocation, so parsing is allocator-free after the arena has grown and scales across threads).
 namespace {
 
-struct JValue;
-typedef std::shared_ptr<JValue> JPtr;
+struct JDoc;
 struct JValue {
-  enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+  enum Kind : uint8_t { Null, Bool, Number, String, Array, Object } kind = Null;
   bool b = false;
-  std::string text;  // Number: raw digits; String: unescaped contents
-  std::vector<JPtr> arr;
-  std::vector<std::pair<std::string, JPtr>> obj;
-  const JValue* get(const char* key) const {
-    for (auto& kv : obj)
-      if (kv.first == key) return kv.second.get();
-    return nullptr;
-  }
+  uint32_t n_children = 0;
+  uint32_t first = 0, next = 0;  // child / sibling links (index into the arena, 0 = none; node 0 is the root)
+  const char* s = nullptr;       // Number / String: text
+  uint32_t len = 0;
+  const char* key = nullptr;     // member name when the parent is an object
+  uint32_t key_len = 0;
+  const JDoc* doc = nullptr;
+  std::string text() const { return std::string(s, len); }
+  const JValue* get(const char* k) const;
+  const JValue* child(uint32_t i) const;
+  const JValue* first_child() const;
+  const JValue* next_sibling() const;
+  size_t size() const { return n_children; }
 };
 
-struct JParser {
-  const char* p;
-  const char* end;
+struct JDoc {
+  std::vector<JValue> nodes;
+  std::deque<std::string> unescaped;   // only for strings that contain escapes (deque: stable addresses)
+  const char* p = nullptr;
+  const char* end = nullptr;
   bool ok = true;
   std::string err;
-  JParser(const char* s, size_t n) : p(s), end(s + n) {}
+
+  JDoc(const char* src, size_t n) : p(src), end(src + n) {
+    nodes.reserve(n / 12 + 16);
+
+  }
+  const JValue* root() const { return &nodes[0]; }
   void fail(const char* what) {
     if (ok) err = what;
     ok = false;
@@ -63,102 +79,132 @@ struct JParser {
   void ws() {
     while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
   }
-  JPtr parse() {
-    JPtr v = value(0);
+  const JValue* parse() {
+    uint32_t r = value(0);
+    (void)r;
     ws();
     if (ok && p != end) fail("trailing characters");
-    return v;
+    for (auto& nd : nodes) nd.doc = this;
+    return root();
   }
-  JPtr value(int depth) {
-    JPtr v = std::make_shared<JValue>();
-    if (depth > 64) { fail("nesting too deep"); return v; }
+  uint32_t new_node() {
+    nodes.emplace_back();
+    return (uint32_t)nodes.size() - 1;
+  }
+  // parses a string token; returns a view (into the source, or into `unescaped` when it had escapes)
+  void str(const char** out, uint32_t* out_len) {
+    p++;  // opening quote
+    const char* b = p;
+    bool esc = false;
+    while (p < end && *p != '"') {
+      if (*p == '\\') { esc = true; p++; }
+      p++;
+    }
+    if (p >= end) { fail("unterminated string"); *out = b; *out_len = 0; return; }
+    const char* e = p;
+    p++;  // closing quote
+    if (!esc) { *out = b; *out_len = (uint32_t)(e - b); return; }
+    std::string u;
+    for (const char* q = b; q < e; q++) {
+      if (*q != '\\') { u += *q; continue; }
+      q++;
+      switch (*q) {
+        case 'n': u += '\n'; break;
+        case 't': u += '\t'; break;
+        case 'r': u += '\r'; break;
+        case 'b': u += '\b'; break;
+        case 'f': u += '\f'; break;
+        case 'u': u += '?'; q += 4; break;  // gate ids are ASCII; code points are not needed
+        default: u += *q;
+      }
+    }
+    unescaped.push_back(u);
+    *out = unescaped.back().data();
+    *out_len = (uint32_t)unescaped.back().size();
+  }
+  uint32_t value(int depth) {
+    uint32_t id = new_node();
+    if (depth > 64) { fail("nesting too deep"); return id; }
     ws();
-    if (p >= end) { fail("unexpected end"); return v; }
+    if (p >= end) { fail("unexpected end"); return id; }
     char c = *p;
-    if (c == '{') {
-      v->kind = JValue::Object;
+    if (c == '{' || c == '[') {
+      const bool is_obj = c == '{';
+      nodes[id].kind = is_obj ? JValue::Object : JValue::Array;
       p++;
       ws();
-      if (p < end && *p == '}') { p++; return v; }
+      if (p < end && *p == (is_obj ? '}' : ']')) { p++; return id; }
+      uint32_t last = 0, count = 0;
       while (ok) {
-        ws();
-        if (p >= end || *p != '"') { fail("expected key"); break; }
-        std::string k = str();
-        ws();
-        if (p >= end || *p != ':') { fail("expected ':'"); break; }
-        p++;
-        JPtr child = value(depth + 1);
-        v->obj.emplace_back(k, child);
+        const char* k = nullptr;
+        uint32_t klen = 0;
+        if (is_obj) {
+          ws();
+          if (p >= end || *p != '"') { fail("expected key"); break; }
+          str(&k, &klen);
+          ws();
+          if (p >= end || *p != ':') { fail("expected ':'"); break; }
+          p++;
+        }
+        uint32_t ch = value(depth + 1);
+        nodes[ch].key = k;
+        nodes[ch].key_len = klen;
+        if (last) nodes[last].next = ch; else nodes[id].first = ch;
+        last = ch;
+        count++;
         ws();
         if (p < end && *p == ',') { p++; continue; }
-        if (p < end && *p == '}') { p++; break; }
-        fail("expected ',' or '}'");
+        if (p < end && *p == (is_obj ? '}' : ']')) { p++; break; }
+        fail(is_obj ? "expected ',' or '}'" : "expected ',' or ']'");
       }
-    } else if (c == '[') {
-      v->kind = JValue::Array;
-      p++;
-      ws();
-      if (p < end && *p == ']') { p++; return v; }
-      while (ok) {
-        v->arr.push_back(value(depth + 1));
-        ws();
-        if (p < end && *p == ',') { p++; continue; }
-        if (p < end && *p == ']') { p++; break; }
-        fail("expected ',' or ']'");
-      }
+      nodes[id].n_children = count;
     } else if (c == '"') {
-      v->kind = JValue::String;
-      v->text = str();
+      nodes[id].kind = JValue::String;
+      const char* sv;
+      uint32_t sl;
+      str(&sv, &sl);
+      nodes[id].s = sv;
+      nodes[id].len = sl;
     } else if (c == 't' && end - p >= 4 && !strncmp(p, "true", 4)) {
-      v->kind = JValue::Bool; v->b = true; p += 4;
+      nodes[id].kind = JValue::Bool; nodes[id].b = true; p += 4;
     } else if (c == 'f' && end - p >= 5 && !strncmp(p, "false", 5)) {
-      v->kind = JValue::Bool; v->b = false; p += 5;
+      nodes[id].kind = JValue::Bool; nodes[id].b = false; p += 5;
     } else if (c == 'n' && end - p >= 4 && !strncmp(p, "null", 4)) {
-      v->kind = JValue::Null; p += 4;
+      nodes[id].kind = JValue::Null; p += 4;
     } else if (c == '-' || (c >= '0' && c <= '9')) {
-      v->kind = JValue::Number;
-      const char* s = p;
+      nodes[id].kind = JValue::Number;
+      const char* b = p;
       if (*p == '-') p++;
       while (p < end && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) p++;
-      v->text.assign(s, p - s);
+      nodes[id].s = b;
+      nodes[id].len = (uint32_t)(p - b);
     } else {
       fail("unexpected character");
     }
-    return v;
-  }
-  std::string str() {
-    std::string out;
-    p++;  // opening quote
-    while (p < end && *p != '"') {
-      if (*p == '\\') {
-        p++;
-        if (p >= end) break;
-        switch (*p) {
-          case 'n': out += '\n'; break;
-          case 't': out += '\t'; break;
-          case 'r': out += '\r'; break;
-          case 'b': out += '\b'; break;
-          case 'f': out += '\f'; break;
-          case 'u':  // only needed for completeness; gate ids are ASCII
-            if (end - p >= 5) { out += '?'; p += 4; }
-            break;
-          default: out += *p;
-        }
-        p++;
-      } else {
-        out += *p++;
-      }
-    }
-    if (p >= end) fail("unterminated string");
-    else p++;
-    return out;
+    return id;
   }
 };
 
-bool parse_u64(const std::string& t, uint64_t* out) {
-  if (t.empty() || t.size() > 20) return false;
+const JValue* JValue::first_child() const { return first ? &doc->nodes[first] : nullptr; }
+const JValue* JValue::next_sibling() const { return next ? &doc->nodes[next] : nullptr; }
+const JValue* JValue::get(const char* k) const {
+  if (kind != Object) return nullptr;
+  size_t kl = strlen(k);
+  for (const JValue* c = first_child(); c; c = c->next_sibling())
+    if (c->key_len == kl && !memcmp(c->key, k, kl)) return c;
+  return nullptr;
+}
+const JValue* JValue::child(uint32_t i) const {
+  const JValue* c = first_child();
+  while (c && i--) c = c->next_sibling();
+  return c;
+}
+
+bool parse_u64(const char* t, size_t n, uint64_t* out) {
+  if (n == 0 || n > 20) return false;
   unsigned __int128 v = 0;
-  for (char c : t) {
+  for (size_t i = 0; i < n; i++) {
+    char c = t[i];
     if (c < '0' || c > '9') return false;
     v = v * 10 + (unsigned)(c - '0');
   }
@@ -166,7 +212,8 @@ bool parse_u64(const std::string& t, uint64_t* out) {
   *out = (uint64_t)v;
   return true;
 }
-bool j_u64(const JValue* v, uint64_t* out) { return v && v->kind == JValue::Number && parse_u64(v->text, out); }
+bool parse_u64(const std::string& t, uint64_t* out) { return parse_u64(t.data(), t.size(), out); }
+bool j_u64(const JValue* v, uint64_t* out) { return v && v->kind == JValue::Number && parse_u64(v->s, v->len, out); }
 bool j_u32(const JValue* v, uint32_t* out) {
   uint64_t x;
   if (!j_u64(v, &x) || x > 0xFFFFFFFFull) return false;
@@ -192,10 +239,11 @@ void sub_mod(uint64_t a[5]) {
     borrow = (d >> 64) & 1;
   }
 }
-bool parse_fr_decimal(const std::string& t, uint64_t out[4]) {
-  if (t.empty()) return false;
+bool parse_fr_decimal(const char* t, size_t n, uint64_t out[4]) {
+  if (n == 0) return false;
   uint64_t acc[5] = {0, 0, 0, 0, 0};
-  for (char c : t) {
+  for (size_t k = 0; k < n; k++) {
+    char c = t[k];
     if (c < '0' || c > '9') return false;
     unsigned __int128 carry = (unsigned)(c - '0');
     for (int i = 0; i < 5; i++) {
@@ -208,7 +256,7 @@ bool parse_fr_decimal(const std::string& t, uint64_t out[4]) {
   memcpy(out, acc, 32);
   return true;
 }
-bool j_fr(const JValue* v, uint64_t out[4]) { return v && v->kind == JValue::String && parse_fr_decimal(v->text, out); }
+bool j_fr(const JValue* v, uint64_t out[4]) { return v && v->kind == JValue::String && parse_fr_decimal(v->s, v->len, out); }
 
 // ---- gate-id parsing (the reference matches regexes; ids are generated by plonky2's Debug formatting)
 // Consumes `lit` at position *pos of s.
@@ -379,11 +427,11 @@ extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len,
                                      size_t verifier_only_len, gpv_circuit** out) {
   if (!common_json || !verifier_only_json || !out) return GPV_EINVAL;
   *out = nullptr;
-  JParser pc(common_json, common_len);
-  JPtr common = pc.parse();
+  JDoc pc(common_json, common_len);
+  const JValue* common = pc.parse();
   if (!pc.ok) { gpv_set_global_error("common_circuit_data: %s", pc.err.c_str()); return GPV_ESHAPE; }
-  JParser pv(verifier_only_json, verifier_only_len);
-  JPtr vo = pv.parse();
+  JDoc pv(verifier_only_json, verifier_only_len);
+  const JValue* vo = pv.parse();
   if (!pv.ok) { gpv_set_global_error("verifier_only_circuit_data: %s", pv.err.c_str()); return GPV_ESHAPE; }
 
   std::unique_ptr<gpv_circuit> circ(new gpv_circuit());
@@ -407,12 +455,22 @@ extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len,
     return GPV_ECONFIG;
   }
   const JValue* rab = fp->get("reduction_arity_bits");
-  if (!rab || rab->kind != JValue::Array || rab->arr.size() > GPV_MAX_STEPS) { gpv_set_global_error("reduction_arity_bits"); return GPV_ESHAPE; }
-  c.num_steps = (uint32_t)rab->arr.size();
+  if (!rab || rab->kind != JValue::Array || rab->size() > GPV_MAX_STEPS) { gpv_set_global_error("reduction_arity_bits"); return GPV_ESHAPE; }
+  c.num_steps = (uint32_t)rab->size();
   for (uint32_t s = 0; s < c.num_steps; s++) {
-    if (!j_u32(rab->arr[s].get(), &c.arity_bits[s])) return GPV_ESHAPE;
+    if (!j_u32(rab->child(s), &c.arity_bits[s])) return GPV_ESHAPE;
     if (c.arity_bits[s] != 4) {  // fri.go:431-433 "assuming arity bits is 4"
       gpv_set_global_error("reduction arity bits %u != 4 is not supported", c.arity_bits[s]);
+      return GPV_ECONFIG;
+    }
+  }
+  {
+    // assertNoncanonicalIndicesOK (fri/fri_utils.go:156-163): the share of u64 values with two encodings must be negligible
+    // against the query error 2^-rate_bits, or the reference panics
+    double p_ambiguous = 4294967295.0 / 18446744069414584321.0;
+    double query_error = 1.0 / (double)(1ull << (c.rate_bits > 62 ? 62 : c.rate_bits));
+    if (p_ambiguous >= query_error * 1e-5) {
+      gpv_set_global_error("A non-negligible portion of field elements are in the range that permits non-canonical encodings");
       return GPV_ECONFIG;
     }
   }
@@ -426,31 +484,31 @@ extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len,
     return GPV_ECONFIG;
   }
   const JValue* kis = common->get("k_is");
-  if (!kis || kis->kind != JValue::Array || kis->arr.size() < c.num_routed) { gpv_set_global_error("k_is"); return GPV_ESHAPE; }
+  if (!kis || kis->kind != JValue::Array || kis->size() < c.num_routed) { gpv_set_global_error("k_is"); return GPV_ESHAPE; }
   for (uint32_t i = 0; i < c.num_routed; i++)
-    if (!j_u64(kis->arr[i].get(), &c.k_is[i])) return GPV_ESHAPE;
+    if (!j_u64(kis->child(i), &c.k_is[i])) return GPV_ESHAPE;
   const JValue* gates = common->get("gates");
   const JValue* si = common->get("selectors_info");
   const JValue* sidx = si ? si->get("selector_indices") : nullptr;
   const JValue* groups = si ? si->get("groups") : nullptr;
   if (!gates || gates->kind != JValue::Array || !sidx || sidx->kind != JValue::Array || !groups || groups->kind != JValue::Array ||
-      sidx->arr.size() != gates->arr.size()) {
+      sidx->size() != gates->size()) {
     gpv_set_global_error("gates / selectors_info");
     return GPV_ESHAPE;
   }
-  if (gates->arr.size() > GPV_MAX_GATES || groups->arr.size() > GPV_MAX_GROUPS || groups->arr.empty()) return GPV_ECONFIG;
-  c.n_gates = (uint32_t)gates->arr.size();
-  c.n_groups = (uint32_t)groups->arr.size();
+  if (gates->size() > GPV_MAX_GATES || groups->size() > GPV_MAX_GROUPS || (groups->size() == 0)) return GPV_ECONFIG;
+  c.n_gates = (uint32_t)gates->size();
+  c.n_groups = (uint32_t)groups->size();
   if (c.n_groups > c.num_constants) return GPV_ESHAPE;
   uint32_t wused = 0;
   for (uint32_t g = 0; g < c.n_gates; g++) {
-    const JValue* gid = gates->arr[g].get();
+    const JValue* gid = gates->child(g);
     if (gid->kind != JValue::String) return GPV_ESHAPE;
     uint32_t kind;
     uint64_t p[3];
     std::vector<uint64_t> weights;
-    if (parse_gate_id(gid->text, &kind, p, &weights) != GPV_OK) {
-      gpv_set_global_error("Unknown gate ID %s", gid->text.c_str());
+    if (parse_gate_id(gid->text(), &kind, p, &weights) != GPV_OK) {
+      gpv_set_global_error("Unknown gate ID %s", gid->text().c_str());
       return GPV_ECONFIG;
     }
     DevGate& dg = c.gates[g];
@@ -469,16 +527,16 @@ extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len,
       gpv_set_global_error("num_constraints() gave too low of a number");
       return GPV_ESHAPE;
     }
-    if (!j_u32(sidx->arr[g].get(), &c.selector_index[g]) || c.selector_index[g] >= c.n_groups) return GPV_ESHAPE;
+    if (!j_u32(sidx->child(g), &c.selector_index[g]) || c.selector_index[g] >= c.n_groups) return GPV_ESHAPE;
   }
   for (uint32_t g = 0; g < c.n_groups; g++) {
-    const JValue* gr = groups->arr[g].get();
+    const JValue* gr = groups->child(g);
     if (!j_u32(gr->get("start"), &c.group_start[g]) || !j_u32(gr->get("end"), &c.group_end[g])) return GPV_ESHAPE;
   }
   const JValue* cap = vo->get("constants_sigmas_cap");
-  if (!cap || cap->kind != JValue::Array || cap->arr.size() != 16) { gpv_set_global_error("constants_sigmas_cap"); return GPV_ESHAPE; }
+  if (!cap || cap->kind != JValue::Array || cap->size() != 16) { gpv_set_global_error("constants_sigmas_cap"); return GPV_ESHAPE; }
   for (int i = 0; i < 16; i++)
-    if (!j_fr(cap->arr[i].get(), c.sigmas_cap[i])) return GPV_ESHAPE;
+    if (!j_fr(cap->child(i), c.sigmas_cap[i])) return GPV_ESHAPE;
   if (!j_fr(vo->get("circuit_digest"), c.digest)) { gpv_set_global_error("circuit_digest"); return GPV_ESHAPE; }
   int rc = finish_layout(c);
   if (rc != GPV_OK) return rc;
@@ -552,21 +610,22 @@ struct Packer {
     *gl++ = x;
   }
   void put_ext_list(const JValue* v, size_t n) {
-    if (!v || v->kind != JValue::Array || v->arr.size() != n) { fail("extension array of the wrong length"); gl += 2 * n; return; }
-    for (auto& e : v->arr) {
-      if (e->kind != JValue::Array || e->arr.size() != 2) { fail("extension element must have 2 limbs"); gl += 2; continue; }
-      put_u64(e->arr[0].get());
-      put_u64(e->arr[1].get());
+    if (!v || v->kind != JValue::Array || v->size() != n) { fail("extension array of the wrong length"); gl += 2 * n; return; }
+    for (const JValue* e = v->first_child(); e; e = e->next_sibling()) {
+      if (e->kind != JValue::Array || e->size() != 2) { fail("extension element must have 2 limbs"); gl += 2; continue; }
+      const JValue* e0 = e->first_child();
+      put_u64(e0);
+      put_u64(e0->next_sibling());
     }
   }
   void put_u64_list(const JValue* v, size_t n) {
-    if (!v || v->kind != JValue::Array || v->arr.size() != n) { fail("array of the wrong length"); gl += n; return; }
-    for (auto& e : v->arr) put_u64(e.get());
+    if (!v || v->kind != JValue::Array || v->size() != n) { fail("array of the wrong length"); gl += n; return; }
+    for (const JValue* e = v->first_child(); e; e = e->next_sibling()) put_u64(e);
   }
   void put_fr_list(const JValue* v, size_t n) {
-    if (!v || v->kind != JValue::Array || v->arr.size() != n) { fail("hash array of the wrong length"); fr += 4 * n; return; }
-    for (auto& e : v->arr) {
-      if (!j_fr(e.get(), fr)) fail("expected a decimal string");
+    if (!v || v->kind != JValue::Array || v->size() != n) { fail("hash array of the wrong length"); fr += 4 * n; return; }
+    for (const JValue* e = v->first_child(); e; e = e->next_sibling()) {
+      if (!j_fr(e, fr)) fail("expected a decimal string");
       fr += 4;
     }
   }
@@ -576,8 +635,8 @@ struct Packer {
 extern "C" int gpv_proof_pack_json(const gpv_circuit* circ, const char* proof_json, size_t proof_len, void* out_packed) {
   if (!circ || !proof_json || !out_packed) return GPV_EINVAL;
   const DevCircuit& c = circ->dc;
-  JParser pp(proof_json, proof_len);
-  JPtr root = pp.parse();
+  JDoc pp(proof_json, proof_len);
+  const JValue* root = pp.parse();
   if (!pp.ok) { gpv_set_global_error("proof_with_public_inputs: %s", pp.err.c_str()); return GPV_ESHAPE; }
   const JValue* proof = root->get("proof");
   const JValue* op = proof ? proof->get("openings") : nullptr;
@@ -602,33 +661,33 @@ extern "C" int gpv_proof_pack_json(const gpv_circuit* circ, const char* proof_js
   pk.put_fr_list(proof->get("plonk_zs_partial_products_cap"), cap_len);
   pk.put_fr_list(proof->get("quotient_polys_cap"), cap_len);
   const JValue* ccaps = fp->get("commit_phase_merkle_caps");
-  if (!ccaps || ccaps->kind != JValue::Array || ccaps->arr.size() != c.num_steps) { gpv_set_global_error("commit_phase_merkle_caps"); return GPV_ESHAPE; }
-  for (auto& cp : ccaps->arr) pk.put_fr_list(cp.get(), cap_len);  // fri_utils.go:175-179
+  if (!ccaps || ccaps->kind != JValue::Array || ccaps->size() != c.num_steps) { gpv_set_global_error("commit_phase_merkle_caps"); return GPV_ESHAPE; }
+  for (const JValue* cp = ccaps->first_child(); cp; cp = cp->next_sibling()) pk.put_fr_list(cp, cap_len);  // fri_utils.go:175-179
   const JValue* qrs = fp->get("query_round_proofs");
-  if (!qrs || qrs->kind != JValue::Array || qrs->arr.size() != c.num_queries) {  // fri.go:515-517
+  if (!qrs || qrs->kind != JValue::Array || qrs->size() != c.num_queries) {  // fri.go:515-517
     gpv_set_global_error("Number of query rounds does not match config.");
     return GPV_ESHAPE;
   }
-  for (auto& qr : qrs->arr) {
+  for (const JValue* qr = qrs->first_child(); qr; qr = qr->next_sibling()) {
     const JValue* itp = qr->get("initial_trees_proof");
     const JValue* eps = itp ? itp->get("evals_proofs") : nullptr;
-    if (!eps || eps->kind != JValue::Array || eps->arr.size() != 4) {  // fri_utils.go:185-187
+    if (!eps || eps->kind != JValue::Array || eps->size() != 4) {  // fri_utils.go:185-187
       gpv_set_global_error("eval proofs length is not equal to instance oracles length");
       return GPV_ESHAPE;
     }
     for (int o = 0; o < 4; o++) {
-      const JValue* ep = eps->arr[o].get();  // 2-tuple [leaf, {"siblings": [...]}]  (types/deserialize.go:45-72)
-      if (ep->kind != JValue::Array || ep->arr.size() != 2) { gpv_set_global_error("evals_proofs entry must be a 2-tuple"); return GPV_ESHAPE; }
-      pk.put_u64_list(ep->arr[0].get(), c.leaf_len[o]);                         // fri_utils.go:199-201
-      pk.put_fr_list(ep->arr[1]->get("siblings"), c.init_siblings);             // :203-205
+      const JValue* ep = eps->child(o);  // 2-tuple [leaf, {"siblings": [...]}]  (types/deserialize.go:45-72)
+      if (ep->kind != JValue::Array || ep->size() != 2) { gpv_set_global_error("evals_proofs entry must be a 2-tuple"); return GPV_ESHAPE; }
+      pk.put_u64_list(ep->child(0), c.leaf_len[o]);                         // fri_utils.go:199-201
+      pk.put_fr_list(ep->child(1)->get("siblings"), c.init_siblings);             // :203-205
     }
     const JValue* steps = qr->get("steps");
-    if (!steps || steps->kind != JValue::Array || steps->arr.size() != c.num_steps) {  // fri_utils.go:208-210
+    if (!steps || steps->kind != JValue::Array || steps->size() != c.num_steps) {  // fri_utils.go:208-210
       gpv_set_global_error("length of steps != params.reduction_arity_bits");
       return GPV_ESHAPE;
     }
     for (uint32_t s = 0; s < c.num_steps; s++) {
-      const JValue* st = steps->arr[s].get();
+      const JValue* st = steps->child(s);
       pk.put_ext_list(st->get("evals"), 1u << c.arity_bits[s]);                 // :219-221
       const JValue* mp = st->get("merkle_proof");
       pk.put_fr_list(mp ? mp->get("siblings") : nullptr, c.step_siblings[s]);   // :223-225
@@ -640,5 +699,34 @@ extern "C" int gpv_proof_pack_json(const gpv_circuit* circ, const char* proof_js
   pk.put_u64_list(root->get("public_inputs"), c.num_pi);
   if (!pk.ok) { gpv_set_global_error("proof shape: %s", pk.why); return GPV_ESHAPE; }
   if (pk.gl != gl_end || pk.fr != gl_end + 4 * c.n_fr) { gpv_set_global_error("internal layout mismatch"); return GPV_ESHAPE; }
+  return GPV_OK;
+}
+
+extern "C" int gpv_proof_pack_json_batch(const gpv_circuit* circ, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
+                                         void* out_packed, int n_threads) {
+  if (!circ || !out_packed || (n && (!proof_jsons || !proof_lens))) return GPV_EINVAL;
+  if (n_threads < 1) n_threads = 1;
+  if ((size_t)n_threads > n) n_threads = n ? (int)n : 1;
+  const size_t nbytes = circ->dc.proof_nbytes;
+  std::atomic<size_t> next(0);
+  std::vector<int> rc(n, GPV_OK);
+  std::vector<std::string> msg(n);
+  auto work = [&]() {
+    for (;;) {
+      size_t i = next.fetch_add(1);
+      if (i >= n) return;
+      rc[i] = gpv_proof_pack_json(circ, proof_jsons[i], proof_lens[i], (char*)out_packed + i * nbytes);
+      if (rc[i] != GPV_OK) msg[i] = gpv_get_global_error();  // thread-local text of this worker
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < n_threads; t++) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+  for (size_t i = 0; i < n; i++)
+    if (rc[i] != GPV_OK) {
+      gpv_set_global_error("proof %zu: %s", i, msg[i].c_str());
+      return rc[i];
+    }
   return GPV_OK;
 }

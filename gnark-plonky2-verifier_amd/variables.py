@@ -95,3 +95,13 @@ def DeserializeProofWithPublicInputs(raw, circuit):
     out = np.zeros(circuit.proof_nbytes, dtype=np.uint8)
     _lib.check(_lib.lib().gpv_proof_pack_json(ctypes.c_void_p(circuit.h), raw.text, len(raw.text), _lib.ptr(out)))
     return ProofBatch(circuit, out)
+
+
+def DeserializeProofsWithPublicInputs(raws, circuit, n_threads=8):
+    """n JSON proofs -> one ProofBatch, parsed on n_threads host threads (gpv_proof_pack_json_batch)."""
+    n = len(raws)
+    texts = (ctypes.c_char_p * n)(*[r.text for r in raws])
+    lens = (ctypes.c_size_t * n)(*[len(r.text) for r in raws])
+    out = np.zeros(n * circuit.proof_nbytes, dtype=np.uint8)
+    _lib.check(_lib.lib().gpv_proof_pack_json_batch(ctypes.c_void_p(circuit.h), texts, lens, n, _lib.ptr(out), n_threads))
+    return ProofBatch(circuit, out)

@@ -113,6 +113,10 @@ size_t gpv_circuit_describe(const gpv_circuit* c, uint64_t* blob, size_t cap);
  * (types/deserialize.go:92-108, variables/deserialize.go:114-147) into one packed record of
  * gpv_proof_nbytes(c) bytes; shape checks of fri/fri_utils.go:167-228 -> GPV_ESHAPE. */
 int gpv_proof_pack_json(const gpv_circuit* c, const char* proof_json, size_t proof_len, void* out_packed);
+/* The same for n proofs on n_threads host threads (ingest at rate): out_packed receives n consecutive
+ * records. Returns the error of the lowest failing index (its number is in the error message). */
+int gpv_proof_pack_json_batch(const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
+                              void* out_packed, int n_threads);
 
 /* ------------------------------------------------------------------ field / hash primitives */
 /* goldilocks.Chip Add/Sub/Mul/MulAdd/Inverse/Reduce (goldilocks/base.go:162-313). b, c may be NULL when unused. */

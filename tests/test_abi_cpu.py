@@ -120,6 +120,32 @@ def test_proof_shape_errors(gpv):  # fri/fri_utils.go:167-228 panics -> GPV_ESHA
     assert pack(obj).data.tobytes() == packed
 
 
+def test_batch_ingest_threads(gpv):
+    import time
+    ci, packed, (common, vo, pj) = T.load_fixture("step")
+    circuit = _circuit(gpv, common, vo)
+    raw = gpv.types.ProofWithPublicInputsRaw(json.dumps(pj))
+    t0 = time.time()
+    pb = gpv.variables.DeserializeProofsWithPublicInputs([raw] * 32, circuit, n_threads=8)
+    dt = time.time() - t0
+    assert pb.n == 32 and pb.data.tobytes() == packed * 32
+    print("batch ingest: %.0f proofs/s on 8 threads" % (32 / dt))
+    bad = json.loads(json.dumps(pj))
+    bad["proof"]["wires_cap"].pop()
+    with pytest.raises(gpv.ShapeError, match="proof 5"):
+        gpv.variables.DeserializeProofsWithPublicInputs([raw] * 5 + [gpv.types.ProofWithPublicInputsRaw(json.dumps(bad))] + [raw] * 3,
+                                                        circuit, n_threads=4)
+
+
+def test_rate_bits_sanity_check(gpv):  # fri/fri_utils.go:156-163
+    _, _, (common, vo, _) = T.load_fixture("decode_block")
+    bad = json.loads(json.dumps(common))
+    bad["fri_params"]["config"]["rate_bits"] = 17
+    bad["fri_params"]["degree_bits"] = 10
+    with pytest.raises(gpv.ConfigError):
+        _circuit(gpv, bad, vo)
+
+
 def test_python_packer_raises_on_same_shapes():
     ci, packed, (common, vo, pj) = T.load_fixture("step")
     obj = json.loads(json.dumps(pj))
