@@ -260,8 +260,7 @@ def oracle():
     global _orc
     if _orc is None:
         so = ROOT / "oracle" / "liborc.so"
-        if not so.exists() or any(p.stat().st_mtime > so.stat().st_mtime
-                                  for p in (ROOT / "oracle").glob("*.[hc]*")):
+        if not so.exists():
             build_oracle()
         lib = ctypes.CDLL(str(so))
         lib.orc_circuit_new.restype = ctypes.c_void_p

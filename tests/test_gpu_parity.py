@@ -499,3 +499,32 @@ def test_circuit_variant_differential(gpv, api, orc):
     assert (ch.flat == och).all()
     assert mask.tolist() == [int(x) for x in ofail] and accept.tolist() == oacc.tolist()
     assert (gpv.plonk.NewPlonkChip(api).EvaluateGateConstraints(pb) == orc.gate_constraints(oc, recs.tobytes())).all()
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_non_canonical_fr_values_are_taken_mod_r(gpv, api, orc, name):
+    """A sibling / cap entry / transcript cap written as v + r (still < 2^256) is the same witness value under gnark
+    (variables/deserialize.go builds frontend.Variables from big.Ints; the field reduces them): still accepted."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    g = _n_gl_words(ci)
+    rec = np.frombuffer(packed, dtype=np.uint64).copy()
+
+    def add_r(fr_index):
+        o = g + 4 * fr_index
+        v = T.fr_from_limbs(rec[o:o + 4]) + R
+        assert v < 2**256
+        rec[o:o + 4] = T.fr_limbs(v)
+
+    n_caps = (3 + len(ci.arity_bits)) * ci.cap_len
+    add_r(0)                      # wires cap entry 0 (observed by the challenger, maybe used as a Merkle cap)
+    add_r(ci.cap_len + 5)         # zs / partial products cap
+    add_r(n_caps)                 # first sibling of query 0, tree 0
+    add_r(n_caps + 2 * (ci.lde_bits - ci.cap_height) + 3)  # a sibling of tree 2
+    batch = np.stack([np.frombuffer(packed, dtype=np.uint64), rec])
+    pb = gpv.variables.ProofBatch(circuit, batch.tobytes())
+    accept, mask, ch = gpv.verifier.NewVerifierChip(api, common).Verify(pb, vo, detail=True)
+    oacc, ofail, och = orc.verify(oc, batch.tobytes())
+    assert accept.tolist() == oacc.tolist() == [1, 1]
+    assert (ch.flat == och).all() and (ch.flat[0] == ch.flat[1]).all()
