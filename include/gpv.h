@@ -25,6 +25,9 @@
  *     in host memory. *_dev entry points take DEVICE pointers on the context's GPU, enqueue on the
  *     context's stream and return without synchronising.
  *   - There is no CPU fallback: without a usable GPU gpv_ctx_create fails with GPV_EDEVICE.
+ *   - Threading: a gpv_circuit is immutable and may be shared; a gpv_ctx owns one stream pair and its scratch, so calls
+ *     on the same context must not overlap in time (use one context per host thread; the reference's chips are not
+ *     re-entrant either, challenger/challenger.go:18-20). The ingest functions are thread-safe.
  */
 #ifndef GPV_H
 #define GPV_H
