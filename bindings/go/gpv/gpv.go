@@ -126,3 +126,29 @@ func (ctx *Context) PlonkVerify(c *Circuit, proofs []byte, challenges []uint64) 
 	check(C.gpv_plonk_verify(ctx.h, c.h, unsafe.Pointer(&proofs[0]), (*C.uint64_t)(unsafe.Pointer(&challenges[0])), C.size_t(n), (*C.uint32_t)(unsafe.Pointer(&out[0]))), ctx.h)
 	return out
 }
+
+// Gl2Op3 = MulAddExtension / SubMulExtension / ScalarMulExtension (op 3 / 7 / 8) on n extension elements.
+func (ctx *Context) Gl2Op3(op int, a, b, c []uint64) []uint64 {
+	out := make([]uint64, len(a))
+	p := func(s []uint64) *C.uint64_t {
+		if len(s) == 0 {
+			return nil
+		}
+		return (*C.uint64_t)(unsafe.Pointer(&s[0]))
+	}
+	check(C.gpv_gl2_op3(ctx.h, C.int(op), p(a), p(b), p(c), p(out), C.size_t(len(a)/2)), ctx.h)
+	return out
+}
+
+// ChallengerRun executes a recorded Observe*/Get* schedule (entries kind<<28|count, kinds 1 observe, 2 observe Fr,
+// 3 squeeze) for n transcripts: in is n x nIn words, the result n x nOut words.
+func (ctx *Context) ChallengerRun(script []uint32, in []uint64, nIn, nOut, n int) []uint64 {
+	out := make([]uint64, nOut*n)
+	var pin *C.uint64_t
+	if len(in) > 0 {
+		pin = (*C.uint64_t)(unsafe.Pointer(&in[0]))
+	}
+	check(C.gpv_challenger_run(ctx.h, (*C.uint32_t)(unsafe.Pointer(&script[0])), C.size_t(len(script)), pin, C.size_t(nIn),
+		(*C.uint64_t)(unsafe.Pointer(&out[0])), C.size_t(nOut), C.size_t(n)), ctx.h)
+	return out
+}

@@ -376,6 +376,111 @@ extern "C" int gpv_gl2_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_
   return GPV_OK;
 }
 
+// copy up to three host operands in, launch, copy one result out
+template <class F>
+static int map_host3(gpv_ctx* ctx, const uint64_t* a, size_t aw, const uint64_t* b, size_t bw, const uint64_t* c, size_t cw,
+                     uint64_t* out, size_t ow, size_t n, F launch) {
+  if (n == 0) return GPV_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf<u64> da, db, dc, dout;
+  HIP_TRY(ctx, da.alloc(aw * n));
+  HIP_TRY(ctx, hipMemcpyAsync(da.p, a, 8 * aw * n, hipMemcpyHostToDevice, ctx->stream));
+  if (b) {
+    HIP_TRY(ctx, db.alloc(bw * n));
+    HIP_TRY(ctx, hipMemcpyAsync(db.p, b, 8 * bw * n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (c) {
+    HIP_TRY(ctx, dc.alloc(cw * n));
+    HIP_TRY(ctx, hipMemcpyAsync(dc.p, c, 8 * cw * n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIP_TRY(ctx, dout.alloc(ow * n));
+  launch(da.p, db.p, dc.p, dout.p);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 8 * ow * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+extern "C" int gpv_gl2_op3(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && a && b && out);
+  REQUIRE(ctx, op == GPV_OP_MULADD || op == GPV_OP_SUBMUL || op == GPV_OP_SCALARMUL);
+  REQUIRE(ctx, op == GPV_OP_SCALARMUL || c);
+  bool scalar = op == GPV_OP_SCALARMUL;
+  return map_host3(ctx, a, 2, b, scalar ? 1 : 2, scalar ? nullptr : c, 2, out, 2, n,
+                   [&](u64* x, u64* y, u64* z, u64* o) { gpvk_gl2_op3(ctx->stream, op, x, y, z, o, n); });
+}
+extern "C" int gpv_gl2_exp(gpv_ctx* ctx, const uint64_t* a, uint64_t exponent, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && a && out);
+  return map_host3(ctx, a, 2, nullptr, 0, nullptr, 0, out, 2, n,
+                   [&](u64* x, u64*, u64*, u64* o) { gpvk_gl2_exp(ctx->stream, x, exponent, o, n); });
+}
+extern "C" int gpv_gl2_reduce_with_powers(gpv_ctx* ctx, const uint64_t* terms, size_t len, const uint64_t* scalar, uint64_t* out,
+                                          size_t n) {
+  REQUIRE(ctx, ctx && scalar && out && (terms || len == 0) && len <= 0x7FFFFFFFu);
+  if (len == 0) {  // empty Horner sum
+    memset(out, 0, 16 * n);
+    return GPV_OK;
+  }
+  return map_host3(ctx, terms, 2 * len, scalar, 2, nullptr, 0, out, 2, n,
+                   [&](u64* t, u64* s, u64*, u64* o) { gpvk_gl2_reduce_with_powers(ctx->stream, t, (u32)len, s, o, n); });
+}
+extern "C" int gpv_gl2alg_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  REQUIRE(ctx, ctx && a && b && out);
+  REQUIRE(ctx, op == GPV_OP_ADD || op == GPV_OP_SUB || op == GPV_OP_MUL || op == GPV_OP_SCALARMUL);
+  return map_host3(ctx, a, 4, b, op == GPV_OP_SCALARMUL ? 2 : 4, nullptr, 0, out, 4, n,
+                   [&](u64* x, u64* y, u64*, u64* o) { gpvk_gl2alg_op(ctx->stream, op, x, y, o, n); });
+}
+extern "C" int gpv_poseidon_gl_hash_n_to_m_no_pad(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n_out,
+                                                  size_t n) {
+  REQUIRE(ctx, ctx && out && (in || len == 0) && len <= 0x7FFFFFFFu && n_out >= 1 && n_out <= 0x7FFFFFFFu);
+  if (n == 0) return GPV_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf<u64> din, dout;
+  HIP_TRY(ctx, din.alloc(len * n + 1));
+  HIP_TRY(ctx, dout.alloc(n_out * n));
+  if (len) HIP_TRY(ctx, hipMemcpyAsync(din.p, in, 8 * len * n, hipMemcpyHostToDevice, ctx->stream));
+  gpvk_poseidon_gl_hash_n_to_m(ctx->stream, din.p, (u32)len, dout.p, (u32)n_out, n);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 8 * n_out * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+extern "C" int gpv_challenger_run(gpv_ctx* ctx, const uint32_t* script, size_t n_ops, const uint64_t* in, size_t n_in, uint64_t* out,
+                                  size_t n_out, size_t n) {
+  REQUIRE(ctx, ctx && (script || n_ops == 0) && (in || n_in == 0) && (out || n_out == 0) && n_ops <= 0x7FFFFFFFu);
+  size_t need_in = 0, need_out = 0;
+  for (size_t k = 0; k < n_ops; k++) {
+    uint32_t kind = script[k] >> 28, cnt = script[k] & 0x0FFFFFFFu;
+    if (kind == GPV_CH_OBSERVE) need_in += cnt;
+    else if (kind == GPV_CH_OBSERVE_FR) need_in += 4 * (size_t)cnt;
+    else if (kind == GPV_CH_SQUEEZE) need_out += cnt;
+    else {
+      ctx_error(ctx, "gpv_challenger_run: unknown script op %u at entry %zu", kind, k);
+      return GPV_EINVAL;
+    }
+  }
+  if (need_in != n_in || need_out != n_out)
+  {
+    ctx_error(ctx, "gpv_challenger_run: script consumes %zu / produces %zu words, caller gave %zu / %zu", need_in, need_out, n_in,
+              n_out);
+    return GPV_ESHAPE;
+  }
+  if (n == 0 || n_out == 0) return GPV_OK;
+  REQUIRE(ctx, n_in <= 0x7FFFFFFFu && n_out <= 0x7FFFFFFFu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf<u64> din, dout;
+  DevBuf<u32> dscript;
+  HIP_TRY(ctx, din.alloc(n_in * n + 1));
+  HIP_TRY(ctx, dout.alloc(n_out * n));
+  HIP_TRY(ctx, dscript.alloc(n_ops));
+  if (n_in) HIP_TRY(ctx, hipMemcpyAsync(din.p, in, 8 * n_in * n, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(dscript.p, script, 4 * n_ops, hipMemcpyHostToDevice, ctx->stream));
+  gpvk_challenger_run(ctx->stream, dscript.p, (u32)n_ops, din.p, (u32)n_in, dout.p, (u32)n_out, n);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 8 * n_out * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+
 extern "C" int gpv_poseidon_gl_permute_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && states && out);
   if (n == 0) return GPV_OK;

@@ -13,6 +13,12 @@ typedef uint64_t u64;
 // gpv_k_prim.hip
 void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n);
 void gpvk_gl2_op(hipStream_t st, int op, const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n);
+void gpvk_gl2_op3(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n);
+void gpvk_gl2_exp(hipStream_t st, const u64* a, u64 exponent, u64* out, size_t n);
+void gpvk_gl2_reduce_with_powers(hipStream_t st, const u64* terms, u32 len, const u64* scalar, u64* out, size_t n);
+void gpvk_gl2alg_op(hipStream_t st, int op, const u64* a, const u64* b, u64* out, size_t n);
+void gpvk_poseidon_gl_hash_n_to_m(hipStream_t st, const u64* in, u32 len, u64* out, u32 n_out, size_t n);
+void gpvk_challenger_run(hipStream_t st, const u32* script, u32 n_ops, const u64* in, u32 n_in, u64* out, u32 n_out, size_t n);
 void gpvk_poseidon_gl_permute(hipStream_t st, const u64* in, u64* out, size_t n);
 void gpvk_poseidon_gl_permute_coop(hipStream_t st, const u64* in, u64* out, size_t n);  // 16 lanes per state
 void gpvk_poseidon_gl_hash_no_pad(hipStream_t st, const u64* in, u32 len, u64* out, size_t n);

@@ -50,6 +50,58 @@ class Chip:
     def InverseExtension(self, a): return self._op2(4, a)        # :123 -> (inverse, ok) ; ok = 0 where the reference asserts
     def DivExtension(self, a, b): return self._op2(6, a, b)      # :137
 
+    def _op3(self, op, a, b, c=None):
+        a = _lib.u64c(a).reshape(-1, 2)
+        b = _lib.u64c(b).reshape(-1) if op == 8 else _lib.u64c(b).reshape(-1, 2)
+        c = None if c is None else _lib.u64c(c).reshape(-1, 2)
+        out = np.empty_like(a)
+        _lib.check(_lib.lib().gpv_gl2_op3(self.ctx.h, op, _lib.ptr(a), _lib.ptr(b), _lib.ptr(c), _lib.ptr(out), a.shape[0]), self.ctx.h)
+        return out
+
+    def MulAddExtension(self, a, b, c): return self._op3(3, a, b, c)   # :75  a*b + c
+    def SubMulExtension(self, a, b, c): return self._op3(7, a, b, c)   # :89  (a - b)*c
+    def ScalarMulExtension(self, a, b): return self._op3(8, a, b)      # :96  b in the base field, [n]
+
+    def ExpExtension(self, a, exponent):                               # :143
+        a = _lib.u64c(a).reshape(-1, 2)
+        out = np.empty_like(a)
+        _lib.check(_lib.lib().gpv_gl2_exp(self.ctx.h, _lib.ptr(a), int(exponent), _lib.ptr(out), a.shape[0]), self.ctx.h)
+        return out
+
+    def ReduceWithPowers(self, terms, scalar):                         # :177  terms [n][len][2], scalar [n][2]
+        t = _lib.u64c(terms)
+        t = t.reshape(1, -1, 2) if t.ndim == 2 else t
+        s = _lib.u64c(scalar).reshape(-1, 2)
+        out = np.empty((t.shape[0], 2), dtype=np.uint64)
+        _lib.check(_lib.lib().gpv_gl2_reduce_with_powers(self.ctx.h, _lib.ptr(t), t.shape[1], _lib.ptr(s), _lib.ptr(out), t.shape[0]),
+                   self.ctx.h)
+        return out
+
+    # selection helpers: no arithmetic, so they stay on the host (quadratic_extension.go:196-221)
+    def IsZero(self, x):
+        x = _lib.u64c(x).reshape(-1, 2)
+        return ((x[:, 0] == 0) & (x[:, 1] == 0)).astype(np.uint8)
+
+    def Lookup(self, b, x, y):
+        b = np.asarray(b).astype(bool).reshape(-1, 1)
+        return np.where(b, _lib.u64c(y).reshape(-1, 2), _lib.u64c(x).reshape(-1, 2))
+
+    def Lookup2(self, b0, b1, qe0, qe1, qe2, qe3):
+        return self.Lookup(b1, self.Lookup(b0, qe0, qe1), self.Lookup(b0, qe2, qe3))
+
+    # QuadraticExtensionAlgebraVariable (quadratic_extension_algebra.go:28-86): [n][2][2]
+    def _alg(self, op, a, b):
+        a = _lib.u64c(a).reshape(-1, 2, 2)
+        b = _lib.u64c(b).reshape(-1, 2) if op == 8 else _lib.u64c(b).reshape(-1, 2, 2)
+        out = np.empty_like(a)
+        _lib.check(_lib.lib().gpv_gl2alg_op(self.ctx.h, op, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.shape[0]), self.ctx.h)
+        return out
+
+    def AddExtensionAlgebra(self, a, b): return self._alg(0, a, b)         # :28
+    def SubExtensionAlgebra(self, a, b): return self._alg(1, a, b)         # :39
+    def MulExtensionAlgebra(self, a, b): return self._alg(2, a, b)         # :50
+    def ScalarMulExtensionAlgebra(self, a, b): return self._alg(8, b, a)   # :77  a = ext scalars [n][2], b = algebra elements
+
 
 def New(api=None):  # base.go:112
     return Chip(api)

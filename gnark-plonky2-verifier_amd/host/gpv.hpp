@@ -3,6 +3,7 @@
 //   goldilocks::Chip              goldilocks/base.go:96-313, quadratic_extension.go:31-235
 //   poseidon::GoldilocksChip      poseidon/goldilocks.go:18-86
 //   poseidon::BN254Chip           poseidon/bn254.go:23-120
+//   challenger::Chip              challenger/challenger.go:14-144 (records Observe*/Get*, runs the script in one launch)
 //   fri::Chip                     fri/fri.go:17-61, :500-548
 //   plonk::PlonkChip              plonk/plonk.go:12-53, :209-250
 //   verifier::VerifierChip        verifier/verifier.go:14-39, :143-170
@@ -84,7 +85,25 @@ class Chip {
   Vars AddExtension(const Vars& a, const Vars& b) { return op2(GPV_OP_ADD, a, &b); }                    // :31
   Vars SubExtension(const Vars& a, const Vars& b) { return op2(GPV_OP_SUB, a, &b); }                    // :45
   Vars DivExtension(const Vars& a, const Vars& b) { return op2(GPV_OP_DIV, a, &b); }                    // :137
+  Vars MulAddExtension(const Vars& a, const Vars& b, const Vars& c) { return op3(GPV_OP_MULADD, a, b, &c); }   // :75
+  Vars SubMulExtension(const Vars& a, const Vars& b, const Vars& c) { return op3(GPV_OP_SUBMUL, a, b, &c); }   // :89
+  Vars ScalarMulExtension(const Vars& a, const Vars& b) { return op3(GPV_OP_SCALARMUL, a, b, nullptr); }       // :96, b base field
+  Vars ExpExtension(const Vars& a, uint64_t exponent) {                                                        // :143
+    Vars out(a.size());
+    gpv::check(gpv_gl2_exp(api_.h(), a.data(), exponent, out.data(), a.size() / 2), api_.h());
+    return out;
+  }
+  Vars ReduceWithPowers(const Vars& terms, size_t len, const Vars& scalar) {                                   // :177, n x len x 2
+    Vars out(scalar.size());
+    gpv::check(gpv_gl2_reduce_with_powers(api_.h(), terms.data(), len, scalar.data(), out.data(), scalar.size() / 2), api_.h());
+    return out;
+  }
  private:
+  Vars op3(int o, const Vars& a, const Vars& b, const Vars* c) {
+    Vars out(a.size());
+    gpv::check(gpv_gl2_op3(api_.h(), o, a.data(), b.data(), c ? c->data() : nullptr, out.data(), a.size() / 2), api_.h());
+    return out;
+  }
   Vars op(int o, const Vars& a, const Vars* b, const Vars* c) {
     Vars out(a.size());
     gpv::check(gpv_gl_op(api_.h(), o, a.data(), b ? b->data() : nullptr, c ? c->data() : nullptr, out.data(), a.size()), api_.h());
@@ -108,6 +127,12 @@ class GoldilocksChip {
   Words Poseidon(const Words& states) {  // goldilocks.go:30, n x 12
     Words out(states.size());
     gpv::check(gpv_poseidon_gl_permute(api_.h(), states.data(), out.data(), states.size() / 12), api_.h());
+    return out;
+  }
+  Words HashNToMNoPad(const Words& in, size_t len, size_t nbOutputs) {  // goldilocks.go:41, n x len -> n x nbOutputs
+    size_t n = len ? in.size() / len : 0;
+    Words out(nbOutputs * n);
+    gpv::check(gpv_poseidon_gl_hash_n_to_m_no_pad(api_.h(), in.data(), len, out.data(), nbOutputs, n), api_.h());
     return out;
   }
   Words HashNoPad(const Words& in, size_t len) {  // goldilocks.go:72, n x len -> n x 4
@@ -149,6 +174,56 @@ class BN254Chip {
 inline GoldilocksChip NewGoldilocksChip(gpv::Api& api) { return GoldilocksChip(api); }  // goldilocks.go:23
 inline BN254Chip NewBN254Chip(gpv::Api& api) { return BN254Chip(api); }                 // bn254.go:31
 }  // namespace poseidon
+
+namespace challenger {
+// The Go chip is driven element by element; here the calls are recorded and `Run()` executes the whole schedule for
+// all n transcripts in one launch (gpv_challenger_run). Get* return the column range of their challenges in Run()'s rows.
+class Chip {
+ public:
+  struct Range { size_t start, count; };
+  Chip(gpv::Api& api, size_t n) : api_(api), n_(n), rows_(n) {}                                          // challenger.go:23
+  void ObserveElements(const std::vector<uint64_t>& v) { observe(GPV_CH_OBSERVE, v, 1); }                 // :51, n x k
+  void ObserveHash(const std::vector<uint64_t>& v) { observe(GPV_CH_OBSERVE, v, 1); }                     // :57, n x 4
+  void ObserveBN254Hash(const std::vector<uint64_t>& v) { observe(GPV_CH_OBSERVE_FR, v, 4); }             // :62, n x 4 limbs
+  void ObserveCap(const std::vector<uint64_t>& v) { observe(GPV_CH_OBSERVE_FR, v, 4); }                   // :67, n x k x 4
+  void ObserveExtensionElements(const std::vector<uint64_t>& v) { observe(GPV_CH_OBSERVE, v, 1); }        // :77, n x k x 2
+  Range GetNChallenges(size_t k) {                                                                        // :100
+    push(GPV_CH_SQUEEZE, k);
+    Range r{n_out_, k};
+    n_out_ += k;
+    return r;
+  }
+  Range GetChallenge() { return GetNChallenges(1); }                                                      // :89
+  Range GetExtensionChallenge() { return GetNChallenges(2); }                                             // :108
+  Range GetHash() { return GetNChallenges(4); }                                                           // :113
+  size_t row_words() const { return n_out_; }
+  std::vector<uint64_t> Run() {  // n x row_words()
+    std::vector<uint64_t> in;
+    size_t n_in = rows_.empty() ? 0 : rows_[0].size();
+    in.reserve(n_in * n_);
+    for (auto& r : rows_) in.insert(in.end(), r.begin(), r.end());
+    std::vector<uint64_t> out(n_out_ * n_);
+    gpv::check(gpv_challenger_run(api_.h(), script_.data(), script_.size(), in.data(), n_in, out.data(), n_out_, n_), api_.h());
+    return out;
+  }
+ private:
+  void push(uint32_t kind, size_t cnt) {
+    if (!script_.empty() && (script_.back() >> 28) == kind) script_.back() += (uint32_t)cnt;
+    else script_.push_back(GPV_CH_OP(kind, cnt));
+  }
+  void observe(uint32_t kind, const std::vector<uint64_t>& v, size_t words) {
+    if (n_ == 0 || v.size() % (n_ * words)) throw gpv::Error(GPV_ESHAPE, "observation does not cover all transcripts");
+    size_t per = v.size() / n_;
+    if (per == 0) return;
+    for (size_t i = 0; i < n_; i++) rows_[i].insert(rows_[i].end(), v.begin() + i * per, v.begin() + (i + 1) * per);
+    push(kind, per / words);
+  }
+  gpv::Api& api_;
+  size_t n_, n_out_ = 0;
+  std::vector<uint32_t> script_;
+  std::vector<std::vector<uint64_t>> rows_;
+};
+}  // namespace challenger
 
 namespace fri {
 class Chip {

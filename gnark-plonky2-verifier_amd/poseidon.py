@@ -33,6 +33,15 @@ class GoldilocksChip:
         return out
 
 
+    def HashNToMNoPad(self, inputs, nbOutputs):  # goldilocks.go:41 -- [n][len] -> [n][nbOutputs]
+        x = _lib.u64c(inputs)
+        x = x.reshape(1, -1) if x.ndim == 1 else x
+        out = np.empty((x.shape[0], nbOutputs), dtype=np.uint64)
+        _lib.check(_lib.lib().gpv_poseidon_gl_hash_n_to_m_no_pad(self.ctx.h, _lib.ptr(x), x.shape[1], _lib.ptr(out), nbOutputs,
+                                                                 x.shape[0]), self.ctx.h)
+        return out
+
+
 class BN254Chip:
     """Fr elements are [4] uint64 little-endian limbs, canonical."""
 

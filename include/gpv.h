@@ -66,7 +66,18 @@ enum {
 };
 
 /* field ops for gpv_gl_op / gpv_gl2_op */
-enum { GPV_OP_ADD = 0, GPV_OP_SUB = 1, GPV_OP_MUL = 2, GPV_OP_MULADD = 3, GPV_OP_INV = 4, GPV_OP_REDUCE = 5, GPV_OP_DIV = 6 };
+enum {
+  GPV_OP_ADD = 0, GPV_OP_SUB = 1, GPV_OP_MUL = 2, GPV_OP_MULADD = 3, GPV_OP_INV = 4, GPV_OP_REDUCE = 5, GPV_OP_DIV = 6,
+  GPV_OP_SUBMUL = 7, GPV_OP_SCALARMUL = 8
+};
+
+/* operations of a gpv_challenger_run script: entry = kind << 28 | count */
+enum {
+  GPV_CH_OBSERVE = 1,    /* ObserveElements: consumes `count` words of the input row                       */
+  GPV_CH_OBSERVE_FR = 2, /* ObserveBN254Hash / ObserveCap: consumes `count` Fr (4 words each, canonical)   */
+  GPV_CH_SQUEEZE = 3     /* GetNChallenges: appends `count` words to the output row                        */
+};
+#define GPV_CH_OP(kind, count) (((uint32_t)(kind) << 28) | ((uint32_t)(count) & 0x0FFFFFFFu))
 
 /* bits of the per-proof diagnostic mask returned by gpv_verify_detail (accept == (mask == 0)) */
 enum {
@@ -127,6 +138,16 @@ int gpv_gl_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, const 
 /* Add/Sub/Mul/Inverse/DivExtension (goldilocks/quadratic_extension.go:31-140), [n][2]; ok[i] = 0 where the
  * reference's "operand != 0" assertion (:124-125) fails. ok may be NULL. */
 int gpv_gl2_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* ok, size_t n);
+/* MulAddExtension a*b+c, SubMulExtension (a-b)*c (GPV_OP_MULADD / GPV_OP_SUBMUL, a b c out [n][2]) and
+ * ScalarMulExtension a*b (GPV_OP_SCALARMUL, b [n] base-field, c unused) -- quadratic_extension.go:75-104. */
+int gpv_gl2_op3(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n);
+/* ExpExtension (quadratic_extension.go:143-171): out[i] = a[i]^exponent, a^0 = 1. */
+int gpv_gl2_exp(gpv_ctx* ctx, const uint64_t* a, uint64_t exponent, uint64_t* out, size_t n);
+/* ReduceWithPowers (quadratic_extension.go:177-193): out[i] = sum_k terms[i][k] * scalar[i]^k, terms [n][len][2]. */
+int gpv_gl2_reduce_with_powers(gpv_ctx* ctx, const uint64_t* terms, size_t len, const uint64_t* scalar, uint64_t* out, size_t n);
+/* QuadraticExtensionAlgebraVariable Add/Sub/Mul ([n][2][2] each) and ScalarMul (GPV_OP_SCALARMUL, b = [n][2] extension
+ * scalars) -- quadratic_extension_algebra.go:28-86. */
+int gpv_gl2alg_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* GoldilocksChip.Poseidon (poseidon/goldilocks.go:30-37): states [n][12] -> out [n][12] */
 int gpv_poseidon_gl_permute(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
 int gpv_poseidon_gl_permute_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
@@ -136,6 +157,14 @@ int gpv_poseidon_gl_permute_coop(gpv_ctx* ctx, const uint64_t* states, uint64_t*
 int gpv_poseidon_gl_permute_coop_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
 /* GoldilocksChip.HashNoPad (poseidon/goldilocks.go:72-86): in [n][len] -> out [n][4] */
 int gpv_poseidon_gl_hash_no_pad(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n);
+/* GoldilocksChip.HashNToMNoPad (poseidon/goldilocks.go:41-68): in [n][len] -> out [n][n_out], n_out >= 1 */
+int gpv_poseidon_gl_hash_n_to_m_no_pad(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n_out, size_t n);
+/* challenger.Chip for an arbitrary schedule (challenger/challenger.go:23-115): n transcripts run the same script of
+ * GPV_CH_OP entries (Observe* / Get*Challenge in call order, starting from a fresh chip); in [n][n_in] holds the observed
+ * words of each transcript in script order, out [n][n_out] receives the challenges in squeeze order. n_in / n_out must
+ * equal what the script consumes / produces (GPV_ESHAPE otherwise). */
+int gpv_challenger_run(gpv_ctx* ctx, const uint32_t* script, size_t n_ops, const uint64_t* in, size_t n_in, uint64_t* out,
+                       size_t n_out, size_t n);
 /* BN254Chip.Poseidon (poseidon/bn254.go:39-45): states [n][4][4] -> out [n][4][4] */
 int gpv_poseidon_bn254_permute(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
 int gpv_poseidon_bn254_permute_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);

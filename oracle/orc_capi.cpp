@@ -70,6 +70,54 @@ int orc_gl2_op(int op, const u64* a, const u64* b, u64* out, uint8_t* ok, size_t
   return 0;
 }
 
+// quadratic_extension.go:75-104 (MulAdd / SubMul / ScalarMul); op codes as in include/gpv.h
+int orc_gl2_op3(int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    Ext x = ext(a[2 * i], a[2 * i + 1]), r;
+    if (op == 3) r = ext_muladd(x, ext(b[2 * i], b[2 * i + 1]), ext(c[2 * i], c[2 * i + 1]));
+    else if (op == 7) r = ext_submul(x, ext(b[2 * i], b[2 * i + 1]), ext(c[2 * i], c[2 * i + 1]));
+    else if (op == 8) r = ext_scalar_mul(x, gl_reduce(b[i]));
+    else return -1;
+    out[2 * i] = r.c[0];
+    out[2 * i + 1] = r.c[1];
+  }
+  return 0;
+}
+int orc_gl2_exp(const u64* a, u64 exponent, u64* out, size_t n) {  // quadratic_extension.go:143-171
+  for (size_t i = 0; i < n; i++) {
+    Ext r = ext_exp(ext(a[2 * i], a[2 * i + 1]), exponent);
+    out[2 * i] = r.c[0];
+    out[2 * i + 1] = r.c[1];
+  }
+  return 0;
+}
+int orc_gl2_reduce_with_powers(const u64* terms, size_t len, const u64* scalar, u64* out, size_t n) {  // :177-193
+  std::vector<Ext> t(len);
+  for (size_t i = 0; i < n; i++) {
+    for (size_t k = 0; k < len; k++) t[k] = ext(gl_reduce(terms[2 * (len * i + k)]), gl_reduce(terms[2 * (len * i + k) + 1]));
+    Ext r = ext_reduce_with_powers(t.data(), len, ext(scalar[2 * i], scalar[2 * i + 1]));
+    out[2 * i] = r.c[0];
+    out[2 * i + 1] = r.c[1];
+  }
+  return 0;
+}
+int orc_gl2alg_op(int op, const u64* a, const u64* b, u64* out, size_t n) {  // quadratic_extension_algebra.go:28-86
+  for (size_t i = 0; i < n; i++) {
+    ExtAlg x = alg(ext(a[4 * i], a[4 * i + 1]), ext(a[4 * i + 2], a[4 * i + 3])), r;
+    if (op == 8) {
+      r = alg_scalar_mul(ext(b[2 * i], b[2 * i + 1]), x);
+    } else {
+      ExtAlg y = alg(ext(b[4 * i], b[4 * i + 1]), ext(b[4 * i + 2], b[4 * i + 3]));
+      if (op == OP_ADD) r = alg_add(x, y);
+      else if (op == OP_SUB) r = alg_sub(x, y);
+      else if (op == OP_MUL) r = alg_mul(x, y);
+      else return -1;
+    }
+    for (int k = 0; k < 4; k++) out[4 * i + k] = r.c[k >> 1].c[k & 1];
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------- hashes
 int orc_poseidon_gl_permute(const u64* states, u64* out, size_t n) {
   for (size_t i = 0; i < n; i++) {
@@ -82,6 +130,30 @@ int orc_poseidon_gl_permute(const u64* states, u64* out, size_t n) {
 }
 int orc_poseidon_gl_hash_no_pad(const u64* in, size_t len, u64* out, size_t n) {
   for (size_t i = 0; i < n; i++) poseidon_gl_hash_no_pad(in + len * i, len, out + 4 * i);
+  return 0;
+}
+int orc_poseidon_gl_hash_n_to_m_no_pad(const u64* in, size_t len, u64* out, size_t n_out, size_t n) {  // goldilocks.go:41-68
+  std::vector<u64> red(len);
+  for (size_t i = 0; i < n; i++) {
+    for (size_t k = 0; k < len; k++) red[k] = gl_reduce(in[len * i + k]);
+    poseidon_gl_hash_n_to_m_no_pad(red.data(), len, out + n_out * i, n_out);
+  }
+  return 0;
+}
+// challenger.Chip driven by a script of (kind << 28 | count) entries: 1 observe words, 2 observe Fr, 3 squeeze
+int orc_challenger_run(const uint32_t* script, size_t n_ops, const u64* in, size_t n_in, u64* out, size_t n_out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    Challenger ch;
+    const u64* src = in + n_in * i;
+    u64* dst = out + n_out * i;
+    for (size_t k = 0; k < n_ops; k++) {
+      uint32_t kind = script[k] >> 28, cnt = script[k] & 0x0FFFFFFFu;
+      if (kind == 1) { ch.observe_elements(src, cnt); src += cnt; }
+      else if (kind == 2) { ch.observe_cap(src, cnt); src += 4 * (size_t)cnt; }
+      else if (kind == 3) { for (uint32_t j = 0; j < cnt; j++) *dst++ = ch.get_challenge(); }
+      else return -1;
+    }
+  }
   return 0;
 }
 // canonical in / canonical out, [n][4][4]

@@ -44,6 +44,24 @@ int main(int argc, char** argv) {
   // goldilocks/base_test.go:97-116
   goldilocks::Chip gl = goldilocks::New(api);
   EXPECT(gl.MulAdd({1ULL << 63}, {1ULL << 63}, {3})[0] == 18446744068340842500ULL);
+  // quadratic_extension.go:75-193 through the mirror: a^2 == a*a, a*b + c, Horner == explicit sum
+  goldilocks::Vars ea = {3, 5, 18446744069414584320ULL, 7}, eb = {11, 13, 2, 0}, ec = {1, 1, 4, 9};
+  EXPECT(gl.ExpExtension(ea, 2) == gl.MulExtension(ea, ea));
+  EXPECT(gl.MulAddExtension(ea, eb, ec) == gl.AddExtension(gl.MulExtension(ea, eb), ec));
+  EXPECT(gl.SubMulExtension(ea, eb, ec) == gl.MulExtension(gl.SubExtension(ea, eb), ec));
+  EXPECT(gl.ReduceWithPowers({1, 2, 3, 4}, 2, {5, 6}) == gl.MulAddExtension({3, 4}, {5, 6}, {1, 2}));
+  // challenger.go:89-98: a fresh chip's first challenge is the LAST rate word of Poseidon(0); then a cap is absorbed
+  {
+    challenger::Chip ch(api, 2);
+    auto first = ch.GetChallenge();
+    ch.ObserveElements({1, 2, 3, /* transcript 1: */ 1, 2, 4});
+    auto rest = ch.GetNChallenges(3);
+    std::vector<uint64_t> rows = ch.Run();
+    EXPECT(ch.row_words() == 4 && rows.size() == 8);
+    EXPECT(rows[first.start] == 2047012902665707362ULL && rows[4 + first.start] == 2047012902665707362ULL);
+    EXPECT(rows[rest.start] != rows[4 + rest.start]);
+    EXPECT(pgl.HashNToMNoPad({1, 2, 3}, 3, 4) == pgl.HashNoPad({1, 2, 3}, 3));
+  }
   // verifier/verifier_test.go:13-41 (+ a tampered copy)
   verifier::VerifierChip chip(api, circuit);
   std::vector<uint8_t> batch = proof;

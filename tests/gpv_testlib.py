@@ -324,6 +324,51 @@ class Oracle:
         assert self.lib.orc_gl2_op(op, _p(a), _p(b), _p(out), _p(ok), ctypes.c_size_t(a.shape[0])) == 0
         return out, ok
 
+    def gl2_op3(self, op, a, b, c=None):
+        a = u64arr(a).reshape(-1, 2)
+        b = u64arr(b)
+        c = None if c is None else u64arr(c)
+        out = np.empty_like(a)
+        assert self.lib.orc_gl2_op3(op, _p(a), _p(b), _p(c), _p(out), ctypes.c_size_t(a.shape[0])) == 0
+        return out
+
+    def gl2_exp(self, a, exponent):
+        a = u64arr(a).reshape(-1, 2)
+        out = np.empty_like(a)
+        assert self.lib.orc_gl2_exp(_p(a), ctypes.c_uint64(exponent), _p(out), ctypes.c_size_t(a.shape[0])) == 0
+        return out
+
+    def gl2_reduce_with_powers(self, terms, scalar):
+        t = u64arr(terms)
+        t = t.reshape(t.shape[0], -1)          # [n][len * 2]
+        s = u64arr(scalar).reshape(-1, 2)
+        out = np.empty((t.shape[0], 2), dtype=np.uint64)
+        assert self.lib.orc_gl2_reduce_with_powers(_p(t), ctypes.c_size_t(t.shape[1] // 2), _p(s), _p(out), ctypes.c_size_t(t.shape[0])) == 0
+        return out
+
+    def gl2alg_op(self, op, a, b):
+        a = u64arr(a).reshape(-1, 2, 2)
+        b = u64arr(b)
+        out = np.empty_like(a)
+        assert self.lib.orc_gl2alg_op(op, _p(a), _p(b), _p(out), ctypes.c_size_t(a.shape[0])) == 0
+        return out
+
+    def poseidon_gl_hash_n_to_m_no_pad(self, inputs, n_out):
+        x = u64arr(inputs)
+        out = np.empty((x.shape[0], n_out), dtype=np.uint64)
+        assert self.lib.orc_poseidon_gl_hash_n_to_m_no_pad(_p(x), ctypes.c_size_t(x.shape[1]), _p(out), ctypes.c_size_t(n_out),
+                                                           ctypes.c_size_t(x.shape[0])) == 0
+        return out
+
+    def challenger_run(self, script, inputs, n_out):
+        """script: list of (kind, count); inputs [n][n_in] -> [n][n_out]"""
+        sc = np.array([(k << 28) | c for k, c in script], dtype=np.uint32)
+        x = u64arr(inputs)
+        out = np.empty((x.shape[0], n_out), dtype=np.uint64)
+        assert self.lib.orc_challenger_run(_p(sc), ctypes.c_size_t(sc.size), _p(x), ctypes.c_size_t(x.shape[1]), _p(out),
+                                           ctypes.c_size_t(n_out), ctypes.c_size_t(x.shape[0])) == 0
+        return out
+
     def poseidon_gl_permute(self, states):
         s = u64arr(states).reshape(-1, 12)
         out = np.empty_like(s)

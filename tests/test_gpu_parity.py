@@ -528,3 +528,165 @@ def test_non_canonical_fr_values_are_taken_mod_r(gpv, api, orc, name):
     oacc, ofail, och = orc.verify(oc, batch.tobytes())
     assert accept.tolist() == oacc.tolist() == [1, 1]
     assert (ch.flat == och).all() and (ch.flat[0] == ch.flat[1]).all()
+
+
+# ---------------------------------------------------------------- remaining chip operators
+def _ext_mul_py(a, b):
+    return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def test_gl_extension_three_operand_ops(gpv, api, orc):  # quadratic_extension.go:75-104,143-193
+    rng = np.random.default_rng(21)
+    n = 4096
+    a, b, c = (rand_gl(rng, (n, 2)) for _ in range(3))
+    a[:EDGE.size, 0] = EDGE % np.uint64(P)
+    b[:EDGE.size, 1] = EDGE[::-1] % np.uint64(P)
+    k = rand_gl(rng, n)
+    chip = gpv.goldilocks.New(api)
+    assert (chip.MulAddExtension(a, b, c) == orc.gl2_op3(3, a, b, c)).all()
+    assert (chip.SubMulExtension(a, b, c) == orc.gl2_op3(7, a, b, c)).all()
+    assert (chip.ScalarMulExtension(a, k) == orc.gl2_op3(8, a, k)).all()
+    # independent big-int check of a few rows
+    got = chip.MulAddExtension(a[:16], b[:16], c[:16])
+    for i in range(16):
+        m = _ext_mul_py([int(x) for x in a[i]], [int(x) for x in b[i]])
+        assert [int(x) for x in got[i]] == [(m[0] + int(c[i, 0])) % P, (m[1] + int(c[i, 1])) % P]
+    for e in (0, 1, 2, 3, 5, 8, 2**13, P - 1, 2**63 + 12345, 2**64 - 1):
+        assert (chip.ExpExtension(a[:256], e) == orc.gl2_exp(a[:256], e)).all(), e
+    one = np.tile(np.array([1, 0], dtype=np.uint64), (8, 1))
+    assert (chip.ExpExtension(a[:8], 0) == one).all()                       # :149-150
+    for ln in (1, 2, 7, 64):
+        terms = rand_gl(rng, (300, ln, 2))
+        sc = rand_gl(rng, (300, 2))
+        assert (chip.ReduceWithPowers(terms, sc) == orc.gl2_reduce_with_powers(terms.reshape(300, -1), sc)).all(), ln
+    # Horner == sum of terms * scalar^k, via ExpExtension / MulExtension
+    terms = rand_gl(rng, (32, 5, 2))
+    sc = rand_gl(rng, (32, 2))
+    acc = np.zeros((32, 2), dtype=np.uint64)
+    for j in range(5):
+        acc = chip.AddExtension(acc, chip.MulExtension(terms[:, j], chip.ExpExtension(sc, j)))
+    assert (chip.ReduceWithPowers(terms, sc) == acc).all()
+    # selection helpers
+    bit0, bit1 = rng.integers(0, 2, 64), rng.integers(0, 2, 64)
+    q = [rand_gl(rng, (64, 2)) for _ in range(4)]
+    sel = chip.Lookup2(bit0, bit1, *q)
+    for i in range(64):
+        assert (sel[i] == q[int(bit0[i]) + 2 * int(bit1[i])][i]).all()    # :208-221 little-endian (b0, b1)
+    z = np.array([[0, 0], [0, 1], [1, 0]], dtype=np.uint64)
+    assert list(chip.IsZero(z)) == [1, 0, 0]
+
+
+def test_gl_extension_algebra_ops(gpv, api, orc):  # quadratic_extension_algebra.go:28-86
+    rng = np.random.default_rng(22)
+    n = 2048
+    a, b = rand_gl(rng, (n, 2, 2)), rand_gl(rng, (n, 2, 2))
+    s = rand_gl(rng, (n, 2))
+    chip = gpv.goldilocks.New(api)
+    assert (chip.AddExtensionAlgebra(a, b) == orc.gl2alg_op(0, a, b)).all()
+    assert (chip.SubExtensionAlgebra(a, b) == orc.gl2alg_op(1, a, b)).all()
+    assert (chip.MulExtensionAlgebra(a, b) == orc.gl2alg_op(2, a, b)).all()
+    assert (chip.ScalarMulExtensionAlgebra(s, a) == orc.gl2alg_op(8, a, s)).all()
+    # (a0 + a1 Y)(b0 + b1 Y) with Y^2 = (0, 1)*... : first component = a0 b0 + W * a1 b1 with W = 7 embedded in the extension
+    got = chip.MulExtensionAlgebra(a[:8], b[:8])
+    for i in range(8):
+        A = [[int(x) for x in a[i, k]] for k in range(2)]
+        B = [[int(x) for x in b[i, k]] for k in range(2)]
+        t = _ext_mul_py(A[1], B[1])
+        u = _ext_mul_py(A[0], B[0])
+        assert [int(x) for x in got[i, 0]] == [(7 * t[0] + u[0]) % P, (7 * t[1] + u[1]) % P]
+        v, w = _ext_mul_py(A[0], B[1]), _ext_mul_py(A[1], B[0])
+        assert [int(x) for x in got[i, 1]] == [(v[0] + w[0]) % P, (v[1] + w[1]) % P]
+
+
+def test_poseidon_gl_hash_n_to_m_no_pad(gpv, api, orc):  # poseidon/goldilocks.go:41-68
+    rng = np.random.default_rng(23)
+    chip = gpv.poseidon.NewGoldilocksChip(api)
+    for ln in (1, 3, 8, 9, 17):
+        x = rand_gl(rng, (200, ln))
+        for n_out in (1, 4, 8, 9, 20):
+            got = chip.HashNToMNoPad(x, n_out)
+            assert (got == orc.poseidon_gl_hash_n_to_m_no_pad(x, n_out)).all(), (ln, n_out)
+        assert (chip.HashNToMNoPad(x, 4) == chip.HashNoPad(x)).all()
+    # squeezing past the rate permutes again: words 8.. are the first words of Poseidon(state)
+    x = rand_gl(rng, (4, 5))
+    h = chip.HashNToMNoPad(x, 12)
+    st = np.zeros((4, 12), dtype=np.uint64)
+    st[:, :5] = x
+    st = chip.Poseidon(st)
+    assert (h[:, :8] == st[:, :8]).all()
+    assert (h[:, 8:] == chip.Poseidon(st)[:, :4]).all()
+
+
+def test_challenger_arbitrary_schedule(gpv, api, orc):  # challenger/challenger.go:42-115
+    rng = np.random.default_rng(24)
+    n = 130  # not a multiple of the 4 transcripts per wave
+    script, cols, n_out = [], [], 0
+    chip = gpv.challenger.NewChip(api)
+    handles = []
+    for step in range(40):
+        kind = int(rng.integers(0, 4))
+        cnt = int(rng.integers(1, 12))
+        if kind == 0:
+            v = rand_gl(rng, (n, cnt))
+            v[0, 0] = np.uint64(P)          # observed values are reduced at duplexing time (challenger.go:154-156)
+            chip.ObserveElements(v)
+            script.append((1, cnt)); cols.append(v)
+        elif kind == 1:
+            cap = np.stack([rand_fr(rng, cnt) for _ in range(n)])
+            chip.ObserveCap(cap)
+            script.append((2, cnt)); cols.append(cap.reshape(n, -1))
+        elif kind == 2:
+            handles.append((chip.GetNChallenges(cnt), n_out, cnt))
+            script.append((3, cnt)); n_out += cnt
+        else:
+            handles.append((chip.GetExtensionChallenge(), n_out, 2))
+            script.append((3, 2)); n_out += 2
+    handles.append((chip.GetHash(), n_out, 4))
+    script.append((3, 4)); n_out += 4
+    want = orc.challenger_run(script, np.concatenate(cols, axis=1), n_out)
+    for h, start, cnt in handles:
+        assert (h.value == want[:, start:start + cnt]).all()
+    # a script whose counts disagree with the buffers is a shape error, not a result
+    lib = gpv._lib.lib()
+    sc = np.array([(1 << 28) | 3, (3 << 28) | 2], dtype=np.uint32)
+    inp = np.zeros((1, 2), dtype=np.uint64)
+    out = np.zeros((1, 2), dtype=np.uint64)
+    assert lib.gpv_challenger_run(api.h, gpv._lib.ptr(sc), 2, gpv._lib.ptr(inp), 2, gpv._lib.ptr(out), 2, 1) == gpv._lib.GPV_ESHAPE
+
+
+@pytest.mark.parametrize("name,expect", [("decode_block", DECODE_BLOCK_CHALLENGES), ("step", STEP_CHALLENGES)])
+def test_challenger_chip_replays_verifier_schedule(gpv, api, orc, name, expect):
+    """verifier/verifier.go:45-82 written against the challenger mirror's Observe*/Get* methods, as Go code would be;
+    the result must be the reference's challenge KATs (fri/fri_test.go:37-67)."""
+    ci, packed, (common, vo, pj) = T.load_fixture(name)
+    n = 3
+
+    def fr(vals):
+        return np.tile(np.array([T.fr_limbs(int(v) % R) for v in vals], dtype=np.uint64), (n, 1, 1))
+
+    def ext(vals):
+        return np.tile(np.array(vals, dtype=np.uint64), (n, 1, 1))
+
+    proof, op, fp = pj["proof"], pj["proof"]["openings"], pj["proof"]["opening_proof"]
+    pih = gpv.poseidon.NewGoldilocksChip(api).HashNoPad(np.tile(np.array(pj["public_inputs"], dtype=np.uint64), (n, 1))) \
+        if pj["public_inputs"] else np.zeros((n, 4), dtype=np.uint64)
+    ch = gpv.challenger.NewChip(api)
+    ch.ObserveBN254Hash(fr([vo["circuit_digest"]])[:, 0])
+    ch.ObserveHash(pih)
+    ch.ObserveCap(fr(proof["wires_cap"]))
+    nc = ci.num_challenges
+    betas, gammas = ch.GetNChallenges(nc), ch.GetNChallenges(nc)
+    ch.ObserveCap(fr(proof["plonk_zs_partial_products_cap"]))
+    alphas = ch.GetNChallenges(nc)
+    ch.ObserveCap(fr(proof["quotient_polys_cap"]))
+    zeta = ch.GetExtensionChallenge()
+    ch.ObserveOpenings([ext(op["constants"] + op["plonk_sigmas"] + op["wires"] + op["plonk_zs"] + op["partial_products"]
+                            + op["quotient_polys"]), ext(op["plonk_zs_next"])])     # fri.go:63-73
+    fc = ch.GetFriChallenges([fr(c) for c in fp["commit_phase_merkle_caps"]], ext(fp["final_poly"]["coeffs"]),
+                             np.full(n, fp["pow_witness"], dtype=np.uint64), ci.num_query_rounds)
+    flat = np.concatenate([betas.value, gammas.value, alphas.value, zeta.value, fc["FriAlpha"].value]
+                          + [b.value for b in fc["FriBetas"]]
+                          + [fc["FriPowResponse"].value.reshape(n, 1), fc["FriQueryIndices"].value], axis=1)
+    assert _named(ci, flat[0]) == expect
+    assert (flat == flat[0]).all()
+    assert (flat[0] == orc.challenges(orc.circuit(ci), packed)[0]).all()
