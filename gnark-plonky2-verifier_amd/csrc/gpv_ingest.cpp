@@ -202,14 +202,20 @@ const JValue* JValue::child(uint32_t i) const {
 
 bool parse_u64(const char* t, size_t n, uint64_t* out) {
   if (n == 0 || n > 20) return false;
-  unsigned __int128 v = 0;
-  for (size_t i = 0; i < n; i++) {
-    char c = t[i];
-    if (c < '0' || c > '9') return false;
-    v = v * 10 + (unsigned)(c - '0');
+  uint64_t v = 0;
+  size_t head = n < 19 ? n : 19;  // 19 digits always fit
+  for (size_t i = 0; i < head; i++) {
+    unsigned d = (unsigned)(t[i] - '0');
+    if (d > 9) return false;
+    v = v * 10 + d;
   }
-  if (v >> 64) return false;
-  *out = (uint64_t)v;
+  if (n == 20) {
+    unsigned d = (unsigned)(t[19] - '0');
+    if (d > 9) return false;
+    if (v > 1844674407370955161ULL || (v == 1844674407370955161ULL && d > 5)) return false;  // > 2^64 - 1
+    v = v * 10 + d;
+  }
+  *out = v;
   return true;
 }
 bool parse_u64(const std::string& t, uint64_t* out) { return parse_u64(t.data(), t.size(), out); }
@@ -239,18 +245,67 @@ void sub_mod(uint64_t a[5]) {
     borrow = (d >> 64) & 1;
   }
 }
+// acc (5 limbs) = acc * m + a
+static inline void mul_add_small(uint64_t acc[5], uint64_t m, uint64_t a) {
+  unsigned __int128 carry = a;
+  for (int i = 0; i < 5; i++) {
+    carry += (unsigned __int128)acc[i] * m;
+    acc[i] = (uint64_t)carry;
+    carry >>= 64;
+  }
+}
 bool parse_fr_decimal(const char* t, size_t n, uint64_t out[4]) {
   if (n == 0) return false;
   uint64_t acc[5] = {0, 0, 0, 0, 0};
-  for (size_t k = 0; k < n; k++) {
+  if (n <= 95) {
+    // 19 digits at a time; 10^95 < 2^320, so the five limbs cannot overflow and one reduction at the end suffices
+    static const uint64_t P10[20] = {1ULL, 10ULL, 100ULL, 1000ULL, 10000ULL, 100000ULL, 1000000ULL, 10000000ULL, 100000000ULL,
+                                     1000000000ULL, 10000000000ULL, 100000000000ULL, 1000000000000ULL, 10000000000000ULL,
+                                     100000000000000ULL, 1000000000000000ULL, 10000000000000000ULL, 100000000000000000ULL,
+                                     1000000000000000000ULL, 10000000000000000000ULL};
+    size_t k = 0;
+    while (k < n) {
+      size_t take = n - k < 19 ? n - k : 19;
+      uint64_t chunk = 0;
+      for (size_t i = 0; i < take; i++) {
+        unsigned d = (unsigned)(t[k + i] - '0');
+        if (d > 9) return false;
+        chunk = chunk * 10 + d;
+      }
+      mul_add_small(acc, P10[take], chunk);
+      k += take;
+    }
+    if (acc[4] || (acc[3] >> 62)) {
+      // rare: the value is far above r (non-canonical input); subtract shifted copies of r, top down
+      for (int sh = 67; sh >= 0; sh--) {
+        uint64_t m[5] = {0, 0, 0, 0, 0};
+        int w = sh >> 6, b = sh & 63;
+        for (int i = 0; i < 4; i++) {
+          if (i + w < 5) m[i + w] |= FR_MOD64[i] << b;
+          if (b && i + w + 1 < 5) m[i + w + 1] |= FR_MOD64[i] >> (64 - b);
+        }
+        bool ge = true;
+        for (int i = 4; i >= 0; i--) {
+          if (acc[i] != m[i]) { ge = acc[i] > m[i]; break; }
+        }
+        if (ge) {
+          unsigned __int128 borrow = 0;
+          for (int i = 0; i < 5; i++) {
+            unsigned __int128 d = (unsigned __int128)acc[i] - m[i] - (uint64_t)borrow;
+            acc[i] = (uint64_t)d;
+            borrow = (d >> 64) & 1;
+          }
+        }
+      }
+    }
+    while (geq_mod(acc)) sub_mod(acc);  // < 4 r here
+    memcpy(out, acc, 32);
+    return true;
+  }
+  for (size_t k = 0; k < n; k++) {  // arbitrarily long strings: digit by digit, reducing as we go
     char c = t[k];
     if (c < '0' || c > '9') return false;
-    unsigned __int128 carry = (unsigned)(c - '0');
-    for (int i = 0; i < 5; i++) {
-      carry += (unsigned __int128)acc[i] * 10;
-      acc[i] = (uint64_t)carry;
-      carry >>= 64;
-    }
+    mul_add_small(acc, 10, (unsigned)(c - '0'));
     while (geq_mod(acc)) sub_mod(acc);  // acc < 10 r + 9 before: at most 10 rounds
   }
   memcpy(out, acc, 32);

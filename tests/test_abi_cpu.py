@@ -120,6 +120,28 @@ def test_proof_shape_errors(gpv):  # fri/fri_utils.go:167-228 panics -> GPV_ESHA
     assert pack(obj).data.tobytes() == packed
 
 
+def test_decimal_parser_edges(gpv):  # types/deserialize.go:9-126 reads big.Int / uint64 decimals
+    ci, packed, (common, vo, pj) = T.load_fixture("step")
+    circuit = _circuit(gpv, common, vo)
+
+    def pack(obj):
+        return gpv.variables.DeserializeProofWithPublicInputs(gpv.types.ProofWithPublicInputsRaw(json.dumps(obj)), circuit)
+
+    R = T.BN_R
+    for val in [0, R - 1, R, R + 5, 2**256 - 1, 2**256 + 12345, 10**94 + 7, 10**95 - 1, 10**96 + 3, 10**120 + 11]:
+        q = json.loads(json.dumps(pj))
+        q["proof"]["wires_cap"][3] = str(val)          # hash values are taken mod r (variables/deserialize.go:28)
+        assert pack(q).data.tobytes() == T.pack_proof(ci, q), val
+    for val, ok in [(2**64 - 1, True), (10**19, True), (2**64, False), (99999999999999999999, False)]:
+        q = json.loads(json.dumps(pj))
+        q["proof"]["opening_proof"]["pow_witness"] = val
+        if ok:
+            assert pack(q).data.tobytes() == T.pack_proof(ci, q), val
+        else:
+            with pytest.raises(gpv.ShapeError):
+                pack(q)
+
+
 def test_batch_ingest_threads(gpv):
     import time
     ci, packed, (common, vo, pj) = T.load_fixture("step")
