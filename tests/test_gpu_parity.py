@@ -690,3 +690,53 @@ def test_challenger_chip_replays_verifier_schedule(gpv, api, orc, name, expect):
     assert _named(ci, flat[0]) == expect
     assert (flat == flat[0]).all()
     assert (flat[0] == orc.challenges(orc.circuit(ci), packed)[0]).all()
+
+
+# ---------------------------------------------------------------- boundary behaviour of the batch API
+def test_api_batch_edges_and_context_reuse(gpv, api, orc):
+    """Empty and ragged batch sizes, one context alternating between circuits (scratch is re-sized, not shared state),
+    and repeated calls giving the same answer."""
+    loaded = {name: (_load(gpv, name), T.load_fixture(name)) for name in ("decode_block", "step")}
+    lib = gpv._lib.lib()
+    for name, ((common, vo, circuit, proofs), (ci, packed, _)) in loaded.items():
+        empty = np.zeros(0, dtype=np.uint8)
+        acc = np.zeros(0, dtype=np.uint8)
+        assert lib.gpv_verify(api.h, circuit.h, gpv._lib.ptr(empty), 0, gpv._lib.ptr(acc)) == 0     # n = 0 is not an error
+    expect = {}
+    for rnd in range(2):
+        for n in (1, 3, 63, 65, 130):
+            for name, ((common, vo, circuit, proofs), (ci, packed, _)) in loaded.items():
+                batch, tampered = T.synthetic_batch(ci, packed, n, seed=100 + n, tamper_every=3)
+                got = gpv.verifier.NewVerifierChip(api, common).Verify(gpv.variables.ProofBatch(circuit, batch), vo).tolist()
+                if (name, n) not in expect:
+                    oacc, _, _ = orc.verify(orc.circuit(ci), batch, n_threads=8)
+                    expect[(name, n)] = oacc.tolist()
+                assert got == expect[(name, n)], (name, n, rnd)
+
+
+def test_two_contexts_on_two_threads(gpv, orc):
+    """One context per host thread (include/gpv.h threading contract): both streams share the GPU, answers stay exact."""
+    import threading
+    results = {}
+
+    def work(name, seed):
+        ctx = gpv.Context(0)
+        try:
+            common, vo, circuit, proofs = _load(gpv, name)
+            ci, packed, _ = T.load_fixture(name)
+            batch, _ = T.synthetic_batch(ci, packed, 200, seed=seed, tamper_every=5)
+            chip = gpv.verifier.NewVerifierChip(ctx, common)
+            out = [chip.Verify(gpv.variables.ProofBatch(circuit, batch), vo).tolist() for _ in range(3)]
+            results[name] = (out, batch, ci)
+        finally:
+            ctx.close()
+
+    th = [threading.Thread(target=work, args=(nm, sd)) for nm, sd in (("decode_block", 5), ("step", 6))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert set(results) == {"decode_block", "step"}
+    for name, (out, batch, ci) in results.items():
+        oacc, _, _ = orc.verify(orc.circuit(ci), batch, n_threads=8)
+        assert out[0] == out[1] == out[2] == oacc.tolist(), name
