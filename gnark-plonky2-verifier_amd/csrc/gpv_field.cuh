@@ -65,8 +65,65 @@ GPV_DEV u64 gl_reduce128_nc(u64 lo, u64 hi) {
   u64 d = c == b ? 0 : (c ? GLEPS : (0 - GLEPS));
   return r2 + d;
 }
-// a * b for any u64 operands -> any-u64 result (explicit 32x32 products: the compiler emits 4 v_mad_u64_u32 + glue)
+// a * b for any u64 operands -> any-u64 result: 15 VALU issue slots, hand-scheduled (the compiler's version of the same
+// arithmetic spends ~27, most of them compare/select glue). gfx950 wants 64-bit operands in even-aligned register pairs,
+// so three 32-bit words have to be moved between pairs (x1, z1, z0); everything else is in place:
+//   X = a0 b0                 v[24:25]
+//   Y = a0 b1 + (x1, 0)       v[26:27]      addend v[28:29], v29 == 0 throughout
+//   Z = a1 b0 + Y             v[26:27]      carry c
+//   W = a1 b1 + (z1, c)       v[30:31]      product = (x0, z0, w0, w1)
+//   T = (x0, z0) + w0 (2^32-1) - w1         2^64 = 2^32 - 1, 2^96 = -1 (mod p); wrap flags c1 / b
+//   r = T + (c1 - b)(2^32 - 1)              never both corrections, and the corrected value cannot wrap (gl_reduce128_nc)
+// Two wait states are required between a VALU that writes VCC and a VALU that reads it; the compiler's hazard
+// recogniser does not look inside asm, hence the explicit s_nop.
 GPV_DEV u64 gl_mul_nc(u64 a, u64 b) {
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 r, c1, sa, sb;
+  u32 zero = 0;
+  asm("v_mad_u64_u32 v[24:25], vcc, %[a0], %[b0], 0\n\t"
+      "v_mov_b32_e32 v28, v25\n\t"
+      "v_mad_u64_u32 v[26:27], vcc, %[a0], %[b1], v[28:29]\n\t"
+      "v_mad_u64_u32 v[26:27], vcc, %[a1], %[b0], v[26:27]\n\t"
+      "v_mov_b32_e32 v30, v27\n\t"
+      "s_nop 0\n\t"
+      "v_addc_co_u32_e64 v31, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 v[30:31], vcc, %[a1], %[b1], v[30:31]\n\t"
+      "v_mov_b32_e32 v25, v26\n\t"
+      "v_mad_u64_u32 v[24:25], %[c1], v30, -1, v[24:25]\n\t"
+      "v_sub_co_u32_e32 v24, vcc, v24, v31\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32_e32 v25, vcc, 0, v25, vcc\n\t"
+      "s_andn2_b64 %[sa], %[c1], vcc\n\t"
+      "s_andn2_b64 %[sb], vcc, %[c1]\n\t"
+      "v_cndmask_b32_e64 v26, 0, -1, %[sa]\n\t"
+      "v_cndmask_b32_e64 v26, v26, 1, %[sb]\n\t"
+      "v_cndmask_b32_e64 v27, 0, -1, %[sb]\n\t"
+      "v_lshl_add_u64 %[r], v[24:25], 0, v[26:27]"
+      : [r] "=v"(r), [c1] "=&s"(c1), [sa] "=&s"(sa), [sb] "=&s"(sb)
+      : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), "{v29}"(zero)
+      : "vcc", "scc", "v24", "v25", "v26", "v27", "v28", "v30", "v31");  // s_andn2 writes SCC
+  return r;
+}
+// sl + sh * 2^32 for sl < 2^64 and sh < 2^42 (Poseidon MDS row sums) -> any-u64 representative, 5 VALU slots:
+// the part above 2^64 is hh = (sh >> 32) + carry < 2^11, so hh * (2^32 - 1) can wrap at most once and only upwards.
+GPV_DEV u64 gl_fold_row_nc(u64 sl, u64 sh) {
+  u32 shlo = (u32)sh, shhi = (u32)(sh >> 32), hh, k;
+  u64 r;
+  asm("v_add_co_u32_e32 v31, vcc, %[shlo], v31\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32_e32 %[hh], vcc, 0, %[shhi], vcc\n\t"
+      "v_mad_u64_u32 %[r], vcc, %[hh], -1, v[30:31]\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32_e64 %[k], vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %[r], vcc, %[k], -1, %[r]"
+      : [r] "=&v"(r), [hh] "=&v"(hh), [k] "=&v"(k), "+{v[30:31]}"(sl)
+      : [shlo] "v"(shlo), [shhi] "v"(shhi)
+      : "vcc");
+  return r;
+}
+// Compiler-scheduled forms of the two routines above. More issue slots (~27 / ~25) but no serial asm block: the scheduler
+// interleaves independent products, which is what a latency-bound kernel with one wave per SIMD wants (the transcript).
+GPV_DEV u64 gl_mul_nc_ilp(u64 a, u64 b) {
   u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
   u64 p00 = (u64)a0 * b0;
   u64 p01 = (u64)a0 * b1 + (p00 >> 32);
@@ -75,6 +132,20 @@ GPV_DEV u64 gl_mul_nc(u64 a, u64 b) {
   u64 lo = (p10 << 32) | (u32)p00;
   return gl_reduce128_nc(lo, p11);
 }
+GPV_DEV u64 gl_fold_row_nc_ilp(u64 sl, u64 sh) {
+  u64 l = sl + (sh << 32);
+  u64 h = (sh >> 32) + (l < sl);
+  return gl_reduce128_nc(l, h);
+}
+// arithmetic policies for the Poseidon-Goldilocks round functions
+struct GlThroughput {
+  static GPV_DEV u64 mul(u64 a, u64 b) { return gl_mul_nc(a, b); }
+  static GPV_DEV u64 fold_row(u64 sl, u64 sh) { return gl_fold_row_nc(sl, sh); }
+};
+struct GlLatency {
+  static GPV_DEV u64 mul(u64 a, u64 b) { return gl_mul_nc_ilp(a, b); }
+  static GPV_DEV u64 fold_row(u64 sl, u64 sh) { return gl_fold_row_nc_ilp(sl, sh); }
+};
 GPV_DEV u64 gl_sqr_n(u64 a, int n) {
   for (int i = 0; i < n; i++) a = gl_sqr(a);
   return a;

@@ -77,15 +77,26 @@ GPV_DEV void pgl_partial_init(u64 s[12]) {
 // reduce ONCE (measured: 690 vs 892 + 155 instructions per partial round). Both forms give identical outputs -- the fast
 // tables are derived from these round constants -- which the parity tests confirm against the oracle's fast form.
 // Intermediates are non-canonical u64 representatives; the next round's constants ride inside the MDS row sums.
+template <class A = GlThroughput>
 GPV_DEV u64 pgl_sbox_nc(u64 x) {
-  u64 x2 = gl_mul_nc(x, x);
-  u64 x3 = gl_mul_nc(x, x2);
-  u64 x6 = gl_mul_nc(x3, x3);
-  return gl_mul_nc(x, x6);
+  u64 x2 = A::mul(x, x);
+  u64 x3 = A::mul(x, x2);
+  u64 x6 = A::mul(x3, x3);
+  return A::mul(x, x6);
 }
-template <bool ADD_RC>
+// Row r of the circulant MDS (+ diag 8 on word 0) of the low and high halves, with the NEXT round's constant riding in
+// as the first addend of the low chain (all 360 constants are < 2^64 - 2^43, so that chain cannot wrap: checked in
+// tests/test_oracle_kat.py). Coefficients 2 and 16 are kept opaque so the compiler does not strength-reduce them into
+// shift/add sequences, which cost more issue slots on gfx950 than the v_mad_u64_u32 they replace.
+template <u32 V>
+GPV_DEV u32 pgl_opaque() {
+  u32 r;
+  asm("s_mov_b32 %0, %1" : "=s"(r) : "n"(V));
+  return r;
+}
+template <bool ADD_RC, class A = GlThroughput>
 GPV_DEV void pgl_mds_nc(u64 s[12], const u64* rc) {
-  constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  const u32 C[12] = {17, 15, 41, pgl_opaque<16>(), pgl_opaque<2>(), 28, 13, 13, 39, 18, 34, 20};
   u32 lo[12], hi[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) {
@@ -94,27 +105,18 @@ GPV_DEV void pgl_mds_nc(u64 s[12], const u64* rc) {
   }
 #pragma unroll
   for (int r = 0; r < 12; r++) {
-    u64 sl = 0, sh = 0;
+    u64 sl = ADD_RC ? rc[r] : 0, sh = 0;
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-      sl += (u64)lo[(i + r) % 12] * C[i];
-      sh += (u64)hi[(i + r) % 12] * C[i];
+      const u32 c = (r == 0 && i == 0) ? 25u : C[i];  // diagonal 8 on word 0 (17 + 8)
+      sl += (u64)lo[(i + r) % 12] * c;
+      sh += (u64)hi[(i + r) % 12] * c;
     }
-    if (r == 0) {
-      sl += (u64)lo[0] * 8;
-      sh += (u64)hi[0] * 8;
-    }
-    u64 l = sl + (sh << 32);
-    u64 h = (sh >> 32) + (l < sl);
-    if (ADD_RC) {
-      u64 l2 = l + rc[r];
-      h += l2 < l;
-      l = l2;
-    }
-    s[r] = gl_reduce128_nc(l, h);
+    s[r] = A::fold_row(sl, sh);
   }
 }
 // goldilocks.go:30-37. Canonical in, canonical out.
+template <class A = GlThroughput>
 GPV_DEV void poseidon_gl_permute(u64 s[12]) {
 #pragma unroll
   for (int i = 0; i < 12; i++) {  // first round constants; canonical + canonical < 2^65: one wrap correction
@@ -124,23 +126,23 @@ GPV_DEV void poseidon_gl_permute(u64 s[12]) {
 #pragma unroll 1
   for (int r = 0; r < 4; r++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = pgl_sbox_nc(s[i]);
-    pgl_mds_nc<true>(s, PGL_ARC + 12 * (r + 1));
+    for (int i = 0; i < 12; i++) s[i] = pgl_sbox_nc<A>(s[i]);
+    pgl_mds_nc<true, A>(s, PGL_ARC + 12 * (r + 1));
   }
 #pragma unroll 1
   for (int r = 4; r < 26; r++) {
-    s[0] = pgl_sbox_nc(s[0]);
-    pgl_mds_nc<true>(s, PGL_ARC + 12 * (r + 1));
+    s[0] = pgl_sbox_nc<A>(s[0]);
+    pgl_mds_nc<true, A>(s, PGL_ARC + 12 * (r + 1));
   }
 #pragma unroll 1
   for (int r = 26; r < 29; r++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = pgl_sbox_nc(s[i]);
-    pgl_mds_nc<true>(s, PGL_ARC + 12 * (r + 1));
+    for (int i = 0; i < 12; i++) s[i] = pgl_sbox_nc<A>(s[i]);
+    pgl_mds_nc<true, A>(s, PGL_ARC + 12 * (r + 1));
   }
 #pragma unroll
-  for (int i = 0; i < 12; i++) s[i] = pgl_sbox_nc(s[i]);
-  pgl_mds_nc<false>(s, nullptr);
+  for (int i = 0; i < 12; i++) s[i] = pgl_sbox_nc<A>(s[i]);
+  pgl_mds_nc<false, A>(s, nullptr);
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }

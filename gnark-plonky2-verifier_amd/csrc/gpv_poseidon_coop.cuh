@@ -52,6 +52,7 @@ GPV_DEV u64 pgl_coop_word(const PglCoop& c, u64 x, int k) {
   return pgl_coop_shfl(x, ((lane - c.g) + k) << 2);
 }
 // MDS row of this lane (+ next round's constant when next_round >= 0), non-canonical result
+template <class A = GlThroughput>
 GPV_DEV u64 pgl_coop_mds(const PglCoop& c, u64 x, int next_round) {
   constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   u64 sl = (u64)(u32)x * c.diag, sh = (u64)(u32)(x >> 32) * c.diag;
@@ -61,17 +62,11 @@ GPV_DEV u64 pgl_coop_mds(const PglCoop& c, u64 x, int next_round) {
     sl += (u64)(u32)xi * C[i];
     sh += (u64)(u32)(xi >> 32) * C[i];
   }
-  u64 l = sl + (sh << 32);
-  u64 h = (sh >> 32) + (l < sl);
-  if (next_round >= 0) {
-    u64 k = c.rc[12 * next_round + (c.g < 12 ? c.g : 0)];
-    u64 l2 = l + k;
-    h += l2 < l;
-    l = l2;
-  }
-  return gl_reduce128_nc(l, h);
+  if (next_round >= 0) sl += c.rc[12 * next_round + (c.g < 12 ? c.g : 0)];  // constants < 2^64 - 2^43: cannot wrap
+  return A::fold_row(sl, sh);
 }
 // One permutation of the group's state. x: this lane's state word (canonical in, canonical out).
+template <class A = GlThroughput>
 GPV_DEV u64 pgl_coop_permute(const PglCoop& c, u64 x) {
   {
     u64 t = x + c.rc[c.g < 12 ? c.g : 0];
@@ -80,9 +75,9 @@ GPV_DEV u64 pgl_coop_permute(const PglCoop& c, u64 x) {
 #pragma unroll 1
   for (int r = 0; r < 30; r++) {
     bool full = r < 4 || r >= 26;
-    u64 y = pgl_sbox_nc(x);
+    u64 y = pgl_sbox_nc<A>(x);
     x = (full || c.g == 0) ? y : x;
-    x = pgl_coop_mds(c, x, r < 29 ? r + 1 : -1);
+    x = pgl_coop_mds<A>(c, x, r < 29 ? r + 1 : -1);
   }
   return gl_canon(x);
 }
@@ -101,7 +96,7 @@ struct CoopChallenger {
     n_out = 0;
   }
   GPV_DEV void duplex() {
-    x = pgl_coop_permute(c, x);
+    x = pgl_coop_permute<GlLatency>(c, x);
     n_in = 0;
     n_out = 8;
   }

@@ -17,7 +17,7 @@ struct PglState {
   u64 s[12];
 };
 __device__ __noinline__ PglState poseidon_gl_permute_call(PglState st) {
-  poseidon_gl_permute(st.s);
+  poseidon_gl_permute<GlLatency>(st.s);  // one wave per SIMD here: ILP beats issue-slot count
   return st;
 }
 

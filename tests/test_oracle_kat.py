@@ -219,3 +219,14 @@ def test_synthetic_batch_matches_tamper_mask(orc):
     batch, tampered = T.synthetic_batch(ci, packed, 24, seed=5, tamper_every=4)
     accept, _, _ = orc.verify(oc, batch, n_threads=4)
     assert (accept == 0).tolist() == tampered.tolist()
+
+
+def test_poseidon_gl_round_constants_leave_headroom():
+    """The HIP MDS row sums start from the next round's constant and add 12 products < 2^38 without carry handling
+    (csrc/gpv_poseidon.cuh pgl_mds_nc): every constant of goldilocks_constants.go:7-368 must be < 2^64 - 2^43."""
+    import re
+    inc = (T.ROOT / "gnark-plonky2-verifier_amd" / "csrc" / "poseidon_tables.inc").read_text()
+    i = inc.index("PGL_ARC")
+    body = inc[inc.index("{", i) + 1:inc.index("};", i)]
+    vals = [int(x.rstrip("UL"), 0) for x in re.findall(r"0x[0-9a-fA-F]+U?L?L?", body)]
+    assert len(vals) == 360 and max(vals) < 2**64 - 2**43
