@@ -60,8 +60,8 @@ def perms_per_proof(ci):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--proofs-per-gpu", type=int, default=8192)
     ap.add_argument("--fixture", default="step", choices=["step", "decode_block"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
