@@ -161,7 +161,6 @@ GPV_DEV u64 gl_inv(u64 x) {
   u64 x30 = gl_mul(gl_sqr_n(x24, 6), x6);    // 2^30 - 1
   u64 x31 = gl_mul(gl_sqr(x30), x);          // 2^31 - 1
   u64 x32 = gl_mul(gl_sqr(x31), x);          // 2^32 - 1
-  // (2^32 - 1) * 2^32 + (2^31 - 1)*... : exponent = (2^32-1) << 32 | (2^32 - 1) - 2^32... build directly:
   // p - 2 = 0xFFFFFFFE_FFFFFFFF = ((2^31 - 1) << 33) | (2^32 - 1)   (bit 32 is the single zero)
   u64 t = gl_sqr_n(x31, 33);
   return gl_mul(t, x32);
