@@ -49,6 +49,14 @@ struct gpv_ctx {
   size_t derived_words = 0;
   u32* fail = nullptr;
   size_t fail_n = 0;
+  // host-batch path (gpv_verify): grow-only staging for the packed records and the accept bytes, and an upload stream so
+  // the copy of chunk k+1 runs while chunk k is being verified
+  uint8_t* stage = nullptr;
+  size_t stage_bytes = 0;
+  uint8_t* stage_accept = nullptr;
+  size_t stage_accept_n = 0;
+  hipStream_t upload = nullptr;
+  hipEvent_t ev_upload = nullptr;
 };
 
 static void ctx_error(gpv_ctx* ctx, const char* fmt, ...) {
@@ -141,7 +149,9 @@ extern "C" int gpv_ctx_create(gpv_ctx** out, int device_id) {
   if (hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_transcript, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_side_done, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->ev_side_done, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->upload, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) {
     gpv_set_global_error("side stream / event creation failed on device %d", device_id);
     delete ctx;
     return GPV_EDEVICE;
@@ -158,6 +168,10 @@ extern "C" int gpv_ctx_destroy(gpv_ctx* ctx) {
   if (ctx->fail) hipFree(ctx->fail);
   if (ctx->digests) hipFree(ctx->digests);
   if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
+  if (ctx->upload) { hipStreamSynchronize(ctx->upload); hipStreamDestroy(ctx->upload); }
+  if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
+  if (ctx->stage) hipFree(ctx->stage);
+  if (ctx->stage_accept) hipFree(ctx->stage_accept);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_transcript) hipEventDestroy(ctx->ev_transcript);
   if (ctx->ev_side_done) hipEventDestroy(ctx->ev_side_done);
@@ -850,8 +864,51 @@ extern "C" int gpv_verify_detail(gpv_ctx* ctx, const gpv_circuit* c, const void*
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GPV_OK;
 }
+// Host batch -> accept bytes, the plain VerifierChip.Verify replacement. The records are uploaded in chunks on their own
+// stream (1024, 2048, then up to 8192 proofs each) so that all but the first copy overlap the verification of the previous
+// chunk; staging lives in the context (no hipMalloc per call). Pageable host memory works (the copy then blocks the host
+// thread, not the GPU); pinned memory (hipHostMalloc / hipHostRegister by the caller) copies faster.
 extern "C" int gpv_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept) {
-  return gpv_verify_detail(ctx, c, proofs, n, accept, nullptr, nullptr);
+  REQUIRE(ctx, ctx && c && proofs && accept);
+  if (n == 0) return GPV_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t rec = c->dc.proof_nbytes;
+  if (rec * n > ctx->stage_bytes) {
+    if (ctx->stage) { hipStreamSynchronize(ctx->stream); hipFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->stage, rec * n));
+    ctx->stage_bytes = rec * n;
+  }
+  if (n > ctx->stage_accept_n) {
+    if (ctx->stage_accept) { hipStreamSynchronize(ctx->stream); hipFree(ctx->stage_accept); ctx->stage_accept = nullptr; ctx->stage_accept_n = 0; }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->stage_accept, n));
+    ctx->stage_accept_n = n;
+  }
+  {
+    int rc = ensure_scratch(ctx, c, n < 8192 ? n : 8192);  // once, for the largest chunk: no re-allocation between chunks
+    if (rc != GPV_OK) return rc;
+  }
+  size_t done = 0, step = 1024;
+  while (done < n) {
+    size_t left = n - done, take;
+    if (step < 4096 && left > 2 * step) {
+      take = step;  // ramp-up: short first copies, so the GPU starts early
+      step *= 2;
+    } else {
+      size_t parts = (left + 8191) / 8192;
+      take = (left + parts - 1) / parts;
+    }
+    const uint8_t* src = (const uint8_t*)proofs + done * rec;
+    uint8_t* dst = ctx->stage + done * rec;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, take * rec, hipMemcpyHostToDevice, ctx->upload));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->upload));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload, 0));
+    int rc = gpv_verify_dev(ctx, c, dst, take, ctx->stage_accept + done);
+    if (rc != GPV_OK) return rc;
+    done += take;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(accept, ctx->stage_accept, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
 }
 
 // ================================================================ instruction-rate microbenchmark (kernels: gpv_k_prim.hip)
