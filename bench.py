@@ -10,7 +10,7 @@ resident in HBM: BASELINE.json config 4's per-GPU shard, 8192 packed `step` proo
 tampered, followed -- for N > 1 -- by the RCCL all-gather of the packed accept bits. Rank 0 prints ONE JSON line.
 
 The same line carries
-  roofline      -- dominant kernel (k_merkle): algorithmic bytes / launch duration against HBM peak, as the contract asks;
+  roofline      -- dominant kernel (k_merkle_leaves): algorithmic bytes / launch duration against HBM peak, as the contract asks;
                    this workload is integer-VALU bound (2 000 32-bit multiply-adds per input byte), so the line also
                    carries `valu_roofline`: achieved v_mad_u64_u32 rate vs the peak measured on this chip.
   cpu_baseline  -- the C++ restatement of the reference algorithm (oracle/, kind "port") timed on the host cores on a
@@ -151,7 +151,7 @@ def main():
         elapsed = float(t.item())
     merkle_ms, merkle_launches = ctx.timing_get(0)
     leaves_ms, _ = ctx.timing_get(7)
-    stage_ms = {nm: ctx.timing_get(k)[0] for nm, k in (("merkle_climb", 0), ("merkle_leaves", 7), ("transcript", 2), ("plonk", 3),
+    stage_ms = {nm: ctx.timing_get(k)[0] for nm, k in (("merkle_walk", 0), ("merkle_leaves", 7), ("transcript", 2), ("plonk", 3),
                                                         ("fri_query", 4), ("range_check", 5))}
     ctx.timing_enable(False)
 
@@ -183,37 +183,40 @@ def main():
     }
     if rank == 0:
         leaf_perms, climb_perms = perms_per_proof(ci)
-        perms = climb_perms
-        # dominant kernel = k_merkle_climb. Its algorithmic bytes per proof: every sibling and cap entry it consumes (the Fr
-        # section of the record, 32 B each) + the leaf digests it reads back (36 B per chain) + the 28 query indices.
         n_chains = ci.num_query_rounds * (4 + len(ci.arity_bits))
-        n_fr = (3 + len(ci.arity_bits)) * ci.cap_len + climb_perms  # caps + one Fr per sibling
-        alg_bytes_per_proof = 32.0 * n_fr + 36.0 * n_chains + 8.0 * ci.num_query_rounds
+        # dominant kernel = k_merkle_leaves (the sibling walk is split over k_merkle_climb_lower and the k_crown_* kernels, each
+        # shorter than the leaf hashing). Its algorithmic bytes per proof: the leaf words of the 28 query blocks, read once
+        # (8 B each), + the digests it writes (36 B per chain).
+        qwords = sum(ci.leaf_len(o) for o in range(4)) + sum(2 << a for a in ci.arity_bits)
+        alg_bytes_per_proof = 8.0 * ci.num_query_rounds * qwords + 36.0 * n_chains
         alg_bytes = alg_bytes_per_proof * n_local
-        achieved = alg_bytes / (merkle_ms * 1e-3) / 1e9 if merkle_ms > 0 else 0.0
+        achieved = alg_bytes / (leaves_ms * 1e-3) / 1e9 if leaves_ms > 0 else 0.0
         # HBM traffic per launch from the PMC passes of the same command (separate rocprofv3 --pmc runs, FETCH_SIZE x2 on
         # gfx950), recorded in profiles/traffic.json; only reported when it was measured on this exact configuration
         traffic = None
         try:
-            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())["k_merkle_climb"]
+            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())["k_merkle_leaves"]
             if tj["fixture"] == args.fixture and tj["proofs_per_gpu"] == n_local:
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
-        line["roofline"] = {"bound": "hbm", "kernel": "k_merkle_climb", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": merkle_ms, "launches": merkle_launches,
+        line["roofline"] = {"bound": "hbm", "kernel": "k_merkle_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": leaves_ms, "launches": merkle_launches,
                             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_proof": alg_bytes_per_proof,
                             "note": "integer-VALU bound workload; see valu_roofline"}
         mad_measured = max(ctx.microbench(0) for _ in range(3))
         mad_peak = MAD_PEAK_MODEL
-        mads = float(perms) * FR_MULS_PER_PERM * MADS_PER_FR_MUL * n_local
-        line["valu_roofline"] = {"bound": "valu_int32_mad", "kernel": "k_merkle_climb", "achieved": mads / (merkle_ms * 1e-3) / 1e12 if merkle_ms > 0 else 0.0,
-                                 "peak": mad_peak / 1e12, "unit": "T v_mad_u64_u32 lane-ops/s",
-                                 "frac": (mads / (merkle_ms * 1e-3)) / mad_peak if merkle_ms > 0 else 0.0,
+        per_perm = FR_MULS_PER_PERM * MADS_PER_FR_MUL
+        leaf_rate = float(leaf_perms) * per_perm * n_local / (leaves_ms * 1e-3) if leaves_ms > 0 else 0.0
+        # the sibling walk: the reference hashes climb_perms times per proof; the shared upper levels execute fewer, so this is
+        # an effective rate (it may exceed the issue peak)
+        walk_rate = float(climb_perms) * per_perm * n_local / (merkle_ms * 1e-3) if merkle_ms > 0 else 0.0
+        line["valu_roofline"] = {"bound": "valu_int32_mad", "kernel": "k_merkle_leaves", "achieved": leaf_rate / 1e12,
+                                 "peak": mad_peak / 1e12, "unit": "T v_mad_u64_u32 lane-ops/s", "frac": leaf_rate / mad_peak,
                                  "peak_definition": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz", "peak_microbench_this_run": mad_measured / 1e12,
-                                 "algorithmic_mads_per_proof": float(perms) * FR_MULS_PER_PERM * MADS_PER_FR_MUL,
-                                 "bn254_perms_per_proof": perms, "bn254_leaf_perms_per_proof": leaf_perms,
-                                 "k_merkle_leaves_frac": (float(leaf_perms) * FR_MULS_PER_PERM * MADS_PER_FR_MUL * n_local / (leaves_ms * 1e-3)) / mad_peak if leaves_ms > 0 else 0.0}
+                                 "algorithmic_mads_per_proof": float(leaf_perms) * per_perm,
+                                 "bn254_leaf_perms_per_proof": leaf_perms, "bn254_sibling_perms_per_proof_reference": climb_perms,
+                                 "sibling_walk_effective_frac": walk_rate / mad_peak, "sibling_walk_ms": merkle_ms}
         line["stage_ms"] = stage_ms
         if not args.no_poseidon_gl:
             n_states = 1 << 20

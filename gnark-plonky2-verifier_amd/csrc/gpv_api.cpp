@@ -51,6 +51,10 @@ struct gpv_ctx {
   size_t fail_n = 0;
   // host-batch path (gpv_verify): grow-only staging for the packed records and the accept bytes, and an upload stream so
   // the copy of chunk k+1 runs while chunk k is being verified
+  // shared upper Merkle levels (gpv_k_crown.hip)
+  int merkle_shared = 1;  // GPV_OPT_MERKLE_SHARED_LEVELS
+  void* crown = nullptr;
+  size_t crown_bytes = 0;
   uint8_t* stage = nullptr;
   size_t stage_bytes = 0;
   uint8_t* stage_accept = nullptr;
@@ -170,6 +174,7 @@ extern "C" int gpv_ctx_destroy(gpv_ctx* ctx) {
   if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
   if (ctx->upload) { hipStreamSynchronize(ctx->upload); hipStreamDestroy(ctx->upload); }
   if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
+  if (ctx->crown) hipFree(ctx->crown);
   if (ctx->stage) hipFree(ctx->stage);
   if (ctx->stage_accept) hipFree(ctx->stage_accept);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
@@ -188,6 +193,10 @@ extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
   if (!ctx) return GPV_EINVAL;
   if (option == GPV_OPT_TRANSCRIPT_VARIANT && value >= 0 && value <= 2) {
     ctx->transcript_variant = value;
+    return GPV_OK;
+  }
+  if (option == GPV_OPT_MERKLE_SHARED_LEVELS && (value == 0 || value == 1)) {
+    ctx->merkle_shared = value;
     return GPV_OK;
   }
   ctx->err = "unknown option or value";
@@ -264,6 +273,14 @@ static int ensure_scratch(gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->digests, dw * sizeof(u32)));
     ctx->digest_words = dw;
   }
+  if (ctx->merkle_shared && gpvk_crown_supported(c->dc)) {
+    size_t cb = gpvk_crown_bytes(c->dc, n);
+    if (cb > ctx->crown_bytes) {
+      if (ctx->crown) { hipStreamSynchronize(ctx->stream); hipFree(ctx->crown); ctx->crown = nullptr; ctx->crown_bytes = 0; }
+      HIP_TRY(ctx, hipMalloc(&ctx->crown, cb));
+      ctx->crown_bytes = cb;
+    }
+  }
   return GPV_OK;
 }
 
@@ -294,6 +311,13 @@ static void launch_merkle_leaves(gpv_ctx* ctx, hipStream_t st, const gpv_circuit
 static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n,
                                 uint8_t* ok_dev) {
   Timed t(ctx, TK_MERKLE, st);
+  if (!ok_dev && ctx->merkle_shared && gpvk_crown_supported(c->dc)) {
+    // per-path hashing up to GPV_CROWN_LEVELS below the cap, then every distinct upper node once
+    CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown);
+    gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS);
+    gpvk_crown(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, b, ctx->fail);
+    return;
+  }
   gpvk_merkle_climb(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, ctx->fail, ok_dev);
 }
 // both Merkle phases back to back on one stream (entry points with caller-supplied challenges)

@@ -26,14 +26,12 @@
 GPV_DEV Fr dev_merkle_leaf(const u64* __restrict__ leaf, u32 leaf_len) {
   return poseidon_bn254_hash_or_noop(leaf, leaf_len);  // fri.go:104
 }
-// Returns true iff the path from `cur` hashes to the cap entry.
-GPV_DEV bool dev_merkle_climb(Fr cur, const u64* __restrict__ siblings, u32 n_siblings, u32 index_bits,
-                              const u64* __restrict__ cap_entry) {
+// `n` levels upwards from `cur`: sibling i pairs with bit i of index_bits (bit = 1: hash(sibling, cur), fri.go:105-116)
+GPV_DEV void dev_merkle_steps(Fr& cur, const u64* __restrict__ siblings, u32 n, u32 index_bits) {
 #pragma unroll 1
-  for (u32 i = 0; i < n_siblings; i++) {
+  for (u32 i = 0; i < n; i++) {
     Fr sib = fr_from_canonical64(siblings + 4 * i);
     bool bit = (index_bits >> i) & 1;
-    // bit = 1: hash(sibling, cur); bit = 0: hash(cur, sibling)   (fri.go:105-116)
     Fr s[4];
     s[0] = fr_zero();
     s[1] = fr_zero();
@@ -45,11 +43,52 @@ GPV_DEV bool dev_merkle_climb(Fr cur, const u64* __restrict__ siblings, u32 n_si
     poseidon_bn254_permute(s);
     cur = s[0];
   }
-  // compare canonical representatives (fri.go:135-143); the digest inside the chain is only reduced up to multiples of r
-  u64 got[4], want[4] = {cap_entry[0], cap_entry[1], cap_entry[2], cap_entry[3]};
+}
+// canonical representatives compared (fri.go:135-143); values inside a chain are only reduced up to multiples of r
+GPV_DEV bool fr_words_equal(const u64 a[4], const u64 b[4]) { return ((a[0] ^ b[0]) | (a[1] ^ b[1]) | (a[2] ^ b[2]) | (a[3] ^ b[3])) == 0; }
+GPV_DEV bool dev_fr_matches(const Fr& cur, const u64* __restrict__ words) {
+  u64 got[4], want[4] = {words[0], words[1], words[2], words[3]};
   fr_to_canonical64(cur, got);
   fr_words_reduce(want);
-  return ((got[0] ^ want[0]) | (got[1] ^ want[1]) | (got[2] ^ want[2]) | (got[3] ^ want[3])) == 0;
+  return fr_words_equal(got, want);
+}
+// Returns true iff the path from `cur` hashes to the cap entry.
+GPV_DEV bool dev_merkle_climb(Fr cur, const u64* __restrict__ siblings, u32 n_siblings, u32 index_bits,
+                              const u64* __restrict__ cap_entry) {
+  dev_merkle_steps(cur, siblings, n_siblings, index_bits);
+  return dev_fr_matches(cur, cap_entry);
+}
+// Where the Merkle path of (query q, tree) of one proof lives (fri.go:146-157 initial trees, :472-483 step trees)
+struct MerklePath {
+  const u64* sib;   // n_sib siblings, 4 words each
+  const u64* cap;   // the 2^cap_height entries of this tree's cap
+  u32 n_sib, bits;  // bit i of `bits` pairs with sibling i; bits >> n_sib is the cap index
+  u32 cap_index;
+};
+GPV_DEV MerklePath dev_merkle_path(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ derived_p, u32 q,
+                                   u32 tree) {
+  const u64* frs = rec + dc->n_gl_words;
+  const u32 n_log = dc->lde_bits;
+  u64 x_index = gl_canon(derived_p[dc->ch_queries + q]);
+  u32 idx = (u32)(x_index & (((u64)1 << n_log) - 1));
+  const u64* qfr = frs + 4 * ((size_t)dc->fr_queries + (size_t)q * dc->query_frs);
+  MerklePath m;
+  m.cap_index = idx >> (n_log - dc->cap_height);  // fri.go:402, reused for every step (:477-483)
+  if (tree < 4) {
+    m.sib = qfr + 4 * (size_t)(tree * dc->init_siblings);
+    m.n_sib = dc->init_siblings;
+    m.bits = idx;
+    m.cap = tree == 0 ? &dc->sigmas_cap[0][0] : frs + 4 * (size_t)((tree - 1) << dc->cap_height);
+  } else {
+    u32 s = tree - 4;
+    u32 shift = 0;
+    for (u32 k = 0; k <= s; k++) shift += dc->arity_bits[k];
+    m.sib = qfr + 4 * (size_t)dc->step_sib_off[s];
+    m.n_sib = dc->step_siblings[s];
+    m.bits = idx >> shift;
+    m.cap = frs + 4 * (size_t)(dc->fr_commit_caps + (s << dc->cap_height));
+  }
+  return m;
 }
 
 // ---------------------------------------------------------------- field part of one query round

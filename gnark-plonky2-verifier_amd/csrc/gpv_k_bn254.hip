@@ -82,36 +82,42 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb(const DevCirc
   u32 q = (u32)(item - p * nq);
   u32 tree = order.cls[blockIdx.y];
   const u64* rec = proofs + p * (dc->proof_nbytes / 8);
-  const u64* frs = rec + dc->n_gl_words;
   const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
-  const u32 n_log = dc->lde_bits;
-  u64 x_index = gl_canon(d[dc->ch_queries + q]);
-  u32 idx = (u32)(x_index & (((u64)1 << n_log) - 1));
-  u32 cap_index = idx >> (n_log - dc->cap_height);  // fri.go:402, reused for every step (:477-483)
-  const u64* qfr = frs + 4 * ((size_t)dc->fr_queries + (size_t)q * dc->query_frs);
-  const u64 *sib, *cap;
-  u32 n_sib, bits;
-  if (tree < 4) {
-    sib = qfr + 4 * (size_t)(tree * dc->init_siblings);
-    n_sib = dc->init_siblings;
-    bits = idx;
-    cap = tree == 0 ? &dc->sigmas_cap[0][0] : frs + 4 * (size_t)((tree - 1) << dc->cap_height);
-  } else {
-    u32 s = tree - 4;
-    u32 shift = 0;
-    for (u32 k = 0; k <= s; k++) shift += dc->arity_bits[k];
-    sib = qfr + 4 * (size_t)dc->step_sib_off[s];
-    n_sib = dc->step_siblings[s];
-    bits = idx >> shift;
-    cap = frs + 4 * (size_t)(dc->fr_commit_caps + (s << dc->cap_height));
-  }
+  MerklePath m = dev_merkle_path(dc, rec, d, q, tree);
   Fr cur;
   const u32* din = digests + ((size_t)tree * items + item) * FR_LIMBS;
 #pragma unroll
   for (int k = 0; k < FR_LIMBS; k++) cur.l[k] = din[k];
-  bool ok = dev_merkle_climb(cur, sib, n_sib, bits, cap + 4 * cap_index);
+  bool ok = dev_merkle_climb(cur, m.sib, m.n_sib, m.bits, m.cap + 4 * m.cap_index);
   if (ok_out) ok_out[item * dc->n_trees + tree] = ok;
   if (!ok) atomicOr(&fail[p], tree < 4 ? (u32)GPV_FAIL_MERKLE_INITIAL : (u32)GPV_FAIL_MERKLE_STEP);
+}
+// The same walk, stopped `crown_levels` levels below the cap: the node reached there is stored as canonical words
+// ([tree][item][4]) and the shared upper levels are hashed once per distinct node by gpv_k_crown.hip.
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_lower(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                         const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                                         const u32* __restrict__ digests, u64* __restrict__ mid,
+                                                                         u32 crown_levels) {
+  size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nq = dc->num_queries;
+  const size_t items = n * nq;
+  if (item >= items) return;
+  size_t p = item / nq;
+  u32 q = (u32)(item - p * nq);
+  u32 tree = order.cls[blockIdx.y];
+  const u64* rec = proofs + p * (dc->proof_nbytes / 8);
+  const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
+  MerklePath m = dev_merkle_path(dc, rec, d, q, tree);
+  Fr cur;
+  const u32* din = digests + ((size_t)tree * items + item) * FR_LIMBS;
+#pragma unroll
+  for (int k = 0; k < FR_LIMBS; k++) cur.l[k] = din[k];
+  u32 top = m.n_sib < crown_levels ? m.n_sib : crown_levels;
+  dev_merkle_steps(cur, m.sib, m.n_sib - top, m.bits);
+  u64 out[4];
+  fr_to_canonical64(cur, out);
+  u64* o = mid + ((size_t)tree * items + item) * 4;
+  o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; o[3] = out[3];
 }
 static MerkleOrder merkle_order(const DevCircuit& c, bool leaves) {
   // cost of a phase-1 chain = ceil(leaf_len / 9) permutations, of a phase-2 chain = number of siblings;
@@ -121,7 +127,7 @@ static MerkleOrder merkle_order(const DevCircuit& c, bool leaves) {
   for (u32 t = 0; t < c.n_trees; t++) {
     u32 len = t < 4 ? c.leaf_len[t] : (2u << c.arity_bits[t - 4]);
     u32 sib = t < 4 ? c.init_siblings : c.step_siblings[t - 4];
-    cost[t] = leaves ? (len <= 3 ? 0 : (len + 8) / 9) : sib;
+    cost[t] = leaves ? (len <= 3 ? 0 : (len + 8) / 9) : sib;  // (the lower-levels mode subtracts the same constant from every class)
     o.cls[t] = t;
   }
   for (u32 i = 0; i < c.n_trees; i++)
@@ -153,4 +159,10 @@ void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& 
   size_t items = n * hc.num_queries;
   hipLaunchKernelGGL(k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd,
                      proofs, derived, n, merkle_order(hc, false), digests, fail, ok_out);
+}
+void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
+                             const u32* digests, u64* mid, u32 crown_levels) {
+  size_t items = n * hc.num_queries;
+  hipLaunchKernelGGL(k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st,
+                     dcd, proofs, derived, n, merkle_order(hc, false), digests, mid, crown_levels);
 }

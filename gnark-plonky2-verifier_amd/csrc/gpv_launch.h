@@ -31,6 +31,27 @@ void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, 
 void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n);
 size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n);  // u32 words of leaf-digest scratch for n proofs
 void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests);
+// shared upper Merkle levels (gpv_k_crown.hip)
+#define GPV_CROWN_LEVELS 4
+#define GPV_CROWN_MAXQ 32
+struct CrownItem;
+struct CrownBufs {
+  u32* count;                       // [GPV_CROWN_LEVELS] distinct nodes per level, whole batch
+  u64* mid;                         // [tree][item][4] node of each path below the crown, canonical
+  u64* res[GPV_CROWN_LEVELS];       // [slot][4] digests of the distinct nodes, canonical
+  CrownItem* item[GPV_CROWN_LEVELS];
+  u32* slot;                        // [proof][tree][query][level] slot of the shared node at the path's position
+  u32* pslot;                       // same shape: the node the path's own chain passes through (shared, or its own)
+  u32* pstate;                      // [proof][tree][query] bit 0: the path has left the shared tree
+  u32* gflag;                       // [proof][tree] cap-mismatch flag
+};
+size_t gpvk_crown_bytes(const DevCircuit& hc, size_t n);
+bool gpvk_crown_supported(const DevCircuit& hc);
+CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base);
+void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
+                             const u32* digests, u64* mid, u32 crown_levels);
+void gpvk_crown(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, CrownBufs b,
+                u32* fail);
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
                        const u32* digests, u32* fail, uint8_t* ok_out);
 // gpv_k_transcript.hip

@@ -740,3 +740,48 @@ def test_two_contexts_on_two_threads(gpv, orc):
     for name, (out, batch, ci) in results.items():
         oacc, _, _ = orc.verify(orc.circuit(ci), batch, n_threads=8)
         assert out[0] == out[1] == out[2] == oacc.tolist(), name
+
+
+# ---------------------------------------------------------------- shared upper Merkle levels
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_shared_merkle_levels_are_exact(gpv, api, orc, name):
+    """GPV_OPT_MERKLE_SHARED_LEVELS hashes each distinct node of the last four tree levels once. Accept bits and failure
+    masks must not depend on it, in particular when paths disagree (corrupted siblings, caps, leaves, query data)."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    n = 384
+    base = np.frombuffer(packed, dtype=np.uint64)
+    words = np.tile(base, (n, 1)).copy()
+    n_gl = _n_gl_words(ci)
+    n_words = words.shape[1]
+    rng = np.random.default_rng(77)
+    for i in range(1, n):
+        if i % 3 == 0:      # an Fr word: caps, siblings of every level (upper levels are shared between paths)
+            w = n_gl + int(rng.integers(0, n_words - n_gl))
+            words[i, w] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 60)))
+        elif i % 3 == 1:    # a Goldilocks word of the query section: leaves and step evaluations
+            w = int(rng.integers(0, n_gl))
+            words[i, w] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 32)))
+        else:               # the last sibling of one path (directly under the cap) replaced by another path's
+            w = n_gl + int(rng.integers(4 * 16 * 3, n_words - n_gl - 8))
+            words[i, w:w + 4] = words[i, w + 4:w + 8]
+    batch = words.reshape(-1).view(np.uint8)
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    chip = gpv.verifier.NewVerifierChip(api, common)
+    oacc, ofail, _ = orc.verify(oc, batch, n_threads=8)
+    results = {}
+    try:
+        for mode in (1, 0):
+            api.set_option(2, mode)
+            acc, mask, _ = chip.Verify(pb, vo, detail=True)
+            results[mode] = (acc.copy(), mask.copy())
+    finally:
+        api.set_option(2, 1)
+    for mode in (1, 0):
+        acc, mask = results[mode]
+        assert acc.tolist() == oacc.tolist(), mode
+        clean = (ofail & 1) == 0
+        assert mask[clean].tolist() == [int(x) for x in ofail[clean]], mode
+    assert (results[0][1] == results[1][1]).all()
+    assert 0 < int(oacc.sum()) < n   # the batch really mixes accepted and rejected proofs
