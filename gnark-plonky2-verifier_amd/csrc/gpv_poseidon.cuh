@@ -286,23 +286,26 @@ GPV_DEV Fr poseidon_bn254_two_to_one(const Fr& l, const Fr& r) {
   poseidon_bn254_permute(s);
   return s[0];
 }
-// HashOrNoop / HashNoPad over a leaf of Goldilocks words (bn254.go:47-94); `leaf` may be strided
+// HashOrNoop / HashNoPad over a leaf of Goldilocks words (bn254.go:47-94); `leaf` may be strided.
+// The nine words of the NEXT absorption are loaded before the current permutation starts, so their HBM latency (each lane
+// walks its own leaf: uncoalesced 8-byte loads) hides under ~100 k instructions instead of stalling the wave 16 times.
 GPV_DEV Fr poseidon_bn254_hash_or_noop(const u64* leaf, u32 len) {
   if (len <= 3) {
     u64 x0 = len > 0 ? leaf[0] : 0, x1 = len > 1 ? leaf[1] : 0, x2 = len > 2 ? leaf[2] : 0;
     return fr_pack_gl(x0, x1, x2);
   }
   Fr s[4] = {fr_zero(), fr_zero(), fr_zero(), fr_zero()};
+  u64 w[9];
+#pragma unroll
+  for (u32 k = 0; k < 9; k++) w[k] = k < len ? leaf[k] : 0;
 #pragma unroll 1
   for (u32 i = 0; i < len; i += 9) {
 #pragma unroll
-    for (u32 k = 0; k < 3; k++) {
-      u32 j = i + 3 * k;
-      if (j < len) {
-        u64 x0 = leaf[j], x1 = j + 1 < len ? leaf[j + 1] : 0, x2 = j + 2 < len ? leaf[j + 2] : 0;
-        s[k + 1] = fr_pack_gl(x0, x1, x2);
-      }
-    }
+    for (u32 k = 0; k < 3; k++)
+      if (i + 3 * k < len) s[k + 1] = fr_pack_gl(w[3 * k], w[3 * k + 1], w[3 * k + 2]);  // words past the end were loaded as 0
+    const u32 nx = i + 9;
+#pragma unroll
+    for (u32 k = 0; k < 9; k++) w[k] = nx + k < len ? leaf[nx + k] : 0;
     poseidon_bn254_permute(s);
   }
   return s[0];
