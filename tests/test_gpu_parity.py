@@ -785,3 +785,69 @@ def test_shared_merkle_levels_are_exact(gpv, api, orc, name):
         assert mask[clean].tolist() == [int(x) for x in ofail[clean]], mode
     assert (results[0][1] == results[1][1]).all()
     assert 0 < int(oacc.sum()) < n   # the batch really mixes accepted and rejected proofs
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_shared_merkle_levels_with_colliding_queries(gpv, api, orc, name):
+    """Query indices normally come out of the transcript; fri.VerifyFriProof takes them as an argument, so collisions can
+    be forced: every query round replaced by a copy of round 0 (28 identical paths: maximal sharing, still a valid FRI
+    proof for those challenges), then single siblings / leaf words of individual copies corrupted, so that one path at a
+    time has to leave the shared tree at every possible level."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    ch = orc.challenges(oc, packed)[0].copy()
+    nq = ci.num_query_rounds
+    rec = np.frombuffer(packed, dtype=np.uint64).copy()
+    n_gl = _n_gl_words(ci)
+    n_open = 2 * (ci.num_constants + ci.num_routed_wires + ci.num_wires + 2 * ci.num_challenges
+                  + ci.num_challenges * ci.num_partial_products + ci.num_challenges * ci.quotient_degree_factor)
+    qwords = sum(ci.leaf_len(o) for o in range(4)) + sum(2 << a for a in ci.arity_bits)
+    n_caps = (3 + len(ci.arity_bits)) * ci.cap_len
+    init_sib = ci.lde_bits - ci.cap_height
+    step_sib, bits = [], ci.lde_bits
+    for a in ci.arity_bits:
+        bits -= a
+        step_sib.append(bits - ci.cap_height)
+    qfrs = 4 * init_sib + sum(step_sib)
+    assert n_gl + 4 * (n_caps + nq * qfrs) == rec.size
+    gl_q = lambda q: slice(n_open + q * qwords, n_open + (q + 1) * qwords)
+    fr_q = lambda q: slice(n_gl + 4 * (n_caps + q * qfrs), n_gl + 4 * (n_caps + (q + 1) * qfrs))
+    for q in range(1, nq):
+        rec[gl_q(q)] = rec[gl_q(0)]
+        rec[fr_q(q)] = rec[fr_q(0)]
+    ch[-nq:] = ch[-nq]          # all query indices = the first
+    fri = gpv.fri.NewChip(api, common)
+    variants = [rec.copy()]
+    # sibling j of tree t in query q: Fr index inside the query's block
+    def sib_word(q, t, j):
+        off = t * init_sib + j if t < 4 else 4 * init_sib + sum(step_sib[:t - 4]) + j
+        return fr_q(q).start + 4 * off
+    for (q, t, j) in [(5, 0, init_sib - 1), (7, 1, init_sib - 2), (9, 2, init_sib - 3), (11, 3, init_sib - 4), (13, 0, init_sib - 5),
+                      (3, 4, step_sib[0] - 1), (4, 4, 0), (6, 5, step_sib[1] - 1), (8, 5, 0), (27, 2, init_sib - 1), (0, 1, init_sib - 1)]:
+        v = rec.copy()
+        v[sib_word(q, t, j)] ^= np.uint64(2)
+        variants.append(v)
+    for q in (2, 0, 27):        # a leaf word and a step evaluation of one copy
+        v = rec.copy()
+        v[gl_q(q).start + 1] ^= np.uint64(1)
+        variants.append(v)
+        v = rec.copy()
+        v[gl_q(q).stop - 3] ^= np.uint64(1)
+        variants.append(v)
+    v = rec.copy()              # two copies corrupted differently at the same node
+    v[sib_word(5, 0, init_sib - 2)] ^= np.uint64(2)
+    v[sib_word(6, 0, init_sib - 2)] ^= np.uint64(4)
+    variants.append(v)
+    batch = np.stack(variants)
+    chs = np.tile(ch, (len(variants), 1))
+    pb = gpv.variables.ProofBatch(circuit, batch.tobytes())
+    exp = orc.fri_verify(oc, batch.tobytes(), chs)
+    assert exp[0] == 0 and (exp[1:] != 0).all()     # the all-copies proof is accepted, every corrupted one rejected
+    try:
+        for mode in (1, 0):
+            api.set_option(2, mode)
+            got = fri.VerifyFriProof(pb, chs)
+            assert got.tolist() == [int(x) for x in exp], mode
+    finally:
+        api.set_option(2, 1)
