@@ -273,7 +273,7 @@ static int ensure_scratch(gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->digests, dw * sizeof(u32)));
     ctx->digest_words = dw;
   }
-  if (ctx->merkle_shared && gpvk_crown_supported(c->dc)) {
+  if (ctx->merkle_shared && gpvk_crown_supported(c->dc, n)) {
     size_t cb = gpvk_crown_bytes(c->dc, n);
     if (cb > ctx->crown_bytes) {
       if (ctx->crown) { hipStreamSynchronize(ctx->stream); hipFree(ctx->crown); ctx->crown = nullptr; ctx->crown_bytes = 0; }
@@ -311,7 +311,7 @@ static void launch_merkle_leaves(gpv_ctx* ctx, hipStream_t st, const gpv_circuit
 static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n,
                                 uint8_t* ok_dev) {
   Timed t(ctx, TK_MERKLE, st);
-  if (!ok_dev && ctx->merkle_shared && gpvk_crown_supported(c->dc)) {
+  if (!ok_dev && ctx->merkle_shared && gpvk_crown_supported(c->dc, n)) {
     // per-path hashing up to GPV_CROWN_LEVELS below the cap, then every distinct upper node once
     CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown);
     gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS);

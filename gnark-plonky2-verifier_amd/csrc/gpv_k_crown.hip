@@ -23,7 +23,6 @@
 #include "gpv_launch.h"
 #include "gpv_fri.cuh"
 
-typedef uint16_t u16;
 #define CROWN_FLAG_CAP_MISMATCH 2u
 #define CROWN_SRC_SIBLING 0x80000000u
 
@@ -287,7 +286,11 @@ size_t gpvk_crown_bytes(const DevCircuit& hc, size_t n) {
   size_t cap = n * hc.n_trees * hc.num_queries;
   return 256 + 32 * cap + GPV_CROWN_LEVELS * (sizeof(CrownItem) + 32) * 2 * cap + 2 * 4 * GPV_CROWN_LEVELS * cap + 4 * cap + 4 * n * hc.n_trees;
 }
-bool gpvk_crown_supported(const DevCircuit& hc) { return hc.num_queries <= GPV_CROWN_MAXQ && hc.cap_height + GPV_CROWN_LEVELS <= 16 && hc.n_trees < 256; }
+// slots and node indices travel as 31-bit numbers (bit 31 marks "sibling supplied by query ...")
+bool gpvk_crown_supported(const DevCircuit& hc, size_t n) {
+  return hc.num_queries <= GPV_CROWN_MAXQ && hc.cap_height + GPV_CROWN_LEVELS <= 16 && hc.n_trees < 256 &&
+         2 * n * hc.n_trees * hc.num_queries < 0x7FFFFFFFull;
+}
 CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base) {
   size_t cap = n * hc.n_trees * hc.num_queries;
   CrownBufs b;

@@ -46,7 +46,7 @@ struct CrownBufs {
   u32* gflag;                       // [proof][tree] cap-mismatch flag
 };
 size_t gpvk_crown_bytes(const DevCircuit& hc, size_t n);
-bool gpvk_crown_supported(const DevCircuit& hc);
+bool gpvk_crown_supported(const DevCircuit& hc, size_t n);
 CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base);
 void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
                              const u32* digests, u64* mid, u32 crown_levels);
