@@ -179,7 +179,9 @@ def main():
         "config": {"workload": "verifier.VerifierChip.Verify end-to-end (BASELINE config 4 shard)", "fixture": args.fixture,
                    "proofs_per_gpu": n_local, "global_batch": n_total, "queries_per_proof": ci.num_query_rounds,
                    "merkle_chains_per_proof": ci.num_query_rounds * (4 + len(ci.arity_bits)), "parallelism": "proof-sharded x%d" % world,
-                   "collective": "RCCL all_gather of packed accept bits" if use_dist else "none"},
+                   "collective": "RCCL all_gather of packed accept bits" if use_dist else "none",
+                   "merkle_shared_levels": "on (default): the last 4 levels of each tree hashed once per distinct node, inputs compared "
+                                           "word for word; accept bits identical to the per-path walk (GPV_OPT_MERKLE_SHARED_LEVELS)"},
     }
     if rank == 0:
         leaf_perms, climb_perms = perms_per_proof(ci)
