@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--proofs-per-gpu", type=int, default=8192)
     ap.add_argument("--fixture", default="step", choices=["step", "decode_block"])
+    ap.add_argument("--per-path-merkle", action="store_true", help="hash every step of every Merkle path, literally fri/fri.go:97-144 (GPV_OPT_MERKLE_SHARED_LEVELS = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-poseidon-gl", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the accept all-gather even at world size 1 (test hook)")
@@ -90,6 +91,8 @@ def main():
     D = importlib.import_module("gnark-plonky2-verifier_amd.distributed")
 
     ctx = gpv.Context(local_rank)
+    if args.per_path_merkle:
+        ctx.set_option(2, 0)  # GPV_OPT_MERKLE_SHARED_LEVELS
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
@@ -180,7 +183,7 @@ def main():
                    "proofs_per_gpu": n_local, "global_batch": n_total, "queries_per_proof": ci.num_query_rounds,
                    "merkle_chains_per_proof": ci.num_query_rounds * (4 + len(ci.arity_bits)), "parallelism": "proof-sharded x%d" % world,
                    "collective": "RCCL all_gather of packed accept bits" if use_dist else "none",
-                   "merkle_shared_levels": "on (default): the last 4 levels of each tree hashed once per distinct node, inputs compared "
+                   "merkle_shared_levels": "off: every path hashed on its own" if args.per_path_merkle else "on (default): the last 4 levels of each tree hashed once per distinct node, inputs compared "
                                            "word for word; accept bits identical to the per-path walk (GPV_OPT_MERKLE_SHARED_LEVELS)"},
     }
     if rank == 0:
