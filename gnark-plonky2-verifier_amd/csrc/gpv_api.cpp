@@ -373,8 +373,9 @@ static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* p
 
 extern "C" int gpv_gl_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && a && out);
-  REQUIRE(ctx, op == GPV_OP_ADD || op == GPV_OP_SUB || op == GPV_OP_MUL || op == GPV_OP_MULADD || op == GPV_OP_INV || op == GPV_OP_REDUCE);
-  REQUIRE(ctx, (op == GPV_OP_INV || op == GPV_OP_REDUCE) || b);
+  REQUIRE(ctx, op == GPV_OP_ADD || op == GPV_OP_SUB || op == GPV_OP_MUL || op == GPV_OP_MULADD || op == GPV_OP_INV || op == GPV_OP_REDUCE ||
+                   op == GPV_OP_RANGECHECK);
+  REQUIRE(ctx, (op == GPV_OP_INV || op == GPV_OP_REDUCE || op == GPV_OP_RANGECHECK) || b);
   REQUIRE(ctx, op != GPV_OP_MULADD || c);
   if (n == 0) return GPV_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -16,6 +16,7 @@ __global__ void k_gl_op(int op, const u64* __restrict__ a, const u64* __restrict
     case GPV_OP_MULADD: r = gl_muladd(a[i], b[i], c[i]); break;
     case GPV_OP_INV: r = gl_inv(a[i]); break;
     case GPV_OP_REDUCE: r = gl_canon(a[i]); break;
+    case GPV_OP_RANGECHECK: r = a[i] < GLP ? 1 : 0; break;
   }
   out[i] = r;
 }

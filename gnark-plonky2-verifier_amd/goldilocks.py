@@ -30,11 +30,11 @@ class Chip:
     def Reduce(self, x): return self._op(5, x)                 # base.go:246
 
     def Inverse(self, x):                                      # base.go:297 -> (inverse, hasInv)
-        x = _lib.u64c(x).reshape(-1)
-        return self._op(4, x), (x % np.uint64(MODULUS) != 0).astype(np.uint8)
+        inv = self._op(4, x)
+        return inv, (inv != 0).astype(np.uint8)                # x * inv = 1 has no solution exactly when inv comes back 0
 
     def RangeCheck(self, x):                                   # base.go:362: True where x < p
-        return _lib.u64c(x) < np.uint64(MODULUS)
+        return self._op(9, x).astype(bool)
 
     def _op2(self, op, a, b=None):
         a = _lib.u64c(a).reshape(-1, 2)

@@ -80,6 +80,7 @@ class Chip {
   Vars MulAdd(const Vars& a, const Vars& b, const Vars& c) { return op(GPV_OP_MULADD, a, &b, &c); }     // base.go:196
   Vars Reduce(const Vars& x) { return op(GPV_OP_REDUCE, x, nullptr, nullptr); }                         // base.go:246
   Vars Inverse(const Vars& x) { return op(GPV_OP_INV, x, nullptr, nullptr); }                           // base.go:297
+  Vars RangeCheck(const Vars& x) { return op(GPV_OP_RANGECHECK, x, nullptr, nullptr); }                  // base.go:362, 1 where x < p
   // extension elements are consecutive pairs
   Vars MulExtension(const Vars& a, const Vars& b) { return op2(GPV_OP_MUL, a, &b); }                    // quadratic_extension.go:59
   Vars AddExtension(const Vars& a, const Vars& b) { return op2(GPV_OP_ADD, a, &b); }                    // :31

@@ -68,7 +68,8 @@ enum {
 /* field ops for gpv_gl_op / gpv_gl2_op */
 enum {
   GPV_OP_ADD = 0, GPV_OP_SUB = 1, GPV_OP_MUL = 2, GPV_OP_MULADD = 3, GPV_OP_INV = 4, GPV_OP_REDUCE = 5, GPV_OP_DIV = 6,
-  GPV_OP_SUBMUL = 7, GPV_OP_SCALARMUL = 8
+  GPV_OP_SUBMUL = 7, GPV_OP_SCALARMUL = 8,
+  GPV_OP_RANGECHECK = 9 /* gpv_gl_op: out[i] = 1 iff a[i] < p (RangeCheck, goldilocks/base.go:362-400) */
 };
 
 /* operations of a gpv_challenger_run script: entry = kind << 28 | count */
@@ -137,7 +138,7 @@ int gpv_proof_pack_json_batch(const gpv_circuit* c, const char* const* proof_jso
                               void* out_packed, int n_threads);
 
 /* ------------------------------------------------------------------ field / hash primitives */
-/* goldilocks.Chip Add/Sub/Mul/MulAdd/Inverse/Reduce (goldilocks/base.go:162-313). b, c may be NULL when unused. */
+/* goldilocks.Chip Add/Sub/Mul/MulAdd/Inverse/Reduce/RangeCheck (goldilocks/base.go:162-400). b, c may be NULL when unused. */
 int gpv_gl_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n);
 /* Add/Sub/Mul/Inverse/DivExtension (goldilocks/quadratic_extension.go:31-140), [n][2]; ok[i] = 0 where the
  * reference's "operand != 0" assertion (:124-125) fails. ok may be NULL. */

@@ -31,7 +31,7 @@ int orc_selftest(void) {
 }
 
 // ---------------------------------------------------------------- field primitives
-enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_MULADD = 3, OP_INV = 4, OP_REDUCE = 5, OP_DIV = 6 };
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_MULADD = 3, OP_INV = 4, OP_REDUCE = 5, OP_DIV = 6, OP_RANGECHECK = 9 };
 
 int orc_gl_op(int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n) {
   for (size_t i = 0; i < n; i++) {
@@ -42,6 +42,7 @@ int orc_gl_op(int op, const u64* a, const u64* b, const u64* c, u64* out, size_t
       case OP_MULADD: out[i] = gl_muladd(a[i], b[i], c[i]); break;
       case OP_INV: out[i] = gl_inverse(a[i]); break;
       case OP_REDUCE: out[i] = gl_reduce(a[i]); break;
+      case OP_RANGECHECK: out[i] = gl_is_canonical(a[i]) ? 1 : 0; break;  // base.go:362-400
       default: return -1;
     }
   }

@@ -66,6 +66,8 @@ def test_gl_base_ops(gpv, api, orc):
     assert gl.MulAdd([2**63], [2**63], [3])[0] == 18446744068340842500
     # goldilocks/base_test.go:26-44
     assert gl.RangeCheck([0, 1, P - 1, P]).tolist() == [True, True, True, False]
+    wide = np.concatenate([EDGE, np.array([P, P + 1, 2**64 - 1], dtype=np.uint64), rng.integers(0, 2**63, 1000, dtype=np.uint64) * np.uint64(2)])
+    assert (gl.RangeCheck(wide) == orc.gl_op(9, wide).astype(bool)).all()
     x = np.array([P, P + 5, 2**64 - 1, 3], dtype=np.uint64)
     assert gl.Reduce(x).tolist() == [0, 5, 2**32 - 2, 3]
 
