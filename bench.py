@@ -154,7 +154,7 @@ def main():
         elapsed = float(t.item())
     merkle_ms, merkle_launches = ctx.timing_get(0)
     leaves_ms, _ = ctx.timing_get(7)
-    stage_ms = {nm: ctx.timing_get(k)[0] for nm, k in (("merkle_walk", 0), ("merkle_leaves", 7), ("transcript", 2), ("plonk", 3),
+    stage_ms = {nm: ctx.timing_get(k)[0] for nm, k in (("merkle_walk", 0), ("merkle_climb_lower", 8), ("merkle_leaves", 7), ("transcript", 2), ("plonk", 3),
                                                         ("fri_query", 4), ("range_check", 5))}
     ctx.timing_enable(False)
 
@@ -183,45 +183,64 @@ def main():
                    "proofs_per_gpu": n_local, "global_batch": n_total, "queries_per_proof": ci.num_query_rounds,
                    "merkle_chains_per_proof": ci.num_query_rounds * (4 + len(ci.arity_bits)), "parallelism": "proof-sharded x%d" % world,
                    "collective": "RCCL all_gather of packed accept bits" if use_dist else "none",
-                   "merkle_shared_levels": "off: every path hashed on its own" if args.per_path_merkle else "on (default): the last 4 levels of each tree hashed once per distinct node, inputs compared "
+                   "merkle_shared_levels": "off: every path hashed on its own" if args.per_path_merkle else "on (default): the last 3 levels of each tree hashed once per distinct node, inputs compared "
                                            "word for word; accept bits identical to the per-path walk (GPV_OPT_MERKLE_SHARED_LEVELS)"},
     }
     if rank == 0:
         leaf_perms, climb_perms = perms_per_proof(ci)
         n_chains = ci.num_query_rounds * (4 + len(ci.arity_bits))
-        # dominant kernel = k_merkle_leaves (the sibling walk is split over k_merkle_climb_lower and the k_crown_* kernels, each
-        # shorter than the leaf hashing). Its algorithmic bytes per proof: the leaf words of the 28 query blocks, read once
-        # (8 B each), + the digests it writes (36 B per chain).
+        # Two kernels of nearly equal length carry the step: k_merkle_leaves (leaf digests) and k_merkle_climb_lower (the sibling
+        # walk up to the shared levels; the whole walk, k_merkle_climb, with --per-path-merkle). The longer one of THIS run is
+        # the dominant kernel. Algorithmic bytes per proof:
+        #   leaves: the leaf words of the 28 query blocks read once (8 B each) + the digests written (36 B per chain)
+        #   walk  : one 32-byte sibling per hash + the digests read back (36 B per chain) + the 28 query indices
+        #           (+ the 32-byte node handed to the shared levels per chain, or the cap entries when it goes all the way)
         qwords = sum(ci.leaf_len(o) for o in range(4)) + sum(2 << a for a in ci.arity_bits)
-        alg_bytes_per_proof = 8.0 * ci.num_query_rounds * qwords + 36.0 * n_chains
+        lower_ms, _ = ctx.timing_get(8)
+        crown_levels = 3  # GPV_CROWN_LEVELS (csrc/gpv_launch.h)
+        sib = [ci.lde_bits - ci.cap_height] * 4
+        bits = ci.lde_bits
+        for a in ci.arity_bits:
+            bits -= a
+            sib.append(bits - ci.cap_height)
+        lower_perms = ci.num_query_rounds * sum(max(x - crown_levels, 0) for x in sib)
+        cand = {"k_merkle_leaves": (leaves_ms, 8.0 * ci.num_query_rounds * qwords + 36.0 * n_chains, leaf_perms)}
+        if args.per_path_merkle:
+            n_fr = (3 + len(ci.arity_bits)) * ci.cap_len + climb_perms
+            cand["k_merkle_climb"] = (merkle_ms, 32.0 * n_fr + 36.0 * n_chains + 8.0 * ci.num_query_rounds, climb_perms)
+        else:
+            cand["k_merkle_climb_lower"] = (lower_ms, 32.0 * lower_perms + (36.0 + 32.0) * n_chains + 8.0 * ci.num_query_rounds, lower_perms)
+        dom = max(cand, key=lambda k: cand[k][0])
+        dom_ms, alg_bytes_per_proof, dom_perms = cand[dom]
         alg_bytes = alg_bytes_per_proof * n_local
-        achieved = alg_bytes / (leaves_ms * 1e-3) / 1e9 if leaves_ms > 0 else 0.0
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM traffic per launch from the PMC passes of the same command (separate rocprofv3 --pmc runs, FETCH_SIZE x2 on
         # gfx950), recorded in profiles/traffic.json; only reported when it was measured on this exact configuration
         traffic = None
         try:
-            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())["k_merkle_leaves"]
+            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())[dom]
             if tj["fixture"] == args.fixture and tj["proofs_per_gpu"] == n_local:
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
-        line["roofline"] = {"bound": "hbm", "kernel": "k_merkle_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": leaves_ms, "launches": merkle_launches,
+        line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": dom_ms, "launches": merkle_launches,
                             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_proof": alg_bytes_per_proof,
+                            "other_kernels_ms": {k: v[0] for k, v in cand.items() if k != dom},
                             "note": "integer-VALU bound workload; see valu_roofline"}
         mad_measured = max(ctx.microbench(0) for _ in range(3))
         mad_peak = MAD_PEAK_MODEL
         per_perm = FR_MULS_PER_PERM * MADS_PER_FR_MUL
-        leaf_rate = float(leaf_perms) * per_perm * n_local / (leaves_ms * 1e-3) if leaves_ms > 0 else 0.0
-        # the sibling walk: the reference hashes climb_perms times per proof; the shared upper levels execute fewer, so this is
-        # an effective rate (it may exceed the issue peak)
-        walk_rate = float(climb_perms) * per_perm * n_local / (merkle_ms * 1e-3) if merkle_ms > 0 else 0.0
-        line["valu_roofline"] = {"bound": "valu_int32_mad", "kernel": "k_merkle_leaves", "achieved": leaf_rate / 1e12,
-                                 "peak": mad_peak / 1e12, "unit": "T v_mad_u64_u32 lane-ops/s", "frac": leaf_rate / mad_peak,
+        rate = lambda perms, ms: float(perms) * per_perm * n_local / (ms * 1e-3) if ms > 0 else 0.0
+        # the sibling walk as a whole: the reference hashes climb_perms times per proof; the shared upper levels execute fewer,
+        # so this is an effective rate
+        line["valu_roofline"] = {"bound": "valu_int32_mad", "kernel": dom, "achieved": rate(dom_perms, dom_ms) / 1e12,
+                                 "peak": mad_peak / 1e12, "unit": "T v_mad_u64_u32 lane-ops/s", "frac": rate(dom_perms, dom_ms) / mad_peak,
                                  "peak_definition": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz", "peak_microbench_this_run": mad_measured / 1e12,
-                                 "algorithmic_mads_per_proof": float(leaf_perms) * per_perm,
+                                 "algorithmic_mads_per_proof": float(dom_perms) * per_perm, "bn254_perms_per_proof": dom_perms,
+                                 "per_kernel_frac": {k: rate(v[2], v[0]) / mad_peak for k, v in cand.items()},
                                  "bn254_leaf_perms_per_proof": leaf_perms, "bn254_sibling_perms_per_proof_reference": climb_perms,
-                                 "sibling_walk_effective_frac": walk_rate / mad_peak, "sibling_walk_ms": merkle_ms}
+                                 "sibling_walk_effective_frac": rate(climb_perms, merkle_ms) / mad_peak, "sibling_walk_ms": merkle_ms}
         line["stage_ms"] = stage_ms
         if not args.no_poseidon_gl:
             n_states = 1 << 20

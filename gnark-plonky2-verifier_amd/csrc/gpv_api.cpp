@@ -22,7 +22,7 @@
 #include "gpv_launch.h"
 
 // ================================================================ context
-enum { TK_MERKLE = 0, TK_PGL = 1, TK_TRANSCRIPT = 2, TK_PLONK = 3, TK_FRI = 4, TK_RANGE = 5, TK_PBN = 6, TK_LEAVES = 7, TK_COUNT = 8 };
+enum { TK_MERKLE = 0, TK_PGL = 1, TK_TRANSCRIPT = 2, TK_PLONK = 3, TK_FRI = 4, TK_RANGE = 5, TK_PBN = 6, TK_LEAVES = 7, TK_LOWER = 8, TK_COUNT = 9 };
 
 struct TimingRec {
   int kind;
@@ -314,7 +314,10 @@ static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit*
   if (!ok_dev && ctx->merkle_shared && gpvk_crown_supported(c->dc, n)) {
     // per-path hashing up to GPV_CROWN_LEVELS below the cap, then every distinct upper node once
     CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown);
-    gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS);
+    {
+      Timed tl(ctx, TK_LOWER, st);
+      gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS);
+    }
     gpvk_crown(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, b, ctx->fail);
     return;
   }

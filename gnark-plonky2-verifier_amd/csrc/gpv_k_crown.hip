@@ -1,5 +1,5 @@
 // Shared upper Merkle levels ("crown"). The 28 queries of a proof walk 28 paths in every tree; near the cap those paths
-// meet: with a cap of 16 entries, the last four levels of a tree hold only ~80 distinct nodes for 112 path steps. The
+// meet: with a cap of 16 entries, the last three levels of a tree hold only ~55 distinct nodes for 84 path steps. The
 // reference hashes every step of every path (fri/fri.go:97-144, once per path); identical inputs give identical digests,
 // so each distinct node is hashed once here -- for the paths whose inputs really are identical, which is checked word for
 // word before every level; a path that disagrees leaves the shared tree and is hashed on its own from there on.

@@ -104,7 +104,7 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
 /* Tuning knobs. GPV_OPT_TRANSCRIPT_VARIANT: 0 = automatic (by batch size), 1 = one lane per proof (least total work; its
  * latency hides under the Merkle leaf hashing for batches >= ~4000 proofs), 2 = cooperative, 16 lanes per proof (about
  * 5x lower latency, 3x the work). Both produce identical challenges.
- * GPV_OPT_MERKLE_SHARED_LEVELS: 1 (default) = the last four levels of every Merkle tree are hashed once per distinct
+ * GPV_OPT_MERKLE_SHARED_LEVELS: 1 (default) = the last three levels of every Merkle tree are hashed once per distinct
  * node instead of once per query path (the paths of a proof's queries meet near the cap; inputs are compared word for
  * word and a proof whose paths disagree is re-hashed path by path, so accept bits are identical); 0 = every path on its
  * own, literally fri/fri.go:97-144. */
@@ -223,9 +223,10 @@ int gpv_merkle_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs
 
 /* ------------------------------------------------------------------ measurement helpers */
 /* Average duration (ms) of the named kernel class over the launches since the last reset, measured with HIP events on
- * the stream each kernel was launched on. kind: 0 = merkle climb (k_merkle_climb), 1 = poseidon_gl_permute,
- * 2 = transcript, 3 = plonk, 4 = fri_query, 5 = range_check, 6 = poseidon_bn254_permute, 7 = merkle leaf digests
- * (k_merkle_leaves). Timing is off by default (no event overhead). */
+ * the stream each kernel was launched on. kind: 0 = the whole Merkle sibling walk (k_merkle_climb, or k_merkle_climb_lower +
+ * k_crown_* with shared levels), 1 = poseidon_gl_permute, 2 = transcript, 3 = plonk, 4 = fri_query, 5 = range_check,
+ * 6 = poseidon_bn254_permute, 7 = merkle leaf digests (k_merkle_leaves), 8 = k_merkle_climb_lower alone.
+ * Timing is off by default (no event overhead). */
 int gpv_timing_enable(gpv_ctx* ctx, int on);
 int gpv_timing_reset(gpv_ctx* ctx);
 int gpv_timing_get(gpv_ctx* ctx, int kind, double* avg_ms, uint64_t* launches);

@@ -747,7 +747,7 @@ def test_two_contexts_on_two_threads(gpv, orc):
 # ---------------------------------------------------------------- shared upper Merkle levels
 @pytest.mark.parametrize("name", ["decode_block", "step"])
 def test_shared_merkle_levels_are_exact(gpv, api, orc, name):
-    """GPV_OPT_MERKLE_SHARED_LEVELS hashes each distinct node of the last four tree levels once. Accept bits and failure
+    """GPV_OPT_MERKLE_SHARED_LEVELS hashes each distinct node of the last tree levels (GPV_CROWN_LEVELS = 3) once. Accept bits and failure
     masks must not depend on it, in particular when paths disagree (corrupted siblings, caps, leaves, query data)."""
     common, vo, circuit, proofs = _load(gpv, name)
     ci, packed, _ = T.load_fixture(name)
