@@ -10,7 +10,8 @@ resident in HBM: BASELINE.json config 4's per-GPU shard, 8192 packed `step` proo
 tampered, followed -- for N > 1 -- by the RCCL all-gather of the packed accept bits. Rank 0 prints ONE JSON line.
 
 The same line carries
-  roofline      -- dominant kernel (k_merkle_leaves): algorithmic bytes / launch duration against HBM peak, as the contract asks;
+  roofline      -- dominant kernel (the longer of k_merkle_leaves / k_merkle_climb_lower in this run): algorithmic bytes /
+                   launch duration against HBM peak, as the contract asks;
                    this workload is integer-VALU bound (2 000 32-bit multiply-adds per input byte), so the line also
                    carries `valu_roofline`: achieved v_mad_u64_u32 rate vs the peak measured on this chip.
   cpu_baseline  -- the C++ restatement of the reference algorithm (oracle/, kind "port") timed on the host cores on a
