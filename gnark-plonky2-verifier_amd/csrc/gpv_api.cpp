@@ -52,7 +52,7 @@ struct gpv_ctx {
   // host-batch path (gpv_verify): grow-only staging for the packed records and the accept bytes, and an upload stream so
   // the copy of chunk k+1 runs while chunk k is being verified
   // shared upper Merkle levels (gpv_k_crown.hip)
-  int merkle_shared = 1;  // GPV_OPT_MERKLE_SHARED_LEVELS
+  int merkle_shared = 1;  // GPV_OPT_MERKLE_SHARED_LEVELS: 0 off, 1 from GPV_MERKLE_SHARED_FROM proofs up, 2 always
   void* crown = nullptr;
   size_t crown_bytes = 0;
   uint8_t* stage = nullptr;
@@ -195,7 +195,7 @@ extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
     ctx->transcript_variant = value;
     return GPV_OK;
   }
-  if (option == GPV_OPT_MERKLE_SHARED_LEVELS && (value == 0 || value == 1)) {
+  if (option == GPV_OPT_MERKLE_SHARED_LEVELS && value >= 0 && value <= 2) {
     ctx->merkle_shared = value;
     return GPV_OK;
   }
@@ -255,6 +255,13 @@ static int circuit_on_device(gpv_ctx* ctx, const gpv_circuit* c, const DevCircui
 // ================================================================ primitive kernels
 // ================================================================ protocol kernels
 // ================================================================ launch helpers (device pointers)
+// The shared upper levels pay from ~1000 proofs up (profiles/r01k_batch_sweep.txt): below that the level kernels are too
+// small to fill the GPU and the extra launches cost more than the saved hashes.
+#define GPV_MERKLE_SHARED_FROM 1024
+static bool merkle_shared_for(const gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
+  if (ctx->merkle_shared == 0 || !gpvk_crown_supported(c->dc, n)) return false;
+  return ctx->merkle_shared == 2 || n >= GPV_MERKLE_SHARED_FROM;
+}
 static int ensure_scratch(gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
   size_t need = n * (c->dc.n_challenge_words + GPV_DERIVED_EXTRA);
   if (need > ctx->derived_words) {
@@ -273,7 +280,7 @@ static int ensure_scratch(gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->digests, dw * sizeof(u32)));
     ctx->digest_words = dw;
   }
-  if (ctx->merkle_shared && gpvk_crown_supported(c->dc, n)) {
+  if (merkle_shared_for(ctx, c, n)) {
     size_t cb = gpvk_crown_bytes(c->dc, n);
     if (cb > ctx->crown_bytes) {
       if (ctx->crown) { hipStreamSynchronize(ctx->stream); hipFree(ctx->crown); ctx->crown = nullptr; ctx->crown_bytes = 0; }
@@ -311,7 +318,7 @@ static void launch_merkle_leaves(gpv_ctx* ctx, hipStream_t st, const gpv_circuit
 static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n,
                                 uint8_t* ok_dev) {
   Timed t(ctx, TK_MERKLE, st);
-  if (!ok_dev && ctx->merkle_shared && gpvk_crown_supported(c->dc, n)) {
+  if (!ok_dev && merkle_shared_for(ctx, c, n)) {
     // per-path hashing up to GPV_CROWN_LEVELS below the cap, then every distinct upper node once
     CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown);
     {

@@ -774,18 +774,18 @@ def test_shared_merkle_levels_are_exact(gpv, api, orc, name):
     oacc, ofail, _ = orc.verify(oc, batch, n_threads=8)
     results = {}
     try:
-        for mode in (1, 0):
+        for mode in (2, 0):      # 2 = shared levels for every batch size, 0 = the per-path walk
             api.set_option(2, mode)
             acc, mask, _ = chip.Verify(pb, vo, detail=True)
             results[mode] = (acc.copy(), mask.copy())
     finally:
         api.set_option(2, 1)
-    for mode in (1, 0):
+    for mode in (2, 0):
         acc, mask = results[mode]
         assert acc.tolist() == oacc.tolist(), mode
         clean = (ofail & 1) == 0
         assert mask[clean].tolist() == [int(x) for x in ofail[clean]], mode
-    assert (results[0][1] == results[1][1]).all()
+    assert (results[0][1] == results[2][1]).all()
     assert 0 < int(oacc.sum()) < n   # the batch really mixes accepted and rejected proofs
 
 
@@ -847,7 +847,7 @@ def test_shared_merkle_levels_with_colliding_queries(gpv, api, orc, name):
     exp = orc.fri_verify(oc, batch.tobytes(), chs)
     assert exp[0] == 0 and (exp[1:] != 0).all()     # the all-copies proof is accepted, every corrupted one rejected
     try:
-        for mode in (1, 0):
+        for mode in (2, 0):
             api.set_option(2, mode)
             got = fri.VerifyFriProof(pb, chs)
             assert got.tolist() == [int(x) for x in exp], mode

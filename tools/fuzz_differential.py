@@ -53,7 +53,7 @@ for name in ("decode_block", "step"):
     t = time.time()
     oacc, ofail, och = orc.verify(oc, batch, n_threads=64)
     t_or = time.time() - t
-    for mode in (1, 0):
+    for mode in (2, 0):
         ctx.set_option(2, mode)
         acc, mask, ch = chip.Verify(pb, vo, detail=True)
         assert acc.tolist() == oacc.tolist(), (name, mode, "accept")
