@@ -9,7 +9,7 @@ Import with importlib.import_module("gnark-plonky2-verifier_amd") (the directory
 from . import _lib  # noqa: F401
 from . import types, variables, goldilocks, poseidon, challenger, fri, plonk, verifier  # noqa: F401
 # `distributed` imports torch; load it on demand: importlib.import_module("gnark-plonky2-verifier_amd.distributed")
-from ._lib import (ConfigError, Context, DeviceError, GpvError, ShapeError, default_context)  # noqa: F401
+from ._lib import (ConfigError, Context, DeviceError, GpvError, Group, ShapeError, default_context, shard_bounds)  # noqa: F401
 
 __all__ = ["types", "variables", "goldilocks", "poseidon", "challenger", "fri", "plonk", "verifier", "Context",
-           "default_context", "GpvError", "ShapeError", "ConfigError", "DeviceError"]
+           "default_context", "Group", "shard_bounds", "GpvError", "ShapeError", "ConfigError", "DeviceError"]

@@ -27,7 +27,12 @@ ABI_SYMBOLS = [
     "gpv_public_inputs_hash", "gpv_challenges", "gpv_plonk_verify", "gpv_gate_constraints", "gpv_fri_verify",
     "gpv_merkle_verify", "gpv_verify", "gpv_verify_detail", "gpv_verify_dev", "gpv_challenges_dev",
     "gpv_merkle_verify_dev", "gpv_timing_enable", "gpv_timing_reset", "gpv_timing_get", "gpv_microbench",
+    "gpv_shard_bounds", "gpv_accept_slot_bytes", "gpv_group_create", "gpv_group_unique_id", "gpv_group_create_rank", "gpv_group_destroy",
+    "gpv_group_world", "gpv_group_local", "gpv_group_rank", "gpv_group_set_option", "gpv_group_last_error_message",
+    "gpv_group_verify", "gpv_group_verify_dev", "gpv_group_read_rank_accept",
 ]
+# declared with a non-int/size_t return type (not matched by the header scan of the tests)
+ABI_SYMBOLS_OTHER = ["gpv_group_ctx"]
 
 
 class GpvError(RuntimeError):
@@ -118,6 +123,23 @@ def lib():
         L.gpv_timing_reset.argtypes = [vp]
         L.gpv_timing_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         L.gpv_microbench.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double)]
+        L.gpv_shard_bounds.argtypes = [sz, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+        L.gpv_accept_slot_bytes.argtypes = [sz, i32]
+        L.gpv_accept_slot_bytes.restype = sz
+        L.gpv_group_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i32), i32]
+        L.gpv_group_unique_id.argtypes = [vp]
+        L.gpv_group_create_rank.argtypes = [ctypes.POINTER(vp), i32, i32, i32, vp]
+        L.gpv_group_destroy.argtypes = [vp]
+        L.gpv_group_world.argtypes = [vp]
+        L.gpv_group_local.argtypes = [vp]
+        L.gpv_group_rank.argtypes = [vp, i32]
+        L.gpv_group_ctx.argtypes = [vp, i32]
+        L.gpv_group_ctx.restype = vp
+        L.gpv_group_set_option.argtypes = [vp, i32, i32]
+        L.gpv_group_last_error_message.argtypes = [vp, ctypes.c_char_p, sz]
+        L.gpv_group_verify.argtypes = [vp, vp, vp, sz, vp]
+        L.gpv_group_verify_dev.argtypes = [vp, vp, ctypes.POINTER(vp), sz, ctypes.POINTER(vp)]
+        L.gpv_group_read_rank_accept.argtypes = [vp, i32, vp, sz]
         _lib = L
     return _lib
 
@@ -195,6 +217,93 @@ class Context:
         v = ctypes.c_double()
         check(lib().gpv_microbench(ctypes.c_void_p(self.h), which, ctypes.byref(v)), self.h)
         return v.value
+
+
+def shard_bounds(n, rank, world):
+    """gpv_shard_bounds: contiguous block [lo, hi) of rank `rank` (host arithmetic, no GPU needed)."""
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib().gpv_shard_bounds(n, rank, world, ctypes.byref(lo), ctypes.byref(hi)))
+    return lo.value, hi.value
+
+
+class _BorrowedContext(Context):
+    """A context owned by a gpv_group (not destroyed on close)."""
+
+    def __init__(self, handle, device_id):
+        self.h = handle
+        self.device_id = device_id
+
+    def close(self):
+        self.h = None
+
+
+GROUP_OPT_COLLECTIVE = 100
+
+
+class Group:
+    """gpv_group: a proof batch sharded over the GPUs of one node behind the C ABI -- contiguous blocks per rank,
+    one RCCL all-gather of the packed accept bits. Group(device_ids=[0, 1, ...]) drives several GPUs from this process;
+    Group(rank=r, world=w, unique_id=..., device_id=d) is one rank of a one-process-per-GPU job."""
+
+    def __init__(self, device_ids=None, rank=None, world=None, unique_id=None, device_id=0):
+        h = ctypes.c_void_p()
+        if rank is None:
+            ids = (ctypes.c_int * len(device_ids))(*device_ids)
+            check(lib().gpv_group_create(ctypes.byref(h), ids, len(device_ids)))
+        else:
+            buf = ctypes.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+            check(lib().gpv_group_create_rank(ctypes.byref(h), device_id, rank, world, buf))
+        self.h = h.value
+        self.world = lib().gpv_group_world(self.h)
+        self.local = lib().gpv_group_local(self.h)
+        self.ranks = [lib().gpv_group_rank(self.h, i) for i in range(self.local)]
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        check(lib().gpv_group_unique_id(buf))
+        return buf.raw
+
+    def _check(self, rc):
+        if rc == GPV_OK:
+            return
+        buf = ctypes.create_string_buffer(1024)
+        lib().gpv_group_last_error_message(ctypes.c_void_p(self.h), buf, 1024)
+        cls = {GPV_ESHAPE: ShapeError, GPV_ECONFIG: ConfigError, GPV_EDEVICE: DeviceError}.get(rc, GpvError)
+        raise cls(rc, buf.value.decode("utf-8", "replace"))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gpv_group_destroy(ctypes.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, option, value):
+        self._check(lib().gpv_group_set_option(ctypes.c_void_p(self.h), option, value))
+
+    def context(self, local_index=0):
+        return _BorrowedContext(lib().gpv_group_ctx(ctypes.c_void_p(self.h), local_index), None)
+
+    def verify(self, circuit, proofs_u8, n_total):
+        """proofs_u8: host array with the records of this process's blocks; returns accept [n_total] of the whole batch."""
+        accept = np.empty(n_total, dtype=np.uint8)
+        self._check(lib().gpv_group_verify(ctypes.c_void_p(self.h), circuit.h, ptr(proofs_u8), n_total, ptr(accept)))
+        return accept
+
+    def verify_dev(self, circuit, shard_ptrs, n_total, accept_all_ptrs):
+        a = (ctypes.c_void_p * self.local)(*[int(x) if x else None for x in shard_ptrs])
+        b = (ctypes.c_void_p * self.local)(*[int(x) for x in accept_all_ptrs])
+        self._check(lib().gpv_group_verify_dev(ctypes.c_void_p(self.h), circuit.h, a, n_total, b))
+
+    def read_rank_accept(self, local_index, n_total):
+        out = np.empty(n_total, dtype=np.uint8)
+        self._check(lib().gpv_group_read_rank_accept(ctypes.c_void_p(self.h), local_index, ptr(out), n_total))
+        return out
 
 
 _default_ctx = None

@@ -6,7 +6,9 @@
 //   k_transcript         GetPublicInputsHash + GetChallenges     verifier/verifier.go:41-82, challenger/challenger.go
 //   k_plonk              PlonkChip.Verify                        plonk/plonk.go:209-250 + plonk/gates/*
 //   k_merkle_leaves      HashOrNoop of every Merkle leaf         fri/fri.go:104, poseidon/bn254.go:47-94
-//   k_merkle_climb       sibling paths + cap comparison          fri/fri.go:105-157, :472-483   <- dominant kernel
+//   k_merkle_climb_lower sibling paths up to 3 levels below the cap   fri/fri.go:105-116          <- dominant kernel (`step`)
+//   k_crown_*            the last 3 levels of every tree, once per distinct node, + cap comparison  fri/fri.go:105-143
+//   k_merkle_climb       the literal per-path walk + cap comparison  fri/fri.go:105-157, :472-483 (GPV_OPT_MERKLE_SHARED_LEVELS = 0)
 //   k_fri_query          verifyQueryRound minus the Merkle paths fri/fri.go:386-498, PoW :75-80
 //   k_finalize           "circuit satisfiable" -> accept byte
 // plus primitive kernels that expose the chip-level operators for parity tests and the Poseidon-GL benchmark.
@@ -15,10 +17,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
-#include "gpv_host.h"
+#include "gpv_internal.h"
 #include "gpv_launch.h"
 
 // ================================================================ context
@@ -30,6 +33,9 @@ struct TimingRec {
 };
 
 struct gpv_ctx {
+  // Every entry point that takes a context holds `mu` for its duration and makes the context's device current: calls from
+  // several host threads on one context are safe (they serialise); for parallelism use one context per thread or a gpv_group.
+  std::recursive_mutex mu;
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
@@ -71,6 +77,22 @@ static void ctx_error(gpv_ctx* ctx, const char* fmt, ...) {
   va_end(ap);
   if (ctx) ctx->err = buf;
   else gpv_set_global_error("%s", buf);
+}
+
+#define ENTER(ctx)                                        \
+  std::lock_guard<std::recursive_mutex> enter_lock_(ctx->mu); \
+  HIP_TRY(ctx, hipSetDevice(ctx->device))
+
+// First failed kernel launch (or async memset) of this host thread since the last CHECK_LAUNCH: every launch wrapper in the
+// gpv_k_*.hip files reports hipGetLastError() right after its launch (GPVK_LAUNCH, gpv_launch.h), so a stage that never
+// started cannot be overwritten by the status of later API calls and leave fail[] == 0 ("accept") behind.
+static thread_local hipError_t g_launch_err = hipSuccess;
+static thread_local const char* g_launch_what = "";
+void gpvk_note_launch(hipError_t e, const char* what) {
+  if (e != hipSuccess && g_launch_err == hipSuccess) {
+    g_launch_err = e;
+    g_launch_what = what;
+  }
 }
 
 #define HIP_TRY(ctx, expr)                                                                      \
@@ -186,11 +208,13 @@ extern "C" int gpv_ctx_destroy(gpv_ctx* ctx) {
 }
 extern "C" int gpv_ctx_set_stream(gpv_ctx* ctx, void* hip_stream) {
   if (!ctx) return GPV_EINVAL;
+  ENTER(ctx);
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   return GPV_OK;
 }
 extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
   if (!ctx) return GPV_EINVAL;
+  ENTER(ctx);
   if (option == GPV_OPT_TRANSCRIPT_VARIANT && value >= 0 && value <= 2) {
     ctx->transcript_variant = value;
     return GPV_OK;
@@ -204,6 +228,7 @@ extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
 }
 extern "C" int gpv_ctx_synchronize(gpv_ctx* ctx) {
   if (!ctx) return GPV_EINVAL;
+  ENTER(ctx);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GPV_OK;
 }
@@ -215,17 +240,20 @@ extern "C" int gpv_last_error_message(gpv_ctx* ctx, char* buf, size_t buf_len) {
 }
 extern "C" int gpv_timing_enable(gpv_ctx* ctx, int on) {
   if (!ctx) return GPV_EINVAL;
+  ENTER(ctx);
   ctx->timing = on != 0;
   return GPV_OK;
 }
 extern "C" int gpv_timing_reset(gpv_ctx* ctx) {
   if (!ctx) return GPV_EINVAL;
+  ENTER(ctx);
   int rc = drain_timing(ctx);
   for (int i = 0; i < TK_COUNT; i++) { ctx->acc_ms[i] = 0; ctx->acc_n[i] = 0; }
   return rc;
 }
 extern "C" int gpv_timing_get(gpv_ctx* ctx, int kind, double* avg_ms, uint64_t* launches) {
   if (!ctx || kind < 0 || kind >= TK_COUNT) return GPV_EINVAL;
+  ENTER(ctx);
   int rc = drain_timing(ctx);
   if (rc != GPV_OK) return rc;
   if (avg_ms) *avg_ms = ctx->acc_n[kind] ? ctx->acc_ms[kind] / (double)ctx->acc_n[kind] : 0.0;
@@ -234,20 +262,41 @@ extern "C" int gpv_timing_get(gpv_ctx* ctx, int kind, double* avg_ms, uint64_t* 
 }
 
 void gpv_circuit_release_device(gpv_circuit* c) {
-  if (c->dev) {
-    hipFree(c->dev);
-    c->dev = nullptr;
-  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  int cur = -1;
+  bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  for (int d = 0; d < GPV_MAX_DEVICES; d++)
+    if (c->dev[d]) {
+      if (hipSetDevice(d) == hipSuccess) {
+        hipDeviceSynchronize();  // kernels of any context may still be reading the descriptor
+        hipFree(c->dev[d]);
+      }
+      c->dev[d] = nullptr;
+    }
+  if (have_cur) hipSetDevice(cur);
 }
+// The descriptor copy of `c` on the context's device: created once per (circuit, device) under the circuit's mutex and kept
+// until gpv_circuit_destroy, so contexts on any devices and threads can share one circuit (the device is current: ENTER).
 static int circuit_on_device(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit** out) {
-  if (!c->dev || c->dev_id != ctx->device) {
-    if (c->dev) hipFree(c->dev);
-    c->dev = nullptr;
-    HIP_TRY(ctx, hipMalloc(&c->dev, sizeof(DevCircuit)));
-    HIP_TRY(ctx, hipMemcpy(c->dev, &c->dc, sizeof(DevCircuit), hipMemcpyHostToDevice));
-    c->dev_id = ctx->device;
+  if (ctx->device < 0 || ctx->device >= GPV_MAX_DEVICES) {
+    ctx_error(ctx, "device ordinal %d beyond GPV_MAX_DEVICES", ctx->device);
+    return GPV_EINVAL;
   }
-  *out = (const DevCircuit*)c->dev;
+  std::lock_guard<std::mutex> lk(c->mu);
+  void*& slot = c->dev[ctx->device];
+  if (!slot) {
+    void* p = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(&p, sizeof(DevCircuit)));
+    hipError_t e = hipMemcpy(p, &c->dc, sizeof(DevCircuit), hipMemcpyHostToDevice);  // synchronous: visible to every stream
+    if (e != hipSuccess) {
+      hipFree(p);
+      ctx_error(ctx, "upload of the circuit descriptor failed: %s", hipGetErrorString(e));
+      return GPV_EDEVICE;
+    }
+    slot = p;
+  }
+  *out = (const DevCircuit*)slot;
   return GPV_OK;
 }
 
@@ -339,7 +388,15 @@ static void launch_fri_query(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c,
   Timed t(ctx, TK_FRI, st);
   gpvk_fri_query(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->fail);
 }
-#define CHECK_LAUNCH(ctx) HIP_TRY(ctx, hipGetLastError())
+#define CHECK_LAUNCH(ctx)                                                                              \
+  do {                                                                                                 \
+    gpvk_note_launch(hipGetLastError(), "HIP runtime");                                                \
+    if (g_launch_err != hipSuccess) {                                                                  \
+      ctx_error(ctx, "launch of %s failed: %s", g_launch_what, hipGetErrorString(g_launch_err));       \
+      g_launch_err = hipSuccess;                                                                       \
+      return GPV_EDEVICE;                                                                              \
+    }                                                                                                  \
+  } while (0)
 
 // Full pipeline on device-resident proofs; leaves the failure masks in ctx->fail and the derived values in ctx->derived.
 //
@@ -387,6 +444,7 @@ extern "C" int gpv_gl_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t
                    op == GPV_OP_RANGECHECK);
   REQUIRE(ctx, (op == GPV_OP_INV || op == GPV_OP_REDUCE || op == GPV_OP_RANGECHECK) || b);
   REQUIRE(ctx, op != GPV_OP_MULADD || c);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   DevBuf<u64> da, db, dc_, dout;
@@ -407,6 +465,7 @@ extern "C" int gpv_gl2_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_
   REQUIRE(ctx, ctx && a && out);
   REQUIRE(ctx, op == GPV_OP_ADD || op == GPV_OP_SUB || op == GPV_OP_MUL || op == GPV_OP_INV || op == GPV_OP_DIV);
   REQUIRE(ctx, op == GPV_OP_INV || b);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   DevBuf<u64> da, db, dout;
@@ -453,18 +512,21 @@ extern "C" int gpv_gl2_op3(gpv_ctx* ctx, int op, const uint64_t* a, const uint64
   REQUIRE(ctx, ctx && a && b && out);
   REQUIRE(ctx, op == GPV_OP_MULADD || op == GPV_OP_SUBMUL || op == GPV_OP_SCALARMUL);
   REQUIRE(ctx, op == GPV_OP_SCALARMUL || c);
+  ENTER(ctx);
   bool scalar = op == GPV_OP_SCALARMUL;
   return map_host3(ctx, a, 2, b, scalar ? 1 : 2, scalar ? nullptr : c, 2, out, 2, n,
                    [&](u64* x, u64* y, u64* z, u64* o) { gpvk_gl2_op3(ctx->stream, op, x, y, z, o, n); });
 }
 extern "C" int gpv_gl2_exp(gpv_ctx* ctx, const uint64_t* a, uint64_t exponent, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && a && out);
+  ENTER(ctx);
   return map_host3(ctx, a, 2, nullptr, 0, nullptr, 0, out, 2, n,
                    [&](u64* x, u64*, u64*, u64* o) { gpvk_gl2_exp(ctx->stream, x, exponent, o, n); });
 }
 extern "C" int gpv_gl2_reduce_with_powers(gpv_ctx* ctx, const uint64_t* terms, size_t len, const uint64_t* scalar, uint64_t* out,
                                           size_t n) {
   REQUIRE(ctx, ctx && scalar && out && (terms || len == 0) && len <= 0x7FFFFFFFu);
+  ENTER(ctx);
   if (len == 0) {  // empty Horner sum
     memset(out, 0, 16 * n);
     return GPV_OK;
@@ -475,12 +537,14 @@ extern "C" int gpv_gl2_reduce_with_powers(gpv_ctx* ctx, const uint64_t* terms, s
 extern "C" int gpv_gl2alg_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && a && b && out);
   REQUIRE(ctx, op == GPV_OP_ADD || op == GPV_OP_SUB || op == GPV_OP_MUL || op == GPV_OP_SCALARMUL);
+  ENTER(ctx);
   return map_host3(ctx, a, 4, b, op == GPV_OP_SCALARMUL ? 2 : 4, nullptr, 0, out, 4, n,
                    [&](u64* x, u64* y, u64*, u64* o) { gpvk_gl2alg_op(ctx->stream, op, x, y, o, n); });
 }
 extern "C" int gpv_poseidon_gl_hash_n_to_m_no_pad(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n_out,
                                                   size_t n) {
   REQUIRE(ctx, ctx && out && (in || len == 0) && len <= 0x7FFFFFFFu && n_out >= 1 && n_out <= 0x7FFFFFFFu);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   DevBuf<u64> din, dout;
@@ -496,6 +560,7 @@ extern "C" int gpv_poseidon_gl_hash_n_to_m_no_pad(gpv_ctx* ctx, const uint64_t* 
 extern "C" int gpv_challenger_run(gpv_ctx* ctx, const uint32_t* script, size_t n_ops, const uint64_t* in, size_t n_in, uint64_t* out,
                                   size_t n_out, size_t n) {
   REQUIRE(ctx, ctx && (script || n_ops == 0) && (in || n_in == 0) && (out || n_out == 0) && n_ops <= 0x7FFFFFFFu);
+  ENTER(ctx);
   size_t need_in = 0, need_out = 0;
   for (size_t k = 0; k < n_ops; k++) {
     uint32_t kind = script[k] >> 28, cnt = script[k] & 0x0FFFFFFFu;
@@ -532,6 +597,7 @@ extern "C" int gpv_challenger_run(gpv_ctx* ctx, const uint32_t* script, size_t n
 
 extern "C" int gpv_poseidon_gl_permute_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && states && out);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   {
     Timed t(ctx, TK_PGL);
@@ -542,6 +608,7 @@ extern "C" int gpv_poseidon_gl_permute_dev(gpv_ctx* ctx, const uint64_t* states,
 }
 extern "C" int gpv_poseidon_gl_permute_coop_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && states && out);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   {
     Timed t(ctx, TK_PGL);
@@ -552,6 +619,7 @@ extern "C" int gpv_poseidon_gl_permute_coop_dev(gpv_ctx* ctx, const uint64_t* st
 }
 extern "C" int gpv_poseidon_bn254_permute_dev(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && states && out);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   {
     Timed t(ctx, TK_PBN);
@@ -580,14 +648,17 @@ static int map_host(gpv_ctx* ctx, const uint64_t* in, size_t in_words, uint64_t*
 
 extern "C" int gpv_poseidon_gl_permute(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && states && out);
+  ENTER(ctx);
   return map_host(ctx, states, 12, out, 12, n, [&](u64* i, u64* o) { return gpv_poseidon_gl_permute_dev(ctx, i, o, n); });
 }
 extern "C" int gpv_poseidon_gl_permute_coop(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && states && out);
+  ENTER(ctx);
   return map_host(ctx, states, 12, out, 12, n, [&](u64* i, u64* o) { return gpv_poseidon_gl_permute_coop_dev(ctx, i, o, n); });
 }
 extern "C" int gpv_poseidon_gl_hash_no_pad(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && out && (in || len == 0) && len <= 0xFFFFFFFFu);
+  ENTER(ctx);
   if (len == 0) {  // goldilocks.go:41-68: no input -> no permutation -> zero hash
     memset(out, 0, 32 * n);
     return GPV_OK;
@@ -599,10 +670,12 @@ extern "C" int gpv_poseidon_gl_hash_no_pad(gpv_ctx* ctx, const uint64_t* in, siz
 }
 extern "C" int gpv_poseidon_bn254_permute(gpv_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && states && out);
+  ENTER(ctx);
   return map_host(ctx, states, 16, out, 16, n, [&](u64* i, u64* o) { return gpv_poseidon_bn254_permute_dev(ctx, i, o, n); });
 }
 extern "C" int gpv_poseidon_bn254_hash_or_noop(gpv_ctx* ctx, const uint64_t* in, size_t len, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && out && (in || len == 0) && len <= 0xFFFFFFFFu);
+  ENTER(ctx);
   if (len == 0) {
     memset(out, 0, 32 * n);
     return GPV_OK;
@@ -614,6 +687,7 @@ extern "C" int gpv_poseidon_bn254_hash_or_noop(gpv_ctx* ctx, const uint64_t* in,
 }
 extern "C" int gpv_poseidon_bn254_two_to_one(gpv_ctx* ctx, const uint64_t* left, const uint64_t* right, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && left && right && out);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   DevBuf<u64> dl, dr, dout;
@@ -630,6 +704,7 @@ extern "C" int gpv_poseidon_bn254_two_to_one(gpv_ctx* ctx, const uint64_t* left,
 }
 extern "C" int gpv_poseidon_bn254_to_vec(gpv_ctx* ctx, const uint64_t* hashes, uint64_t* out, size_t n) {
   REQUIRE(ctx, ctx && hashes && out);
+  ENTER(ctx);
   return map_host(ctx, hashes, 4, out, 5, n, [&](u64* i, u64* o) {
     gpvk_poseidon_bn254_to_vec(ctx->stream, i, o, n);
     return GPV_OK;
@@ -642,6 +717,7 @@ extern "C" int gpv_gate_eval_unfiltered(gpv_ctx* ctx, int kind, uint64_t p0, uin
                                         size_t n) {
   REQUIRE(ctx, ctx && wires && pi_hash && out && (constants || n_constants == 0));
   REQUIRE(ctx, kind >= 0 && kind <= GPV_GATE_POSEIDON_MDS && p0 <= 0xFFFFFFFFu && p1 <= 0xFFFFFFFFu && p2 <= 0xFFFFFFFFu);
+  ENTER(ctx);
   DevGate g;
   memset(&g, 0, sizeof g);
   g.kind = (u32)kind;
@@ -717,6 +793,7 @@ static int upload_challenges(gpv_ctx* ctx, const gpv_circuit* c, const DevCircui
 
 extern "C" int gpv_challenges_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint64_t* challenges_dev) {
   REQUIRE(ctx, ctx && c && proofs_dev && challenges_dev);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   const DevCircuit* dcd;
   int rc = circuit_on_device(ctx, c, &dcd);
@@ -732,6 +809,7 @@ extern "C" int gpv_challenges_dev(gpv_ctx* ctx, const gpv_circuit* c, const void
 }
 extern "C" int gpv_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* out) {
   REQUIRE(ctx, ctx && c && proofs && out);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   HostBatch hb;
   int rc = hb.upload(ctx, c, proofs, n);
@@ -747,6 +825,7 @@ extern "C" int gpv_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* pr
 }
 extern "C" int gpv_public_inputs_hash(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* out) {
   REQUIRE(ctx, ctx && c && proofs && out);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   HostBatch hb;
   int rc = hb.upload(ctx, c, proofs, n);
@@ -786,6 +865,7 @@ struct StageSetup {
 extern "C" int gpv_plonk_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n,
                                 uint32_t* fail_mask) {
   REQUIRE(ctx, ctx && c && proofs && challenges && fail_mask);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   StageSetup st;
   int rc = st.run(ctx, c, proofs, challenges, n);
@@ -798,6 +878,7 @@ extern "C" int gpv_plonk_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* 
 }
 extern "C" int gpv_gate_constraints(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* out) {
   REQUIRE(ctx, ctx && c && proofs && out);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   HostBatch hb;
   int rc = hb.upload(ctx, c, proofs, n);
@@ -821,6 +902,7 @@ extern "C" int gpv_gate_constraints(gpv_ctx* ctx, const gpv_circuit* c, const vo
 extern "C" int gpv_fri_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n,
                               uint32_t* fail_mask) {
   REQUIRE(ctx, ctx && c && proofs && challenges && fail_mask);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   StageSetup st;
   int rc = st.run(ctx, c, proofs, challenges, n);
@@ -835,6 +917,7 @@ extern "C" int gpv_fri_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* pr
 extern "C" int gpv_merkle_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, const uint64_t* challenges_dev, size_t n,
                                      uint8_t* ok_dev) {
   REQUIRE(ctx, ctx && c && proofs_dev && challenges_dev && ok_dev);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   const DevCircuit* dcd;
   int rc = circuit_on_device(ctx, c, &dcd);
@@ -851,6 +934,7 @@ extern "C" int gpv_merkle_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const v
 }
 extern "C" int gpv_merkle_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n, uint8_t* ok) {
   REQUIRE(ctx, ctx && c && proofs && challenges && ok);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   StageSetup st;
   int rc = st.run(ctx, c, proofs, challenges, n);
@@ -867,6 +951,7 @@ extern "C" int gpv_merkle_verify(gpv_ctx* ctx, const gpv_circuit* c, const void*
 
 extern "C" int gpv_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint8_t* accept_dev) {
   REQUIRE(ctx, ctx && c && proofs_dev && accept_dev);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   int rc = verify_pipeline_dev(ctx, c, proofs_dev, n);
   if (rc != GPV_OK) return rc;
@@ -877,6 +962,7 @@ extern "C" int gpv_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* pr
 extern "C" int gpv_verify_detail(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept, uint32_t* fail_mask,
                                  uint64_t* challenges) {
   REQUIRE(ctx, ctx && c && proofs && accept);
+  ENTER(ctx);
   if (n == 0) return GPV_OK;
   HostBatch hb;
   int rc = hb.upload(ctx, c, proofs, n);
@@ -903,10 +989,8 @@ extern "C" int gpv_verify_detail(gpv_ctx* ctx, const gpv_circuit* c, const void*
 // stream (1024, 2048, then up to 8192 proofs each) so that all but the first copy overlap the verification of the previous
 // chunk; staging lives in the context (no hipMalloc per call). Pageable host memory works (the copy then blocks the host
 // thread, not the GPU); pinned memory (hipHostMalloc / hipHostRegister by the caller) copies faster.
-extern "C" int gpv_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept) {
-  REQUIRE(ctx, ctx && c && proofs && accept);
-  if (n == 0) return GPV_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+int gpvi_verify_host_batch(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t** accept_dev) {
+  ENTER(ctx);
   const size_t rec = c->dc.proof_nbytes;
   if (rec * n > ctx->stage_bytes) {
     if (ctx->stage) { hipStreamSynchronize(ctx->stream); hipFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
@@ -941,14 +1025,35 @@ extern "C" int gpv_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs
     if (rc != GPV_OK) return rc;
     done += take;
   }
-  HIP_TRY(ctx, hipMemcpyAsync(accept, ctx->stage_accept, n, hipMemcpyDeviceToHost, ctx->stream));
+  *accept_dev = ctx->stage_accept;
+  return GPV_OK;
+}
+extern "C" int gpv_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept) {
+  REQUIRE(ctx, ctx && c && proofs && accept);
+  ENTER(ctx);
+  if (n == 0) return GPV_OK;
+  uint8_t* acc_dev = nullptr;
+  int rc = gpvi_verify_host_batch(ctx, c, proofs, n, &acc_dev);
+  if (rc != GPV_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(accept, acc_dev, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+
+// ---- internal accessors for gpv_group.cpp (one worker per context)
+hipStream_t gpvi_ctx_stream(gpv_ctx* ctx) { return ctx->stream; }
+int gpvi_ctx_device(const gpv_ctx* ctx) { return ctx->device; }
+void gpvi_ctx_set_error(gpv_ctx* ctx, const char* msg) { ctx->err = msg; }
+const char* gpvi_ctx_get_error(const gpv_ctx* ctx) { return ctx->err.c_str(); }
+int gpvi_take_launch_error(gpv_ctx* ctx) {
+  CHECK_LAUNCH(ctx);
   return GPV_OK;
 }
 
 // ================================================================ instruction-rate microbenchmark (kernels: gpv_k_prim.hip)
 extern "C" int gpv_microbench(gpv_ctx* ctx, int which, double* lane_ops_per_sec) {
   REQUIRE(ctx, ctx && lane_ops_per_sec && which >= 0 && which <= 7);
+  ENTER(ctx);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int blocks = 256 * 8, threads = 256, iters = 4096;
   DevBuf<u64> out;

@@ -1,0 +1,421 @@
+// gpv_group -- proof batches sharded over the GPUs of one node behind the C ABI (north star: "proof batches
+// shard trivially across the 8 GPUs of one node with an RCCL all-gather of per-proof accept bits over xGMI").
+//
+// The reference has no counterpart (pure single-goroutine Go). Proofs are independent, so:
+//   * rank r of `world` owns the contiguous block gpv_shard_bounds(n, r, world) -- no data-path collective;
+//   * the only exchange is ONE ncclAllGather of the accept bits packed 8 per byte (1 KiB per rank at 65 536 proofs), after
+//     which every rank's device buffer and the host hold the verdict of the whole batch. It is latency-bound (tens of us),
+//     xGMI bandwidth is irrelevant.
+// Two ways to form a group:
+//   gpv_group_create       one process drives n devices: a worker thread + gpv_ctx per device, ncclCommInitAll clique
+//   gpv_group_create_rank  one process per GPU (torch.distributed.run, MPI, a Go supervisor): ncclCommInitRank with a unique
+//                          id the caller distributes
+// RCCL is loaded with dlopen at the first use that needs it ("librccl.so.1": the copy already mapped by PyTorch when there is
+// one, else the ROCm one), so libgpv.so has no link-time dependency on it and single-GPU hosts never touch it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only; every function is resolved with dlsym
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "gpv_internal.h"
+#include "gpv_launch.h"
+
+extern "C" int gpv_shard_bounds(size_t n, int rank, int world, size_t* lo, size_t* hi) {
+  if (world <= 0 || rank < 0 || rank >= world || !lo || !hi) return GPV_EINVAL;
+  const size_t base = n / (size_t)world, rem = n % (size_t)world, r = (size_t)rank;
+  *lo = r * base + (r < rem ? r : rem);
+  *hi = *lo + base + (r < rem ? 1 : 0);
+  return GPV_OK;
+}
+extern "C" size_t gpv_accept_slot_bytes(size_t n, int world) {
+  if (world <= 0) return 0;
+  const size_t max_block = (n + (size_t)world - 1) / (size_t)world;
+  return (max_block + 7) / 8;
+}
+
+namespace {
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+// returns nullptr and fills `why` when RCCL cannot be loaded
+const Rccl* rccl(std::string* why) {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.handle) return &g_rccl;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* nm : names) {
+    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    *why = std::string("RCCL not loadable: ") + (dlerror() ? dlerror() : "dlopen failed");
+    return nullptr;
+  }
+  Rccl r;
+  r.handle = h;
+#define SYM(field, name)                                                         \
+  *(void**)(&r.field) = dlsym(h, name);                                          \
+  if (!r.field) { *why = std::string("RCCL symbol missing: ") + name; dlclose(h); return nullptr; }
+  SYM(GetUniqueId, "ncclGetUniqueId");
+  SYM(CommInitRank, "ncclCommInitRank");
+  SYM(CommInitAll, "ncclCommInitAll");
+  SYM(CommDestroy, "ncclCommDestroy");
+  SYM(AllGather, "ncclAllGather");
+  SYM(GroupStart, "ncclGroupStart");
+  SYM(GroupEnd, "ncclGroupEnd");
+  SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  g_rccl = r;
+  return &g_rccl;
+}
+
+struct Worker {
+  int rank = 0, device = 0;
+  gpv_ctx* ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  uint8_t* bits = nullptr;  // [world][slot] gathered accept bits, on this rank's device
+  size_t bits_cap = 0;
+  uint8_t* accept_all = nullptr;  // [n_total] unpacked, for the host-batch entry point
+  size_t accept_all_cap = 0;
+  int rc = GPV_OK;
+  std::string err;
+};
+}  // namespace
+
+struct gpv_group {
+  int world = 1;
+  std::vector<Worker> w;  // local ranks, ascending
+  bool comm_ready = false;
+  bool in_process = true;  // every rank is local (ncclCommInitAll) vs one rank of a multi-process job
+  ncclUniqueId uid;
+  int collective = 0;  // GPV_GROUP_OPT_COLLECTIVE: 0 = RCCL only when world > 1, 1 = always
+  std::string err;
+  std::mutex call_mu;  // one group call at a time
+  // persistent worker threads (only when more than one local rank)
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::function<void(Worker&)> job;
+  uint64_t seq = 0;
+  int pending = 0;
+  bool stop = false;
+};
+
+static void group_error(gpv_group* g, const char* fmt, ...) {
+  char buf[768];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (g) g->err = buf;
+  gpv_set_global_error("%s", buf);
+}
+
+static void worker_loop(gpv_group* g, size_t idx) {
+  uint64_t seen = 0;
+  hipSetDevice(g->w[idx].device);
+  for (;;) {
+    std::function<void(Worker&)> job;
+    {
+      std::unique_lock<std::mutex> lk(g->mu);
+      g->cv_job.wait(lk, [&] { return g->stop || g->seq != seen; });
+      if (g->stop) return;
+      seen = g->seq;
+      job = g->job;
+    }
+    job(g->w[idx]);
+    {
+      std::lock_guard<std::mutex> lk(g->mu);
+      if (--g->pending == 0) g->cv_done.notify_all();
+    }
+  }
+}
+// runs `job` once per local rank (on the rank's own thread when there are several) and returns the first failure
+static int run_all(gpv_group* g, const std::function<void(Worker&)>& job) {
+  for (auto& w : g->w) { w.rc = GPV_OK; w.err.clear(); }
+  if (g->w.size() == 1) {
+    job(g->w[0]);
+  } else {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->job = job;
+    g->pending = (int)g->w.size();
+    g->seq++;
+    g->cv_job.notify_all();
+    g->cv_done.wait(lk, [&] { return g->pending == 0; });
+  }
+  for (auto& w : g->w)
+    if (w.rc != GPV_OK) {
+      group_error(g, "rank %d (device %d): %s", w.rank, w.device, w.err.c_str());
+      return w.rc;
+    }
+  return GPV_OK;
+}
+static void worker_fail(Worker& w, int rc, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (w.rc == GPV_OK) { w.rc = rc; w.err = buf; }
+}
+#define W_HIP(w, expr)                                                                   \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) { worker_fail(w, GPV_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_)); return; } \
+  } while (0)
+#define W_GPV(w, expr)                                                                   \
+  do {                                                                                   \
+    int rc_ = (expr);                                                                    \
+    if (rc_ != GPV_OK) { worker_fail(w, rc_, "%s: %s", #expr, gpvi_ctx_get_error(w.ctx)); return; } \
+  } while (0)
+
+static int group_alloc(gpv_group** out, const int* device_ids, int n_local, int first_rank, int world) {
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0) {
+    gpv_set_global_error("no usable GPU: hipGetDeviceCount -> %s (count %d). libgpv has no CPU fallback.", hipGetErrorString(e), n_dev);
+    return GPV_EDEVICE;
+  }
+  for (int i = 0; i < n_local; i++) {
+    if (device_ids[i] < 0 || device_ids[i] >= n_dev) {
+      gpv_set_global_error("device id %d out of range (0..%d)", device_ids[i], n_dev - 1);
+      return GPV_EINVAL;
+    }
+    for (int j = 0; j < i; j++)
+      if (device_ids[j] == device_ids[i]) {
+        gpv_set_global_error("device id %d listed twice", device_ids[i]);
+        return GPV_EINVAL;
+      }
+  }
+  gpv_group* g = new gpv_group();
+  g->world = world;
+  g->w.resize((size_t)n_local);
+  for (int i = 0; i < n_local; i++) {
+    g->w[i].rank = first_rank + i;
+    g->w[i].device = device_ids[i];
+    int rc = gpv_ctx_create(&g->w[i].ctx, device_ids[i]);
+    if (rc != GPV_OK) {
+      for (int j = 0; j < i; j++) gpv_ctx_destroy(g->w[j].ctx);
+      delete g;
+      return rc;
+    }
+  }
+  if (n_local > 1)
+    for (size_t i = 0; i < g->w.size(); i++) g->threads.emplace_back(worker_loop, g, i);
+  *out = g;
+  return GPV_OK;
+}
+
+extern "C" int gpv_group_create(gpv_group** out, const int* device_ids, int n_devices) {
+  if (!out || !device_ids || n_devices < 1 || n_devices > GPV_MAX_DEVICES) return GPV_EINVAL;
+  *out = nullptr;
+  int rc = group_alloc(out, device_ids, n_devices, 0, n_devices);
+  if (rc == GPV_OK) (*out)->in_process = true;
+  return rc;
+}
+extern "C" int gpv_group_unique_id(void* id128) {
+  if (!id128) return GPV_EINVAL;
+  std::string why;
+  const Rccl* r = rccl(&why);
+  if (!r) { gpv_set_global_error("%s", why.c_str()); return GPV_EDEVICE; }
+  ncclUniqueId id;
+  ncclResult_t e = r->GetUniqueId(&id);
+  if (e != ncclSuccess) { gpv_set_global_error("ncclGetUniqueId: %s", r->GetErrorString(e)); return GPV_EDEVICE; }
+  static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+  memcpy(id128, &id, 128);
+  return GPV_OK;
+}
+extern "C" int gpv_group_create_rank(gpv_group** out, int device_id, int rank, int world, const void* id128) {
+  if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return GPV_EINVAL;
+  *out = nullptr;
+  int rc = group_alloc(out, &device_id, 1, rank, world);
+  if (rc != GPV_OK) return rc;
+  (*out)->in_process = world == 1;
+  if (id128) memcpy(&(*out)->uid, id128, 128);
+  return GPV_OK;
+}
+extern "C" int gpv_group_destroy(gpv_group* g) {
+  if (!g) return GPV_EINVAL;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->stop = true;
+    g->cv_job.notify_all();
+  }
+  for (auto& t : g->threads) t.join();
+  const Rccl* r = g->comm_ready ? &g_rccl : nullptr;
+  for (auto& w : g->w) {
+    hipSetDevice(w.device);
+    gpv_ctx_synchronize(w.ctx);
+    if (r && w.comm) r->CommDestroy(w.comm);
+    if (w.bits) hipFree(w.bits);
+    if (w.accept_all) hipFree(w.accept_all);
+    gpv_ctx_destroy(w.ctx);
+  }
+  delete g;
+  return GPV_OK;
+}
+extern "C" int gpv_group_world(const gpv_group* g) { return g ? g->world : 0; }
+extern "C" int gpv_group_local(const gpv_group* g) { return g ? (int)g->w.size() : 0; }
+extern "C" int gpv_group_rank(const gpv_group* g, int local_index) {
+  return g && local_index >= 0 && (size_t)local_index < g->w.size() ? g->w[local_index].rank : -1;
+}
+extern "C" gpv_ctx* gpv_group_ctx(gpv_group* g, int local_index) {
+  return g && local_index >= 0 && (size_t)local_index < g->w.size() ? g->w[local_index].ctx : nullptr;
+}
+extern "C" int gpv_group_set_option(gpv_group* g, int option, int value) {
+  if (!g) return GPV_EINVAL;
+  std::lock_guard<std::mutex> lk(g->call_mu);
+  if (option == GPV_GROUP_OPT_COLLECTIVE && (value == 0 || value == 1)) {
+    g->collective = value;
+    return GPV_OK;
+  }
+  int rc = GPV_OK;
+  for (auto& w : g->w) {  // anything else is a per-context option
+    int r = gpv_ctx_set_option(w.ctx, option, value);
+    if (r != GPV_OK) rc = r;
+  }
+  if (rc != GPV_OK) group_error(g, "unknown option or value");
+  return rc;
+}
+extern "C" int gpv_group_last_error_message(gpv_group* g, char* buf, size_t buf_len) {
+  if (!buf || !buf_len) return GPV_EINVAL;
+  snprintf(buf, buf_len, "%s", g ? g->err.c_str() : gpv_get_global_error());
+  return GPV_OK;
+}
+
+static bool wants_collective(const gpv_group* g) { return g->world > 1 || g->collective == 1; }
+
+// communicator(s), created at the first call that needs them
+static int ensure_comm(gpv_group* g) {
+  if (g->comm_ready) return GPV_OK;
+  std::string why;
+  const Rccl* r = rccl(&why);
+  if (!r) { group_error(g, "%s", why.c_str()); return GPV_EDEVICE; }
+  if (g->in_process) {
+    std::vector<int> devs;
+    std::vector<ncclComm_t> comms(g->w.size());
+    for (auto& w : g->w) devs.push_back(w.device);
+    ncclResult_t e = r->CommInitAll(comms.data(), (int)devs.size(), devs.data());
+    if (e != ncclSuccess) { group_error(g, "ncclCommInitAll(%d devices): %s", (int)devs.size(), r->GetErrorString(e)); return GPV_EDEVICE; }
+    for (size_t i = 0; i < g->w.size(); i++) g->w[i].comm = comms[i];
+  } else {
+    Worker& w = g->w[0];
+    if (hipSetDevice(w.device) != hipSuccess) { group_error(g, "hipSetDevice(%d) failed", w.device); return GPV_EDEVICE; }
+    ncclResult_t e = r->CommInitRank(&w.comm, g->world, g->uid, w.rank);
+    if (e != ncclSuccess) { group_error(g, "ncclCommInitRank(rank %d of %d): %s", w.rank, g->world, r->GetErrorString(e)); return GPV_EDEVICE; }
+  }
+  g->comm_ready = true;
+  return GPV_OK;
+}
+
+// Exchange step of one rank, enqueued on its context's stream: accept bytes of its block -> bits in its slot of the gather
+// buffer -> in-place ncclAllGather (world == 1 without the collective option: the slot is already the whole buffer) ->
+// accept bytes of the whole batch in `accept_all_dev`.
+static void exchange(gpv_group* g, Worker& w, const uint8_t* accept_local_dev, size_t n_total, uint8_t* accept_all_dev) {
+  size_t lo, hi;
+  gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
+  const size_t slot = gpv_accept_slot_bytes(n_total, g->world);
+  const size_t need = slot * (size_t)g->world;
+  hipStream_t st = gpvi_ctx_stream(w.ctx);
+  if (need > w.bits_cap) {
+    if (w.bits) { W_HIP(w, hipStreamSynchronize(st)); hipFree(w.bits); w.bits = nullptr; w.bits_cap = 0; }
+    W_HIP(w, hipMalloc((void**)&w.bits, need));
+    w.bits_cap = need;
+  }
+  gpvk_pack_accept_bits(st, accept_local_dev, hi - lo, w.bits + (size_t)w.rank * slot, slot);
+  if (wants_collective(g)) {
+    ncclResult_t e = g_rccl.AllGather(w.bits + (size_t)w.rank * slot, w.bits, slot, ncclUint8, w.comm, st);
+    if (e != ncclSuccess) { worker_fail(w, GPV_EDEVICE, "ncclAllGather: %s", g_rccl.GetErrorString(e)); return; }
+  }
+  gpvk_unpack_accept_bits(st, w.bits, slot, n_total, (u32)g->world, accept_all_dev);
+  W_GPV(w, gpvi_take_launch_error(w.ctx));
+}
+
+extern "C" int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const void* const* shard_dev, size_t n_total,
+                                    uint8_t* const* accept_all_dev) {
+  if (!g || !c || !shard_dev || !accept_all_dev) return GPV_EINVAL;
+  std::lock_guard<std::mutex> lk(g->call_mu);
+  if (n_total == 0) return GPV_OK;
+  if (wants_collective(g)) {
+    int rc = ensure_comm(g);
+    if (rc != GPV_OK) return rc;
+  }
+  const size_t first = g->w[0].rank;
+  return run_all(g, [&](Worker& w) {
+    const size_t i = (size_t)w.rank - first;
+    W_HIP(w, hipSetDevice(w.device));
+    size_t lo, hi;
+    gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
+    if (hi > lo && !shard_dev[i]) { worker_fail(w, GPV_EINVAL, "shard pointer %zu is NULL", i); return; }
+    if (!accept_all_dev[i]) { worker_fail(w, GPV_EINVAL, "accept pointer %zu is NULL", i); return; }
+    // the block's own accept bytes land directly in its range of the full-batch buffer, then are packed from there
+    uint8_t* mine = accept_all_dev[i] + lo;
+    if (hi > lo) W_GPV(w, gpv_verify_dev(w.ctx, c, shard_dev[i], hi - lo, mine));
+    exchange(g, w, mine, n_total, accept_all_dev[i]);
+    if (w.rc != GPV_OK) return;
+    W_HIP(w, hipStreamSynchronize(gpvi_ctx_stream(w.ctx)));
+  });
+}
+
+extern "C" int gpv_group_verify(gpv_group* g, const gpv_circuit* c, const void* proofs, size_t n_total, uint8_t* accept) {
+  if (!g || !c || !accept || (n_total && !proofs)) return GPV_EINVAL;
+  std::lock_guard<std::mutex> lk(g->call_mu);
+  if (n_total == 0) return GPV_OK;
+  if (wants_collective(g)) {
+    int rc = ensure_comm(g);
+    if (rc != GPV_OK) return rc;
+  }
+  const size_t rec = gpv_proof_nbytes(c);
+  size_t first_lo, tmp;
+  gpv_shard_bounds(n_total, g->w[0].rank, g->world, &first_lo, &tmp);  // `proofs` starts at the first local rank's block
+  return run_all(g, [&](Worker& w) {
+    W_HIP(w, hipSetDevice(w.device));
+    size_t lo, hi;
+    gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
+    hipStream_t st = gpvi_ctx_stream(w.ctx);
+    if (n_total > w.accept_all_cap) {
+      if (w.accept_all) { W_HIP(w, hipStreamSynchronize(st)); hipFree(w.accept_all); w.accept_all = nullptr; w.accept_all_cap = 0; }
+      W_HIP(w, hipMalloc((void**)&w.accept_all, n_total));
+      w.accept_all_cap = n_total;
+    }
+    uint8_t* acc_local = w.accept_all + lo;  // unused when the block is empty
+    if (hi > lo) W_GPV(w, gpvi_verify_host_batch(w.ctx, c, (const uint8_t*)proofs + (lo - first_lo) * rec, hi - lo, &acc_local));
+    exchange(g, w, acc_local, n_total, w.accept_all);
+    if (w.rc != GPV_OK) return;
+    // every rank holds the whole verdict on its device; the lowest local rank hands it to the caller
+    if (w.rank == g->w[0].rank) W_HIP(w, hipMemcpyAsync(accept, w.accept_all, n_total, hipMemcpyDeviceToHost, st));
+    W_HIP(w, hipStreamSynchronize(st));
+  });
+}
+
+// Test / diagnostics: the gathered accept bytes as rank `local_index` holds them on ITS device after the last
+// gpv_group_verify (proves that the all-gather delivered the whole verdict to every rank, not only to the reporting one).
+extern "C" int gpv_group_read_rank_accept(gpv_group* g, int local_index, uint8_t* accept, size_t n_total) {
+  if (!g || !accept || local_index < 0 || (size_t)local_index >= g->w.size()) return GPV_EINVAL;
+  std::lock_guard<std::mutex> lk(g->call_mu);
+  Worker& w = g->w[local_index];
+  if (!w.accept_all || n_total > w.accept_all_cap) { group_error(g, "no gathered verdict of that size on rank %d", w.rank); return GPV_EINVAL; }
+  if (hipSetDevice(w.device) != hipSuccess || hipMemcpy(accept, w.accept_all, n_total, hipMemcpyDeviceToHost) != hipSuccess) {
+    group_error(g, "device read-back failed on rank %d", w.rank);
+    return GPV_EDEVICE;
+  }
+  return GPV_OK;
+}

@@ -3,14 +3,20 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/gpv.h"
 #include "gpv_circuit_dev.h"
 
+#define GPV_MAX_DEVICES 64
+
+// A circuit is immutable after gpv_circuit_from_json. The device-side copies of its descriptor are a cache keyed by device
+// ordinal: created on first use under `mu`, never replaced or freed before gpv_circuit_destroy, so any number of contexts
+// (on the same or on different GPUs, on any threads) can share one circuit while their kernels are in flight.
 struct gpv_circuit {
   DevCircuit dc;
-  // device copy of `dc`, created on first use with a context (one process drives one GPU)
-  mutable void* dev = nullptr;
-  mutable int dev_id = -1;
+  mutable std::mutex mu;
+  mutable void* dev[GPV_MAX_DEVICES] = {nullptr};
 };
 
 void gpv_set_global_error(const char* fmt, ...);

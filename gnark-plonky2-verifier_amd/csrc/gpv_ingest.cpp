@@ -413,37 +413,91 @@ uint32_t gate_num_constraints(const DevGate& g) {
   return 0;
 }
 
+// Highest wire index + 1 and number of (non-selector) constants a gate's evaluator reads -- the reference would panic
+// with "index out of range" on vars.localWires[i] / vars.localConstants[i] (plonk/gates/*.go) when the circuit config has
+// fewer. 64-bit: the parameters are unbounded JSON numbers.
+void gate_needs(const DevGate& g, uint64_t* wires, uint64_t* consts) {
+  const uint64_t p0 = g.p0, p1 = g.p1, p2 = g.p2;
+  *wires = 0;
+  *consts = 0;
+  switch (g.kind) {
+    case GPV_GATE_NOOP: break;
+    case GPV_GATE_CONSTANT: *wires = p0; *consts = p0; break;
+    case GPV_GATE_PUBLIC_INPUT: *wires = 4; break;
+    case GPV_GATE_BASE_SUM: *wires = 1 + p0; break;
+    case GPV_GATE_ARITHMETIC: *wires = 4 * p0; *consts = 2; break;
+    case GPV_GATE_ARITHMETIC_EXT: *wires = 8 * p0; *consts = 2; break;
+    case GPV_GATE_MUL_EXT: *wires = 6 * p0; *consts = 1; break;
+    case GPV_GATE_REDUCING: *wires = 6 + p0 + (p0 ? 2 * (p0 - 1) : 0); break;
+    case GPV_GATE_REDUCING_EXT: *wires = 6 + 2 * p0 + (p0 ? 2 * (p0 - 1) : 0); break;
+    case GPV_GATE_EXPONENTIATION: *wires = 2 + 2 * p0; break;
+    case GPV_GATE_RANDOM_ACCESS: *wires = (2 + (1ull << (p0 > 32 ? 32 : p0))) * p1 + p2 + p1 * p0; *consts = p2; break;
+    case GPV_GATE_COSET_INTERPOLATION: {
+      const uint64_t np = 1ull << (p0 > 32 ? 32 : p0), n_inter = p1 > 1 ? (np - 2) / (p1 - 1) : 0;
+      *wires = 1 + 2 * np + 2 + 2 + 4 * n_inter + 2;
+      break;
+    }
+    case GPV_GATE_POSEIDON: *wires = 135; break;
+    case GPV_GATE_POSEIDON_MDS: *wires = 48; break;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- layout
+// Upper bounds on what a circuit description may ask for. They are far above anything plonky2 emits (the fixtures: 136
+// wires, 6 constants, 28 queries, 36 public inputs, 123 gate constraints) and keep every offset below 2^31 words, so the
+// 32-bit layout fields of DevCircuit cannot wrap; the arithmetic itself is done in 64 bits and re-checked.
+#define GPV_LIM_WIRES 4096u
+#define GPV_LIM_CONSTANTS 4096u
+#define GPV_LIM_PUBLIC_INPUTS (1u << 20)
+#define GPV_LIM_QUERIES 1024u
+#define GPV_LIM_GATE_CONSTRAINTS (1u << 16)
+#define GPV_LIM_FINAL_POLY_BITS 16u
+#define GPV_LIM_PROOF_BYTES (1ull << 30)
 static int finish_layout(DevCircuit& c) {
+  if (c.num_wires > GPV_LIM_WIRES || c.num_constants > GPV_LIM_CONSTANTS || c.num_pi > GPV_LIM_PUBLIC_INPUTS ||
+      c.num_queries > GPV_LIM_QUERIES || c.num_gate_constraints > GPV_LIM_GATE_CONSTRAINTS || c.num_pp > GPV_MAX_ROUTED ||
+      c.qdf > GPV_MAX_ROUTED) {
+    gpv_set_global_error("circuit dimensions beyond the supported limits (wires %u, constants %u, public inputs %u, queries %u, "
+                         "gate constraints %u)", c.num_wires, c.num_constants, c.num_pi, c.num_queries, c.num_gate_constraints);
+    return GPV_ECONFIG;
+  }
   c.lde_bits = c.degree_bits + c.rate_bits;
   uint32_t total_arity = 0;
-  for (uint32_t s = 0; s < c.num_steps; s++) total_arity += c.arity_bits[s];
-  if (total_arity > c.degree_bits) return GPV_ECONFIG;
+  for (uint32_t s = 0; s < c.num_steps; s++) {
+    if (c.arity_bits[s] > 8) return GPV_ECONFIG;
+    total_arity += c.arity_bits[s];
+  }
+  if (total_arity > c.degree_bits || c.degree_bits - total_arity > GPV_LIM_FINAL_POLY_BITS) {
+    gpv_set_global_error("degree_bits %u / reduction arities (sum %u): final polynomial length out of range", c.degree_bits, total_arity);
+    return GPV_ECONFIG;
+  }
   c.final_len = 1u << (c.degree_bits - total_arity);
-  uint32_t w = 0;
-  c.off_constants = w; w += 2 * c.num_constants;
-  c.off_sigmas = w; w += 2 * c.num_routed;
-  c.off_wires = w; w += 2 * c.num_wires;
-  c.off_zs = w; w += 2 * c.num_challenges;
-  c.off_zs_next = w; w += 2 * c.num_challenges;
-  c.off_pp = w; w += 2 * c.num_challenges * c.num_pp;
-  c.off_quot = w; w += 2 * c.num_challenges * c.qdf;
-  c.off_queries = w;
+  uint64_t w = 0;  // 64-bit running offset; every stored offset is checked against 2^31 at the end
+  c.off_constants = (uint32_t)w; w += 2ull * c.num_constants;
+  c.off_sigmas = (uint32_t)w; w += 2ull * c.num_routed;
+  c.off_wires = (uint32_t)w; w += 2ull * c.num_wires;
+  c.off_zs = (uint32_t)w; w += 2ull * c.num_challenges;
+  c.off_zs_next = (uint32_t)w; w += 2ull * c.num_challenges;
+  c.off_pp = (uint32_t)w; w += 2ull * c.num_challenges * c.num_pp;
+  c.off_quot = (uint32_t)w; w += 2ull * c.num_challenges * c.qdf;
+  c.off_queries = (uint32_t)w;
   c.leaf_len[0] = c.num_constants + c.num_routed;                 // fri_utils.go:60-72 numPreprocessedPolys
   c.leaf_len[1] = c.num_wires;
   c.leaf_len[2] = c.num_challenges * (1 + c.num_pp);               // :74-76
   c.leaf_len[3] = c.num_challenges * c.qdf;                        // :78-80
-  uint32_t qw = 0;
-  for (int o = 0; o < 4; o++) { c.leaf_off[o] = qw; qw += c.leaf_len[o]; }
-  for (uint32_t s = 0; s < c.num_steps; s++) { c.step_evals_off[s] = qw; qw += 2u << c.arity_bits[s]; }
-  c.query_words = qw;
-  w += c.num_queries * qw;
-  c.off_final = w; w += 2 * c.final_len;
-  c.off_pow = w; w += 1;
-  c.off_pi = w; w += c.num_pi;
-  c.n_gl_words = w;
+  uint64_t qw = 0;
+  for (int o = 0; o < 4; o++) { c.leaf_off[o] = (uint32_t)qw; qw += c.leaf_len[o]; }
+  for (uint32_t s = 0; s < c.num_steps; s++) { c.step_evals_off[s] = (uint32_t)qw; qw += 2ull << c.arity_bits[s]; }
+  c.query_words = (uint32_t)qw;
+  w += (uint64_t)c.num_queries * qw;
+  if (w >= (1ull << 31)) return GPV_ECONFIG;
+  c.off_final = (uint32_t)w; w += 2ull * c.final_len;
+  c.off_pow = (uint32_t)w; w += 1;
+  c.off_pi = (uint32_t)w; w += c.num_pi;
+  if (w >= (1ull << 31)) return GPV_ECONFIG;
+  c.n_gl_words = (uint32_t)w;
   uint32_t cap_len = 1u << c.cap_height;
   c.fr_wires_cap = 0;
   c.fr_zs_pp_cap = cap_len;
@@ -460,9 +514,15 @@ static int finish_layout(DevCircuit& c) {
     qf += bits;
   }
   c.query_frs = qf;
-  c.n_fr = c.fr_queries + c.num_queries * qf;
+  const uint64_t n_fr = (uint64_t)c.fr_queries + (uint64_t)c.num_queries * qf;
+  const uint64_t nbytes = 8ull * c.n_gl_words + 32ull * n_fr;
+  if (n_fr >= (1ull << 31) || nbytes > GPV_LIM_PROOF_BYTES) {
+    gpv_set_global_error("packed proof record of %llu bytes is beyond the supported limit", (unsigned long long)nbytes);
+    return GPV_ECONFIG;
+  }
+  c.n_fr = (uint32_t)n_fr;
   c.n_trees = 4 + c.num_steps;
-  c.proof_nbytes = 8ull * c.n_gl_words + 32ull * c.n_fr;
+  c.proof_nbytes = nbytes;
   uint32_t k = 0;
   c.ch_betas = k; k += c.num_challenges;
   c.ch_gammas = k; k += c.num_challenges;
@@ -577,6 +637,24 @@ extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len,
     if (kind == GPV_GATE_COSET_INTERPOLATION && (dg.p0 > 8 || weights.size() != (1ull << dg.p0))) return GPV_ECONFIG;
     if (kind == GPV_GATE_RANDOM_ACCESS && dg.p0 > GPV_MAX_RA_BITS) return GPV_ECONFIG;
     if (kind == GPV_GATE_BASE_SUM && dg.p1 > 256) return GPV_ECONFIG;
+    {
+      // what the evaluator indexes must exist: vars.localWires has num_wires entries, vars.localConstants what is left of
+      // num_constants after the selector prefix (plonk/gates/vars.go:26-28); the reference panics (index out of range)
+      uint64_t need_w, need_c;
+      gate_needs(dg, &need_w, &need_c);
+      if (need_w > c.num_wires || need_c + groups->size() > c.num_constants) {
+        gpv_set_global_error("gate %u (%s) reads %llu wires / %llu constants, the circuit has %u / %u after %zu selectors", g,
+                             gid->text().c_str(), (unsigned long long)need_w, (unsigned long long)need_c, c.num_wires,
+                             c.num_constants, groups->size());
+        return GPV_ESHAPE;
+      }
+    }
+    {
+      const uint64_t nk = kind == GPV_GATE_COSET_INTERPOLATION ? 4 + 4 * (((1ull << dg.p0) - 2) / (dg.p1 - 1))
+                          : kind == GPV_GATE_RANDOM_ACCESS     ? (uint64_t)dg.p1 * (dg.p0 + 2) + dg.p2
+                                                               : 2ull * dg.p0 + 2;  // upper bound of the other formulas
+      if (nk > GPV_LIM_GATE_CONSTRAINTS) return GPV_ECONFIG;  // keeps gate_num_constraints inside 32 bits
+    }
     dg.n_constraints = gate_num_constraints(dg);
     if (dg.n_constraints > c.num_gate_constraints) {  // evaluate_gates.go:97-99
       gpv_set_global_error("num_constraints() gave too low of a number");
@@ -587,6 +665,18 @@ extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len,
   for (uint32_t g = 0; g < c.n_groups; g++) {
     const JValue* gr = groups->child(g);
     if (!j_u32(gr->get("start"), &c.group_start[g]) || !j_u32(gr->get("end"), &c.group_end[g])) return GPV_ESHAPE;
+    // a selector group is a range of gate rows (plonk/gates/types.go:10-36, evaluate_gates.go:33-55)
+    if (c.group_start[g] > c.group_end[g] || c.group_end[g] > c.n_gates) {
+      gpv_set_global_error("selector group %u: range [%u, %u) outside the %u gates", g, c.group_start[g], c.group_end[g], c.n_gates);
+      return GPV_ESHAPE;
+    }
+  }
+  for (uint32_t g = 0; g < c.n_gates; g++) {  // every gate lies in the group its selector index names
+    const uint32_t sel = c.selector_index[g];
+    if (g < c.group_start[sel] || g >= c.group_end[sel]) {
+      gpv_set_global_error("gate %u is outside its selector group %u", g, sel);
+      return GPV_ESHAPE;
+    }
   }
   const JValue* cap = vo->get("constants_sigmas_cap");
   if (!cap || cap->kind != JValue::Array || cap->size() != 16) { gpv_set_global_error("constants_sigmas_cap"); return GPV_ESHAPE; }
@@ -653,34 +743,42 @@ extern "C" size_t gpv_circuit_describe(const gpv_circuit* circ, uint64_t* blob, 
 
 // ---------------------------------------------------------------- proof packing
 namespace {
-struct Packer {
+struct Packer {  // writes strictly inside [gl, gl_end) / [fr, fr_end) and nothing at all after the first failure
   uint64_t* gl;
+  uint64_t* gl_end;
   uint64_t* fr;
+  uint64_t* fr_end;
   bool ok = true;
   const char* why = "";
   void fail(const char* w) { if (ok) why = w; ok = false; }
   void put_u64(const JValue* v) {
+    if (!ok) return;
     uint64_t x = 0;
-    if (!j_u64(v, &x)) fail("expected a uint64");
+    if (!j_u64(v, &x)) { fail("expected a uint64"); return; }
+    if (gl >= gl_end) { fail("more Goldilocks words than the circuit's layout holds"); return; }
     *gl++ = x;
   }
   void put_ext_list(const JValue* v, size_t n) {
-    if (!v || v->kind != JValue::Array || v->size() != n) { fail("extension array of the wrong length"); gl += 2 * n; return; }
-    for (const JValue* e = v->first_child(); e; e = e->next_sibling()) {
-      if (e->kind != JValue::Array || e->size() != 2) { fail("extension element must have 2 limbs"); gl += 2; continue; }
+    if (!ok) return;
+    if (!v || v->kind != JValue::Array || v->size() != n) { fail("extension array of the wrong length"); return; }
+    for (const JValue* e = v->first_child(); e && ok; e = e->next_sibling()) {
+      if (e->kind != JValue::Array || e->size() != 2) { fail("extension element must have 2 limbs"); return; }
       const JValue* e0 = e->first_child();
       put_u64(e0);
       put_u64(e0->next_sibling());
     }
   }
   void put_u64_list(const JValue* v, size_t n) {
-    if (!v || v->kind != JValue::Array || v->size() != n) { fail("array of the wrong length"); gl += n; return; }
-    for (const JValue* e = v->first_child(); e; e = e->next_sibling()) put_u64(e);
+    if (!ok) return;
+    if (!v || v->kind != JValue::Array || v->size() != n) { fail("array of the wrong length"); return; }
+    for (const JValue* e = v->first_child(); e && ok; e = e->next_sibling()) put_u64(e);
   }
   void put_fr_list(const JValue* v, size_t n) {
-    if (!v || v->kind != JValue::Array || v->size() != n) { fail("hash array of the wrong length"); fr += 4 * n; return; }
-    for (const JValue* e = v->first_child(); e; e = e->next_sibling()) {
-      if (!j_fr(e, fr)) fail("expected a decimal string");
+    if (!ok) return;
+    if (!v || v->kind != JValue::Array || v->size() != n) { fail("hash array of the wrong length"); return; }
+    for (const JValue* e = v->first_child(); e && ok; e = e->next_sibling()) {
+      if (fr + 4 > fr_end) { fail("more hashes than the circuit's layout holds"); return; }
+      if (!j_fr(e, fr)) { fail("expected a decimal string"); return; }
       fr += 4;
     }
   }
@@ -701,6 +799,8 @@ extern "C" int gpv_proof_pack_json(const gpv_circuit* circ, const char* proof_js
   Packer pk;
   pk.gl = (uint64_t*)out_packed;
   pk.fr = pk.gl + c.n_gl_words;
+  pk.gl_end = pk.fr;
+  pk.fr_end = pk.fr + 4 * (size_t)c.n_fr;
   uint64_t* gl_end = pk.fr;
   const uint32_t nc = c.num_challenges, cap_len = 1u << c.cap_height;
   // openings (types/deserialize.go:14-22)
@@ -723,7 +823,7 @@ extern "C" int gpv_proof_pack_json(const gpv_circuit* circ, const char* proof_js
     gpv_set_global_error("Number of query rounds does not match config.");
     return GPV_ESHAPE;
   }
-  for (const JValue* qr = qrs->first_child(); qr; qr = qr->next_sibling()) {
+  for (const JValue* qr = qrs->first_child(); qr && pk.ok; qr = qr->next_sibling()) {
     const JValue* itp = qr->get("initial_trees_proof");
     const JValue* eps = itp ? itp->get("evals_proofs") : nullptr;
     if (!eps || eps->kind != JValue::Array || eps->size() != 4) {  // fri_utils.go:185-187

@@ -137,32 +137,32 @@ static MerkleOrder merkle_order(const DevCircuit& c, bool leaves) {
 }
 
 void gpvk_poseidon_bn254_permute(hipStream_t st, const u64* in, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_poseidon_bn254_permute, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, out, n);
+  GPVK_LAUNCH(k_poseidon_bn254_permute, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, out, n);
 }
 void gpvk_poseidon_bn254_hash_or_noop(hipStream_t st, const u64* in, u32 len, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_poseidon_bn254_hash_or_noop, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
+  GPVK_LAUNCH(k_poseidon_bn254_hash_or_noop, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
 }
 void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_poseidon_bn254_two_to_one, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, l, r, out, n);
+  GPVK_LAUNCH(k_poseidon_bn254_two_to_one, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, l, r, out, n);
 }
 void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_poseidon_bn254_to_vec, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, h, out, n);
+  GPVK_LAUNCH(k_poseidon_bn254_to_vec, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, h, out, n);
 }
 size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n) { return n * hc.num_queries * hc.n_trees * FR_LIMBS; }
 void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests) {
   size_t items = n * hc.num_queries;
-  hipLaunchKernelGGL(k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd,
+  GPVK_LAUNCH(k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd,
                      proofs, n, merkle_order(hc, true), digests);
 }
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
                        const u32* digests, u32* fail, uint8_t* ok_out) {
   size_t items = n * hc.num_queries;
-  hipLaunchKernelGGL(k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd,
+  GPVK_LAUNCH(k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd,
                      proofs, derived, n, merkle_order(hc, false), digests, fail, ok_out);
 }
 void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
                              const u32* digests, u64* mid, u32 crown_levels) {
   size_t items = n * hc.num_queries;
-  hipLaunchKernelGGL(k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st,
+  GPVK_LAUNCH(k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st,
                      dcd, proofs, derived, n, merkle_order(hc, false), digests, mid, crown_levels);
 }

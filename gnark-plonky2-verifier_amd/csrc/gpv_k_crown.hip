@@ -309,12 +309,12 @@ CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base) {
 void gpvk_crown(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, CrownBufs b,
                 u32* fail) {
   size_t groups = n * hc.n_trees, items = n * hc.num_queries, cap = groups * hc.num_queries;
-  (void)hipMemsetAsync(b.count, 0, 4 * GPV_CROWN_LEVELS, st);
-  (void)hipMemsetAsync(b.gflag, 0, 4 * groups, st);
-  hipLaunchKernelGGL(k_crown_plan, dim3(gpvk_blocks_for(groups, 2 * CROWN_PAIRS_PER_WAVE)), dim3(64), 0, st, dcd, derived, n, b);
+  gpvk_note_launch(hipMemsetAsync(b.count, 0, 4 * GPV_CROWN_LEVELS, st), "memset(crown counters)");
+  gpvk_note_launch(hipMemsetAsync(b.gflag, 0, 4 * groups, st), "memset(crown flags)");
+  GPVK_LAUNCH(k_crown_plan, dim3(gpvk_blocks_for(groups, 2 * CROWN_PAIRS_PER_WAVE)), dim3(64), 0, st, dcd, derived, n, b);
   for (u32 k = 0; k < GPV_CROWN_LEVELS; k++) {
-    hipLaunchKernelGGL(k_crown_reconcile, dim3(gpvk_blocks_for(groups, 2)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
-    hipLaunchKernelGGL(k_crown_level, dim3(gpvk_blocks_for(2 * cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
+    GPVK_LAUNCH(k_crown_reconcile, dim3(gpvk_blocks_for(groups, 2)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
+    GPVK_LAUNCH(k_crown_level, dim3(gpvk_blocks_for(2 * cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
   }
-  hipLaunchKernelGGL(k_crown_finish, dim3(gpvk_blocks_for(items, 256), hc.n_trees), dim3(256), 0, st, dcd, proofs, derived, n, b, fail);
+  GPVK_LAUNCH(k_crown_finish, dim3(gpvk_blocks_for(items, 256), hc.n_trees), dim3(256), 0, st, dcd, proofs, derived, n, b, fail);
 }

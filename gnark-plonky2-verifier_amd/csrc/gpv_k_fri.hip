@@ -21,5 +21,5 @@ __global__ __launch_bounds__(64) void k_fri_query(const DevCircuit* __restrict__
 void gpvk_fri_query(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
                     u32* fail) {
   size_t items = n * hc.num_queries;
-  hipLaunchKernelGGL(k_fri_query, dim3(gpvk_blocks_for(items, 64)), dim3(64), 0, st, dcd, proofs, derived, n, fail);
+  GPVK_LAUNCH(k_fri_query, dim3(gpvk_blocks_for(items, 64)), dim3(64), 0, st, dcd, proofs, derived, n, fail);
 }

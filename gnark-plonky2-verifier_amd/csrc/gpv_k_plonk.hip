@@ -68,13 +68,13 @@ __global__ __launch_bounds__(GPV_PLONK_BLOCK) void k_gate_constraints(const DevC
 
 void gpvk_gate_eval_unfiltered(hipStream_t st, DevGate g, const u64* weights, const u64* constants, u32 n_constants, const u64* wires,
                                u32 n_wires, const u64* pih, u64* out, u32 max_out, size_t n) {
-  hipLaunchKernelGGL(k_gate_eval_unfiltered, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, g, weights, constants,
+  GPVK_LAUNCH(k_gate_eval_unfiltered, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, g, weights, constants,
                      n_constants, wires, n_wires, pih, out, max_out, n);
 }
 void gpvk_plonk(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u32* fail) {
-  hipLaunchKernelGGL(k_plonk, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, dcd, proofs, derived, n, fail);
+  GPVK_LAUNCH(k_plonk, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, dcd, proofs, derived, n, fail);
 }
 void gpvk_gate_constraints(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u64* out) {
-  hipLaunchKernelGGL(k_gate_constraints, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, dcd, proofs, derived, n,
+  GPVK_LAUNCH(k_gate_constraints, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, dcd, proofs, derived, n,
                      out);
 }

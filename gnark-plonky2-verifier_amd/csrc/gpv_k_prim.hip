@@ -250,49 +250,49 @@ __global__ __launch_bounds__(256) void k_microbench(u64* out, int iters) {
 
 
 void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_gl_op, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, c, out, n);
+  GPVK_LAUNCH(k_gl_op, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, c, out, n);
 }
 void gpvk_gl2_op(hipStream_t st, int op, const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n) {
-  hipLaunchKernelGGL(k_gl2_op, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, out, ok, n);
+  GPVK_LAUNCH(k_gl2_op, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, out, ok, n);
 }
 void gpvk_gl2_op3(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_gl2_op3, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, c, out, n);
+  GPVK_LAUNCH(k_gl2_op3, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, c, out, n);
 }
 void gpvk_gl2_exp(hipStream_t st, const u64* a, u64 exponent, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_gl2_exp, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, a, exponent, out, n);
+  GPVK_LAUNCH(k_gl2_exp, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, a, exponent, out, n);
 }
 void gpvk_gl2_reduce_with_powers(hipStream_t st, const u64* terms, u32 len, const u64* scalar, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_gl2_reduce_with_powers, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, terms, len, scalar, out, n);
+  GPVK_LAUNCH(k_gl2_reduce_with_powers, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, terms, len, scalar, out, n);
 }
 void gpvk_gl2alg_op(hipStream_t st, int op, const u64* a, const u64* b, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_gl2alg_op, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, out, n);
+  GPVK_LAUNCH(k_gl2alg_op, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, out, n);
 }
 void gpvk_poseidon_gl_hash_n_to_m(hipStream_t st, const u64* in, u32 len, u64* out, u32 n_out, size_t n) {
-  hipLaunchKernelGGL(k_poseidon_gl_hash_n_to_m, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, in, len, out, n_out, n);
+  GPVK_LAUNCH(k_poseidon_gl_hash_n_to_m, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, in, len, out, n_out, n);
 }
 void gpvk_challenger_run(hipStream_t st, const u32* script, u32 n_ops, const u64* in, u32 n_in, u64* out, u32 n_out, size_t n) {
-  hipLaunchKernelGGL(k_challenger_run, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 64)), dim3(64), 0, st, script, n_ops, in, n_in, out,
+  GPVK_LAUNCH(k_challenger_run, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 64)), dim3(64), 0, st, script, n_ops, in, n_in, out,
                      n_out, n);
 }
 void gpvk_poseidon_gl_permute(hipStream_t st, const u64* in, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_poseidon_gl_permute, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
+  GPVK_LAUNCH(k_poseidon_gl_permute, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
 }
 void gpvk_poseidon_gl_permute_coop(hipStream_t st, const u64* in, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_poseidon_gl_permute_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 256)), dim3(256), 0, st, in, out, n);
+  GPVK_LAUNCH(k_poseidon_gl_permute_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 256)), dim3(256), 0, st, in, out, n);
 }
 void gpvk_poseidon_gl_hash_no_pad(hipStream_t st, const u64* in, u32 len, u64* out, size_t n) {
-  hipLaunchKernelGGL(k_poseidon_gl_hash_no_pad, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
+  GPVK_LAUNCH(k_poseidon_gl_hash_no_pad, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
 }
 int gpvk_microbench_ops_per_iter() { return 4 * MB_CHAINS; }
 void gpvk_microbench(hipStream_t st, int which, u64* out, int blocks, int threads, int iters) {
   switch (which) {
-    case 0: hipLaunchKernelGGL(k_microbench<0>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 1: hipLaunchKernelGGL(k_microbench<1>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 2: hipLaunchKernelGGL(k_microbench<2>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 3: hipLaunchKernelGGL(k_microbench<3>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 4: hipLaunchKernelGGL(k_microbench<4>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 5: hipLaunchKernelGGL(k_microbench<5>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 6: hipLaunchKernelGGL(k_microbench<6>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 7: hipLaunchKernelGGL(k_microbench<7>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 0: GPVK_LAUNCH(k_microbench<0>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 1: GPVK_LAUNCH(k_microbench<1>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 2: GPVK_LAUNCH(k_microbench<2>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 3: GPVK_LAUNCH(k_microbench<3>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 4: GPVK_LAUNCH(k_microbench<4>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 5: GPVK_LAUNCH(k_microbench<5>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 6: GPVK_LAUNCH(k_microbench<6>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 7: GPVK_LAUNCH(k_microbench<7>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
   }
 }

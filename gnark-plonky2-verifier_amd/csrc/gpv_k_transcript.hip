@@ -64,6 +64,37 @@ __global__ void k_finalize(const u32* __restrict__ fail, uint8_t* __restrict__ a
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) accept[i] = fail[i] == 0;
 }
+// Multi-GPU exchange: the accept bytes of one rank's block -> bits, 8 per byte (bit i of byte j = accept[8 j + i]),
+// zero-padded to the fixed slot size every rank contributes to the all-gather ...
+__global__ void k_pack_accept_bits(const uint8_t* __restrict__ accept, size_t m, uint8_t* __restrict__ bits, size_t slot_bytes) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= slot_bytes) return;
+  u32 v = 0;
+#pragma unroll
+  for (u32 i = 0; i < 8; i++) {
+    size_t k = 8 * j + i;
+    if (k < m && accept[k]) v |= 1u << i;
+  }
+  bits[j] = (uint8_t)v;
+}
+// ... and the gathered [world][slot_bytes] bits -> accept bytes of the whole batch: proof g lies in the block of rank r with
+// bounds [lo, hi) = gpv_shard_bounds(n_total, r, world): the first `rem` ranks own base + 1 proofs, the others base.
+__global__ void k_unpack_accept_bits(const uint8_t* __restrict__ gathered, size_t slot_bytes, size_t n_total, u32 world,
+                                     uint8_t* __restrict__ accept_all) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_total) return;
+  const size_t base = n_total / world, rem = n_total - base * world;
+  size_t r, lo;
+  if (g < rem * (base + 1)) {
+    r = g / (base + 1);
+    lo = r * (base + 1);
+  } else {
+    r = rem + (g - rem * (base + 1)) / (base ? base : 1);
+    lo = r * base + rem;
+  }
+  const size_t k = g - lo;
+  accept_all[g] = (gathered[r * slot_bytes + (k >> 3)] >> (k & 7)) & 1;
+}
 __global__ void k_scatter_challenges(const u64* __restrict__ ch, u64* __restrict__ derived, u32 ncw, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * ncw) return;
@@ -85,26 +116,32 @@ __global__ void k_gather_pih(const u64* __restrict__ derived, u64* __restrict__ 
 
 
 void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u32* fail) {
-  hipLaunchKernelGGL(k_range_check, dim3(2048), dim3(256), 0, st, dcd, proofs, n, fail);
+  GPVK_LAUNCH(k_range_check, dim3(2048), dim3(256), 0, st, dcd, proofs, n, fail);
 }
 void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived) {
-  hipLaunchKernelGGL(k_transcript, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
+  GPVK_LAUNCH(k_transcript, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
 }
 void gpvk_transcript_coop(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived) {
-  hipLaunchKernelGGL(k_transcript_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
+  GPVK_LAUNCH(k_transcript_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
 }
 void gpvk_derive_extra(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived) {
-  hipLaunchKernelGGL(k_derive_extra, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
+  GPVK_LAUNCH(k_derive_extra, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
 }
 void gpvk_finalize(hipStream_t st, const u32* fail, uint8_t* accept, size_t n) {
-  hipLaunchKernelGGL(k_finalize, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, fail, accept, n);
+  GPVK_LAUNCH(k_finalize, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, fail, accept, n);
+}
+void gpvk_pack_accept_bits(hipStream_t st, const uint8_t* accept, size_t m, uint8_t* bits, size_t slot_bytes) {
+  GPVK_LAUNCH(k_pack_accept_bits, dim3(gpvk_blocks_for(slot_bytes, 256)), dim3(256), 0, st, accept, m, bits, slot_bytes);
+}
+void gpvk_unpack_accept_bits(hipStream_t st, const uint8_t* gathered, size_t slot_bytes, size_t n_total, u32 world, uint8_t* accept_all) {
+  GPVK_LAUNCH(k_unpack_accept_bits, dim3(gpvk_blocks_for(n_total, 256)), dim3(256), 0, st, gathered, slot_bytes, n_total, world, accept_all);
 }
 void gpvk_scatter_challenges(hipStream_t st, const u64* ch, u64* derived, u32 ncw, size_t n) {
-  hipLaunchKernelGGL(k_scatter_challenges, dim3(gpvk_blocks_for((size_t)ncw * n, 256)), dim3(256), 0, st, ch, derived, ncw, n);
+  GPVK_LAUNCH(k_scatter_challenges, dim3(gpvk_blocks_for((size_t)ncw * n, 256)), dim3(256), 0, st, ch, derived, ncw, n);
 }
 void gpvk_gather_challenges(hipStream_t st, const u64* derived, u64* ch, u32 ncw, size_t n) {
-  hipLaunchKernelGGL(k_gather_challenges, dim3(gpvk_blocks_for((size_t)ncw * n, 256)), dim3(256), 0, st, derived, ch, ncw, n);
+  GPVK_LAUNCH(k_gather_challenges, dim3(gpvk_blocks_for((size_t)ncw * n, 256)), dim3(256), 0, st, derived, ch, ncw, n);
 }
 void gpvk_gather_pih(hipStream_t st, const u64* derived, u64* out, u32 ncw, size_t n) {
-  hipLaunchKernelGGL(k_gather_pih, dim3(gpvk_blocks_for(4 * n, 256)), dim3(256), 0, st, derived, out, ncw, n);
+  GPVK_LAUNCH(k_gather_pih, dim3(gpvk_blocks_for(4 * n, 256)), dim3(256), 0, st, derived, out, ncw, n);
 }

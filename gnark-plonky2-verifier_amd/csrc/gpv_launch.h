@@ -10,6 +10,16 @@
 typedef uint32_t u32;
 typedef uint64_t u64;
 
+// Every kernel launch goes through GPVK_LAUNCH: the launch status is read back at once and the first failure of the host
+// thread is kept (gpv_api.cpp) until the entry point's CHECK_LAUNCH turns it into GPV_EDEVICE -- a stage that did not start
+// can therefore never end as "fail mask still zero" = accept.
+void gpvk_note_launch(hipError_t e, const char* what);
+#define GPVK_LAUNCH(kernel, grid, block, lds, st, ...)             \
+  do {                                                             \
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__); \
+    gpvk_note_launch(hipGetLastError(), #kernel);                  \
+  } while (0)
+
 // gpv_k_prim.hip
 void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n);
 void gpvk_gl2_op(hipStream_t st, int op, const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n);
@@ -62,6 +72,8 @@ void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, s
 void gpvk_transcript_coop(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);  // 16 lanes per proof
 void gpvk_derive_extra(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);
 void gpvk_finalize(hipStream_t st, const u32* fail, uint8_t* accept, size_t n);
+void gpvk_pack_accept_bits(hipStream_t st, const uint8_t* accept, size_t m, uint8_t* bits, size_t slot_bytes);
+void gpvk_unpack_accept_bits(hipStream_t st, const uint8_t* gathered, size_t slot_bytes, size_t n_total, u32 world, uint8_t* accept_all);
 void gpvk_scatter_challenges(hipStream_t st, const u64* ch, u64* derived, u32 ncw, size_t n);
 void gpvk_gather_challenges(hipStream_t st, const u64* derived, u64* ch, u32 ncw, size_t n);
 void gpvk_gather_pih(hipStream_t st, const u64* derived, u64* out, u32 ncw, size_t n);

@@ -25,9 +25,12 @@
  *     in host memory. *_dev entry points take DEVICE pointers on the context's GPU, enqueue on the
  *     context's stream and return without synchronising.
  *   - There is no CPU fallback: without a usable GPU gpv_ctx_create fails with GPV_EDEVICE.
- *   - Threading: a gpv_circuit is immutable and may be shared; a gpv_ctx owns one stream pair and its scratch, so calls
- *     on the same context must not overlap in time (use one context per host thread; the reference's chips are not
- *     re-entrant either, challenger/challenger.go:18-20). The ingest functions are thread-safe.
+ *   - Threading: a gpv_circuit is immutable and may be shared by any number of contexts, devices and host threads (its
+ *     per-device descriptor copies are created once under a lock and live until gpv_circuit_destroy). Every call that
+ *     takes a gpv_ctx is safe to issue from any thread: it makes the context's device current and holds the context's
+ *     lock, so concurrent calls on ONE context serialise (it owns one stream pair and its scratch; the reference's chips
+ *     are not re-entrant either, challenger/challenger.go:18-20). For parallelism use one context per thread / device, or
+ *     a gpv_group (below), which does exactly that. The ingest functions are thread-safe.
  */
 #ifndef GPV_H
 #define GPV_H
@@ -220,6 +223,45 @@ int gpv_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, s
 int gpv_challenges_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint64_t* challenges_dev);
 int gpv_merkle_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, const uint64_t* challenges_dev,
                           size_t n, uint8_t* ok_dev);
+
+/* ------------------------------------------------------------------ multi-GPU: proof batches sharded over one node */
+/* No reference counterpart (the reference is single-goroutine Go); contract: SURVEY 8b / 8e. Proofs are
+ * independent, so rank r of `world` owns the contiguous block [lo, hi) of the batch and the only exchange is one RCCL
+ * ncclAllGather of the accept bits packed 8 per byte, after which EVERY rank's device buffer (and the host) holds the
+ * verdict of the whole batch. RCCL is dlopen'ed on first use; a group of one device never needs it. */
+/* Block of rank `rank`: sizes differ by at most one, lower ranks get the extra proof. Pure host arithmetic. */
+int gpv_shard_bounds(size_t n, int rank, int world, size_t* lo, size_t* hi);
+/* Bytes every rank contributes to the all-gather: ceil(ceil(n / world) / 8). */
+size_t gpv_accept_slot_bytes(size_t n, int world);
+typedef struct gpv_group gpv_group;
+/* One process drives n_devices GPUs: a worker thread and a gpv_ctx per device, RCCL clique via ncclCommInitAll. Rank i runs
+ * on device_ids[i]. */
+int gpv_group_create(gpv_group** out, const int* device_ids, int n_devices);
+/* One process per GPU (torch.distributed.run, MPI, a Go supervisor): rank 0 calls gpv_group_unique_id, the caller hands the
+ * 128 bytes to every rank, each rank calls gpv_group_create_rank (ncclCommInitRank happens at the first verify call). */
+int gpv_group_unique_id(void* id128);
+int gpv_group_create_rank(gpv_group** out, int device_id, int rank, int world, const void* id128);
+int gpv_group_destroy(gpv_group* g);
+int gpv_group_world(const gpv_group* g);           /* ranks in the job */
+int gpv_group_local(const gpv_group* g);           /* ranks driven by this process */
+int gpv_group_rank(const gpv_group* g, int local_index);
+gpv_ctx* gpv_group_ctx(gpv_group* g, int local_index); /* the rank's context (timing, options, primitives) */
+/* GPV_GROUP_OPT_COLLECTIVE: 0 (default) = the RCCL all-gather runs only when world > 1, 1 = always (exercises the RCCL
+ * path on a single GPU). Any other option id is forwarded to every rank's context (gpv_ctx_set_option). */
+enum { GPV_GROUP_OPT_COLLECTIVE = 100 };
+int gpv_group_set_option(gpv_group* g, int option, int value);
+int gpv_group_last_error_message(gpv_group* g, char* buf, size_t buf_len);
+/* VerifierChip.Verify (verifier/verifier.go:143-170) for a batch of n_total proofs sharded over the group. `proofs` is HOST
+ * memory holding the records of the blocks owned by this process's ranks back to back (the whole batch for
+ * gpv_group_create; the rank's own block for gpv_group_create_rank); accept [n_total] receives the verdict of the WHOLE
+ * batch. Returns when it is in host memory. Every rank of the job must make the call (it contains a collective). */
+int gpv_group_verify(gpv_group* g, const gpv_circuit* c, const void* proofs, size_t n_total, uint8_t* accept);
+/* Device-resident shards: shard_dev[i] = the block of local rank i on ITS device, accept_all_dev[i] = n_total bytes on that
+ * device, filled with the verdict of the whole batch. Returns after every local rank has finished (stream-synchronised). */
+int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const void* const* shard_dev, size_t n_total,
+                         uint8_t* const* accept_all_dev);
+/* Diagnostics: the gathered verdict as local rank `local_index` holds it on its own device after gpv_group_verify. */
+int gpv_group_read_rank_accept(gpv_group* g, int local_index, uint8_t* accept, size_t n_total);
 
 /* ------------------------------------------------------------------ measurement helpers */
 /* Average duration (ms) of the named kernel class over the launches since the last reset, measured with HIP events on

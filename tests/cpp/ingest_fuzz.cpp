@@ -3,6 +3,7 @@
 // in a crash or undefined behaviour.   usage: ingest_fuzz <fixture dir> <iterations>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -56,6 +57,45 @@ int main(int argc, char** argv) {
     int rc = gpv_circuit_from_json(m.data(), m.size(), mv.data(), mv.size(), &c2);
     if (rc == 0) { cok++; gpv_circuit_destroy(c2); } else cerr++;
   }
+  // Structured mutation of the circuit's dimensions (byte flips rarely produce a *valid* circuit with hostile
+  // numbers): set one or two numeric fields / gate parameters to boundary values; every circuit the parser accepts must
+  // then pack the fixture proof -- or refuse it -- strictly inside a buffer of gpv_proof_nbytes(c) bytes (ASan watches),
+  // and its gates must fit its wires and constants.
+  const char* keys[] = {"\"num_wires\":", "\"num_routed_wires\":", "\"num_constants\":", "\"num_challenges\":", "\"num_partial_products\":",
+                        "\"quotient_degree_factor\":", "\"num_gate_constraints\":", "\"num_public_inputs\":", "\"degree_bits\":", "\"rate_bits\":",
+                        "\"cap_height\":", "\"proof_of_work_bits\":", "\"num_query_rounds\":", "\"start\":", "\"end\":", "num_ops: ", "num_coeffs: ",
+                        "num_power_bits: ", "num_limbs: ", "num_consts: ", "bits: ", "num_copies: ", "num_extra_constants: ", "degree: "};
+  const unsigned long long vals[] = {0, 1, 2, 3, 4, 5, 7, 8, 15, 16, 28, 63, 64, 80, 135, 136, 137, 255, 256, 257, 4095, 4096, 4097, 65535, 65536,
+                                     1ull << 20, (1ull << 31) - 1, 1ull << 31, (1ull << 32) - 1, 1ull << 32, ~0ull};
+  long sok = 0, serr = 0, spacked = 0, sbig = 0;
+  for (int it = 0; it < iters; it++) {
+    std::string m = c;
+    for (int k = 0; k < 1 + (int)(rng() % 2); k++) {
+      const char* key = keys[rng() % (sizeof keys / sizeof *keys)];
+      std::vector<size_t> at;
+      for (size_t f = m.find(key); f != std::string::npos; f = m.find(key, f + 1)) at.push_back(f + strlen(key));
+      if (at.empty()) continue;
+      size_t pos = at[rng() % at.size()];
+      while (pos < m.size() && m[pos] == ' ') pos++;
+      size_t e = pos;
+      while (e < m.size() && m[e] >= '0' && m[e] <= '9') e++;
+      unsigned long long v = (rng() % 4 == 0) ? rng() % 300 : vals[rng() % (sizeof vals / sizeof *vals)];
+      m.replace(pos, e - pos, std::to_string(v));
+    }
+    gpv_circuit* c2 = nullptr;
+    int rc = gpv_circuit_from_json(m.data(), m.size(), v.data(), v.size(), &c2);
+    if (rc != 0) { serr++; continue; }
+    sok++;
+    size_t nb = gpv_proof_nbytes(c2);
+    if (nb <= (64u << 20)) {
+      std::vector<uint8_t> buf(nb);  // exactly the promised size: one byte past it is an ASan report
+      int prc = gpv_proof_pack_json(c2, p.data(), p.size(), buf.data());
+      if (prc != 0 && prc != GPV_ESHAPE) other++;
+      spacked++;
+    } else sbig++;
+    gpv_circuit_destroy(c2);
+  }
+  printf("structured: %ld circuits accepted (%ld packed against, %ld too large to try), %ld rejected\n", sok, spacked, sbig, serr);
   printf("proof: %ld accepted, %ld shape errors, %ld other errors; circuit: %ld accepted, %ld errors\n", ok, shape, other, cok, cerr);
   gpv_circuit_destroy(ci);
   return 0;

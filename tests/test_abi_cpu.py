@@ -33,8 +33,10 @@ def test_library_exports_every_declared_symbol(gpv):
     hdr = (T.ROOT / "include" / "gpv.h").read_text()
     declared = set(re.findall(r"^(?:int|size_t)\s+(gpv_\w+)\s*\(", hdr, re.M))
     assert declared == set(gpv._lib.ABI_SYMBOLS)
+    other = set(re.findall(r"^gpv_ctx\*\s+(gpv_\w+)\s*\(", hdr, re.M))
+    assert other == set(gpv._lib.ABI_SYMBOLS_OTHER)
     L = ctypes.CDLL(str(gpv._lib.LIB_PATH))
-    for sym in sorted(declared):
+    for sym in sorted(declared | other):
         assert hasattr(L, sym), sym
 
 
@@ -44,6 +46,37 @@ def test_no_cpu_fallback(gpv):
         gpv.Context(0)
     with pytest.raises(gpv.DeviceError):
         gpv.goldilocks.New().Add([1], [2])
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a GPU")
+def test_group_has_no_cpu_fallback_either(gpv):
+    with pytest.raises(gpv.DeviceError):
+        gpv.Group(device_ids=[0])
+    with pytest.raises(gpv.DeviceError):
+        gpv.Group(rank=0, world=1, device_id=0)
+
+
+def test_group_shard_arithmetic_matches_distributed(gpv):
+    """gpv_shard_bounds / gpv_accept_slot_bytes (the C-ABI group) == distributed.shard_bounds (the torch.distributed path):
+    contiguous blocks that tile [0, n), sizes differing by at most one, the extra proofs on the low ranks."""
+    D = importlib.import_module("gnark-plonky2-verifier_amd.distributed")
+    L = gpv._lib.lib()
+    for world in (1, 2, 3, 4, 7, 8):
+        for n in (0, 1, 5, 8, 13, 64, 8191, 8192, 65536, 65537):
+            prev = 0
+            sizes = []
+            for r in range(world):
+                lo, hi = gpv.shard_bounds(n, r, world)
+                assert (lo, hi) == D.shard_bounds(n, r, world)
+                assert lo == prev
+                prev = hi
+                sizes.append(hi - lo)
+            assert prev == n and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+            assert L.gpv_accept_slot_bytes(n, world) == (max(sizes) + 7) // 8
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    for bad in ((8, -1, 2), (8, 2, 2), (8, 0, 0)):
+        assert L.gpv_shard_bounds(bad[0], bad[1], bad[2], ctypes.byref(lo), ctypes.byref(hi)) == gpv._lib.GPV_EINVAL
+    assert gpv.shard_bounds(65536, 7, 8) == (57344, 65536)
 
 
 @pytest.mark.parametrize("name", ["decode_block", "step"])
