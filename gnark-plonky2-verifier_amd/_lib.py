@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "gpv_circuit_from_json", "gpv_circuit_destroy", "gpv_proof_nbytes", "gpv_num_challenge_words",
     "gpv_num_gate_constraints", "gpv_num_query_rounds", "gpv_num_merkle_trees", "gpv_circuit_describe",
     "gpv_proof_pack_json", "gpv_proof_pack_json_batch",
-    "gpv_gl_op", "gpv_gl2_op", "gpv_gl2_op3", "gpv_gl2_exp", "gpv_gl2_reduce_with_powers", "gpv_gl2alg_op",
+    "gpv_gl_op", "gpv_gl_hints", "gpv_gl2_op", "gpv_gl2_op3", "gpv_gl2_exp", "gpv_gl2_reduce_with_powers", "gpv_gl2alg_op",
     "gpv_poseidon_gl_hash_n_to_m_no_pad", "gpv_challenger_run", "gpv_poseidon_gl_permute", "gpv_poseidon_gl_permute_dev", "gpv_poseidon_gl_permute_coop",
     "gpv_poseidon_gl_permute_coop_dev", "gpv_poseidon_gl_hash_no_pad",
     "gpv_poseidon_bn254_permute", "gpv_poseidon_bn254_permute_dev", "gpv_poseidon_bn254_hash_or_noop",
@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "gpv_public_inputs_hash", "gpv_challenges", "gpv_plonk_verify", "gpv_gate_constraints", "gpv_fri_verify",
     "gpv_merkle_verify", "gpv_verify", "gpv_verify_detail", "gpv_verify_dev", "gpv_challenges_dev",
     "gpv_merkle_verify_dev", "gpv_timing_enable", "gpv_timing_reset", "gpv_timing_get", "gpv_microbench",
+    "gpv_verify_given_challenges", "gpv_verify_given_challenges_dev",
     "gpv_shard_bounds", "gpv_accept_slot_bytes", "gpv_group_create", "gpv_group_unique_id", "gpv_group_create_rank", "gpv_group_destroy",
     "gpv_group_world", "gpv_group_local", "gpv_group_rank", "gpv_group_set_option", "gpv_group_last_error_message",
     "gpv_group_verify", "gpv_group_verify_dev", "gpv_group_read_rank_accept",
@@ -91,6 +92,7 @@ def lib():
         L.gpv_proof_pack_json.argtypes = [vp, ctypes.c_char_p, sz, vp]
         L.gpv_proof_pack_json_batch.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), sz, vp, i32]
         L.gpv_gl_op.argtypes = [vp, i32, vp, vp, vp, vp, sz]
+        L.gpv_gl_hints.argtypes = [vp, i32, vp, vp, vp, sz]
         L.gpv_gl2_op.argtypes = [vp, i32, vp, vp, vp, vp, sz]
         L.gpv_gl2_op3.argtypes = [vp, i32, vp, vp, vp, vp, sz]
         L.gpv_gl2_exp.argtypes = [vp, vp, ctypes.c_uint64, vp, sz]
@@ -123,6 +125,8 @@ def lib():
         L.gpv_timing_reset.argtypes = [vp]
         L.gpv_timing_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         L.gpv_microbench.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double)]
+        L.gpv_verify_given_challenges.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+        L.gpv_verify_given_challenges_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.gpv_shard_bounds.argtypes = [sz, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
         L.gpv_accept_slot_bytes.argtypes = [sz, i32]
         L.gpv_accept_slot_bytes.restype = sz

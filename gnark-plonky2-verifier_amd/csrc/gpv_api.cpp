@@ -461,6 +461,26 @@ extern "C" int gpv_gl_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GPV_OK;
 }
+extern "C" int gpv_gl_hints(gpv_ctx* ctx, int hint, const uint64_t* in, uint64_t* out, uint8_t* ok, size_t n) {
+  REQUIRE(ctx, ctx && in && out);
+  REQUIRE(ctx, hint == GPV_HINT_MULADD || hint == GPV_HINT_REDUCE || hint == GPV_HINT_INVERSE || hint == GPV_HINT_SPLIT_LIMBS);
+  ENTER(ctx);
+  if (n == 0) return GPV_OK;
+  static const size_t words_in[4] = {3, 4, 1, 1}, words_out[4] = {2, 5, 1, 2};
+  const size_t wi = words_in[hint], wo = words_out[hint];
+  DevBuf<u64> din, dout;
+  DevBuf<uint8_t> dok;
+  HIP_TRY(ctx, din.alloc(wi * n));
+  HIP_TRY(ctx, dout.alloc(wo * n));
+  HIP_TRY(ctx, dok.alloc(n));
+  HIP_TRY(ctx, hipMemcpyAsync(din.p, in, 8 * wi * n, hipMemcpyHostToDevice, ctx->stream));
+  gpvk_gl_hints(ctx->stream, hint, din.p, dout.p, dok.p, n);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 8 * wo * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (ok) HIP_TRY(ctx, hipMemcpyAsync(ok, dok.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
 extern "C" int gpv_gl2_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* ok, size_t n) {
   REQUIRE(ctx, ctx && a && out);
   REQUIRE(ctx, op == GPV_OP_ADD || op == GPV_OP_SUB || op == GPV_OP_MUL || op == GPV_OP_INV || op == GPV_OP_DIV);
@@ -957,6 +977,63 @@ extern "C" int gpv_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* pr
   if (rc != GPV_OK) return rc;
   gpvk_finalize(ctx->stream, (const u32*)ctx->fail, accept_dev, n);
   CHECK_LAUNCH(ctx);
+  return GPV_OK;
+}
+// VerifierChip.Verify with step 2 of verifier.go:143-170 (GetChallenges, :150) replaced by caller-supplied ProofChallenges --
+// the shape of the reference's own fri_test.go:106-133 / plonk_test.go:39-66, which feed fixed challenges to VerifyFriProof
+// and PlonkChip.Verify. Range checks, public-inputs hash, plonk, Merkle paths and FRI all run; only the transcript is skipped.
+static int verify_given_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, const uint64_t* challenges_dev, size_t n) {
+  const DevCircuit* dcd;
+  int rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  rc = ensure_scratch(ctx, c, n);
+  if (rc != GPV_OK) return rc;
+  hipStream_t main_st = ctx->stream, side = ctx->side;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), main_st));
+  launch_range_check(ctx, main_st, dcd, proofs_dev, n);
+  rc = upload_challenges(ctx, c, dcd, proofs_dev, challenges_dev, n, true);
+  if (rc != GPV_OK) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_st));
+  HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
+  launch_plonk(ctx, side, dcd, proofs_dev, n);
+  launch_fri_query(ctx, side, c, dcd, proofs_dev, n);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));
+  launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n);
+  launch_merkle_climb(ctx, main_st, c, dcd, proofs_dev, n, nullptr);
+  HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_side_done, 0));
+  CHECK_LAUNCH(ctx);
+  return GPV_OK;
+}
+extern "C" int gpv_verify_given_challenges_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, const uint64_t* challenges_dev,
+                                               size_t n, uint8_t* accept_dev) {
+  REQUIRE(ctx, ctx && c && proofs_dev && challenges_dev && accept_dev);
+  ENTER(ctx);
+  if (n == 0) return GPV_OK;
+  int rc = verify_given_pipeline_dev(ctx, c, proofs_dev, challenges_dev, n);
+  if (rc != GPV_OK) return rc;
+  gpvk_finalize(ctx->stream, (const u32*)ctx->fail, accept_dev, n);
+  CHECK_LAUNCH(ctx);
+  return GPV_OK;
+}
+extern "C" int gpv_verify_given_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n,
+                                           uint8_t* accept, uint32_t* fail_mask) {
+  REQUIRE(ctx, ctx && c && proofs && challenges && accept);
+  ENTER(ctx);
+  if (n == 0) return GPV_OK;
+  HostBatch hb;
+  int rc = hb.upload(ctx, c, proofs, n);
+  if (rc != GPV_OK) return rc;
+  DevBuf<u64> dch;
+  DevBuf<uint8_t> dacc;
+  const size_t ncw = c->dc.n_challenge_words;
+  HIP_TRY(ctx, dch.alloc(ncw * n));
+  HIP_TRY(ctx, dacc.alloc(n));
+  HIP_TRY(ctx, hipMemcpyAsync(dch.p, challenges, 8 * ncw * n, hipMemcpyHostToDevice, ctx->stream));
+  rc = gpv_verify_given_challenges_dev(ctx, c, hb.proofs.p, dch.p, n, dacc.p);
+  if (rc != GPV_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(accept, dacc.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  if (fail_mask) HIP_TRY(ctx, hipMemcpyAsync(fail_mask, ctx->fail, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GPV_OK;
 }
 extern "C" int gpv_verify_detail(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept, uint32_t* fail_mask,

@@ -50,6 +50,16 @@ GPV_DEV u64 gl_muladd(u64 a, u64 b, u64 c) {
   return gl_reduce128(s, hi);
 }
 GPV_DEV u64 gl_sqr(u64 a) { return gl_mul(a, a); }
+// Euclidean division of the 128-bit value (hi:lo) by p for hi < p (so the quotient fits one word): the witness pair of
+// MulAddHint / ReduceHint (goldilocks/base.go:223-243, :284-294). The remainder is the usual reduction; the quotient is the
+// exact division of (value - remainder) by p, and since p = 1 - 2^32 (mod 2^64) has the inverse 1 + 2^32 modulo 2^64,
+// q = d + (d << 32) with d = lo - remainder (mod 2^64).
+GPV_DEV u64 gl_divmod128(u64 lo, u64 hi, u64* quotient) {
+  u64 r = gl_reduce128(lo, hi);
+  u64 d = lo - r;
+  *quotient = d + (d << 32);
+  return r;
+}
 
 // ---- non-canonical ("any u64 representative") variants for long multiplication chains.
 // A 128 -> 64 reduction whose result is only required to be SOME u64 congruent to the input skips the final

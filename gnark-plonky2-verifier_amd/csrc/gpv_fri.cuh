@@ -40,7 +40,7 @@ GPV_DEV void dev_merkle_steps(Fr& cur, const u64* __restrict__ siblings, u32 n, 
       s[2].l[k] = bit ? sib.l[k] : cur.l[k];
       s[3].l[k] = bit ? cur.l[k] : sib.l[k];
     }
-    poseidon_bn254_permute(s);
+    poseidon_bn254_permute<true>(s);  // TwoToOne: s[0] = s[1] = 0 (bn254.go:96-104)
     cur = s[0];
   }
 }

@@ -20,6 +20,50 @@ __global__ void k_gl_op(int op, const u64* __restrict__ a, const u64* __restrict
   }
   out[i] = r;
 }
+// goldilocks hint functions (goldilocks/base.go:223-243 MulAddHint, :284-294 ReduceHint, :316-336 InverseHint, :339-359
+// SplitLimbsHint): the witness values gnark's solver asks the hints for, one item per lane. ok = 0 (and zero outputs) where
+// the reference hint panics / returns an error because an operand is not in the field.
+__global__ void k_gl_hints(int hint, const u64* __restrict__ in, u64* __restrict__ out, uint8_t* __restrict__ ok, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool good = true;
+  switch (hint) {
+    case GPV_HINT_MULADD: {  // a * b + c = quotient * p + remainder, operands < p
+      u64 a = in[3 * i], b = in[3 * i + 1], c = in[3 * i + 2];
+      good = a < GLP && b < GLP && c < GLP;
+      u64 lo = a * b, hi = __umul64hi(a, b);
+      u64 s = lo + c;
+      hi += s < lo;
+      u64 q = 0, r = good ? gl_divmod128(s, hi, &q) : 0;
+      out[2 * i] = good ? q : 0;
+      out[2 * i + 1] = r;
+      break;
+    }
+    case GPV_HINT_REDUCE: {  // x (4 little-endian words) = quotient (4 words) * p + remainder: schoolbook division, top word first
+      u64 rem = 0, q[4];
+#pragma unroll
+      for (int k = 3; k >= 0; k--) rem = gl_divmod128(in[4 * i + k], rem, &q[k]);  // rem < p: every partial quotient fits a word
+#pragma unroll
+      for (int k = 0; k < 4; k++) out[5 * i + k] = q[k];
+      out[5 * i + 4] = rem;
+      break;
+    }
+    case GPV_HINT_INVERSE: {  // x^-1, 0 for x = 0; x >= p panics in the reference
+      u64 x = in[i];
+      good = x < GLP;
+      out[i] = good ? gl_inv(x) : 0;
+      break;
+    }
+    case GPV_HINT_SPLIT_LIMBS: {  // (x >> 32, x & 0xFFFFFFFF); x >= p is an error in the reference
+      u64 x = in[i];
+      good = x < GLP;
+      out[2 * i] = good ? x >> 32 : 0;
+      out[2 * i + 1] = good ? (x & 0xFFFFFFFFu) : 0;
+      break;
+    }
+  }
+  if (ok) ok[i] = good;
+}
 __global__ void k_gl2_op(int op, const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out,
                          uint8_t* __restrict__ ok, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,6 +295,9 @@ __global__ __launch_bounds__(256) void k_microbench(u64* out, int iters) {
 
 void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n) {
   GPVK_LAUNCH(k_gl_op, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, c, out, n);
+}
+void gpvk_gl_hints(hipStream_t st, int hint, const u64* in, u64* out, uint8_t* ok, size_t n) {
+  GPVK_LAUNCH(k_gl_hints, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, hint, in, out, ok, n);
 }
 void gpvk_gl2_op(hipStream_t st, int op, const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n) {
   GPVK_LAUNCH(k_gl2_op, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, out, ok, n);

@@ -22,6 +22,7 @@ void gpvk_note_launch(hipError_t e, const char* what);
 
 // gpv_k_prim.hip
 void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n);
+void gpvk_gl_hints(hipStream_t st, int hint, const u64* in, u64* out, uint8_t* ok, size_t n);
 void gpvk_gl2_op(hipStream_t st, int op, const u64* a, const u64* b, u64* out, uint8_t* ok, size_t n);
 void gpvk_gl2_op3(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n);
 void gpvk_gl2_exp(hipStream_t st, const u64* a, u64 exponent, u64* out, size_t n);

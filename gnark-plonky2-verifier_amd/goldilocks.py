@@ -36,6 +36,35 @@ class Chip:
     def RangeCheck(self, x):                                   # base.go:362: True where x < p
         return self._op(9, x).astype(bool)
 
+    # ---- the hint functions behind MulAdd / Reduce / Inverse / RangeCheck (base.go:223-243, :284-294, :316-336, :339-359):
+    # witness values for the wrapping gnark circuit. Each returns (outputs..., ok) with ok = 0 where the reference hint panics.
+    def _hint(self, hint, inp, words_in, words_out):
+        inp = _lib.u64c(inp).reshape(-1, words_in)
+        out = np.empty((inp.shape[0], words_out), dtype=np.uint64)
+        ok = np.ones(inp.shape[0], dtype=np.uint8)
+        _lib.check(_lib.lib().gpv_gl_hints(self.ctx.h, hint, _lib.ptr(inp), _lib.ptr(out), _lib.ptr(ok), inp.shape[0]), self.ctx.h)
+        return out, ok
+
+    def MulAddHint(self, a, b, c):
+        """(quotient, remainder, ok) with a*b + c = quotient * p + remainder."""
+        out, ok = self._hint(0, np.stack([_lib.u64c(a).reshape(-1), _lib.u64c(b).reshape(-1), _lib.u64c(c).reshape(-1)], axis=1), 3, 2)
+        return out[:, 0].copy(), out[:, 1].copy(), ok
+
+    def ReduceHint(self, x_limbs):
+        """x_limbs [n][4]: the lazily accumulated value (an Fr-sized integer, base.go:246-281) as little-endian 64-bit words.
+        Returns (quotient [n][4], remainder [n], ok)."""
+        out, ok = self._hint(1, x_limbs, 4, 5)
+        return out[:, :4].copy(), out[:, 4].copy(), ok
+
+    def InverseHint(self, x):
+        out, ok = self._hint(2, x, 1, 1)
+        return out[:, 0].copy(), ok
+
+    def SplitLimbsHint(self, x):
+        """(most significant 32 bits, least significant 32 bits, ok)"""
+        out, ok = self._hint(3, x, 1, 2)
+        return out[:, 0].copy(), out[:, 1].copy(), ok
+
     def _op2(self, op, a, b=None):
         a = _lib.u64c(a).reshape(-1, 2)
         b = None if b is None else _lib.u64c(b).reshape(-1, 2)

@@ -41,6 +41,22 @@ class VerifierChip:
                                                 _lib.ptr(ch)), self.ctx.h)
         return accept, mask, ProofChallenges(c, ch)
 
+    def VerifyWithChallenges(self, proofs, challenges):
+        """Verify with caller-supplied ProofChallenges instead of GetChallenges (verifier.go:150) -- the way the reference's
+        fri_test.go:106-133 / plonk_test.go:39-66 call VerifyFriProof / PlonkChip.Verify. Returns (accept [n], mask [n])."""
+        c = proofs.circuit
+        flat = challenges.flat if hasattr(challenges, "flat") else challenges
+        flat = _lib.u64c(flat).reshape(proofs.n, c.num_challenge_words)
+        accept = np.empty(proofs.n, dtype=np.uint8)
+        mask = np.empty(proofs.n, dtype=np.uint32)
+        _lib.check(_lib.lib().gpv_verify_given_challenges(self.ctx.h, c.h, _lib.ptr(proofs.data), _lib.ptr(flat), proofs.n, _lib.ptr(accept),
+                                                          _lib.ptr(mask)), self.ctx.h)
+        return accept, mask
+
+    def VerifyWithChallengesDevice(self, circuit, proofs_dev_ptr, challenges_dev_ptr, n, accept_dev_ptr):
+        _lib.check(_lib.lib().gpv_verify_given_challenges_dev(self.ctx.h, circuit.h, _lib.ptr(proofs_dev_ptr), _lib.ptr(challenges_dev_ptr), n,
+                                                              _lib.ptr(accept_dev_ptr)), self.ctx.h)
+
     def VerifyDevice(self, circuit, proofs_dev_ptr, n, accept_dev_ptr):
         """Device-resident batch (torch tensors' data_ptr()); asynchronous on the context's stream."""
         _lib.check(_lib.lib().gpv_verify_dev(self.ctx.h, circuit.h, _lib.ptr(proofs_dev_ptr), n, _lib.ptr(accept_dev_ptr)), self.ctx.h)

@@ -75,6 +75,14 @@ enum {
   GPV_OP_RANGECHECK = 9 /* gpv_gl_op: out[i] = 1 iff a[i] < p (RangeCheck, goldilocks/base.go:362-400) */
 };
 
+/* hint functions of goldilocks.Chip for gpv_gl_hints: words per item in -> out */
+enum {
+  GPV_HINT_MULADD = 0,      /* MulAddHint      base.go:223-243: (a, b, c) -> (quotient, remainder) of a*b + c by p; 3 -> 2 */
+  GPV_HINT_REDUCE = 1,      /* ReduceHint      base.go:284-294: x as 4 little-endian words -> (quotient[4], remainder); 4 -> 5 */
+  GPV_HINT_INVERSE = 2,     /* InverseHint     base.go:316-336: x -> x^-1 (0 for x = 0); 1 -> 1 */
+  GPV_HINT_SPLIT_LIMBS = 3  /* SplitLimbsHint  base.go:339-359: x -> (x >> 32, x mod 2^32); 1 -> 2 */
+};
+
 /* operations of a gpv_challenger_run script: entry = kind << 28 | count */
 enum {
   GPV_CH_OBSERVE = 1,    /* ObserveElements: consumes `count` words of the input row                       */
@@ -143,6 +151,11 @@ int gpv_proof_pack_json_batch(const gpv_circuit* c, const char* const* proof_jso
 /* ------------------------------------------------------------------ field / hash primitives */
 /* goldilocks.Chip Add/Sub/Mul/MulAdd/Inverse/Reduce/RangeCheck (goldilocks/base.go:162-400). b, c may be NULL when unused. */
 int gpv_gl_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out, size_t n);
+/* The witness values the reference's gnark hints compute (MulAdd / Reduce / Inverse / RangeCheck call them through
+ * api.Compiler().NewHint, base.go:197,262,298,371) -- the field layer of a witness generator for the wrapping circuit
+ * (SURVEY 8f.3). in [n][words_in], out [n][words_out] as listed at GPV_HINT_*; ok[i] = 0 (outputs zero) where the reference
+ * hint panics or errors because an operand is not in the field (>= p). ok may be NULL. */
+int gpv_gl_hints(gpv_ctx* ctx, int hint, const uint64_t* in, uint64_t* out, uint8_t* ok, size_t n);
 /* Add/Sub/Mul/Inverse/DivExtension (goldilocks/quadratic_extension.go:31-140), [n][2]; ok[i] = 0 where the
  * reference's "operand != 0" assertion (:124-125) fails. ok may be NULL. */
 int gpv_gl2_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* ok, size_t n);
@@ -216,6 +229,14 @@ int gpv_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n,
 /* Same, plus the diagnostic mask and the derived challenges (either may be NULL). */
 int gpv_verify_detail(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept,
                       uint32_t* fail_mask, uint64_t* challenges);
+/* VerifierChip.Verify with the GetChallenges step (verifier/verifier.go:150) replaced by caller-supplied ProofChallenges --
+ * how the reference's own fri_test.go:106-133 and plonk_test.go:39-66 drive VerifyFriProof / PlonkChip.Verify. Everything
+ * else runs (range checks, public-inputs hash, plonk, Merkle paths, FRI). challenges [n][gpv_num_challenge_words];
+ * fail_mask may be NULL. */
+int gpv_verify_given_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n,
+                                uint8_t* accept, uint32_t* fail_mask);
+int gpv_verify_given_challenges_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, const uint64_t* challenges_dev,
+                                    size_t n, uint8_t* accept_dev);
 /* Device-resident batch: proofs_dev [n][nbytes] and accept_dev [n] are device pointers; enqueued on the context's
  * stream, no host synchronisation (the caller owns ordering, e.g. torch stream semantics). */
 int gpv_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint8_t* accept_dev);

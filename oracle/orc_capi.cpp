@@ -6,6 +6,7 @@
 // known-answer vector the reference's own tests hold and that both
 // testdata fixtures verify.
 #include <stdio.h>
+#include <atomic>
 #include <thread>
 
 #include "orc_protocol.h"
@@ -45,6 +46,52 @@ int orc_gl_op(int op, const u64* a, const u64* b, const u64* c, u64* out, size_t
       case OP_RANGECHECK: out[i] = gl_is_canonical(a[i]) ? 1 : 0; break;  // base.go:362-400
       default: return -1;
     }
+  }
+  return 0;
+}
+
+// The reference's hint functions, literally (goldilocks/base.go): big.Int Div / Rem by MODULUS, with the operand checks that
+// make the reference panic or error reported through ok[]. `in` / `out` rows as in include/gpv.h GPV_HINT_*.
+int orc_gl_hints(int hint, const u64* in, u64* out, uint8_t* ok, size_t n) {
+  typedef unsigned __int128 u128;
+  const u128 P = GL_P;
+  for (size_t i = 0; i < n; i++) {
+    bool good = true;
+    switch (hint) {
+      case 0: {  // MulAddHint base.go:223-243
+        u64 a = in[3 * i], b = in[3 * i + 1], c = in[3 * i + 2];
+        good = a < GL_P && b < GL_P && c < GL_P;  // :229-233 "is not in the field"
+        u128 sum = (u128)a * b + c;               // :235-236
+        out[2 * i] = good ? (u64)(sum / P) : 0;   // :237
+        out[2 * i + 1] = good ? (u64)(sum % P) : 0;  // :238
+        break;
+      }
+      case 1: {  // ReduceHint base.go:284-294: input is an Fr-sized integer, 4 words here; long division word by word
+        u128 rem = 0;
+        for (int k = 3; k >= 0; k--) {
+          u128 cur = (rem << 64) | in[4 * i + k];
+          out[5 * i + k] = (u64)(cur / P);
+          rem = cur % P;
+        }
+        out[5 * i + 4] = (u64)rem;
+        break;
+      }
+      case 2: {  // InverseHint base.go:316-336
+        u64 x = in[i];
+        good = x < GL_P;  // :322-324 "Input is not in the field"
+        out[i] = good ? gl_inverse(x) : 0;
+        break;
+      }
+      case 3: {  // SplitLimbsHint base.go:339-359
+        u64 x = in[i];
+        good = x < GL_P;  // :347-349
+        out[2 * i] = good ? x >> 32 : 0;
+        out[2 * i + 1] = good ? (x & 0xFFFFFFFFull) : 0;
+        break;
+      }
+      default: return -1;
+    }
+    if (ok) ok[i] = good;
   }
   return 0;
 }
@@ -236,18 +283,23 @@ int orc_fri_verify(const void* cv, const void* proofs, const u64* challenges, si
 int orc_verify(const void* cv, const void* proofs, size_t n, uint8_t* accept, int32_t* fail, u64* challenges, int n_threads) {
   const Circuit& c = *(const Circuit*)cv;
   if (n_threads < 1) n_threads = 1;
-  auto work = [&](size_t lo, size_t hi) {
-    for (size_t i = lo; i < hi; i++) {
+  // dynamic distribution (one proof at a time from a shared counter): with more threads than free cores -- the GPU box's host
+  // is shared -- a static split waits for the slowest thread
+  std::atomic<size_t> next(0);
+  auto work = [&]() {
+    for (;;) {
+      size_t i = next.fetch_add(1);
+      if (i >= n) return;
       int f = verify(c, (const char*)proofs + i * c.proof_nbytes(), challenges ? challenges + i * c.n_challenge_words() : nullptr);
       accept[i] = f == 0;
       if (fail) fail[i] = f;
     }
   };
   if (n_threads == 1) {
-    work(0, n);
+    work();
   } else {
     std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; t++) th.emplace_back(work, n * t / n_threads, n * (t + 1) / n_threads);
+    for (int t = 0; t < n_threads; t++) th.emplace_back(work);
     for (auto& t : th) t.join();
   }
   return 0;

@@ -316,6 +316,13 @@ class Oracle:
         assert self.lib.orc_gl_op(op, _p(a), _p(b), _p(c), _p(out), ctypes.c_size_t(a.size)) == 0
         return out
 
+    def gl_hints(self, hint, inp, words_in, words_out):
+        inp = u64arr(inp).reshape(-1, words_in)
+        out = np.zeros((inp.shape[0], words_out), dtype=np.uint64)
+        ok = np.ones(inp.shape[0], dtype=np.uint8)
+        assert self.lib.orc_gl_hints(hint, _p(inp), _p(out), _p(ok), ctypes.c_size_t(inp.shape[0])) == 0
+        return out, ok
+
     def gl2_op(self, op, a, b=None):
         a = u64arr(a).reshape(-1, 2)
         b = None if b is None else u64arr(b).reshape(-1, 2)
@@ -503,3 +510,42 @@ def synthetic_batch(ci, packed, n, seed=1, tamper_every=16):
             batch[i, w] ^= np.uint64(1)
             tampered[i] = True
     return batch.view(np.uint8).reshape(n, -1), tampered
+
+
+def query_section_layout(ci):
+    """(first word of the query blocks, words per query block, first Fr of the query Fr blocks, Fr per query, n GL words) of
+    the packed record (csrc/gpv_ingest.cpp finish_layout; types/deserialize.go:26-72)."""
+    n_open = 2 * (ci.num_constants + ci.num_routed_wires + ci.num_wires + 2 * ci.num_challenges
+                  + ci.num_challenges * ci.num_partial_products + ci.num_challenges * ci.quotient_degree_factor)
+    qwords = sum(ci.leaf_len(o) for o in range(4)) + sum(2 << a for a in ci.arity_bits)
+    n_gl = n_open + ci.num_query_rounds * qwords + 2 * ci.final_poly_len + 1 + ci.num_public_inputs
+    sib = ci.lde_bits - ci.cap_height
+    qfr, bits = 4 * sib, sib
+    for a in ci.arity_bits:
+        bits -= a
+        qfr += bits
+    fr_queries = (3 + len(ci.arity_bits)) * ci.cap_len
+    return n_open, qwords, fr_queries, qfr, n_gl
+
+
+def permuted_query_batch(ci, packed, challenges, perms):
+    """Heterogeneous but VALID batch: proof i = the fixture with its query rounds re-ordered by perms[i] (round j takes the
+    data of round perms[i][j]), and the matching challenge rows (query indices re-ordered the same way). The transcript does
+    not observe the query rounds, so such a record is what the same prover would have sent had the verifier drawn the
+    indices in that order: it verifies under gpv_verify_given_challenges. Returns (uint8 [n][nbytes], uint64 [n][ncw])."""
+    perms = np.asarray(perms)
+    n, nq = perms.shape
+    assert nq == ci.num_query_rounds
+    q0, qwords, f0, qfr, n_gl = query_section_layout(ci)
+    rec = np.frombuffer(packed, dtype=np.uint64)
+    out = np.tile(rec, (n, 1))
+    gl_blocks = rec[q0:q0 + nq * qwords].reshape(nq, qwords)
+    out[:, q0:q0 + nq * qwords] = gl_blocks[perms].reshape(n, -1)
+    fr0 = n_gl + 4 * f0
+    fr_blocks = rec[fr0:fr0 + 4 * nq * qfr].reshape(nq, 4 * qfr)
+    out[:, fr0:fr0 + 4 * nq * qfr] = fr_blocks[perms].reshape(n, -1)
+    ch = np.tile(np.asarray(challenges, dtype=np.uint64).reshape(1, -1), (n, 1))
+    ncw = ch.shape[1]
+    idx = ch[0, ncw - nq:]
+    ch[:, ncw - nq:] = idx[perms]
+    return out.view(np.uint8).reshape(n, -1), ch

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import gpv_testlib as T
-from test_oracle_kat import (DECODE_BLOCK_CHALLENGES, PBN_KATS, PGL_ZERO_OUT, STEP_CHALLENGES, _named)
+from test_oracle_kat import (DECODE_BLOCK_CHALLENGES, PBN_KATS, PGL_ZERO_OUT, STEP_CHALLENGES, _named, check_hints, hint_cases)
 
 pytestmark = pytest.mark.gpu
 P = T.GL_P
@@ -410,13 +410,27 @@ def test_bench_collective_path_single_rank():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", LOCAL_RANK="0",
                WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, str(T.ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--proofs-per-gpu",
-                          "512", "--force-dist", "--no-cpu-baseline", "--no-poseidon-gl"], capture_output=True, text=True, env=env,
+                          "512", "--force-dist", "--no-cpu-baseline", "--no-poseidon-gl", "--no-heterogeneous"], capture_output=True, text=True, env=env,
                          timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     json_lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(json_lines) == 1, out.stdout + out.stderr
     line = _json.loads(json_lines[0])
-    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["collective"].startswith("RCCL")
+    # default exchange: the C ABI's own group (rank mode, ncclCommInitRank + ncclAllGather inside libgpv.so), no fallback taken
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["collective"].startswith("ncclAllGather"), line["config"]
+    out = subprocess.run([sys.executable, str(T.ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--proofs-per-gpu",
+                          "512", "--force-dist", "--exchange", "torch", "--no-cpu-baseline", "--no-poseidon-gl", "--no-heterogeneous"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = _json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["config"]["collective"].startswith("torch.distributed"), line["config"]
+    env1 = {k: v for k, v in env.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, str(T.ROOT / "bench.py"), "--gpus", "1", "--group-in-process", "--force-dist", "--steps", "1", "--warmup",
+                          "1", "--proofs-per-gpu", "512", "--no-cpu-baseline", "--no-poseidon-gl", "--no-heterogeneous"],
+                         capture_output=True, text=True, env=env1, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = _json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert "one worker thread per GPU" in line["config"]["collective"], line["config"]
 
 
 # ---------------------------------------------------------------- differential tests on random records
@@ -866,6 +880,77 @@ def test_group_multi_device_if_present(gpv, orc):
             assert grp.read_rank_accept(i, n).tolist() == acc.tolist(), i
     finally:
         grp.close()
+
+
+# ---------------------------------------------------------------- hint functions (witness generation)
+def test_gl_hint_functions(gpv, api, orc):
+    """gpv_gl_hints == exact integers == oracle: MulAddHint (incl. base_test.go:97-116), ReduceHint on Fr-sized inputs,
+    InverseHint, SplitLimbsHint; operands outside the field come back with ok = 0 (the reference panics / errors)."""
+    gl = gpv.goldilocks.New(api)
+
+    def run(h, rows, wi, wo):
+        out, ok = gl._hint(h, rows, wi, wo)
+        oout, ook = orc.gl_hints(h, rows, wi, wo)
+        assert (out == oout).all() and (ok == ook).all()
+        return out, ok
+
+    check_hints(run)
+    muladd, big, single = hint_cases()
+    a, b, c = (np.array(x, dtype=np.uint64) for x in zip(*muladd))
+    q, r, ok = gl.MulAddHint(a, b, c)
+    good = ok == 1
+    assert (r[good] == gl.MulAdd(a[good], b[good], c[good])).all()  # the remainder IS MulAdd's result (base.go:196-213)
+    inv, iok = gl.InverseHint(np.array(single, dtype=np.uint64))
+    g = iok == 1
+    assert (inv[g] == gl.Inverse(np.array(single, dtype=np.uint64)[g])[0]).all()
+
+
+# ---------------------------------------------------------------- Verify with caller-supplied challenges; heterogeneous batches
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_verify_given_challenges_on_permuted_query_rounds(gpv, api, orc, name):
+    """gpv_verify_given_challenges = VerifierChip.Verify with GetChallenges replaced by supplied ProofChallenges (the shape of
+    fri_test.go:106-133 / plonk_test.go:39-66). Batch: every proof carries its 28 query rounds in a different order with the
+    query indices re-ordered to match -- distinct records, distinct per-proof Merkle work lists, all valid -- plus tampered
+    ones. Accept and failure mask == oracle (plonk | fri with the same challenges); the shared upper Merkle levels (forced on)
+    and the per-path walk agree."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    chip = gpv.verifier.NewVerifierChip(api, common)
+    ch0 = chip.GetChallenges(proofs).flat[0]
+    n = 160
+    rng = np.random.default_rng(5)
+    perms = np.stack([rng.permutation(ci.num_query_rounds) for _ in range(n)])
+    batch, chs = T.permuted_query_batch(ci, packed, ch0, perms)
+    assert len({batch[i].tobytes() for i in range(n)}) == n
+    words = batch.view(np.uint64).reshape(n, -1)
+    q0, qwords, f0, qfr, n_gl = T.query_section_layout(ci)
+    tampered = np.zeros(n, dtype=bool)
+    for i in range(0, n, 5):
+        site = i // 5 % 4
+        if site == 0:
+            words[i, q0 + int(rng.integers(0, ci.num_query_rounds * qwords))] ^= np.uint64(1)      # leaf / step evaluation
+        elif site == 1:
+            words[i, n_gl + 4 * (f0 + int(rng.integers(0, ci.num_query_rounds * qfr)))] ^= np.uint64(1)   # a sibling
+        elif site == 2:
+            words[i, int(rng.integers(0, q0))] ^= np.uint64(2)                                      # an opening
+        else:
+            chs[i, -1 - int(rng.integers(0, ci.num_query_rounds))] ^= np.uint64(4)                  # a wrong query index
+        tampered[i] = True
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    expect_mask = orc.plonk_verify(oc, batch, chs).astype(np.int64) | orc.fri_verify(oc, batch, chs).astype(np.int64)
+    assert ((expect_mask != 0) == tampered).all()
+    for shared in (2, 0):
+        api.set_option(2, shared)  # GPV_OPT_MERKLE_SHARED_LEVELS: forced on / off
+        try:
+            accept, mask = chip.VerifyWithChallenges(pb, chs)
+        finally:
+            api.set_option(2, 1)
+        assert accept.tolist() == (~tampered).astype(np.uint8).tolist(), shared
+        assert mask.tolist() == expect_mask.tolist(), shared
+    # the same records under the transcript's own indices: the query rounds no longer match them
+    ident = (perms == np.arange(ci.num_query_rounds)).all(axis=1)
+    assert (chip.Verify(pb, vo)[~ident] == 0).all()
 
 
 # ---------------------------------------------------------------- BASELINE config 4: the 8192-proof per-GPU shard at size

@@ -230,3 +230,55 @@ def test_poseidon_gl_round_constants_leave_headroom():
     body = inc[inc.index("{", i) + 1:inc.index("};", i)]
     vals = [int(x.rstrip("UL"), 0) for x in re.findall(r"0x[0-9a-fA-F]+U?L?L?", body)]
     assert len(vals) == 360 and max(vals) < 2**64 - 2**43
+
+
+# ---------------------------------------------------------------- hint functions (goldilocks/base.go:223-359)
+def hint_cases(seed=5, n=400):
+    """Shared by the oracle KAT test and the GPU parity test: inputs of the four hints incl. the reference's own MulAdd case
+    (base_test.go:97-116), edge values and operands outside the field."""
+    rng = np.random.default_rng(seed)
+    P = T.GL_P
+    edge = [0, 1, 2, P - 1, P - 2, 2**32, 2**32 - 1, 2**63, P, P + 1, 2**64 - 1]
+    r = [int(x) for x in rng.integers(0, 2**63, size=3 * n, dtype=np.uint64) * 2 + rng.integers(0, 2, size=3 * n, dtype=np.uint64)]
+    muladd = [(1, 2, 3), (2**63, 2**63, 3)] + [(a, b, c) for a in edge for b in edge[:6] for c in (0, P - 1, P)] \
+        + [(r[3 * i] % P, r[3 * i + 1] % P, r[3 * i + 2] % P) for i in range(n)]
+    big = [int.from_bytes(rng.bytes(32), "little") % T.BN_R for _ in range(n)] + [0, 1, P - 1, P, P + 1, 2**64, 2**128 - 1, 2**192, T.BN_R - 1,
+                                                                               (P - 1) * (P - 1) * 12 + 7]
+    single = edge + r[:n]
+    return muladd, big, single
+
+
+def hint_expect(muladd, big, single):
+    P = T.GL_P
+    ma = [((a * b + c) // P, (a * b + c) % P, 1) if max(a, b, c) < P else (0, 0, 0) for a, b, c in muladd]
+    rd = [(x // P, x % P) for x in big]
+    inv = [(pow(x, P - 2, P), 1) if x < P else (0, 0) for x in single]
+    sp = [(x >> 32, x & 0xFFFFFFFF, 1) if x < P else (0, 0, 0) for x in single]
+    return ma, rd, inv, sp
+
+
+def limbs4(x):
+    return [(x >> (64 * k)) & (2**64 - 1) for k in range(4)]
+
+
+def check_hints(run):
+    """run(hint, rows, words_in, words_out) -> (out [n][words_out], ok [n]); compares with exact Python integers."""
+    muladd, big, single = hint_cases()
+    ma, rd, inv, sp = hint_expect(muladd, big, single)
+    out, ok = run(0, np.array(muladd, dtype=np.uint64), 3, 2)
+    assert [(int(q), int(r), int(k)) for (q, r), k in zip(out, ok)] == ma
+    assert ma[0] == (0, 5, 1) and ma[1][1] == 18446744068340842500  # base_test.go:97-116
+    out, ok = run(1, np.array([limbs4(x) for x in big], dtype=np.uint64), 4, 5)
+    assert ok.all()
+    assert [(sum(int(w) << (64 * k) for k, w in enumerate(row[:4])), int(row[4])) for row in out] == rd
+    out, ok = run(2, np.array(single, dtype=np.uint64), 1, 1)
+    assert [(int(v[0]), int(k)) for v, k in zip(out, ok)] == inv
+    out, ok = run(3, np.array(single, dtype=np.uint64), 1, 2)
+    assert [(int(v[0]), int(v[1]), int(k)) for v, k in zip(out, ok)] == sp
+
+
+def test_hint_functions_oracle():
+    """MulAddHint / ReduceHint / InverseHint / SplitLimbsHint restated in the oracle == exact integer arithmetic, incl. the
+    reference's MulAdd known answer (2^63 * 2^63 + 3 -> remainder 18446744068340842500, base_test.go:109-116)."""
+    orc = T.oracle()
+    check_hints(lambda h, rows, wi, wo: orc.gl_hints(h, rows, wi, wo))
