@@ -17,7 +17,7 @@ GPV_OK, GPV_ESHAPE, GPV_ECONFIG, GPV_EDEVICE, GPV_EINVAL, GPV_ENOMEM = 0, -1, -2
 ABI_SYMBOLS = [
     "gpv_ctx_create", "gpv_ctx_destroy", "gpv_ctx_set_stream", "gpv_ctx_set_option", "gpv_ctx_synchronize", "gpv_last_error_message",
     "gpv_circuit_from_json", "gpv_circuit_destroy", "gpv_proof_nbytes", "gpv_num_challenge_words",
-    "gpv_num_gate_constraints", "gpv_num_query_rounds", "gpv_num_merkle_trees", "gpv_circuit_describe",
+    "gpv_num_gate_constraints", "gpv_num_query_rounds", "gpv_num_merkle_trees", "gpv_circuit_hash_kind", "gpv_circuit_describe",
     "gpv_proof_pack_json", "gpv_proof_pack_json_batch",
     "gpv_gl_op", "gpv_gl_hints", "gpv_gl2_op", "gpv_gl2_op3", "gpv_gl2_exp", "gpv_gl2_reduce_with_powers", "gpv_gl2alg_op",
     "gpv_poseidon_gl_hash_n_to_m_no_pad", "gpv_challenger_run", "gpv_poseidon_gl_permute", "gpv_poseidon_gl_permute_dev", "gpv_poseidon_gl_permute_coop",
@@ -84,7 +84,7 @@ def lib():
         L.gpv_circuit_from_json.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, ctypes.POINTER(vp)]
         L.gpv_circuit_destroy.argtypes = [vp]
         for f in ("gpv_proof_nbytes", "gpv_num_challenge_words", "gpv_num_gate_constraints", "gpv_num_query_rounds",
-                  "gpv_num_merkle_trees"):
+                  "gpv_num_merkle_trees", "gpv_circuit_hash_kind"):
             getattr(L, f).argtypes = [vp]
             getattr(L, f).restype = sz
         L.gpv_circuit_describe.argtypes = [vp, vp, sz]

@@ -16,6 +16,11 @@
 #define GPV_MAX_WEIGHTS 256
 #define GPV_MAX_CHALLENGES 4
 #define GPV_MAX_RA_BITS 6
+// Merkle / cap hash configurations. In both a hash is 4 x u64 in the packed record ("Fr section"): the canonical BN254
+// scalar (the reference's PoseidonBN254GoldilocksConfig, poseidon/bn254.go) or the four Goldilocks elements of a plonky2
+// HashOut (PoseidonGoldilocksConfig).
+#define GPV_HASH_POSEIDON_BN254 0
+#define GPV_HASH_POSEIDON_GOLDILOCKS 1
 
 struct DevGate {
   uint32_t kind, p0, p1, p2;
@@ -41,7 +46,7 @@ struct DevCircuit {
   uint32_t n_trees;  // 4 + num_steps
   // ---- challenge vector layout (words)
   uint32_t n_challenge_words, ch_betas, ch_gammas, ch_alphas, ch_zeta, ch_fri_alpha, ch_fri_betas, ch_pow, ch_queries;
-  uint32_t _pad0;
+  uint32_t hash_kind;  // GPV_HASH_*: which hash the Merkle trees, caps and the circuit digest use
   uint64_t proof_nbytes;
   // ---- gates / selectors (plonk/gates/types.go:10-36)
   DevGate gates[GPV_MAX_GATES];

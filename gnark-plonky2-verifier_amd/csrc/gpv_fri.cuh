@@ -20,43 +20,148 @@
 #include "gpv_circuit_dev.h"
 #include "gpv_poseidon.cuh"
 
+// ---------------------------------------------------------------- Merkle hashers
+// The Merkle kernels are written once over a hasher policy. At every interface between kernels a node is four u64 words
+// ("canonical words"): the canonical Fr value for Poseidon-BN254, the four Goldilocks elements of a HashOut for
+// Poseidon-Goldilocks -- which is also how both appear in the packed record (32 bytes per hash either way).
+//   HashBN  the reference's configuration (fri/fri.go:97-144 over poseidon/bn254.go:47-104)
+//   HashGL  plonky2's default PoseidonGoldilocksConfig (no reference counterpart -- fri.go:104,113 hash with
+//           BN254 only): hash_or_noop = the elements themselves padded with zeros when there are at most 4, else the
+//           rate-8 overwrite sponge (poseidon/goldilocks.go:72-86); two_to_one = first four words of
+//           permute([left, right, 0, 0, 0, 0])
+struct HashBN {
+  typedef Fr Node;
+  static constexpr u32 kind = 0;
+  GPV_DEV static Node leaf(const u64* __restrict__ leaf, u32 len) { return poseidon_bn254_hash_or_noop(leaf, len); }  // fri.go:104
+  GPV_DEV static Node two_to_one(const Node& l, const Node& r) { return poseidon_bn254_two_to_one(l, r); }
+  GPV_DEV static Node from_words(const u64* __restrict__ w) { return fr_from_canonical64(w); }
+  GPV_DEV static void to_words(const Node& a, u64 out[4]) { fr_to_canonical64(a, out); }
+  GPV_DEV static void words_reduce(u64 w[4]) { fr_words_reduce(w); }  // a supplied 256-bit value is taken mod r like a gnark witness
+  GPV_DEV static void store_digest(u32* __restrict__ o, const Node& d) {
+#pragma unroll
+    for (int k = 0; k < FR_LIMBS; k++) o[k] = d.l[k];
+  }
+  GPV_DEV static Node load_digest(const u32* __restrict__ in) {
+    Node d;
+#pragma unroll
+    for (int k = 0; k < FR_LIMBS; k++) d.l[k] = in[k];
+    return d;
+  }
+  GPV_DEV static Node select(bool take_a, const Node& a, const Node& b) {
+    Node r;
+#pragma unroll
+    for (int k = 0; k < FR_LIMBS; k++) r.l[k] = take_a ? a.l[k] : b.l[k];
+    return r;
+  }
+};
+struct GlNode {
+  u64 w[4];
+};
+struct HashGL {
+  typedef GlNode Node;
+  static constexpr u32 kind = 1;
+  GPV_DEV static Node leaf(const u64* __restrict__ leaf, u32 len) {
+    Node d;
+    if (len <= 4) {  // hash_or_noop: short inputs are their own digest, zero-padded
+#pragma unroll
+      for (u32 k = 0; k < 4; k++) d.w[k] = k < len ? gl_canon(leaf[k]) : 0;
+      return d;
+    }
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+#pragma unroll 1
+    for (u32 i = 0; i < len; i += 8) {  // goldilocks.go:41-68: overwrite mode, no padding
+#pragma unroll
+      for (u32 j = 0; j < 8; j++)
+        if (i + j < len) s[j] = gl_canon(leaf[i + j]);
+      poseidon_gl_permute(s);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) d.w[k] = s[k];
+    return d;
+  }
+  GPV_DEV static Node two_to_one(const Node& l, const Node& r) {
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      s[k] = l.w[k];
+      s[4 + k] = r.w[k];
+      s[8 + k] = 0;
+    }
+    poseidon_gl_permute(s);
+    Node d;
+#pragma unroll
+    for (int k = 0; k < 4; k++) d.w[k] = s[k];
+    return d;
+  }
+  GPV_DEV static Node from_words(const u64* __restrict__ w) {
+    Node d;
+#pragma unroll
+    for (int k = 0; k < 4; k++) d.w[k] = gl_canon(w[k]);
+    return d;
+  }
+  GPV_DEV static void to_words(const Node& a, u64 out[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = a.w[k];
+  }
+  GPV_DEV static void words_reduce(u64 w[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = gl_canon(w[k]);
+  }
+  GPV_DEV static void store_digest(u32* __restrict__ o, const Node& d) {  // the scratch row is FR_LIMBS u32 wide: 8 are used
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      o[2 * k] = (u32)d.w[k];
+      o[2 * k + 1] = (u32)(d.w[k] >> 32);
+    }
+  }
+  GPV_DEV static Node load_digest(const u32* __restrict__ in) {
+    Node d;
+#pragma unroll
+    for (int k = 0; k < 4; k++) d.w[k] = (u64)in[2 * k] | ((u64)in[2 * k + 1] << 32);
+    return d;
+  }
+  GPV_DEV static Node select(bool take_a, const Node& a, const Node& b) {
+    Node r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r.w[k] = take_a ? a.w[k] : b.w[k];
+    return r;
+  }
+};
+
 // ---------------------------------------------------------------- Merkle path (one lane), in two phases
 // Phase 1 (leaf digest) needs only the proof bytes; phase 2 (climb + cap comparison) needs the query index from the
 // Fiat-Shamir transcript. Splitting them lets the latency-bound transcript kernel run concurrently with phase 1.
-GPV_DEV Fr dev_merkle_leaf(const u64* __restrict__ leaf, u32 leaf_len) {
-  return poseidon_bn254_hash_or_noop(leaf, leaf_len);  // fri.go:104
+template <class H>
+GPV_DEV typename H::Node dev_merkle_leaf(const u64* __restrict__ leaf, u32 leaf_len) {
+  return H::leaf(leaf, leaf_len);  // fri.go:104
 }
 // `n` levels upwards from `cur`: sibling i pairs with bit i of index_bits (bit = 1: hash(sibling, cur), fri.go:105-116)
-GPV_DEV void dev_merkle_steps(Fr& cur, const u64* __restrict__ siblings, u32 n, u32 index_bits) {
+template <class H>
+GPV_DEV void dev_merkle_steps(typename H::Node& cur, const u64* __restrict__ siblings, u32 n, u32 index_bits) {
 #pragma unroll 1
   for (u32 i = 0; i < n; i++) {
-    Fr sib = fr_from_canonical64(siblings + 4 * i);
+    typename H::Node sib = H::from_words(siblings + 4 * i);
     bool bit = (index_bits >> i) & 1;
-    Fr s[4];
-    s[0] = fr_zero();
-    s[1] = fr_zero();
-#pragma unroll
-    for (int k = 0; k < FR_LIMBS; k++) {
-      s[2].l[k] = bit ? sib.l[k] : cur.l[k];
-      s[3].l[k] = bit ? cur.l[k] : sib.l[k];
-    }
-    poseidon_bn254_permute<true>(s);  // TwoToOne: s[0] = s[1] = 0 (bn254.go:96-104)
-    cur = s[0];
+    cur = H::two_to_one(H::select(bit, sib, cur), H::select(bit, cur, sib));  // TwoToOne (bn254.go:96-104)
   }
 }
 // canonical representatives compared (fri.go:135-143); values inside a chain are only reduced up to multiples of r
 GPV_DEV bool fr_words_equal(const u64 a[4], const u64 b[4]) { return ((a[0] ^ b[0]) | (a[1] ^ b[1]) | (a[2] ^ b[2]) | (a[3] ^ b[3])) == 0; }
-GPV_DEV bool dev_fr_matches(const Fr& cur, const u64* __restrict__ words) {
+template <class H>
+GPV_DEV bool dev_node_matches(const typename H::Node& cur, const u64* __restrict__ words) {
   u64 got[4], want[4] = {words[0], words[1], words[2], words[3]};
-  fr_to_canonical64(cur, got);
-  fr_words_reduce(want);
+  H::to_words(cur, got);
+  H::words_reduce(want);
   return fr_words_equal(got, want);
 }
 // Returns true iff the path from `cur` hashes to the cap entry.
-GPV_DEV bool dev_merkle_climb(Fr cur, const u64* __restrict__ siblings, u32 n_siblings, u32 index_bits,
+template <class H>
+GPV_DEV bool dev_merkle_climb(typename H::Node cur, const u64* __restrict__ siblings, u32 n_siblings, u32 index_bits,
                               const u64* __restrict__ cap_entry) {
-  dev_merkle_steps(cur, siblings, n_siblings, index_bits);
-  return dev_fr_matches(cur, cap_entry);
+  dev_merkle_steps<H>(cur, siblings, n_siblings, index_bits);
+  return dev_node_matches<H>(cur, cap_entry);
 }
 // Where the Merkle path of (query q, tree) of one proof lives (fri.go:146-157 initial trees, :472-483 step trees)
 struct MerklePath {

@@ -312,6 +312,19 @@ bool parse_fr_decimal(const char* t, size_t n, uint64_t out[4]) {
   return true;
 }
 bool j_fr(const JValue* v, uint64_t out[4]) { return v && v->kind == JValue::String && parse_fr_decimal(v->s, v->len, out); }
+// A Poseidon-Goldilocks HashOut as plonky2's serde writes it, {"elements": [a, b, c, d]} (a bare 4-array is accepted too):
+// four u64 words. Canonical form is not enforced here -- the verifier's range check rejects such a proof.
+bool j_gl_hash(const JValue* v, uint64_t out[4]) {
+  if (v && v->kind == JValue::Object) v = v->get("elements");
+  if (!v || v->kind != JValue::Array || v->size() != 4) return false;
+  int k = 0;
+  for (const JValue* e = v->first_child(); e; e = e->next_sibling())
+    if (!j_u64(e, &out[k++])) return false;
+  return true;
+}
+bool j_hash(const JValue* v, uint32_t hash_kind, uint64_t out[4]) {
+  return hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS ? j_gl_hash(v, out) : j_fr(v, out);
+}
 
 // ---- gate-id parsing (the reference matches regexes; ids are generated by plonky2's Debug formatting)
 // Consumes `lit` at position *pos of s.
@@ -680,9 +693,19 @@ extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len,
   }
   const JValue* cap = vo->get("constants_sigmas_cap");
   if (!cap || cap->kind != JValue::Array || cap->size() != 16) { gpv_set_global_error("constants_sigmas_cap"); return GPV_ESHAPE; }
+  // Which hash the circuit was built with shows in the shape of its hashes: a decimal string is a BN254 scalar (the
+  // reference's PoseidonBN254GoldilocksConfig), {"elements": [4 x u64]} a Poseidon-Goldilocks HashOut.
+  c.hash_kind = cap->child(0)->kind == JValue::String ? GPV_HASH_POSEIDON_BN254 : GPV_HASH_POSEIDON_GOLDILOCKS;
   for (int i = 0; i < 16; i++)
-    if (!j_fr(cap->child(i), c.sigmas_cap[i])) return GPV_ESHAPE;
-  if (!j_fr(vo->get("circuit_digest"), c.digest)) { gpv_set_global_error("circuit_digest"); return GPV_ESHAPE; }
+    if (!j_hash(cap->child(i), c.hash_kind, c.sigmas_cap[i])) { gpv_set_global_error("constants_sigmas_cap[%d]", i); return GPV_ESHAPE; }
+  if (!j_hash(vo->get("circuit_digest"), c.hash_kind, c.digest)) { gpv_set_global_error("circuit_digest"); return GPV_ESHAPE; }
+  if (c.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS) {  // plonky2 refuses to deserialise a non-canonical field element
+    for (int i = 0; i < 16; i++)
+      for (int k = 0; k < 4; k++)
+        if (c.sigmas_cap[i][k] >= 0xFFFFFFFF00000001ULL) { gpv_set_global_error("constants_sigmas_cap: non-canonical element"); return GPV_ESHAPE; }
+    for (int k = 0; k < 4; k++)
+      if (c.digest[k] >= 0xFFFFFFFF00000001ULL) { gpv_set_global_error("circuit_digest: non-canonical element"); return GPV_ESHAPE; }
+  }
   int rc = finish_layout(c);
   if (rc != GPV_OK) return rc;
   *out = circ.release();
@@ -700,13 +723,14 @@ extern "C" size_t gpv_num_challenge_words(const gpv_circuit* c) { return c ? c->
 extern "C" size_t gpv_num_gate_constraints(const gpv_circuit* c) { return c ? c->dc.num_gate_constraints : 0; }
 extern "C" size_t gpv_num_query_rounds(const gpv_circuit* c) { return c ? c->dc.num_queries : 0; }
 extern "C" size_t gpv_num_merkle_trees(const gpv_circuit* c) { return c ? c->dc.n_trees : 0; }
+extern "C" size_t gpv_circuit_hash_kind(const gpv_circuit* c) { return c ? c->dc.hash_kind : 0; }
 
 // circuit blob: 32-word header + sections (same format the tests build independently, tests/gpv_testlib.py)
 extern "C" size_t gpv_circuit_describe(const gpv_circuit* circ, uint64_t* blob, size_t cap) {
   if (!circ) return 0;
   const DevCircuit& c = circ->dc;
   std::vector<uint64_t> b(32, 0);
-  b[0] = 0x0001435650470000ULL;
+  b[0] = 0x0001435650470000ULL | c.hash_kind;  // low byte: GPV_HASH_*
   b[1] = c.num_wires; b[2] = c.num_routed; b[3] = c.num_constants; b[4] = c.num_challenges; b[5] = c.num_pp; b[6] = c.qdf;
   b[7] = c.num_gate_constraints; b[8] = c.num_pi; b[9] = c.degree_bits; b[10] = c.rate_bits; b[11] = c.cap_height;
   b[12] = c.pow_bits; b[13] = c.num_queries; b[14] = c.num_steps;
@@ -748,6 +772,7 @@ struct Packer {  // writes strictly inside [gl, gl_end) / [fr, fr_end) and nothi
   uint64_t* gl_end;
   uint64_t* fr;
   uint64_t* fr_end;
+  uint32_t hash_kind = GPV_HASH_POSEIDON_BN254;
   bool ok = true;
   const char* why = "";
   void fail(const char* w) { if (ok) why = w; ok = false; }
@@ -778,7 +803,7 @@ struct Packer {  // writes strictly inside [gl, gl_end) / [fr, fr_end) and nothi
     if (!v || v->kind != JValue::Array || v->size() != n) { fail("hash array of the wrong length"); return; }
     for (const JValue* e = v->first_child(); e && ok; e = e->next_sibling()) {
       if (fr + 4 > fr_end) { fail("more hashes than the circuit's layout holds"); return; }
-      if (!j_fr(e, fr)) { fail("expected a decimal string"); return; }
+      if (!j_hash(e, hash_kind, fr)) { fail(hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS ? "expected a hash {\"elements\": [4 x u64]}" : "expected a decimal string"); return; }
       fr += 4;
     }
   }
@@ -799,6 +824,7 @@ extern "C" int gpv_proof_pack_json(const gpv_circuit* circ, const char* proof_js
   Packer pk;
   pk.gl = (uint64_t*)out_packed;
   pk.fr = pk.gl + c.n_gl_words;
+  pk.hash_kind = c.hash_kind;
   pk.gl_end = pk.fr;
   pk.fr_end = pk.fr + 4 * (size_t)c.n_fr;
   uint64_t* gl_end = pk.fr;

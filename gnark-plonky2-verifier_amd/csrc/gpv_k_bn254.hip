@@ -42,11 +42,13 @@ struct MerkleOrder {
   u32 cls[4 + GPV_MAX_STEPS];  // tree classes, most expensive first
 };
 // One lane per (proof, query, tree). blockIdx.y picks the tree class, so every lane of a wave hashes a leaf of the same
-// length / climbs the same number of levels. Leaf digests travel between the two phases as 9 x u32 redundant limbs,
-// laid out [tree][item][9].
+// length / climbs the same number of levels. Leaf digests travel between the two phases in a [tree][item][9] u32 scratch
+// (9 redundant limbs for Poseidon-BN254, 4 x u64 for Poseidon-Goldilocks). The bodies are written over the hasher policy
+// (gpv_fri.cuh); the __global__ entry points keep one name per configuration so profiles stay comparable across rounds.
 #define GPV_MERKLE_BLOCK 64
-__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_leaves(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                                    size_t n, MerkleOrder order, u32* __restrict__ digests) {
+template <class H>
+GPV_DEV void merkle_leaves_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n, const MerkleOrder& order,
+                                u32* __restrict__ digests) {
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries;
   const size_t items = n * nq;
@@ -65,15 +67,13 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_leaves(const DevCir
     leaf = qrec + dc->step_evals_off[tree - 4];
     leaf_len = 2u << dc->arity_bits[tree - 4];
   }
-  Fr d = dev_merkle_leaf(leaf, leaf_len);
-  u32* o = digests + ((size_t)tree * items + item) * FR_LIMBS;
-#pragma unroll
-  for (int k = 0; k < FR_LIMBS; k++) o[k] = d.l[k];
+  typename H::Node d = dev_merkle_leaf<H>(leaf, leaf_len);
+  H::store_digest(digests + ((size_t)tree * items + item) * FR_LIMBS, d);
 }
-__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                                   const u64* __restrict__ derived, size_t n, MerkleOrder order,
-                                                                   const u32* __restrict__ digests, u32* __restrict__ fail,
-                                                                   uint8_t* __restrict__ ok_out) {
+template <class H>
+GPV_DEV void merkle_climb_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
+                               const MerkleOrder& order, const u32* __restrict__ digests, u32* __restrict__ fail,
+                               uint8_t* __restrict__ ok_out) {
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries;
   const size_t items = n * nq;
@@ -84,20 +84,17 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb(const DevCirc
   const u64* rec = proofs + p * (dc->proof_nbytes / 8);
   const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
   MerklePath m = dev_merkle_path(dc, rec, d, q, tree);
-  Fr cur;
-  const u32* din = digests + ((size_t)tree * items + item) * FR_LIMBS;
-#pragma unroll
-  for (int k = 0; k < FR_LIMBS; k++) cur.l[k] = din[k];
-  bool ok = dev_merkle_climb(cur, m.sib, m.n_sib, m.bits, m.cap + 4 * m.cap_index);
+  typename H::Node cur = H::load_digest(digests + ((size_t)tree * items + item) * FR_LIMBS);
+  bool ok = dev_merkle_climb<H>(cur, m.sib, m.n_sib, m.bits, m.cap + 4 * m.cap_index);
   if (ok_out) ok_out[item * dc->n_trees + tree] = ok;
   if (!ok) atomicOr(&fail[p], tree < 4 ? (u32)GPV_FAIL_MERKLE_INITIAL : (u32)GPV_FAIL_MERKLE_STEP);
 }
 // The same walk, stopped `crown_levels` levels below the cap: the node reached there is stored as canonical words
 // ([tree][item][4]) and the shared upper levels are hashed once per distinct node by gpv_k_crown.hip.
-__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_lower(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                                         const u64* __restrict__ derived, size_t n, MerkleOrder order,
-                                                                         const u32* __restrict__ digests, u64* __restrict__ mid,
-                                                                         u32 crown_levels) {
+template <class H>
+GPV_DEV void merkle_climb_lower_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived,
+                                     size_t n, const MerkleOrder& order, const u32* __restrict__ digests, u64* __restrict__ mid,
+                                     u32 crown_levels) {
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries;
   const size_t items = n * nq;
@@ -108,16 +105,48 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_lower(const D
   const u64* rec = proofs + p * (dc->proof_nbytes / 8);
   const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
   MerklePath m = dev_merkle_path(dc, rec, d, q, tree);
-  Fr cur;
-  const u32* din = digests + ((size_t)tree * items + item) * FR_LIMBS;
-#pragma unroll
-  for (int k = 0; k < FR_LIMBS; k++) cur.l[k] = din[k];
+  typename H::Node cur = H::load_digest(digests + ((size_t)tree * items + item) * FR_LIMBS);
   u32 top = m.n_sib < crown_levels ? m.n_sib : crown_levels;
-  dev_merkle_steps(cur, m.sib, m.n_sib - top, m.bits);
+  dev_merkle_steps<H>(cur, m.sib, m.n_sib - top, m.bits);
   u64 out[4];
-  fr_to_canonical64(cur, out);
+  H::to_words(cur, out);
   u64* o = mid + ((size_t)tree * items + item) * 4;
   o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; o[3] = out[3];
+}
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_leaves(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                    size_t n, MerkleOrder order, u32* __restrict__ digests) {
+  merkle_leaves_body<HashBN>(dc, proofs, n, order, digests);
+}
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                   const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                                   const u32* __restrict__ digests, u32* __restrict__ fail,
+                                                                   uint8_t* __restrict__ ok_out) {
+  merkle_climb_body<HashBN>(dc, proofs, derived, n, order, digests, fail, ok_out);
+}
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_lower(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                         const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                                         const u32* __restrict__ digests, u64* __restrict__ mid,
+                                                                         u32 crown_levels) {
+  merkle_climb_lower_body<HashBN>(dc, proofs, derived, n, order, digests, mid, crown_levels);
+}
+// Poseidon-Goldilocks configuration: ~20x less arithmetic per hash, so 256-lane blocks
+#define GPV_MERKLE_BLOCK_GL 256
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK_GL) void k_merkle_leaves_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                          size_t n, MerkleOrder order, u32* __restrict__ digests) {
+  merkle_leaves_body<HashGL>(dc, proofs, n, order, digests);
+}
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK_GL) void k_merkle_climb_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                         const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                                         const u32* __restrict__ digests, u32* __restrict__ fail,
+                                                                         uint8_t* __restrict__ ok_out) {
+  merkle_climb_body<HashGL>(dc, proofs, derived, n, order, digests, fail, ok_out);
+}
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK_GL) void k_merkle_climb_lower_gl(const DevCircuit* __restrict__ dc,
+                                                                               const u64* __restrict__ proofs,
+                                                                               const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                                               const u32* __restrict__ digests, u64* __restrict__ mid,
+                                                                               u32 crown_levels) {
+  merkle_climb_lower_body<HashGL>(dc, proofs, derived, n, order, digests, mid, crown_levels);
 }
 static MerkleOrder merkle_order(const DevCircuit& c, bool leaves) {
   // cost of a phase-1 chain = ceil(leaf_len / 9) permutations, of a phase-2 chain = number of siblings;
@@ -127,7 +156,8 @@ static MerkleOrder merkle_order(const DevCircuit& c, bool leaves) {
   for (u32 t = 0; t < c.n_trees; t++) {
     u32 len = t < 4 ? c.leaf_len[t] : (2u << c.arity_bits[t - 4]);
     u32 sib = t < 4 ? c.init_siblings : c.step_siblings[t - 4];
-    cost[t] = leaves ? (len <= 3 ? 0 : (len + 8) / 9) : sib;  // (the lower-levels mode subtracts the same constant from every class)
+    // (the lower-levels mode subtracts the same constant from every class)
+    cost[t] = !leaves ? sib : c.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS ? (len <= 4 ? 0 : (len + 7) / 8) : (len <= 3 ? 0 : (len + 8) / 9);
     o.cls[t] = t;
   }
   for (u32 i = 0; i < c.n_trees; i++)
@@ -151,18 +181,30 @@ void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n
 size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n) { return n * hc.num_queries * hc.n_trees * FR_LIMBS; }
 void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests) {
   size_t items = n * hc.num_queries;
-  GPVK_LAUNCH(k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd,
-                     proofs, n, merkle_order(hc, true), digests);
+  if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
+    GPVK_LAUNCH(k_merkle_leaves_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs, n,
+                merkle_order(hc, true), digests);
+  else
+    GPVK_LAUNCH(k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
+                merkle_order(hc, true), digests);
 }
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
                        const u32* digests, u32* fail, uint8_t* ok_out) {
   size_t items = n * hc.num_queries;
-  GPVK_LAUNCH(k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd,
-                     proofs, derived, n, merkle_order(hc, false), digests, fail, ok_out);
+  if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
+    GPVK_LAUNCH(k_merkle_climb_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs,
+                derived, n, merkle_order(hc, false), digests, fail, ok_out);
+  else
+    GPVK_LAUNCH(k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
+                merkle_order(hc, false), digests, fail, ok_out);
 }
 void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
                              const u32* digests, u64* mid, u32 crown_levels) {
   size_t items = n * hc.num_queries;
-  GPVK_LAUNCH(k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st,
-                     dcd, proofs, derived, n, merkle_order(hc, false), digests, mid, crown_levels);
+  if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
+    GPVK_LAUNCH(k_merkle_climb_lower_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd,
+                proofs, derived, n, merkle_order(hc, false), digests, mid, crown_levels);
+  else
+    GPVK_LAUNCH(k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
+                derived, n, merkle_order(hc, false), digests, mid, crown_levels);
 }

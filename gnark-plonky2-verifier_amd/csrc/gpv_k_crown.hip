@@ -81,9 +81,10 @@ GPV_DEV u32 crown_first(u32 key, u32 want, int base, u32 nq) {
   }
   return first;
 }
+template <class H>
 GPV_DEV void load_words_reduced(const u64* __restrict__ p, u64 w[4]) {
   w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; w[3] = p[3];
-  fr_words_reduce(w);
+  H::words_reduce(w);
 }
 
 // One wave plans CROWN_PAIRS_PER_WAVE consecutive pairs of groups: a counting pass, ONE slot reservation per level for the
@@ -158,12 +159,13 @@ __global__ __launch_bounds__(64) void k_crown_plan(const DevCircuit* __restrict_
 // One lane per node of level k, grid-stride: the grid is sized for the node count of a valid batch (at most one shared node per
 // path and level, in practice 0.5-0.8 of that); only batches in which paths left the shared tree make a lane take a second
 // node. (A grid of 2 x paths, the worst case, launched 2.75 M lanes for ~0.9 M nodes: 8 % of the kernel's time, r02b PMC.)
-__global__ __launch_bounds__(64) void k_crown_level(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                    const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
+template <class H>
+GPV_DEV void crown_level_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
+                              const CrownBufs& b, u32 k) {
   const size_t total = b.count[k];
 #pragma unroll 1
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    Fr in[2];
+    typename H::Node in[2];
     {
       const CrownItem it = b.item[k][i];
       const u64* below = k == 0 ? b.mid : b.res[k - 1];
@@ -178,12 +180,12 @@ __global__ __launch_bounds__(64) void k_crown_level(const DevCircuit* __restrict
           u32 top = m.n_sib < GPV_CROWN_LEVELS ? m.n_sib : GPV_CROWN_LEVELS;
           w = m.sib + 4 * (size_t)(m.n_sib - top + k);
         }
-        in[side] = fr_from_canonical64(w);
+        in[side] = H::from_words(w);
       }
     }
-    Fr h = poseidon_bn254_two_to_one(in[0], in[1]);
+    typename H::Node h = H::two_to_one(in[0], in[1]);
     u64 out[4];
-    fr_to_canonical64(h, out);
+    H::to_words(h, out);
     u64* o = b.res[k] + 4 * i;
     o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; o[3] = out[3];
     const u32 meta = b.item[k][i].meta;  // re-read after the hash: nothing of the item stays live across it
@@ -193,15 +195,24 @@ __global__ __launch_bounds__(64) void k_crown_level(const DevCircuit* __restrict
       MerklePath m = dev_merkle_path(dc, proofs + p * (dc->proof_nbytes / 8), derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA), meta >> 24,
                                      tree);
       u64 want[4];
-      load_words_reduced(m.cap + 4 * m.cap_index, want);
+      load_words_reduced<H>(m.cap + 4 * m.cap_index, want);
       if (!fr_words_equal(out, want)) atomicOr(&b.gflag[p * dc->n_trees + tree], CROWN_FLAG_CAP_MISMATCH);
     }
   }
 }
+__global__ __launch_bounds__(64) void k_crown_level(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                    const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
+  crown_level_body<HashBN>(dc, proofs, derived, n, b, k);
+}
+__global__ __launch_bounds__(256) void k_crown_level_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                        const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
+  crown_level_body<HashGL>(dc, proofs, derived, n, b, k);
+}
 
 // Two groups per wave like the plan; run before level k.
-__global__ __launch_bounds__(64) void k_crown_reconcile(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                        const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
+template <class H>
+GPV_DEV void crown_reconcile_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
+                                  const CrownBufs& b, u32 k) {
   const CrownLane L = crown_lane(dc, n, blockIdx.x);
   const u32 nq = dc->num_queries;
   const size_t items = n * nq;
@@ -234,14 +245,14 @@ __global__ __launch_bounds__(64) void k_crown_reconcile(const DevCircuit* __rest
   if (!alone) {
     u64 mine[4], used[4];
     const MerklePath m = dev_merkle_path(dc, rec, d, L.q, L.tree);
-    load_words_reduced(m.sib + 4 * (size_t)(geo.n_sib - geo.top + k), mine);
+    load_words_reduced<H>(m.sib + 4 * (size_t)(geo.n_sib - geo.top + k), mine);
     bool differs = false;
     if (k == 0 && shared_below != own_below) differs |= !fr_words_equal(b.mid + 4 * (size_t)own_below, b.mid + 4 * (size_t)shared_below);
     if (via < nq) {  // the shared node hashes the computed other child: this path's sibling must be that value
       differs |= !fr_words_equal(mine, below + 4 * (size_t)via_shared_below);
     } else if (leader != L.q) {  // it hashes the leader's sibling: this path must supply the same one
       const MerklePath ml = dev_merkle_path(dc, rec, d, leader, L.tree);
-      load_words_reduced(ml.sib + 4 * (size_t)(geo.n_sib - geo.top + k), used);
+      load_words_reduced<H>(ml.sib + 4 * (size_t)(geo.n_sib - geo.top + k), used);
       differs |= !fr_words_equal(mine, used);
     }
     if (!differs) {
@@ -261,10 +272,19 @@ __global__ __launch_bounds__(64) void k_crown_reconcile(const DevCircuit* __rest
   b.item[k][slot] = it;
   b.pslot[pq * GPV_CROWN_LEVELS + k] = slot;
 }
+__global__ __launch_bounds__(64) void k_crown_reconcile(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                        const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
+  crown_reconcile_body<HashBN>(dc, proofs, derived, n, b, k);
+}
+__global__ __launch_bounds__(64) void k_crown_reconcile_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                           const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
+  crown_reconcile_body<HashGL>(dc, proofs, derived, n, b, k);
+}
 
 // one lane per (proof, query), blockIdx.y = tree
-__global__ void k_crown_finish(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
-                               CrownBufs b, u32* __restrict__ fail) {
+template <class H>
+GPV_DEV void crown_finish_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
+                               const CrownBufs& b, u32* __restrict__ fail) {
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries, nt = dc->n_trees;
   const size_t items = n * nq;
@@ -282,8 +302,16 @@ __global__ void k_crown_finish(const DevCircuit* __restrict__ dc, const u64* __r
   const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
   const MerklePath m = dev_merkle_path(dc, rec, d, q, tree);
   u64 want[4];
-  load_words_reduced(m.cap + 4 * m.cap_index, want);
+  load_words_reduced<H>(m.cap + 4 * m.cap_index, want);
   if (!fr_words_equal(b.mid + 4 * ((size_t)tree * items + item), want)) atomicOr(&fail[p], bit);
+}
+__global__ void k_crown_finish(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
+                               CrownBufs b, u32* __restrict__ fail) {
+  crown_finish_body<HashBN>(dc, proofs, derived, n, b, fail);
+}
+__global__ void k_crown_finish_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
+                                  CrownBufs b, u32* __restrict__ fail) {
+  crown_finish_body<HashGL>(dc, proofs, derived, n, b, fail);
 }
 
 // work lists hold the shared nodes (at most one per path and level) plus one node per path that left the shared tree
@@ -317,9 +345,18 @@ void gpvk_crown(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, con
   gpvk_note_launch(hipMemsetAsync(b.count, 0, 4 * GPV_CROWN_LEVELS, st), "memset(crown counters)");
   gpvk_note_launch(hipMemsetAsync(b.gflag, 0, 4 * groups, st), "memset(crown flags)");
   GPVK_LAUNCH(k_crown_plan, dim3(gpvk_blocks_for(groups, 2 * CROWN_PAIRS_PER_WAVE)), dim3(64), 0, st, dcd, derived, n, b);
+  const bool gl = hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS;
   for (u32 k = 0; k < GPV_CROWN_LEVELS; k++) {
-    GPVK_LAUNCH(k_crown_reconcile, dim3(gpvk_blocks_for(groups, 2)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
-    GPVK_LAUNCH(k_crown_level, dim3(gpvk_blocks_for(cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
+    if (gl) {
+      GPVK_LAUNCH(k_crown_reconcile_gl, dim3(gpvk_blocks_for(groups, 2)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
+      GPVK_LAUNCH(k_crown_level_gl, dim3(gpvk_blocks_for(cap, 256)), dim3(256), 0, st, dcd, proofs, derived, n, b, k);
+    } else {
+      GPVK_LAUNCH(k_crown_reconcile, dim3(gpvk_blocks_for(groups, 2)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
+      GPVK_LAUNCH(k_crown_level, dim3(gpvk_blocks_for(cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
+    }
   }
-  GPVK_LAUNCH(k_crown_finish, dim3(gpvk_blocks_for(items, 256), hc.n_trees), dim3(256), 0, st, dcd, proofs, derived, n, b, fail);
+  if (gl)
+    GPVK_LAUNCH(k_crown_finish_gl, dim3(gpvk_blocks_for(items, 256), hc.n_trees), dim3(256), 0, st, dcd, proofs, derived, n, b, fail);
+  else
+    GPVK_LAUNCH(k_crown_finish, dim3(gpvk_blocks_for(items, 256), hc.n_trees), dim3(256), 0, st, dcd, proofs, derived, n, b, fail);
 }

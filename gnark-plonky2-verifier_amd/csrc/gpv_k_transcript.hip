@@ -6,12 +6,16 @@
 // Canonical-form check of every Goldilocks word except the public inputs: one coalesced pass over the batch.
 __global__ __launch_bounds__(256) void k_range_check(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
                                                      u32* __restrict__ fail) {
-  const u32 words = dc->off_pi;
+  // Poseidon-Goldilocks configuration: the hashes (caps, siblings) are Goldilocks elements of the proof too, so the words of
+  // the hash section are checked as well; a BN254 hash is taken mod r like a gnark witness and has no canonical-form check
+  const u32 gl_part = dc->off_pi;
+  const u32 words = gl_part + (dc->hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS ? 4 * dc->n_fr : 0);
   const size_t stride_words = dc->proof_nbytes / 8;
   const size_t total = (size_t)words * n;
   for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
     size_t p = w / words;
     u32 k = (u32)(w - p * words);
+    if (k >= gl_part) k = dc->n_gl_words + (k - gl_part);
     u64 x = proofs[p * stride_words + k];
     if (x >= GLP) atomicOr(&fail[p], (u32)GPV_FAIL_RANGE);
   }

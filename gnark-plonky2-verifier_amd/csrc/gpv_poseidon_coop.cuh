@@ -121,8 +121,16 @@ struct CoopChallenger {
 #pragma unroll
     for (int i = 0; i < 5; i++) observe(v[i]);
   }
-  GPV_DEV void observe_cap(const u64* cap, u32 n) {
+  GPV_DEV void observe_hash(const u64* h, u32 hash_kind) {  // see DevChallenger::observe_hash
+    if (hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) observe(h[i]);
+    } else {
+      observe_fr(h);
+    }
+  }
+  GPV_DEV void observe_cap(const u64* cap, u32 n, u32 hash_kind) {
 #pragma unroll 1
-    for (u32 i = 0; i < n; i++) observe_fr(cap + 4 * i);
+    for (u32 i = 0; i < n; i++) observe_hash(cap + 4 * i, hash_kind);
   }
 };

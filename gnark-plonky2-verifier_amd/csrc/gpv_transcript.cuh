@@ -67,9 +67,19 @@ struct DevChallenger {
 #pragma unroll
     for (int i = 0; i < 5; i++) observe(v[i]);
   }
-  GPV_DEV void observe_cap(const u64* cap, u32 n) {  // challenger.go:67-71
+  // ObserveHash: a Poseidon-Goldilocks HashOut is observed as its four elements (plonky2 Challenger::observe_hash; the
+  // reference only has the BN254 form above, challenger.go:62-65)
+  GPV_DEV void observe_hash(const u64* h, u32 hash_kind) {
+    if (hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) observe(h[i]);
+    } else {
+      observe_fr(h);
+    }
+  }
+  GPV_DEV void observe_cap(const u64* cap, u32 n, u32 hash_kind) {  // challenger.go:67-71
 #pragma unroll 1
-    for (u32 i = 0; i < n; i++) observe_fr(cap + 4 * i);
+    for (u32 i = 0; i < n; i++) observe_hash(cap + 4 * i, hash_kind);
   }
 };
 
@@ -123,17 +133,17 @@ GPV_DEV void dev_transcript(const DevCircuit* __restrict__ dc, const u64* __rest
   dev_public_inputs_hash(dc, rec, pih);
   DevChallenger ch;
   ch.init();
-  ch.observe_fr(dc->digest);                                   // verifier.go:56
+  ch.observe_hash(dc->digest, dc->hash_kind);                                   // verifier.go:56
 #pragma unroll
   for (int i = 0; i < 4; i++) ch.observe(pih[i]);              // :57
   const u32 cap_len = 1u << dc->cap_height;
-  ch.observe_cap(frs + 4 * dc->fr_wires_cap, cap_len);         // :58
+  ch.observe_cap(frs + 4 * dc->fr_wires_cap, cap_len, dc->hash_kind);         // :58
   const u32 nc = dc->num_challenges;
   for (u32 i = 0; i < nc; i++) derived[dc->ch_betas + i] = ch.challenge();   // :59
   for (u32 i = 0; i < nc; i++) derived[dc->ch_gammas + i] = ch.challenge();  // :60
-  ch.observe_cap(frs + 4 * dc->fr_zs_pp_cap, cap_len);         // :62
+  ch.observe_cap(frs + 4 * dc->fr_zs_pp_cap, cap_len, dc->hash_kind);         // :62
   for (u32 i = 0; i < nc; i++) derived[dc->ch_alphas + i] = ch.challenge();  // :63
-  ch.observe_cap(frs + 4 * dc->fr_quot_cap, cap_len);          // :65
+  ch.observe_cap(frs + 4 * dc->fr_quot_cap, cap_len, dc->hash_kind);          // :65
   derived[dc->ch_zeta] = ch.challenge();                        // :66, challenger.go:108-111
   derived[dc->ch_zeta + 1] = ch.challenge();
   OpeningRanges orr = opening_ranges(dc);                       // :68, challenger.go:83-87
@@ -151,7 +161,7 @@ GPV_DEV void dev_transcript(const DevCircuit* __restrict__ dc, const u64* __rest
   derived[dc->ch_fri_alpha + 1] = fri_alpha.b;
 #pragma unroll 1
   for (u32 s = 0; s < dc->num_steps; s++) {
-    ch.observe_cap(frs + 4 * (dc->fr_commit_caps + s * cap_len), cap_len);
+    ch.observe_cap(frs + 4 * (dc->fr_commit_caps + s * cap_len), cap_len, dc->hash_kind);
     derived[dc->ch_fri_betas + 2 * s] = ch.challenge();
     derived[dc->ch_fri_betas + 2 * s + 1] = ch.challenge();
   }
@@ -206,17 +216,17 @@ GPV_DEV void dev_transcript_coop(const DevCircuit* __restrict__ dc, const u64* _
 #pragma unroll
     for (int k = 0; k < 4; k++) pih[k] = pgl_coop_word(ch.c, x, k);
   }
-  ch.observe_fr(dc->digest);
+  ch.observe_hash(dc->digest, dc->hash_kind);
 #pragma unroll
   for (int i = 0; i < 4; i++) ch.observe(pih[i]);
   const u32 cap_len = 1u << dc->cap_height;
-  ch.observe_cap(frs + 4 * dc->fr_wires_cap, cap_len);
+  ch.observe_cap(frs + 4 * dc->fr_wires_cap, cap_len, dc->hash_kind);
   const u32 nc = dc->num_challenges;
   for (u32 i = 0; i < nc; i++) { u64 v = ch.challenge(); if (writer) derived[dc->ch_betas + i] = v; }
   for (u32 i = 0; i < nc; i++) { u64 v = ch.challenge(); if (writer) derived[dc->ch_gammas + i] = v; }
-  ch.observe_cap(frs + 4 * dc->fr_zs_pp_cap, cap_len);
+  ch.observe_cap(frs + 4 * dc->fr_zs_pp_cap, cap_len, dc->hash_kind);
   for (u32 i = 0; i < nc; i++) { u64 v = ch.challenge(); if (writer) derived[dc->ch_alphas + i] = v; }
-  ch.observe_cap(frs + 4 * dc->fr_quot_cap, cap_len);
+  ch.observe_cap(frs + 4 * dc->fr_quot_cap, cap_len, dc->hash_kind);
   {
     u64 z0 = ch.challenge(), z1 = ch.challenge();
     if (writer) { derived[dc->ch_zeta] = z0; derived[dc->ch_zeta + 1] = z1; }
@@ -234,7 +244,7 @@ GPV_DEV void dev_transcript_coop(const DevCircuit* __restrict__ dc, const u64* _
   if (writer) { derived[dc->ch_fri_alpha] = fri_alpha.a; derived[dc->ch_fri_alpha + 1] = fri_alpha.b; }
 #pragma unroll 1
   for (u32 s = 0; s < dc->num_steps; s++) {
-    ch.observe_cap(frs + 4 * (dc->fr_commit_caps + s * cap_len), cap_len);
+    ch.observe_cap(frs + 4 * (dc->fr_commit_caps + s * cap_len), cap_len, dc->hash_kind);
     u64 b0 = ch.challenge(), b1 = ch.challenge();
     if (writer) { derived[dc->ch_fri_betas + 2 * s] = b0; derived[dc->ch_fri_betas + 2 * s + 1] = b1; }
   }

@@ -41,6 +41,7 @@ class Circuit:
         self.num_gate_constraints = L.gpv_num_gate_constraints(h)
         self.num_query_rounds = L.gpv_num_query_rounds(h)
         self.num_merkle_trees = L.gpv_num_merkle_trees(h)
+        self.hash_kind = L.gpv_circuit_hash_kind(h)  # 0 Poseidon-BN254 (the reference), 1 Poseidon-Goldilocks
 
     def describe(self):
         L = _lib.lib()

@@ -136,6 +136,13 @@ size_t gpv_num_challenge_words(const gpv_circuit* c);  /* 43 for the fixtures */
 size_t gpv_num_gate_constraints(const gpv_circuit* c);
 size_t gpv_num_query_rounds(const gpv_circuit* c);
 size_t gpv_num_merkle_trees(const gpv_circuit* c);     /* per query: 4 initial + one per reduction step */
+/* Hash configuration of the circuit, read off its verifier-only data: GPV_HASH_POSEIDON_BN254 = hashes are decimal strings
+ * (BN254 scalars: the reference's PoseidonBN254GoldilocksConfig, poseidon/bn254.go, fri/fri.go:104,113) or
+ * GPV_HASH_POSEIDON_GOLDILOCKS = hashes are {"elements": [4 x u64]} (plonky2's default PoseidonGoldilocksConfig: leaf hash
+ * = hash_or_noop over Goldilocks, 2-to-1 = permutation of 8 words, caps / digest observed as 4 elements -- SURVEY 8f.4; the
+ * reference has no such path, see DESIGN.md "parity unpinned"). Either way a hash is 4 x u64 in the packed record. */
+enum { GPV_HASH_KIND_POSEIDON_BN254 = 0, GPV_HASH_KIND_POSEIDON_GOLDILOCKS = 1 };
+size_t gpv_circuit_hash_kind(const gpv_circuit* c);
 /* Flat description ("circuit blob", layout in DESIGN.md) -- lets a caller inspect what was parsed.
  * Returns the number of words needed; writes at most cap words. */
 size_t gpv_circuit_describe(const gpv_circuit* c, uint64_t* blob, size_t cap);

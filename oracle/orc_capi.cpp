@@ -50,6 +50,22 @@ int orc_gl_op(int op, const u64* a, const u64* b, const u64* c, u64* out, size_t
   return 0;
 }
 
+// Poseidon-Goldilocks Merkle primitives (plonky2, unpinned): in [n][len] -> out [n][4]; l, r [n][4] -> out [n][4]
+int orc_poseidon_gl_hash_or_noop(const u64* in, size_t len, u64* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    GlHash h = poseidon_gl_hash_or_noop(in + i * len, len);
+    memcpy(out + 4 * i, h.w, 32);
+  }
+  return 0;
+}
+int orc_poseidon_gl_two_to_one(const u64* l, const u64* r, u64* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    GlHash h = poseidon_gl_two_to_one(gl_hash_from_words(l + 4 * i), gl_hash_from_words(r + 4 * i));
+    memcpy(out + 4 * i, h.w, 32);
+  }
+  return 0;
+}
+
 // The reference's hint functions, literally (goldilocks/base.go): big.Int Div / Rem by MODULUS, with the operand checks that
 // make the reference panic or error reported through ok[]. `in` / `out` rows as in include/gpv.h GPV_HINT_*.
 int orc_gl_hints(int hint, const u64* in, u64* out, uint8_t* ok, size_t n) {
@@ -323,14 +339,14 @@ int orc_merkle_chains(const void* cv, const void* proofs, const u64* challenges,
       uint8_t* o = ok + (i * c.num_query_rounds + q) * per_q;
       for (int t = 0; t < 4; t++)
         o[t] = verify_merkle_proof_to_cap(pv.leaf(q, t), c.leaf_len(t), bits.data(), cap_index, caps[t],
-                                          pv.fr_at(c.fr_off_query_tree(q, t)), c.initial_siblings());
+                                          pv.fr_at(c.fr_off_query_tree(q, t)), c.initial_siblings(), c.hash_kind);
       u64 shift = 0;
       for (u64 s = 0; s < c.num_steps(); s++) {
         shift += c.arity_bits[s];
         std::vector<u64> fe;
         for (u64 j = 0; j < ((u64)1 << c.arity_bits[s]); j++) { Ext e = pv.step_eval(q, s, j); fe.push_back(e.c[0]); fe.push_back(e.c[1]); }
         o[4 + s] = verify_merkle_proof_to_cap(fe.data(), fe.size(), bits.data() + shift, cap_index, pv.fr_at(c.fr_off_commit_cap(s)),
-                                              pv.fr_at(c.fr_off_query_step(q, s)), c.step_siblings(s));
+                                              pv.fr_at(c.fr_off_query_step(q, s)), c.step_siblings(s), c.hash_kind);
       }
     }
   }

@@ -37,7 +37,8 @@ struct Gate {
   std::vector<u64> weights;
 };
 
-static const u64 BLOB_MAGIC = 0x0001435650470000ULL;  // "\0\0GPVC" v1
+static const u64 BLOB_MAGIC = 0x0001435650470000ULL;  // "\0\0GPVC" v1; the low byte carries the hash configuration
+enum { HASH_POSEIDON_BN254 = 0, HASH_POSEIDON_GOLDILOCKS = 1 };
 static const int BLOB_HEADER_WORDS = 32;
 
 struct Circuit {
@@ -53,6 +54,9 @@ struct Circuit {
   // variables/circuit.go:21-24 (VerifierOnlyCircuitData)
   u64 constants_sigmas_cap[16][4];
   u64 circuit_digest[4];
+  // HASH_POSEIDON_BN254: the reference (poseidon/bn254.go). HASH_POSEIDON_GOLDILOCKS: plonky2's default configuration, restated
+  // from plonky2's published algorithm -- the reference has no such path, so that branch is PARITY UNPINNED.
+  int hash_kind = HASH_POSEIDON_BN254;
 
   // ---- derived shape
   u64 lde_bits() const { return degree_bits + rate_bits; }                     // types.go:47
@@ -131,8 +135,9 @@ struct Circuit {
 };
 
 static inline Circuit circuit_from_blob(const u64* b, size_t n) {
-  if (n < (size_t)BLOB_HEADER_WORDS || b[0] != BLOB_MAGIC) throw std::runtime_error("bad circuit blob");
+  if (n < (size_t)BLOB_HEADER_WORDS || (b[0] & ~(u64)0xFF) != BLOB_MAGIC || (b[0] & 0xFF) > 1) throw std::runtime_error("bad circuit blob");
   Circuit c;
+  c.hash_kind = (int)(b[0] & 0xFF);
   c.num_wires = b[1]; c.num_routed_wires = b[2]; c.num_constants = b[3]; c.num_challenges = b[4];
   c.num_partial_products = b[5]; c.quotient_degree_factor = b[6]; c.num_gate_constraints = b[7];
   c.num_public_inputs = b[8]; c.degree_bits = b[9]; c.rate_bits = b[10]; c.cap_height = b[11];

@@ -51,7 +51,14 @@ struct Challenger {
     poseidon_bn254_to_vec(fr_from_canonical(canon), v);
     observe_elements(v, 5);
   }
-  void observe_cap(const u64* cap, size_t n) { for (size_t i = 0; i < n; i++) observe_bn254_hash(cap + 4 * i); }  // :67-71
+  // hash_kind selects ObserveBN254Hash (the reference) or ObserveHash on the four elements of a Poseidon-Goldilocks HashOut
+  // (plonky2 Challenger::observe_hash / observe_cap; unpinned)
+  void observe_merkle_hash(const u64 h[4], int hash_kind) {
+    if (hash_kind == HASH_POSEIDON_GOLDILOCKS) observe_hash(h); else observe_bn254_hash(h);
+  }
+  void observe_cap(const u64* cap, size_t n, int hash_kind = HASH_POSEIDON_BN254) {  // :67-71
+    for (size_t i = 0; i < n; i++) observe_merkle_hash(cap + 4 * i, hash_kind);
+  }
   void observe_ext(Ext e) { observe_elements(e.c, 2); }                                                             // :73-75
   u64 get_challenge() {  // :89-98  pops from the END of the output buffer
     if (!in_buf.empty() || out_buf.empty()) duplexing();
@@ -120,14 +127,14 @@ static inline Challenges get_challenges(const ProofView& pv, const u64 pi_hash[4
   const Circuit& c = *pv.c;
   Challenger ch;
   Challenges out;
-  ch.observe_bn254_hash(c.circuit_digest);
+  ch.observe_merkle_hash(c.circuit_digest, c.hash_kind);
   ch.observe_hash(pi_hash);
-  ch.observe_cap(pv.fr_at(c.fr_off_wires_cap()), c.cap_len());
+  ch.observe_cap(pv.fr_at(c.fr_off_wires_cap()), c.cap_len(), c.hash_kind);
   for (u64 i = 0; i < c.num_challenges; i++) out.betas.push_back(ch.get_challenge());
   for (u64 i = 0; i < c.num_challenges; i++) out.gammas.push_back(ch.get_challenge());
-  ch.observe_cap(pv.fr_at(c.fr_off_zs_pp_cap()), c.cap_len());
+  ch.observe_cap(pv.fr_at(c.fr_off_zs_pp_cap()), c.cap_len(), c.hash_kind);
   for (u64 i = 0; i < c.num_challenges; i++) out.alphas.push_back(ch.get_challenge());
-  ch.observe_cap(pv.fr_at(c.fr_off_quotient_cap()), c.cap_len());
+  ch.observe_cap(pv.fr_at(c.fr_off_quotient_cap()), c.cap_len(), c.hash_kind);
   out.zeta = ch.get_ext_challenge();
   std::vector<Ext> zb, znb;
   fri_openings(pv, zb, znb);
@@ -136,7 +143,7 @@ static inline Challenges get_challenges(const ProofView& pv, const u64 pi_hash[4
   // GetFriChallenges
   out.fri_alpha = ch.get_ext_challenge();
   for (u64 s = 0; s < c.num_steps(); s++) {
-    ch.observe_cap(pv.fr_at(c.fr_off_commit_cap(s)), c.cap_len());
+    ch.observe_cap(pv.fr_at(c.fr_off_commit_cap(s)), c.cap_len(), c.hash_kind);
     out.fri_betas.push_back(ch.get_ext_challenge());
   }
   for (u64 i = 0; i < c.final_poly_len(); i++) ch.observe_ext(pv.final_coeff(i));
@@ -525,9 +532,44 @@ static inline std::vector<PolyInfo> fri_zs_polys(const Circuit& c) {  // fri_uti
 }
 
 // fri.go:97-144. leaf_index_bits[i] in {0,1}; cap_index = value of the cap index bits.
+// Poseidon-Goldilocks Merkle hashing as in plonky2 (hash/poseidon.rs PoseidonHash, hash/hashing.rs, hash/merkle_proofs.rs
+// verify_merkle_proof_to_cap) -- NOT in the reference, which hashes with BN254 only (fri.go:104,113): parity unpinned.
+//   hash_or_noop: at most 4 elements are their own digest, zero-padded; otherwise hash_no_pad (rate 8, overwrite mode)
+//   two_to_one  : first 4 words of permute([left, right, 0, 0, 0, 0])
+struct GlHash {
+  u64 w[4];
+  bool operator==(const GlHash& o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+};
+static inline GlHash gl_hash_from_words(const u64* p) { return GlHash{{gl_reduce(p[0]), gl_reduce(p[1]), gl_reduce(p[2]), gl_reduce(p[3])}}; }
+static inline GlHash poseidon_gl_hash_or_noop(const u64* in, size_t n) {
+  GlHash h{{0, 0, 0, 0}};
+  if (n <= 4) {
+    for (size_t i = 0; i < n; i++) h.w[i] = gl_reduce(in[i]);
+    return h;
+  }
+  poseidon_gl_hash_no_pad(in, n, h.w);
+  return h;
+}
+static inline GlHash poseidon_gl_two_to_one(const GlHash& l, const GlHash& r) {
+  u64 s[12] = {l.w[0], l.w[1], l.w[2], l.w[3], r.w[0], r.w[1], r.w[2], r.w[3], 0, 0, 0, 0};
+  poseidon_gl_permute(s);
+  return GlHash{{s[0], s[1], s[2], s[3]}};
+}
+static inline bool verify_merkle_proof_to_cap_gl(const u64* leaf, size_t leaf_len, const int* leaf_index_bits, unsigned cap_index,
+                                                 const u64* cap, const u64* siblings, size_t n_siblings) {
+  GlHash cur = poseidon_gl_hash_or_noop(leaf, leaf_len);
+  for (size_t i = 0; i < n_siblings; i++) {
+    GlHash sib = gl_hash_from_words(siblings + 4 * i);
+    cur = leaf_index_bits[i] ? poseidon_gl_two_to_one(sib, cur) : poseidon_gl_two_to_one(cur, sib);
+  }
+  return cur == gl_hash_from_words(cap + 4 * cap_index);
+}
 static inline bool verify_merkle_proof_to_cap(const u64* leaf, size_t leaf_len, const int* leaf_index_bits,
                                               unsigned cap_index, const u64* cap /*[16][4] canonical*/,
-                                              const u64* siblings /*[n][4] canonical*/, size_t n_siblings) {
+                                              const u64* siblings /*[n][4] canonical*/, size_t n_siblings,
+                                              int hash_kind = HASH_POSEIDON_BN254) {
+  if (hash_kind == HASH_POSEIDON_GOLDILOCKS)
+    return verify_merkle_proof_to_cap_gl(leaf, leaf_len, leaf_index_bits, cap_index, cap, siblings, n_siblings);
   Fr cur = poseidon_bn254_hash_or_noop(leaf, leaf_len);
   for (size_t i = 0; i < n_siblings; i++) {
     Fr sib = fr_from_canonical(siblings + 4 * i);
@@ -609,7 +651,7 @@ static inline int fri_verify_query_round(const ProofView& pv, const Challenges& 
                         pv.fr_at(c.fr_off_quotient_cap())};
   for (int o = 0; o < 4; o++) {
     if (!verify_merkle_proof_to_cap(pv.leaf(q, o), c.leaf_len(o), bits.data(), cap_index, caps[o],
-                                    pv.fr_at(c.fr_off_query_tree(q, o)), c.initial_siblings()))
+                                    pv.fr_at(c.fr_off_query_tree(q, o)), c.initial_siblings(), c.hash_kind))
       fail |= FAIL_MERKLE_INITIAL;
   }
   // calculateSubgroupX :187-206
@@ -654,7 +696,7 @@ static inline int fri_verify_query_round(const ProofView& pv, const Challenges& 
     std::vector<u64> field_evals;
     for (size_t j = 0; j < arity; j++) { field_evals.push_back(evals[j].c[0]); field_evals.push_back(evals[j].c[1]); }
     if (!verify_merkle_proof_to_cap(field_evals.data(), field_evals.size(), coset_index_bits.data(), cap_index,
-                                    pv.fr_at(c.fr_off_commit_cap(s)), pv.fr_at(c.fr_off_query_step(q, s)), c.step_siblings(s)))
+                                    pv.fr_at(c.fr_off_commit_cap(s)), pv.fr_at(c.fr_off_query_step(q, s)), c.step_siblings(s), c.hash_kind))
       fail |= FAIL_MERKLE_STEP;
     for (u64 j = 0; j < ab; j++) subgroup_x = gl_mul(subgroup_x, subgroup_x);  // :486-488
     cur_bits = coset_index_bits;
@@ -689,6 +731,10 @@ static inline int range_check_proof(const ProofView& pv) {
   // everything in the GL section except the public inputs
   for (u64 i = 0; i < c.off_public_inputs(); i++)
     if (!gl_is_canonical(pv.gl[i])) return FAIL_RANGE;
+  // Poseidon-Goldilocks configuration: caps and siblings are Goldilocks elements of the proof as well (unpinned)
+  if (c.hash_kind == HASH_POSEIDON_GOLDILOCKS)
+    for (u64 i = 0; i < 4 * c.n_fr(); i++)
+      if (!gl_is_canonical(pv.frs[i])) return FAIL_RANGE;
   return 0;
 }
 

@@ -24,6 +24,7 @@ GL_P = 2**64 - 2**32 + 1
 BN_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
 BLOB_MAGIC = 0x0001435650470000
+HASH_POSEIDON_BN254, HASH_POSEIDON_GOLDILOCKS = 0, 1
 BLOB_HEADER_WORDS = 32
 
 # gate kinds (include/gpv.h GPV_GATE_*)
@@ -96,8 +97,20 @@ class CircuitInfo:
         self.gates = [parse_gate_id(g) for g in common["gates"]]
         self.selector_indices = list(common["selectors_info"]["selector_indices"])
         self.groups = [(g["start"], g["end"]) for g in common["selectors_info"]["groups"]]
-        self.constants_sigmas_cap = [int(x) % BN_R for x in verifier_only["constants_sigmas_cap"]]
-        self.circuit_digest = int(verifier_only["circuit_digest"]) % BN_R
+        # hash configuration, read off the shape of the hashes: decimal strings = BN254 scalars (the reference's
+        # PoseidonBN254GoldilocksConfig), {"elements": [4 x u64]} = Poseidon-Goldilocks HashOut (plonky2's default)
+        self.hash_kind = HASH_POSEIDON_BN254 if isinstance(verifier_only["constants_sigmas_cap"][0], str) else HASH_POSEIDON_GOLDILOCKS
+        self.constants_sigmas_cap = [self.hash_words(x) for x in verifier_only["constants_sigmas_cap"]]
+        self.circuit_digest = self.hash_words(verifier_only["circuit_digest"])
+
+    def hash_words(self, x):
+        """one hash of the JSON -> its 4 words in the packed record"""
+        if self.hash_kind == HASH_POSEIDON_BN254:
+            return fr_limbs(int(x) % BN_R)
+        el = x["elements"] if isinstance(x, dict) else x
+        if len(el) != 4 or not all(0 <= int(v) < 2**64 for v in el):
+            raise ValueError("shape")
+        return [int(v) for v in el]
 
     # ---- layout
     @property
@@ -123,7 +136,7 @@ class CircuitInfo:
 
     def blob(self):
         hdr = [0] * BLOB_HEADER_WORDS
-        hdr[0] = BLOB_MAGIC
+        hdr[0] = BLOB_MAGIC | self.hash_kind
         hdr[1:14] = [self.num_wires, self.num_routed_wires, self.num_constants, self.num_challenges,
                      self.num_partial_products, self.quotient_degree_factor, self.num_gate_constraints,
                      self.num_public_inputs, self.degree_bits, self.rate_bits, self.cap_height, self.pow_bits,
@@ -149,8 +162,8 @@ class CircuitInfo:
             body[gate_off - BLOB_HEADER_WORDS + 8 * gi: gate_off - BLOB_HEADER_WORDS + 8 * gi + 8] = rec
         hdr[27] = put(self.selector_indices)
         hdr[28] = put([x for g in self.groups for x in g])
-        hdr[29] = put([w for v in self.constants_sigmas_cap for w in fr_limbs(v)])
-        hdr[30] = put(fr_limbs(self.circuit_digest))
+        hdr[29] = put([w for v in self.constants_sigmas_cap for w in v])
+        hdr[30] = put(self.circuit_digest)
         hdr[31] = BLOB_HEADER_WORDS + len(body)
         return np.array(hdr + body, dtype=np.uint64)
 
@@ -190,7 +203,7 @@ def pack_proof(ci, pj):
     def put_cap(cap):
         if len(cap) != ci.cap_len:
             raise ValueError("shape")  # fri_utils.go:175-179
-        frs.extend(int(x) % BN_R for x in cap)
+        frs.extend(ci.hash_words(x) for x in cap)
 
     put_cap(proof["wires_cap"])
     put_cap(proof["plonk_zs_partial_products_cap"])
@@ -209,7 +222,7 @@ def pack_proof(ci, pj):
             if len(leaf) != ci.leaf_len(o) or len(mp["siblings"]) + ci.cap_height != ci.lde_bits:
                 raise ValueError("shape")  # fri_utils.go:199-205
             gl.extend(leaf)
-            frs.extend(int(x) % BN_R for x in mp["siblings"])
+            frs.extend(ci.hash_words(x) for x in mp["siblings"])
         if len(qr["steps"]) != len(ci.arity_bits):
             raise ValueError("shape")  # fri_utils.go:208-210
         bits = ci.lde_bits
@@ -218,7 +231,7 @@ def pack_proof(ci, pj):
             if len(st["evals"]) != (1 << ci.arity_bits[s]) or len(st["merkle_proof"]["siblings"]) + ci.cap_height != bits:
                 raise ValueError("shape")  # fri_utils.go:219-225
             put_ext(st["evals"], 1 << ci.arity_bits[s])
-            frs.extend(int(x) % BN_R for x in st["merkle_proof"]["siblings"])
+            frs.extend(ci.hash_words(x) for x in st["merkle_proof"]["siblings"])
     put_ext(fp["final_poly"]["coeffs"], ci.final_poly_len)
     gl.append(fp["pow_witness"])
     if len(pj["public_inputs"]) != ci.num_public_inputs:
@@ -229,7 +242,7 @@ def pack_proof(ci, pj):
             raise ValueError("not a uint64")
     words = list(gl)
     for v in frs:
-        words.extend(fr_limbs(v))
+        words.extend(v)
     return np.array(words, dtype=np.uint64).tobytes()
 
 
@@ -322,6 +335,21 @@ class Oracle:
         ok = np.ones(inp.shape[0], dtype=np.uint8)
         assert self.lib.orc_gl_hints(hint, _p(inp), _p(out), _p(ok), ctypes.c_size_t(inp.shape[0])) == 0
         return out, ok
+
+    def poseidon_gl_hash_or_noop(self, inputs):
+        """plonky2 PoseidonHash::hash_or_noop on [n][len] -> [n][4] (unpinned: no reference counterpart)"""
+        a = u64arr(inputs)
+        a = a.reshape(1, -1) if a.ndim == 1 else a
+        out = np.empty((a.shape[0], 4), dtype=np.uint64)
+        assert self.lib.orc_poseidon_gl_hash_or_noop(_p(a), ctypes.c_size_t(a.shape[1]), _p(out), ctypes.c_size_t(a.shape[0])) == 0
+        return out
+
+    def poseidon_gl_two_to_one(self, l, r):
+        l = u64arr(l).reshape(-1, 4)
+        r = u64arr(r).reshape(-1, 4)
+        out = np.empty_like(l)
+        assert self.lib.orc_poseidon_gl_two_to_one(_p(l), _p(r), _p(out), ctypes.c_size_t(l.shape[0])) == 0
+        return out
 
     def gl2_op(self, op, a, b=None):
         a = u64arr(a).reshape(-1, 2)
@@ -549,3 +577,89 @@ def permuted_query_batch(ci, packed, challenges, perms):
     idx = ch[0, ncw - nq:]
     ch[:, ncw - nq:] = idx[perms]
     return out.view(np.uint8).reshape(n, -1), ch
+
+
+# ---------------------------------------------------------------- Poseidon-Goldilocks configuration
+def poseidon_gl_config_fixture(name):
+    """The fixture re-committed under plonky2's default PoseidonGoldilocksConfig -- there is no such fixture in the reference
+    (it hashes with BN254 only, fri/fri.go:104,113), so this builds one: every field element of the proof (openings, leaves,
+    evaluations, final polynomial, public inputs) is kept, and the Merkle data is rebuilt with Poseidon-Goldilocks hashing so
+    that all 28 query paths of every tree are consistent with one cap:
+      * leaf digests = hash_or_noop of the same leaves;
+      * a sibling that is itself on (or the parent of) another query's path is that path's computed node; every other
+        sibling is free -- the fixture's BN254 sibling is reused, its four 64-bit limbs reduced mod p;
+      * cap entries reached by a path are the computed roots, the others the reduced BN254 entries; circuit digest likewise.
+    The Fiat-Shamir transcript of such a record differs (different caps), so it is NOT a valid proof under its own
+    challenges; under the ORIGINAL challenges (query indices, alphas, betas ... of the BN254 fixture) every assertion of
+    plonk.Verify and VerifyFriProof holds, which is exactly what gpv_verify_given_challenges checks.
+    Returns (CircuitInfo, packed bytes, (common, verifier_only, proof) json dicts, original challenges [ncw])."""
+    key = name + "/poseidon_gl"
+    if key in _fixture_cache:
+        return _fixture_cache[key]
+    ci0, packed0, (common, vo, pj) = load_fixture(name)
+    orc = oracle()
+    one = np.frombuffer(packed0, dtype=np.uint8).reshape(1, -1)
+    ch = orc.challenges(orc.circuit(ci0), one)[0]
+    nq = ci0.num_query_rounds
+    idx = [int(ch[len(ch) - nq + q]) % GL_P & ((1 << ci0.lde_bits) - 1) for q in range(nq)]
+
+    def conv(x):  # a BN254 hash of the fixture -> four Goldilocks words (a "free" value)
+        return [w % GL_P for w in fr_limbs(int(x) % BN_R)]
+
+    def H(v):
+        return {"elements": [int(w) for w in v]}
+
+    pj2 = json.loads(json.dumps(pj))
+    fp = pj2["proof"]["opening_proof"]
+    n_steps = len(ci0.arity_bits)
+    trees = []  # (n_sib, positions[q], leaves[q], sibling lists (json, by reference), original cap)
+    caps_json = [vo["constants_sigmas_cap"], pj["proof"]["wires_cap"], pj["proof"]["plonk_zs_partial_products_cap"],
+                 pj["proof"]["quotient_polys_cap"]] + list(pj["proof"]["opening_proof"]["commit_phase_merkle_caps"])
+    for t in range(4 + n_steps):
+        if t < 4:
+            n_sib, shift = ci0.lde_bits - ci0.cap_height, 0
+            leaves = [fp["query_round_proofs"][q]["initial_trees_proof"]["evals_proofs"][t][0] for q in range(nq)]
+            sibs = [fp["query_round_proofs"][q]["initial_trees_proof"]["evals_proofs"][t][1]["siblings"] for q in range(nq)]
+        else:
+            s_ = t - 4
+            shift = sum(ci0.arity_bits[:s_ + 1])
+            n_sib = ci0.lde_bits - ci0.cap_height - shift
+            leaves = [[w for e in fp["query_round_proofs"][q]["steps"][s_]["evals"] for w in e] for q in range(nq)]
+            sibs = [fp["query_round_proofs"][q]["steps"][s_]["merkle_proof"]["siblings"] for q in range(nq)]
+        trees.append((n_sib, [i >> shift for i in idx], leaves, sibs, caps_json[t]))
+    new_caps = []
+    for n_sib, pos, leaves, sibs, cap0 in trees:
+        digests = orc.poseidon_gl_hash_or_noop(np.array(leaves, dtype=np.uint64))
+        level = {pos[q]: [int(w) for w in digests[q]] for q in range(nq)}
+        free = {}  # (level, position) -> value of a sibling no path computes
+        known = []
+        for l in range(n_sib):
+            known.append(level)
+            todo = sorted({p >> 1 for p in level})
+            lefts, rights = [], []
+            for par in todo:
+                pair = []
+                for child in (2 * par, 2 * par + 1):
+                    if child in level:
+                        pair.append(level[child])
+                    else:
+                        if (l, child) not in free:
+                            q = next(q for q in range(nq) if (pos[q] >> l) == (child ^ 1))
+                            free[(l, child)] = conv(sibs[q][l])
+                        pair.append(free[(l, child)])
+                lefts.append(pair[0])
+                rights.append(pair[1])
+            out = orc.poseidon_gl_two_to_one(np.array(lefts, dtype=np.uint64), np.array(rights, dtype=np.uint64))
+            level = {par: [int(w) for w in out[i]] for i, par in enumerate(todo)}
+        for q in range(nq):
+            for l in range(n_sib):
+                sp = (pos[q] >> l) ^ 1
+                sibs[q][l] = H(known[l][sp] if sp in known[l] else free[(l, sp)])
+        new_caps.append([H(level[i]) if i in level else H(conv(cap0[i])) for i in range(ci0.cap_len)])
+    vo2 = {"constants_sigmas_cap": new_caps[0], "circuit_digest": H(conv(vo["circuit_digest"]))}
+    pj2["proof"]["wires_cap"], pj2["proof"]["plonk_zs_partial_products_cap"], pj2["proof"]["quotient_polys_cap"] = new_caps[1:4]
+    fp["commit_phase_merkle_caps"] = new_caps[4:]
+    ci = CircuitInfo(common, vo2)
+    assert ci.hash_kind == HASH_POSEIDON_GOLDILOCKS
+    _fixture_cache[key] = (ci, pack_proof(ci, pj2), (common, vo2, pj2), ch.copy())
+    return _fixture_cache[key]

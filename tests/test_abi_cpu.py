@@ -94,6 +94,32 @@ def test_ingest_matches_python_reference_reading(gpv, name):  # types/*_test.go,
     assert proofs.data.tobytes() == packed
 
 
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_ingest_poseidon_goldilocks_configuration(gpv, name):
+    """a circuit / proof whose hashes are Poseidon-Goldilocks HashOuts ({"elements": [4 x u64]}, plonky2's serde
+    form) is recognised by the shape of its hashes; the C++ ingest packs it exactly like the independent Python packer, same
+    record size as the BN254 form (a hash is 4 x u64 either way). Non-canonical circuit hashes are refused."""
+    ci, packed, (common, vo, pj), _ = T.poseidon_gl_config_fixture(name)
+    circuit = _circuit(gpv, common, vo)
+    assert circuit.hash_kind == 1 and circuit.proof_nbytes == len(packed) == {"decode_block": 127256, "step": 133416}[name]
+    assert (circuit.describe() == ci.blob()).all()
+    got = gpv.variables.DeserializeProofWithPublicInputs(gpv.types.ProofWithPublicInputsRaw(json.dumps(pj)), circuit)
+    assert got.data.tobytes() == packed
+    ci0, packed0, (c0, vo0, pj0) = T.load_fixture(name)
+    assert _circuit(gpv, c0, vo0).hash_kind == 0
+    # wrong hash form for the circuit's configuration -> shape error, never a mis-parse
+    with pytest.raises(gpv.ShapeError):
+        gpv.variables.DeserializeProofWithPublicInputs(gpv.types.ProofWithPublicInputsRaw(json.dumps(pj0)), circuit)
+    bad = json.loads(json.dumps(vo))
+    bad["constants_sigmas_cap"][3]["elements"][1] = 2**64 - 1
+    with pytest.raises(gpv.ShapeError):
+        _circuit(gpv, common, bad)
+    bad = json.loads(json.dumps(vo))
+    bad["circuit_digest"] = {"elements": [1, 2, 3]}
+    with pytest.raises(gpv.ShapeError):
+        _circuit(gpv, common, bad)
+
+
 def _circuit(gpv, common_obj, vo_obj):
     return gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(common_obj)),
                                  gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo_obj)))

@@ -882,6 +882,95 @@ def test_group_multi_device_if_present(gpv, orc):
         grp.close()
 
 
+# ---------------------------------------------------------------- Poseidon-Goldilocks Merkle configuration
+def _load_gl(gpv, name):
+    ci, packed, (common, vo, pj), ch = T.poseidon_gl_config_fixture(name)
+    circuit = gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(common)), gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)))
+    proofs = gpv.variables.DeserializeProofWithPublicInputs(gpv.types.ProofWithPublicInputsRaw(json.dumps(pj)), circuit)
+    assert proofs.data.tobytes() == packed and circuit.hash_kind == 1
+    return ci, packed, circuit, proofs, ch, gpv.types.CommonCircuitData(json.dumps(common))
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_poseidon_goldilocks_config_verifies_rebuilt_trees(gpv, api, orc, name):
+    """PARITY UNPINNED (no reference path or fixture: fri/fri.go:104,113 hash with BN254 only). What can be pinned: the
+    Poseidon-Goldilocks permutation and HashNoPad themselves are (goldilocks_test.go, public_inputs_hash_test.go), the
+    oracle restates plonky2's hash_or_noop / two_to_one / verify_merkle_proof_to_cap on top of them, and here the GPU path must
+    (a) ACCEPT the fixture whose Merkle trees were rebuilt with that hashing (tests/gpv_testlib.poseidon_gl_config_fixture:
+    all 28 paths of all 6 trees consistent with one cap) under the original challenges, (b) match the oracle bit for bit --
+    per-chain Merkle results, failure masks, transcript challenges -- on tampered records, with the shared upper levels forced
+    on and off."""
+    ci, packed, circuit, proofs, ch0, common = _load_gl(gpv, name)
+    oc = orc.circuit(ci)
+    chip = gpv.verifier.NewVerifierChip(api, common)
+    one = gpv.variables.ProofBatch(circuit, np.frombuffer(packed, dtype=np.uint8).reshape(1, -1).copy())
+    acc, mask = chip.VerifyWithChallenges(one, ch0.reshape(1, -1))
+    assert acc.tolist() == [1] and mask.tolist() == [0]
+    # transcript under this configuration: ObserveHash on 4-element digests / caps
+    got_ch = chip.GetChallenges(one).flat
+    assert (got_ch == orc.challenges(oc, one.data)).all() and (got_ch[0] != ch0).any()
+    n = 200
+    rng = np.random.default_rng(21)
+    words = np.tile(np.frombuffer(packed, dtype=np.uint64), (n, 1)).copy()
+    q0, qwords, f0, qfr, n_gl = T.query_section_layout(ci)
+    chs = np.tile(ch0.reshape(1, -1), (n, 1)).copy()
+    tampered = np.zeros(n, dtype=bool)
+    for i in range(0, n, 3):
+        site = (i // 3) % 6
+        if site == 0:
+            words[i, q0 + int(rng.integers(0, ci.num_query_rounds * qwords))] ^= np.uint64(1)            # a leaf word / evaluation
+        elif site == 1:
+            words[i, n_gl + 4 * f0 + int(rng.integers(0, 4 * ci.num_query_rounds * qfr))] ^= np.uint64(1 << 7)   # one word of a sibling
+        elif site == 2:
+            qi = int(ch0[len(ch0) - 1 - int(rng.integers(0, ci.num_query_rounds))]) % P            # an entry some query path ends in
+            cap_index = (qi & ((1 << ci.lde_bits) - 1)) >> (ci.lde_bits - ci.cap_height)
+            tree = int(rng.integers(0, 3 + len(ci.arity_bits)))                                        # wires / zs / quotient / commit caps
+            words[i, n_gl + 4 * (tree * ci.cap_len + cap_index) + int(rng.integers(0, 4))] ^= np.uint64(2)
+        elif site == 3:
+            words[i, n_gl + 4 * f0 + int(rng.integers(0, 4 * ci.num_query_rounds * qfr))] = np.uint64(P + 5)   # non-canonical hash word
+        elif site == 4:
+            words[i, int(rng.integers(0, q0))] ^= np.uint64(4)                                        # an opening
+        else:
+            chs[i, -1 - int(rng.integers(0, ci.num_query_rounds))] ^= np.uint64(8)                     # a wrong query index
+        tampered[i] = True
+    batch = words.view(np.uint8).reshape(n, -1)
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    noncanon = (words[:, :n_gl - ci.num_public_inputs] >= np.uint64(P)).any(axis=1) | (words[:, n_gl:] >= np.uint64(P)).any(axis=1)
+    expect = orc.plonk_verify(oc, batch, chs).astype(np.int64) | orc.fri_verify(oc, batch, chs).astype(np.int64) | noncanon.astype(np.int64)
+    assert ((expect != 0) == tampered).all()
+    chains = gpv.fri.NewChip(api).VerifyMerkleProofsToCap(pb, chs)
+    assert (chains == orc.merkle_chains(oc, batch, chs).reshape(chains.shape)).all()
+    for shared in (2, 0):
+        api.set_option(2, shared)
+        try:
+            acc, mask = chip.VerifyWithChallenges(pb, chs)
+        finally:
+            api.set_option(2, 1)
+        assert acc.tolist() == (~tampered).astype(np.uint8).tolist(), shared
+        clean = ~noncanon  # with a non-canonical word the remaining diagnostics are unspecified
+        assert mask[clean].tolist() == expect[clean].tolist(), shared
+        assert ((mask[noncanon] & 1) == 1).all()
+    # full Verify (own transcript): rejects -- the rebuilt caps change every challenge -- with the oracle's masks
+    accept, fmask, fch = chip.Verify(pb, None, detail=True)
+    oacc, ofail, och = orc.verify(oc, batch, n_threads=8)
+    assert accept.tolist() == oacc.tolist() == [0] * n and (fch.flat == och).all()
+    assert fmask[clean].tolist() == [int(x) for x in ofail[clean]]
+
+
+def test_poseidon_goldilocks_merkle_primitives(gpv, api, orc):
+    """hash_or_noop / two_to_one of the Poseidon-Goldilocks configuration through the product's own chip operators:
+    HashNoPad for > 4 words (pinned by public_inputs_hash_test.go), identity-with-padding below, 2-to-1 = Poseidon of 8 words."""
+    rng = np.random.default_rng(4)
+    pg = gpv.poseidon.NewGoldilocksChip(api)
+    for ln in (5, 16, 20, 32, 85, 136):
+        x = rand_gl(rng, (64, ln))
+        assert (pg.HashNoPad(x) == orc.poseidon_gl_hash_or_noop(x)).all()
+    l, r = rand_gl(rng, (64, 4)), rand_gl(rng, (64, 4))
+    st = np.concatenate([l, r, np.zeros((64, 4), dtype=np.uint64)], axis=1)
+    assert (pg.Poseidon(st)[:, :4] == orc.poseidon_gl_two_to_one(l, r)).all()
+    assert orc.poseidon_gl_hash_or_noop(np.array([[7, 8, 9]], dtype=np.uint64)).tolist() == [[7, 8, 9, 0]]
+
+
 # ---------------------------------------------------------------- hint functions (witness generation, SURVEY 8f.3)
 def test_gl_hint_functions(gpv, api, orc):
     """gpv_gl_hints == exact integers == oracle: MulAddHint (incl. base_test.go:97-116), ReduceHint on Fr-sized inputs,
