@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-poseidon-gl", action="store_true")
     ap.add_argument("--no-heterogeneous", action="store_true")
+    ap.add_argument("--no-poseidon-gl-config", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the accept all-gather even at world size 1 (test hook)")
     args = ap.parse_args()
 
@@ -347,6 +348,8 @@ def main():
             line["poseidon_gl"] = bench_poseidon_gl(gpv, T, ctx, dev)
         if not args.no_heterogeneous and n_ranks == 1:
             line["heterogeneous"] = bench_heterogeneous(gpv, T, ctx, wl, dev, n_local, max(2, min(args.steps, 5)), proofs_per_s)
+        if not args.no_poseidon_gl_config and n_ranks == 1:
+            line["poseidon_gl_config"] = bench_poseidon_gl_config(gpv, T, ctx, args.fixture, dev, n_local, max(2, min(args.steps, 5)))
         if not args.no_cpu_baseline and n_ranks == 1:
             line["cpu_baseline"] = bench_cpu_baseline(T, ci, batch, expect)
     if torch_dist:
@@ -460,6 +463,35 @@ def bench_heterogeneous(gpv, T, ctx, wl, dev, n, steps, cloned_rate):
     out["all_invalid_no_sharing"] = {"proofs_per_s": n / dt, "ms_per_step": 1e3 * dt,
                                      "note": "every path of the four initial trees carries random top siblings: nothing can be shared, every proof rejected"}
     return out
+
+
+def bench_poseidon_gl_config(gpv, T, ctx, fixture, dev, n, steps):
+    """NOT the headline and not the reference's configuration: the same fixture with its Merkle trees rebuilt under plonky2's
+    default Poseidon-Goldilocks hashing (parity unpinned -- tests/gpv_testlib.poseidon_gl_config_fixture), n valid
+    copies verified with the original challenges (gpv_verify_given_challenges_dev). Shows what the engine does when the hash is
+    ~20x cheaper: the Merkle kernels stop dominating."""
+    ci, packed, (common, vo, pj), ch = T.poseidon_gl_config_fixture(fixture)
+    circuit = gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(common)), gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)))
+    rec = torch.from_numpy(np.frombuffer(packed, dtype=np.int64).copy()).to(dev)
+    batch = rec.repeat(n, 1).contiguous()
+    q0, qwords, f0, qfr, n_gl = T.query_section_layout(ci)
+    tam = np.array([T.splitmix64(1 + i) % 16 == 0 for i in range(n)])
+    rows = torch.tensor(np.nonzero(tam)[0], device=dev)
+    cols = torch.tensor([q0 + T.splitmix64(2 + int(i)) % (ci.num_query_rounds * qwords) for i in np.nonzero(tam)[0]], device=dev)
+    batch[rows, cols] = batch[rows, cols] ^ 1
+    chs = torch.from_numpy(np.asarray(ch, dtype=np.uint64).view(np.int64).copy()).to(dev).repeat(n, 1).contiguous()
+    acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+    chip = gpv.verifier.NewVerifierChip(ctx, None)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    dt = _time_steps(ctx, lambda: chip.VerifyWithChallengesDevice(circuit, batch.data_ptr(), chs.data_ptr(), n, acc.data_ptr()), steps)
+    stage = {nm: ctx.timing_get(k)[0] for nm, k in (("merkle_walk", 0), ("merkle_leaves", 7), ("plonk", 3), ("fri_query", 4), ("range_check", 5))}
+    ctx.timing_enable(False)
+    if not (acc.cpu().numpy() == (~tam).astype(np.uint8)).all():
+        raise SystemExit("poseidon_gl_config: accept vector mismatch")
+    return {"proofs_per_s": n / dt, "ms_per_step": 1e3 * dt, "proofs": n, "steps": steps, "stage_ms": stage,
+            "hash": "Poseidon-Goldilocks (plonky2 PoseidonGoldilocksConfig); parity unpinned: no reference implementation or fixture",
+            "entry_point": "gpv_verify_given_challenges_dev on rebuilt-tree copies of testdata/%s, 1 in 16 tampered" % fixture}
 
 
 def _cgroup_cpu_limit():

@@ -152,3 +152,264 @@ func (ctx *Context) ChallengerRun(script []uint32, in []uint64, nIn, nOut, n int
 		(*C.uint64_t)(unsafe.Pointer(&out[0])), C.size_t(nOut), C.size_t(n)), ctx.h)
 	return out
 }
+
+// ---------------------------------------------------------------- the rest of include/gpv.h (round 2; still UNCOMPILED)
+
+func u64p(s []uint64) *C.uint64_t {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.uint64_t)(unsafe.Pointer(&s[0]))
+}
+
+func (c *Circuit) Close()                 { C.gpv_circuit_destroy(c.h) }
+func (c *Circuit) NumChallengeWords() int { return int(C.gpv_num_challenge_words(c.h)) }
+func (c *Circuit) NumQueryRounds() int    { return int(C.gpv_num_query_rounds(c.h)) }
+func (c *Circuit) NumMerkleTrees() int    { return int(C.gpv_num_merkle_trees(c.h)) }
+
+// HashKind: 0 = Poseidon-BN254 (the reference's configuration), 1 = Poseidon-Goldilocks (plonky2's default).
+func (c *Circuit) HashKind() int { return int(C.gpv_circuit_hash_kind(c.h)) }
+
+// PackProofs converts n proof JSON documents on nThreads host threads (gpv_proof_pack_json_batch).
+func (c *Circuit) PackProofs(proofJSONs [][]byte, nThreads int) []byte {
+	n := len(proofJSONs)
+	out := make([]byte, n*c.ProofNBytes())
+	ptrs := make([]*C.char, n)
+	lens := make([]C.size_t, n)
+	for i, p := range proofJSONs {
+		ptrs[i] = (*C.char)(C.CBytes(p)) // C copies: cgo must not hold Go pointers to Go pointers
+		lens[i] = C.size_t(len(p))
+	}
+	defer func() {
+		for _, p := range ptrs {
+			C.free(unsafe.Pointer(p))
+		}
+	}()
+	check(C.gpv_proof_pack_json_batch(c.h, (**C.char)(unsafe.Pointer(&ptrs[0])), &lens[0], C.size_t(n), unsafe.Pointer(&out[0]), C.int(nThreads)), nil)
+	return out
+}
+
+// SetOption: GPV_OPT_TRANSCRIPT_VARIANT (1) / GPV_OPT_MERKLE_SHARED_LEVELS (2).
+func (ctx *Context) SetOption(option, value int) { check(C.gpv_ctx_set_option(ctx.h, C.int(option), C.int(value)), ctx.h) }
+
+// GlHints = the hint functions of goldilocks.Chip (base.go:223-359): hint 0 MulAdd (3 -> 2 words per item), 1 Reduce (4 -> 5),
+// 2 Inverse (1 -> 1), 3 SplitLimbs (1 -> 2). ok[i] is false where the reference hint panics.
+func (ctx *Context) GlHints(hint int, in []uint64, wordsIn, wordsOut int) ([]uint64, []bool) {
+	n := len(in) / wordsIn
+	out := make([]uint64, n*wordsOut)
+	okb := make([]byte, n)
+	check(C.gpv_gl_hints(ctx.h, C.int(hint), u64p(in), u64p(out), (*C.uint8_t)(unsafe.Pointer(&okb[0])), C.size_t(n)), ctx.h)
+	ok := make([]bool, n)
+	for i := range okb {
+		ok[i] = okb[i] == 1
+	}
+	return out, ok
+}
+
+// Gl2Op = Add/Sub/Mul/Inverse/DivExtension (op 0/1/2/4/6); ok[i] false where the reference asserts a non-zero operand.
+func (ctx *Context) Gl2Op(op int, a, b []uint64) ([]uint64, []bool) {
+	n := len(a) / 2
+	out := make([]uint64, len(a))
+	okb := make([]byte, n)
+	check(C.gpv_gl2_op(ctx.h, C.int(op), u64p(a), u64p(b), u64p(out), (*C.uint8_t)(unsafe.Pointer(&okb[0])), C.size_t(n)), ctx.h)
+	ok := make([]bool, n)
+	for i := range okb {
+		ok[i] = okb[i] == 1
+	}
+	return out, ok
+}
+
+func (ctx *Context) Gl2Exp(a []uint64, exponent uint64) []uint64 {
+	out := make([]uint64, len(a))
+	check(C.gpv_gl2_exp(ctx.h, u64p(a), C.uint64_t(exponent), u64p(out), C.size_t(len(a)/2)), ctx.h)
+	return out
+}
+
+func (ctx *Context) Gl2ReduceWithPowers(terms []uint64, termsPerItem int, scalar []uint64) []uint64 {
+	n := len(scalar) / 2
+	out := make([]uint64, 2*n)
+	check(C.gpv_gl2_reduce_with_powers(ctx.h, u64p(terms), C.size_t(termsPerItem), u64p(scalar), u64p(out), C.size_t(n)), ctx.h)
+	return out
+}
+
+func (ctx *Context) Gl2AlgOp(op int, a, b []uint64) []uint64 {
+	out := make([]uint64, len(a))
+	check(C.gpv_gl2alg_op(ctx.h, C.int(op), u64p(a), u64p(b), u64p(out), C.size_t(len(a)/4)), ctx.h)
+	return out
+}
+
+func (ctx *Context) PoseidonGLHashNoPad(in []uint64, length int) []uint64 {
+	n := len(in) / length
+	out := make([]uint64, 4*n)
+	check(C.gpv_poseidon_gl_hash_no_pad(ctx.h, u64p(in), C.size_t(length), u64p(out), C.size_t(n)), ctx.h)
+	return out
+}
+
+func (ctx *Context) PoseidonGLHashNToMNoPad(in []uint64, length, nOut int) []uint64 {
+	n := len(in) / length
+	out := make([]uint64, nOut*n)
+	check(C.gpv_poseidon_gl_hash_n_to_m_no_pad(ctx.h, u64p(in), C.size_t(length), u64p(out), C.size_t(nOut), C.size_t(n)), ctx.h)
+	return out
+}
+
+func (ctx *Context) PoseidonBN254HashOrNoop(in []uint64, length int) []uint64 {
+	n := len(in) / length
+	out := make([]uint64, 4*n)
+	check(C.gpv_poseidon_bn254_hash_or_noop(ctx.h, u64p(in), C.size_t(length), u64p(out), C.size_t(n)), ctx.h)
+	return out
+}
+
+func (ctx *Context) PoseidonBN254TwoToOne(left, right []uint64) []uint64 {
+	out := make([]uint64, len(left))
+	check(C.gpv_poseidon_bn254_two_to_one(ctx.h, u64p(left), u64p(right), u64p(out), C.size_t(len(left)/4)), ctx.h)
+	return out
+}
+
+func (ctx *Context) PoseidonBN254ToVec(hashes []uint64) []uint64 {
+	n := len(hashes) / 4
+	out := make([]uint64, 5*n)
+	check(C.gpv_poseidon_bn254_to_vec(ctx.h, u64p(hashes), u64p(out), C.size_t(n)), ctx.h)
+	return out
+}
+
+// GateEvalUnfiltered = gates.Gate.EvalUnfiltered on n variable sets (plonk/gates/gates.go:11-18).
+func (ctx *Context) GateEvalUnfiltered(kind int, p0, p1, p2 uint64, weights, constants []uint64, nConstants int, wires []uint64, nWires int,
+	piHash []uint64, maxOut int) ([]uint64, int) {
+	n := len(piHash) / 4
+	out := make([]uint64, 2*maxOut*n)
+	var nOut C.size_t
+	check(C.gpv_gate_eval_unfiltered(ctx.h, C.int(kind), C.uint64_t(p0), C.uint64_t(p1), C.uint64_t(p2), u64p(weights), C.size_t(len(weights)),
+		u64p(constants), C.size_t(nConstants), u64p(wires), C.size_t(nWires), u64p(piHash), u64p(out), C.size_t(maxOut), &nOut, C.size_t(n)), ctx.h)
+	return out, int(nOut)
+}
+
+func (ctx *Context) PublicInputsHash(c *Circuit, proofs []byte) []uint64 {
+	n := len(proofs) / c.ProofNBytes()
+	out := make([]uint64, 4*n)
+	check(C.gpv_public_inputs_hash(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(out)), ctx.h)
+	return out
+}
+
+func (ctx *Context) GateConstraints(c *Circuit, proofs []byte) []uint64 {
+	n := len(proofs) / c.ProofNBytes()
+	out := make([]uint64, 2*n*int(C.gpv_num_gate_constraints(c.h)))
+	check(C.gpv_gate_constraints(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(out)), ctx.h)
+	return out
+}
+
+// MerkleVerify = verifyMerkleProofToCapWithCapIndex for every (proof, query, tree) (fri/fri.go:97-144).
+func (ctx *Context) MerkleVerify(c *Circuit, proofs []byte, challenges []uint64) []bool {
+	n := len(proofs) / c.ProofNBytes()
+	okb := make([]byte, n*c.NumQueryRounds()*c.NumMerkleTrees())
+	check(C.gpv_merkle_verify(ctx.h, c.h, unsafe.Pointer(&proofs[0]), u64p(challenges), C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&okb[0]))), ctx.h)
+	ok := make([]bool, len(okb))
+	for i := range okb {
+		ok[i] = okb[i] == 1
+	}
+	return ok
+}
+
+// VerifyWithChallenges = Verify with the GetChallenges step replaced by the caller's ProofChallenges (the shape of
+// fri_test.go:106-133 / plonk_test.go:39-66).
+func (ctx *Context) VerifyWithChallenges(c *Circuit, proofs []byte, challenges []uint64) ([]bool, []uint32) {
+	n := len(proofs) / c.ProofNBytes()
+	acc := make([]byte, n)
+	mask := make([]uint32, n)
+	check(C.gpv_verify_given_challenges(ctx.h, c.h, unsafe.Pointer(&proofs[0]), u64p(challenges), C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&acc[0])),
+		(*C.uint32_t)(unsafe.Pointer(&mask[0]))), ctx.h)
+	out := make([]bool, n)
+	for i := range acc {
+		out[i] = acc[i] == 1
+	}
+	return out, mask
+}
+
+// VerifyDetail = Verify plus the failure mask and the derived challenges.
+func (ctx *Context) VerifyDetail(c *Circuit, proofs []byte) ([]bool, []uint32, []uint64) {
+	n := len(proofs) / c.ProofNBytes()
+	acc := make([]byte, n)
+	mask := make([]uint32, n)
+	ch := make([]uint64, n*c.NumChallengeWords())
+	check(C.gpv_verify_detail(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&acc[0])),
+		(*C.uint32_t)(unsafe.Pointer(&mask[0])), u64p(ch)), ctx.h)
+	out := make([]bool, n)
+	for i := range acc {
+		out[i] = acc[i] == 1
+	}
+	return out, mask, ch
+}
+
+// Device-resident entry points take raw device addresses (e.g. from a HIP allocator binding); they enqueue on the context's
+// stream and do not synchronise.
+func (ctx *Context) VerifyDev(c *Circuit, proofsDev unsafe.Pointer, n int, acceptDev unsafe.Pointer) {
+	check(C.gpv_verify_dev(ctx.h, c.h, proofsDev, C.size_t(n), (*C.uint8_t)(acceptDev)), ctx.h)
+}
+func (ctx *Context) ChallengesDev(c *Circuit, proofsDev unsafe.Pointer, n int, challengesDev unsafe.Pointer) {
+	check(C.gpv_challenges_dev(ctx.h, c.h, proofsDev, C.size_t(n), (*C.uint64_t)(challengesDev)), ctx.h)
+}
+func (ctx *Context) MerkleVerifyDev(c *Circuit, proofsDev, challengesDev unsafe.Pointer, n int, okDev unsafe.Pointer) {
+	check(C.gpv_merkle_verify_dev(ctx.h, c.h, proofsDev, (*C.uint64_t)(challengesDev), C.size_t(n), (*C.uint8_t)(okDev)), ctx.h)
+}
+func (ctx *Context) VerifyWithChallengesDev(c *Circuit, proofsDev, challengesDev unsafe.Pointer, n int, acceptDev unsafe.Pointer) {
+	check(C.gpv_verify_given_challenges_dev(ctx.h, c.h, proofsDev, (*C.uint64_t)(challengesDev), C.size_t(n), (*C.uint8_t)(acceptDev)), ctx.h)
+}
+func (ctx *Context) Synchronize() { check(C.gpv_ctx_synchronize(ctx.h), ctx.h) }
+
+// ---------------------------------------------------------------- multi-GPU group (SURVEY 8e)
+
+// ShardBounds: the contiguous block [lo, hi) of a batch of n proofs owned by rank of world.
+func ShardBounds(n, rank, world int) (int, int) {
+	var lo, hi C.size_t
+	check(C.gpv_shard_bounds(C.size_t(n), C.int(rank), C.int(world), &lo, &hi), nil)
+	return int(lo), int(hi)
+}
+
+// Group shards a proof batch over the GPUs of one node; the only exchange is one RCCL all-gather of the packed accept bits.
+type Group struct{ h *C.gpv_group }
+
+func groupCheck(rc C.int, g *C.gpv_group) {
+	if rc != C.GPV_OK {
+		buf := make([]byte, 1024)
+		C.gpv_group_last_error_message(g, (*C.char)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)))
+		panic(&Error{Code: int(rc), Msg: C.GoString((*C.char)(unsafe.Pointer(&buf[0])))})
+	}
+}
+
+// NewGroup: this process drives all listed devices (one worker thread and context per device inside libgpv).
+func NewGroup(deviceIDs []int) *Group {
+	ids := make([]C.int, len(deviceIDs))
+	for i, d := range deviceIDs {
+		ids[i] = C.int(d)
+	}
+	var h *C.gpv_group
+	groupCheck(C.gpv_group_create(&h, &ids[0], C.int(len(ids))), nil)
+	return &Group{h}
+}
+
+// GroupUniqueID / NewGroupRank: one process per GPU; rank 0 creates the id, the caller hands it to the other ranks.
+func GroupUniqueID() [128]byte {
+	var id [128]byte
+	groupCheck(C.gpv_group_unique_id(unsafe.Pointer(&id[0])), nil)
+	return id
+}
+func NewGroupRank(device, rank, world int, id [128]byte) *Group {
+	var h *C.gpv_group
+	groupCheck(C.gpv_group_create_rank(&h, C.int(device), C.int(rank), C.int(world), unsafe.Pointer(&id[0])), nil)
+	return &Group{h}
+}
+func (g *Group) Close()     { C.gpv_group_destroy(g.h) }
+func (g *Group) World() int { return int(C.gpv_group_world(g.h)) }
+func (g *Group) Local() int { return int(C.gpv_group_local(g.h)) }
+func (g *Group) SetOption(option, value int) { groupCheck(C.gpv_group_set_option(g.h, C.int(option), C.int(value)), g.h) }
+
+// Verify: proofs = the records of this process's blocks back to back (the whole batch for NewGroup); the result is the
+// verdict of all nTotal proofs, identical on every rank.
+func (g *Group) Verify(c *Circuit, proofs []byte, nTotal int) []bool {
+	acc := make([]byte, nTotal)
+	groupCheck(C.gpv_group_verify(g.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(nTotal), (*C.uint8_t)(unsafe.Pointer(&acc[0]))), g.h)
+	out := make([]bool, nTotal)
+	for i := range acc {
+		out[i] = acc[i] == 1
+	}
+	return out
+}

@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gpv.h"
@@ -74,10 +75,21 @@ typedef std::vector<uint64_t> Vars;  // n canonical Goldilocks elements (gl.Vari
 class Chip {
  public:
   explicit Chip(gpv::Api& api) : api_(api) {}
+
   Vars Add(const Vars& a, const Vars& b) { return op(GPV_OP_ADD, a, &b, nullptr); }                    // base.go:162
   Vars Sub(const Vars& a, const Vars& b) { return op(GPV_OP_SUB, a, &b, nullptr); }                    // base.go:174
   Vars Mul(const Vars& a, const Vars& b) { return op(GPV_OP_MUL, a, &b, nullptr); }                    // base.go:184
   Vars MulAdd(const Vars& a, const Vars& b, const Vars& c) { return op(GPV_OP_MULADD, a, &b, &c); }     // base.go:196
+  // The hint functions behind MulAdd / Reduce / Inverse / RangeCheck (base.go:223-243, :284-294, :316-336, :339-359): rows
+  // of inputs in, rows of witness values out (layout: include/gpv.h GPV_HINT_*); ok[i] == 0 where the reference hint panics.
+  struct HintResult {
+    Vars out;
+    std::vector<uint8_t> ok;
+  };
+  HintResult MulAddHint(const Vars& abc_rows) { return hint(GPV_HINT_MULADD, abc_rows, 3, 2); }       // -> (quotient, remainder)
+  HintResult ReduceHint(const Vars& x_limb_rows) { return hint(GPV_HINT_REDUCE, x_limb_rows, 4, 5); } // -> (quotient[4], remainder)
+  HintResult InverseHint(const Vars& x) { return hint(GPV_HINT_INVERSE, x, 1, 1); }
+  HintResult SplitLimbsHint(const Vars& x) { return hint(GPV_HINT_SPLIT_LIMBS, x, 1, 2); }             // -> (hi 32, lo 32)
   Vars Reduce(const Vars& x) { return op(GPV_OP_REDUCE, x, nullptr, nullptr); }                         // base.go:246
   Vars Inverse(const Vars& x) { return op(GPV_OP_INV, x, nullptr, nullptr); }                           // base.go:297
   Vars RangeCheck(const Vars& x) { return op(GPV_OP_RANGECHECK, x, nullptr, nullptr); }                  // base.go:362, 1 where x < p
@@ -104,6 +116,14 @@ class Chip {
     Vars out(a.size());
     gpv::check(gpv_gl2_op3(api_.h(), o, a.data(), b.data(), c ? c->data() : nullptr, out.data(), a.size() / 2), api_.h());
     return out;
+  }
+  HintResult hint(int which, const Vars& in, size_t words_in, size_t words_out) {
+    HintResult r;
+    const size_t n = in.size() / words_in;
+    r.out.resize(n * words_out);
+    r.ok.resize(n);
+    gpv::check(gpv_gl_hints(api_.h(), which, in.data(), r.out.data(), r.ok.data(), n), api_.h());
+    return r;
   }
   Vars op(int o, const Vars& a, const Vars* b, const Vars* c) {
     Vars out(a.size());
@@ -275,6 +295,17 @@ class VerifierChip {
     gpv::check(gpv_challenges(api_.h(), c_.h(), proofs.data(), n, out.data()), api_.h());
     return out;
   }
+  // Verify with supplied ProofChallenges instead of GetChallenges (verifier.go:150) -- the way fri_test.go:106-133 and
+  // plonk_test.go:39-66 drive the chips
+  std::vector<uint8_t> VerifyWithChallenges(const std::vector<uint8_t>& proofs, const std::vector<uint64_t>& challenges,
+                                            std::vector<uint32_t>* fail_mask = nullptr) {
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint8_t> accept(n);
+    if (fail_mask) fail_mask->resize(n);
+    gpv::check(gpv_verify_given_challenges(api_.h(), c_.h(), proofs.data(), challenges.data(), n, accept.data(),
+                                           fail_mask ? fail_mask->data() : nullptr), api_.h());
+    return accept;
+  }
   // Verify (verifier.go:143): accept[i] == 1 iff the reference's circuit is satisfiable for proof i
   std::vector<uint8_t> Verify(const std::vector<uint8_t>& proofs) {
     size_t n = proofs.size() / c_.proof_nbytes();
@@ -284,6 +315,58 @@ class VerifierChip {
   }
  private:
   gpv::Api& api_;
+  const gpv::Circuit& c_;
+};
+}  // namespace verifier
+
+// Multi-GPU: a proof batch sharded over the GPUs of one node (include/gpv.h gpv_group_*). The reference has no
+// counterpart. One process drives the listed devices; Verify returns the verdict of the whole batch, which every rank also
+// holds on its own device after the RCCL all-gather of the packed accept bits.
+namespace verifier {
+class VerifierGroup {
+ public:
+  explicit VerifierGroup(const std::vector<int>& device_ids, const gpv::Circuit& c) : c_(c) {
+    gpv::check(gpv_group_create(&g_, device_ids.data(), (int)device_ids.size()));
+  }
+  // one rank of a one-process-per-GPU job; id128 from UniqueId() on rank 0, distributed by the caller
+  VerifierGroup(int device_id, int rank, int world, const std::vector<uint8_t>& id128, const gpv::Circuit& c) : c_(c) {
+    gpv::check(gpv_group_create_rank(&g_, device_id, rank, world, id128.empty() ? nullptr : id128.data()));
+  }
+  ~VerifierGroup() { if (g_) gpv_group_destroy(g_); }
+  VerifierGroup(const VerifierGroup&) = delete;
+  VerifierGroup& operator=(const VerifierGroup&) = delete;
+  static std::vector<uint8_t> UniqueId() {
+    std::vector<uint8_t> id(128);
+    gpv::check(gpv_group_unique_id(id.data()));
+    return id;
+  }
+  int world() const { return gpv_group_world(g_); }
+  int local() const { return gpv_group_local(g_); }
+  void set_option(int option, int value) { check(gpv_group_set_option(g_, option, value)); }
+  // `proofs`: the records of this process's blocks, back to back (the whole batch for the in-process form)
+  std::vector<uint8_t> Verify(const std::vector<uint8_t>& proofs, size_t n_total) {
+    std::vector<uint8_t> accept(n_total);
+    check(gpv_group_verify(g_, c_.h(), proofs.data(), n_total, accept.data()));
+    return accept;
+  }
+  std::vector<uint8_t> RankVerdict(int local_index, size_t n_total) {  // what that rank holds on its device
+    std::vector<uint8_t> accept(n_total);
+    check(gpv_group_read_rank_accept(g_, local_index, accept.data(), n_total));
+    return accept;
+  }
+  static std::pair<size_t, size_t> ShardBounds(size_t n, int rank, int world) {
+    size_t lo = 0, hi = 0;
+    gpv::check(gpv_shard_bounds(n, rank, world, &lo, &hi));
+    return {lo, hi};
+  }
+ private:
+  void check(int rc) {
+    if (rc == GPV_OK) return;
+    char buf[1024];
+    gpv_group_last_error_message(g_, buf, sizeof buf);
+    throw gpv::Error(rc, buf);
+  }
+  gpv_group* g_ = nullptr;
   const gpv::Circuit& c_;
 };
 }  // namespace verifier

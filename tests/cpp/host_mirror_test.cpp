@@ -28,7 +28,14 @@ int main(int argc, char** argv) {
     circuit.pack_proof("{\"proof\": {}}");
     EXPECT(false);
   } catch (const gpv::Error& e) { EXPECT(e.code == GPV_ESHAPE); }
+  // shard arithmetic is host-only: contiguous blocks, the extra proofs on the low ranks
+  EXPECT(verifier::VerifierGroup::ShardBounds(65536, 7, 8) == std::make_pair((size_t)57344, (size_t)65536));
+  EXPECT(verifier::VerifierGroup::ShardBounds(10, 1, 4) == std::make_pair((size_t)3, (size_t)6));
   if (no_gpu) {
+    try {
+      verifier::VerifierGroup grp({0}, circuit);
+      EXPECT(false);
+    } catch (const gpv::Error& e) { EXPECT(e.code == GPV_EDEVICE); }
     try {
       gpv::Api api(0);
       EXPECT(false);  // a GPU must not appear out of nowhere
@@ -72,6 +79,34 @@ int main(int argc, char** argv) {
   std::vector<uint64_t> ch = chip.GetChallenges(proof);
   EXPECT(fri::Chip(api, circuit).VerifyFriProof(proof, ch)[0] == 0);
   EXPECT(plonk::PlonkChip(api, circuit).Verify(proof, ch)[0] == 0);
+  // the same through supplied challenges, the way fri_test.go / plonk_test.go call the chips
+  {
+    std::vector<uint64_t> ch2 = ch;
+    ch2.insert(ch2.end(), ch.begin(), ch.end());
+    std::vector<uint32_t> mask;
+    std::vector<uint8_t> acc2 = chip.VerifyWithChallenges(batch, ch2, &mask);
+    EXPECT(acc2[0] == 1 && acc2[1] == 0 && mask[0] == 0 && mask[1] != 0);
+  }
+  // hint functions (base.go:223-243 and base_test.go:97-116): 2^63 * 2^63 + 3 = quotient * p + 18446744068340842500
+  {
+    auto h = gl.MulAddHint({1ULL << 63, 1ULL << 63, 3, /* not in the field: */ 0xFFFFFFFF00000001ULL, 1, 1});
+    EXPECT(h.ok[0] == 1 && h.out[1] == 18446744068340842500ULL && h.ok[1] == 0);
+    unsigned __int128 lhs = ((unsigned __int128)1 << 126) + 3, rhs = (unsigned __int128)h.out[0] * 0xFFFFFFFF00000001ULL + h.out[1];
+    EXPECT(lhs == rhs);
+    auto sp = gl.SplitLimbsHint({0x123456789ABCDEF0ULL});
+    EXPECT(sp.out[0] == 0x12345678ULL && sp.out[1] == 0x9ABCDEF0ULL);
+  }
+  // one process, a group of one device with the RCCL all-gather forced on: 5 proofs, 2 tampered
+  {
+    verifier::VerifierGroup grp({0}, circuit);
+    grp.set_option(GPV_GROUP_OPT_COLLECTIVE, 1);
+    std::vector<uint8_t> five;
+    for (int i = 0; i < 5; i++) five.insert(five.end(), proof.begin(), proof.end());
+    five[1 * proof.size() + 8 * 700] ^= 1;
+    five[4 * proof.size() + 8 * 900] ^= 1;
+    std::vector<uint8_t> acc = grp.Verify(five, 5);
+    EXPECT(acc == (std::vector<uint8_t>{1, 0, 1, 1, 0}) && grp.RankVerdict(0, 5) == acc && grp.world() == 1);
+  }
   printf("host mirror ok\n");
   return 0;
 }
