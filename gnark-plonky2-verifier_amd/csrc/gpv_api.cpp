@@ -1154,3 +1154,68 @@ extern "C" int gpv_microbench(gpv_ctx* ctx, int which, double* lane_ops_per_sec)
   *lane_ops_per_sec = ops / (best * 1e-3);
   return GPV_OK;
 }
+
+// ================================================================ MFMA feasibility probe (kernels: gpv_k_mfma_probe.hip)
+extern "C" int gpv_mfma_probe(gpv_ctx* ctx, int which, const uint32_t* x, const uint32_t* c_limbs, const uint8_t* q, uint64_t* out, size_t n,
+                              int iters, double* ms) {
+  REQUIRE(ctx, ctx && x && c_limbs && q && out && ms && which >= 0 && which <= 7 && iters >= 1 && n >= 1);
+  ENTER(ctx);
+  DevBuf<u32> dx, dc;
+  DevBuf<uint8_t> dq;
+  DevBuf<u64> dout, dout2;
+  HIP_TRY(ctx, dx.alloc(36 * n));
+  HIP_TRY(ctx, dc.alloc(36));
+  const size_t q_bytes = 4 * 96 + 4 * 2 * 64 * 16;  // digit strings, then the Toeplitz register images
+  HIP_TRY(ctx, dq.alloc(q_bytes));
+  HIP_TRY(ctx, dout.alloc(18 * n));
+  HIP_TRY(ctx, dout2.alloc(18 * n));
+  HIP_TRY(ctx, hipMemcpy(dx.p, x, 4 * 36 * n, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(dc.p, c_limbs, 4 * 36, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(dq.p, q, q_bytes, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIP_TRY(ctx, hipEventCreate(&e0));
+  HIP_TRY(ctx, hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    hipEventRecord(e0, ctx->stream);
+    if (which == 0) {
+      gpvk_probe_row_valu(ctx->stream, dx.p, dc.p, dout.p, iters, n);
+    } else if (which == 1) {
+      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 7);
+    } else if (which == 3) {
+      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 2);
+    } else if (which == 4) {
+      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 5);
+    } else if (which == 5) {
+      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 7 + 8);
+    } else if (which == 6) {
+      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 2 + 8);
+    } else if (which == 7) {  // VALU row beside the image-operand MFMA row
+      hipEventRecord(ctx->ev_fork, ctx->stream);
+      hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
+      gpvk_probe_row_valu(ctx->side, dx.p, dc.p, dout2.p, iters, n);
+      hipEventRecord(ctx->ev_side_done, ctx->side);
+      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 7 + 8);
+      hipStreamWaitEvent(ctx->stream, ctx->ev_side_done, 0);
+    } else {  // both at once: the VALU kernel on the side stream, the MFMA kernel on the main one
+      hipEventRecord(ctx->ev_fork, ctx->stream);
+      hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
+      gpvk_probe_row_valu(ctx->side, dx.p, dc.p, dout2.p, iters, n);
+      hipEventRecord(ctx->ev_side_done, ctx->side);
+      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 7);
+      hipStreamWaitEvent(ctx->stream, ctx->ev_side_done, 0);
+    }
+    hipEventRecord(e1, ctx->stream);
+    if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); ctx_error(ctx, "probe launch failed"); return GPV_EDEVICE; }
+    float t = 0;
+    hipEventElapsedTime(&t, e0, e1);
+    if (rep > 0 && t < best) best = t;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  CHECK_LAUNCH(ctx);
+  *ms = best;
+  HIP_TRY(ctx, hipMemcpy(out, dout.p, 8 * 18 * n, hipMemcpyDeviceToHost));
+  return GPV_OK;
+}

@@ -305,6 +305,18 @@ int gpv_timing_get(gpv_ctx* ctx, int kind, double* avg_ms, uint64_t* launches);
  * Returns lane-operations per second over the whole chip. */
 int gpv_microbench(gpv_ctx* ctx, int which, double* lane_ops_per_sec);
 
+/* MFMA feasibility probe (evidence only, not on the product path; DESIGN.md "what next"): one mix row sum_j C_j * X_j (4 wave-
+ * uniform 254-bit constants, one 254-bit X_j per lane) computed `iters` times per lane either the product's way (which = 0:
+ * 4 x 81 v_mad_u64_u32 into carry-free columns) or as a byte-plane Toeplitz GEMM on v_mfma_i32_32x32x32_i8 including the digit
+ * split, the lane-layout round trip and the recombination (which = 1); which = 2 runs both kernels concurrently on two streams;
+ * which = 3 / 4 time the MFMA path's two halves alone (the 16 MFMAs / everything but the MFMAs; their outputs are meaningless);
+ * which = 5 / 6 / 7 = 1 / 3 / 2 with the A operands read from precomputed Toeplitz register images (q then holds 4 x 96 bytes of
+ * digit strings followed by [4][2][64][16] image bytes) instead of unaligned windows of the digit strings.
+ * x [n][4][9] radix-2^29 limbs (values < 2^255), c_limbs [4][9], q = 384 + 8192 bytes (reversed zero-padded signed digits of the
+ * constants, then their Toeplitz images; built by tools/mfma_probe.py), out [n][18] normalised 29-bit limbs of the exact integer. *ms = duration of the timed launch(es). */
+int gpv_mfma_probe(gpv_ctx* ctx, int which, const uint32_t* x, const uint32_t* c_limbs, const uint8_t* q, uint64_t* out, size_t n,
+                   int iters, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

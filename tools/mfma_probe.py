@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""MFMA feasibility probe (evidence only): one Poseidon-BN254 mix row, sum_j C_j * X_j with four
+wave-uniform constants, on the VALU (the product's form) and as a byte-plane Toeplitz GEMM on v_mfma_i32_32x32x32_i8 including
+the digit split / lane-layout round trip / recombination. Checks both against exact integers, then times them alone and
+together.   python tools/mfma_probe.py"""
+import ctypes
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import gpv_testlib as T  # noqa: E402
+
+gpv = importlib.import_module("gnark-plonky2-verifier_amd")
+L = gpv._lib.lib()
+ctx = gpv.default_context()
+R = T.BN_R
+MASK = (1 << 29) - 1
+
+
+def limbs29(v, n=9):
+    return [(v >> (29 * i)) & MASK for i in range(n)]
+
+
+def signed_digits(v):  # 32 balanced digits in [-128, 127]
+    t = v + int("80" * 32, 16)
+    assert t < 1 << 256
+    return [((t >> (8 * k)) & 0xFF) - 128 for k in range(32)]
+
+
+rng = np.random.default_rng(9)
+consts = [int.from_bytes(rng.bytes(32), "little") % R for _ in range(4)]
+q = np.zeros((4, 96), dtype=np.int8)
+for j, c in enumerate(consts):
+    d = signed_digits(c)
+    assert sum(x << (8 * k) for k, x in enumerate(d)) == c
+    for u in range(96):  # Q[u] = P[63 - u], P[i] = digit i of the constant (0 outside 0..31)
+        i = 63 - u
+        q[j, u] = d[i] if 0 <= i < 32 else 0
+c_limbs = np.array([limbs29(c) for c in consts], dtype=np.uint32)
+# Toeplitz register images: [constant][M tile][lane][16]: lane l supplies row m = 32 mt + (l & 31), K bytes 16 (l >> 5) .. +16
+img = np.zeros((4, 2, 64, 16), dtype=np.int8)
+for j, c in enumerate(consts):
+    d = signed_digits(c)
+    for mt in range(2):
+        for l in range(64):
+            m, k0 = 32 * mt + (l & 31), 16 * (l >> 5)
+            for k in range(16):
+                i = m - (k0 + k)
+                img[j, mt, l, k] = d[i] if 0 <= i < 32 else 0
+qbuf = np.concatenate([q.reshape(-1), img.reshape(-1)]).view(np.uint8).copy()
+
+
+def run(which, xs, iters):
+    n = len(xs)
+    x = np.array([[limbs29(v) for v in row] for row in xs], dtype=np.uint32)
+    out = np.zeros((n, 18), dtype=np.uint64)
+    ms = ctypes.c_double()
+    gpv._lib.check(L.gpv_mfma_probe(ctx.h, which, gpv._lib.ptr(x), gpv._lib.ptr(c_limbs), gpv._lib.ptr(qbuf), gpv._lib.ptr(out), n,
+                                    iters, ctypes.byref(ms)), ctx.h)
+    return out, ms.value
+
+
+# ---- correctness on 200 lanes (ragged: not a multiple of 64), incl. edge values
+xs = [[int.from_bytes(rng.bytes(32), "little") % (2 * R) for _ in range(4)] for _ in range(197)]
+xs += [[0, 0, 0, 0], [1, 0, 0, 0], [2 * R - 1] * 4]
+expect = [[(sum(c * x for c, x in zip(consts, row)) >> (29 * k)) & MASK for k in range(18)] for row in xs]
+for which, name in ((0, "VALU"), (1, "MFMA (window operands)"), (5, "MFMA (image operands)")):
+    out, _ = run(which, xs, 1)
+    bad = [i for i in range(len(xs)) if [int(v) for v in out[i]] != expect[i]]
+    print("%s row == exact integers: %s" % (name, "yes (%d lanes)" % len(xs) if not bad else "NO, first bad lane %d" % bad[0]), flush=True)
+    if bad:
+        print(" got   ", [int(v) for v in out[bad[0]]])
+        print(" expect", expect[bad[0]])
+        sys.exit(1)
+
+# ---- timing: 2 waves per SIMD worth of lanes x 8, 400 rows per lane
+n = 256 * 4 * 2 * 64 * 8
+big = [xs[i % len(xs)] for i in range(4096)]
+x1 = np.array([[limbs29(v) for v in row] for row in big], dtype=np.uint32)
+xbig = np.tile(x1, (n // 4096, 1, 1))
+out = np.zeros((n, 18), dtype=np.uint64)
+iters = 400
+res = {}
+for which, name in ((0, "VALU row alone"), (1, "MFMA row, unaligned window operands"), (3, "  of which: the 16 MFMAs + operand loads"),
+                    (4, "  of which: split + swaps + fold"), (5, "MFMA row, Toeplitz image operands"), (6, "  of which: the 16 MFMAs + operand loads"),
+                    (2, "VALU row beside the window MFMA row"), (7, "VALU row beside the image MFMA row")):
+    ms = ctypes.c_double()
+    gpv._lib.check(L.gpv_mfma_probe(ctx.h, which, gpv._lib.ptr(xbig), gpv._lib.ptr(c_limbs), gpv._lib.ptr(qbuf), gpv._lib.ptr(out), n, iters,
+                                    ctypes.byref(ms)), ctx.h)
+    rows = n * iters * (2 if which in (2, 7) else 1)
+    res[which] = ms.value
+    # a wave takes rows/64 row-evaluations; per SIMD: time * clock / (wave-rows per SIMD)
+    cyc = ms.value * 1e-3 * 2.4e9 / (rows / 64 / 1024)
+    print("%-44s %8.2f ms  %7.3f G rows/s  ~%5.0f SIMD cycles per wave-row at 2.4 GHz" % (name, ms.value, rows / ms.value / 1e6, cyc), flush=True)
+for alone, both, nm in ((1, 2, "window"), (5, 7, "image")):
+    print("%s: VALU row + MFMA row alone %.2f ms, side by side %.2f ms -> overlap factor %.2f (1.0 = none, %.2f = perfect)"
+          % (nm, res[0] + res[alone], res[both], (res[0] + res[alone]) / res[both], (res[0] + res[alone]) / max(res[0], res[alone])))
