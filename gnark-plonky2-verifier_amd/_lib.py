@@ -16,7 +16,7 @@ GPV_OK, GPV_ESHAPE, GPV_ECONFIG, GPV_EDEVICE, GPV_EINVAL, GPV_ENOMEM = 0, -1, -2
 # every symbol include/gpv.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "gpv_ctx_create", "gpv_ctx_destroy", "gpv_ctx_set_stream", "gpv_ctx_set_option", "gpv_ctx_synchronize", "gpv_last_error_message",
-    "gpv_circuit_from_json", "gpv_circuit_destroy", "gpv_proof_nbytes", "gpv_num_challenge_words",
+    "gpv_circuit_from_json", "gpv_circuit_from_json_ex", "gpv_circuit_destroy", "gpv_proof_nbytes", "gpv_num_challenge_words",
     "gpv_num_gate_constraints", "gpv_num_query_rounds", "gpv_num_merkle_trees", "gpv_circuit_hash_kind", "gpv_circuit_describe",
     "gpv_proof_pack_json", "gpv_proof_pack_json_batch",
     "gpv_gl_op", "gpv_gl_hints", "gpv_gl2_op", "gpv_gl2_op3", "gpv_gl2_exp", "gpv_gl2_reduce_with_powers", "gpv_gl2alg_op",
@@ -82,6 +82,7 @@ def lib():
         L.gpv_poseidon_gl_permute_coop_dev.argtypes = [vp, vp, vp, sz]
         L.gpv_last_error_message.argtypes = [vp, ctypes.c_char_p, sz]
         L.gpv_circuit_from_json.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, ctypes.POINTER(vp)]
+        L.gpv_circuit_from_json_ex.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, ctypes.c_uint, ctypes.POINTER(vp)]
         L.gpv_circuit_destroy.argtypes = [vp]
         for f in ("gpv_proof_nbytes", "gpv_num_challenge_words", "gpv_num_gate_constraints", "gpv_num_query_rounds",
                   "gpv_num_merkle_trees", "gpv_circuit_hash_kind"):

@@ -16,6 +16,9 @@
 #define GPV_MAX_WEIGHTS 256
 #define GPV_MAX_CHALLENGES 4
 #define GPV_MAX_RA_BITS 6
+#define GPV_MAX_CAP_HEIGHT 6
+#define GPV_MAX_CAP (1 << GPV_MAX_CAP_HEIGHT)
+#define GPV_SALT_SIZE 4  // plonky2 SALT_SIZE
 // Merkle / cap hash configurations. In both a hash is 4 x u64 in the packed record ("Fr section"): the canonical BN254
 // scalar (the reference's PoseidonBN254GoldilocksConfig, poseidon/bn254.go) or the four Goldilocks elements of a plonky2
 // HashOut (PoseidonGoldilocksConfig).
@@ -37,7 +40,8 @@ struct DevCircuit {
   // ---- Goldilocks section offsets (u64 words from the start of the record)
   uint32_t off_constants, off_sigmas, off_wires, off_zs, off_zs_next, off_pp, off_quot;
   uint32_t off_queries, query_words, off_final, off_pow, off_pi, n_gl_words;
-  uint32_t leaf_len[4], leaf_off[4];          // within one query block
+  uint32_t leaf_len[4], leaf_off[4];          // within one query block; leaf_len includes the salt
+  uint32_t leaf_salt[4];                      // blinding elements at the end of a leaf (hiding circuits: 4 for oracles 1..3), hashed only
   uint32_t step_evals_off[GPV_MAX_STEPS];     // within one query block
   // ---- Fr section offsets (Fr elements from the start of the Fr section)
   uint32_t fr_wires_cap, fr_zs_pp_cap, fr_quot_cap, fr_commit_caps, fr_queries, query_frs, n_fr;
@@ -55,7 +59,7 @@ struct DevCircuit {
   uint64_t k_is[GPV_MAX_ROUTED];
   uint64_t weights[GPV_MAX_WEIGHTS];
   // ---- VerifierOnlyCircuitData, canonical limbs
-  uint64_t sigmas_cap[16][4];
+  uint64_t sigmas_cap[GPV_MAX_CAP][4];
   uint64_t digest[4];
   // ---- derived constants
   uint64_t root_degree;  // primitive 2^degree_bits-th root of unity (fri.go:46)

@@ -183,7 +183,7 @@ GPV_DEV MerklePath dev_merkle_path(const DevCircuit* __restrict__ dc, const u64*
     m.sib = qfr + 4 * (size_t)(tree * dc->init_siblings);
     m.n_sib = dc->init_siblings;
     m.bits = idx;
-    m.cap = tree == 0 ? &dc->sigmas_cap[0][0] : frs + 4 * (size_t)((tree - 1) << dc->cap_height);
+    m.cap = tree == 0 ? &dc->sigmas_cap[0][0] : frs + 4 * (size_t)((tree - 1) << dc->cap_height);  // cap_height = 4 in the reference (fri.go:118-126); 0..6 here
   } else {
     u32 s = tree - 4;
     u32 shift = 0;
@@ -216,31 +216,44 @@ GPV_DEV void gl_batch_inv(u64 v[N]) {
   v[0] = inv;
 }
 
-// computeEvaluation for arity 16 (fri.go:314-384, :261-312). x = current subgroup point, idx4 = index within coset.
-GPV_DEV Ext dev_fri_fold16(u64 x, u32 idx4, const u64* __restrict__ evals, Ext beta, u32* fail) {
-  // g = primitive 16th root of unity, g_inv = g^15 (fri.go:329-331)
+// computeEvaluation for arity A = 2^AB (fri.go:314-384, :261-312). x = current subgroup point, idx_in = index within the coset.
+// The reference supports AB = 4 only (it panics otherwise, fri.go:431-433); the closed form holds for every arity: the coset points
+// are x_i = s g^i with g a primitive A-th root of unity, so prod_{j != i} (x_i - x_j) = A s^(A-1) g^(-i), i.e. the barycentric
+// weights are g^i / (A s^(A-1)), and l(beta) = prod (beta - x_i) = beta^A - s^A. AB = 1..3 are SURVEY 8f.2 (no reference
+// counterpart; checked against the oracle's literal n^2 form and an independent Python implementation).
+template <int AB>
+GPV_DEV Ext dev_fri_fold(u64 x, u32 idx_in, const u64* __restrict__ evals, Ext beta, u32* fail) {
+  constexpr int A = 1 << AB;
+  // g = primitive A-th root of unity, g_inv = g^(A-1) (fri.go:329-331)
   u64 g = 1753635133440165772ULL;
 #pragma unroll 1
-  for (int i = 0; i < 28; i++) g = gl_sqr(g);
-  u64 g2 = gl_sqr(g), g4 = gl_sqr(g2), g8 = gl_sqr(g4);
-  u64 g_inv = gl_mul(gl_mul(g8, g4), gl_mul(g2, g));
-  // start = g_inv^rev(idx4), coset start s = start * x   (fri.go:344-350)
-  u32 rev = bitrev(idx4, 4);
+  for (int i = 0; i < 32 - AB; i++) g = gl_sqr(g);
+  u64 g_inv = 1;
+  {
+    u64 gp = g;  // g^(A-1) = product of g^(2^b), b < AB
+#pragma unroll
+    for (int b = 0; b < AB; b++) {
+      g_inv = gl_mul(g_inv, gp);
+      gp = gl_sqr(gp);
+    }
+  }
+  // start = g_inv^rev(idx_in), coset start s = start * x   (fri.go:344-350)
+  u32 rev = bitrev(idx_in, AB);
   u64 start = 1, gp = g_inv;
 #pragma unroll
-  for (int b = 0; b < 4; b++) {
+  for (int b = 0; b < AB; b++) {
     if ((rev >> b) & 1) start = gl_mul(start, gp);
     gp = gl_sqr(gp);
   }
   u64 s = gl_mul(start, x);
   // norms N_i = (beta0 - x_i)^2 - 7 beta1^2, x_i = s g^i
-  u64 inv[17];
-  u64 xi[16];
+  u64 inv[A + 1];
+  u64 xi[A];
   u64 b1sq7 = gl_mul7(gl_sqr(beta.b));
   u64 cur = s;
   bool on_coset = false;
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
+  for (int i = 0; i < A; i++) {
     xi[i] = cur;
     u64 d0 = gl_sub(beta.a, cur);
     u64 nrm = gl_sub(gl_sqr(d0), b1sq7);
@@ -249,29 +262,38 @@ GPV_DEV Ext dev_fri_fold16(u64 x, u32 idx4, const u64* __restrict__ evals, Ext b
     inv[i] = nrm;
     cur = gl_mul(cur, g);
   }
-  // 16 s^15 (never zero: s != 0)
-  u64 s2 = gl_sqr(s), s4 = gl_sqr(s2), s8 = gl_sqr(s4), s16 = gl_sqr(s8);
-  u64 s15 = gl_mul(gl_mul(s8, s4), gl_mul(s2, s));
-  inv[16] = gl_mul(s15, 16);
-  gl_batch_inv<17>(inv);
+  // A s^(A-1) (never zero: s != 0), s^A
+  u64 sp = s, s_am1 = 1;
+#pragma unroll
+  for (int b = 0; b < AB; b++) {
+    s_am1 = gl_mul(s_am1, sp);
+    sp = gl_sqr(sp);
+  }
+  const u64 s_a = sp;
+  inv[A] = gl_mul(s_am1, (u64)A);
+  gl_batch_inv<A + 1>(inv);
   if (on_coset) *fail |= 256;  // GPV_FAIL_FRI_INTERP
-  // sum_i y_i g^i conj(beta - x_i) / N_i, with y_i = evals[bitrev4(i)]  (fri.go:337-342)
+  // sum_i y_i g^i conj(beta - x_i) / N_i, with y_i = evals[bitrev(i)]  (fri.go:337-342)
   Ext sum = ext_make(0, 0);
   u64 gi = 1;
   u64 nb1 = gl_neg(beta.b);
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int r = ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+  for (int i = 0; i < A; i++) {
+    int r = 0;
+#pragma unroll
+    for (int b = 0; b < AB; b++) r |= ((i >> b) & 1) << (AB - 1 - b);
     Ext y = ext_make(evals[2 * r], evals[2 * r + 1]);
     Ext q = ext_make(gl_sub(beta.a, xi[i]), nb1);  // conj(beta - x_i)
     u64 scale = gl_mul(inv[i], gi);
     sum = ext_add(sum, ext_scalar_mul(ext_mul(y, q), scale));
     gi = gl_mul(gi, g);
   }
-  // l(beta) = beta^16 - s^16
-  Ext b2 = ext_sqr(beta), b4 = ext_sqr(b2), b8 = ext_sqr(b4), b16 = ext_sqr(b8);
-  Ext l = ext_make(gl_sub(b16.a, s16), b16.b);
-  return ext_scalar_mul(ext_mul(l, sum), inv[16]);
+  // l(beta) = beta^A - s^A
+  Ext bp = beta;
+#pragma unroll
+  for (int b = 0; b < AB; b++) bp = ext_sqr(bp);
+  Ext l = ext_make(gl_sub(bp.a, s_a), bp.b);
+  return ext_scalar_mul(ext_mul(l, sum), inv[A]);
 }
 
 // verifyQueryRound without the Merkle paths. Returns failure bits.
@@ -296,13 +318,17 @@ GPV_DEV u32 dev_fri_query(const DevCircuit* __restrict__ dc, const u64* __restri
   Ext zeta = ext_make(derived[dc->ch_zeta], derived[dc->ch_zeta + 1]);
   const u64* extra = derived + dc->n_challenge_words;
   Ext ro0 = ext_make(extra[4], extra[5]), ro1 = ext_make(extra[6], extra[7]);
-  // zeta batch: all four leaves in oracle order (fri_utils.go:144-152); Horner from the last polynomial
+  // zeta batch: the polynomial values of all four leaves in oracle order (fri_utils.go:144-152); Horner from the last polynomial.
+  // A salted leaf (hiding circuits) ends in leaf_salt[o] blinding elements that are hashed but never evaluated.
   Ext red0 = ext_make(0, 0);
-  u32 total = dc->leaf_off[3] + dc->leaf_len[3];  // the four leaves are contiguous in the query block
 #pragma unroll 1
-  for (u32 w = total; w-- > 0;) {
-    Ext t = ext_mul(red0, alpha);
-    red0 = ext_make(gl_add(t.a, qrec[w]), t.b);
+  for (u32 o = 4; o-- > 0;) {
+    const u64* leaf = qrec + dc->leaf_off[o];
+#pragma unroll 1
+    for (u32 w = dc->leaf_len[o] - dc->leaf_salt[o]; w-- > 0;) {
+      Ext t = ext_mul(red0, alpha);
+      red0 = ext_make(gl_add(t.a, leaf[w]), t.b);
+    }
   }
   // zeta*g batch: the first num_challenges columns of oracle 2 (fri_utils.go:114-121)
   Ext red1 = ext_make(0, 0);
@@ -324,17 +350,24 @@ GPV_DEV u32 dev_fri_query(const DevCircuit* __restrict__ dc, const u64* __restri
   for (u32 i = 0; i < nc; i++) apow = ext_mul(apow, alpha);
   Ext old_eval = ext_mul(ext_sub(red0, ro0), inv0);
   old_eval = ext_add(ext_mul(apow, old_eval), ext_mul(ext_sub(red1, ro1), inv1));
-  // reduction steps (fri.go:421-491); arity is 16 (the reference panics otherwise, :431-433)
+  // reduction steps (fri.go:421-491); the reference's arity is 16 (it panics otherwise, :431-433), 2 / 4 / 8 are SURVEY 8f.2
 #pragma unroll 1
   for (u32 s = 0; s < dc->num_steps; s++) {
     const u64* evals = qrec + dc->step_evals_off[s];
-    u32 idx4 = idx & 15;
-    Ext chosen = ext_make(evals[2 * idx4], evals[2 * idx4 + 1]);
+    const u32 ab = dc->arity_bits[s];  // wave-uniform
+    u32 idx_in = idx & ((1u << ab) - 1);
+    Ext chosen = ext_make(evals[2 * idx_in], evals[2 * idx_in + 1]);
     if (!ext_eq(chosen, old_eval)) fail |= 128;  // GPV_FAIL_FRI_EVAL (fri.go:460-461)
     Ext beta = ext_make(derived[dc->ch_fri_betas + 2 * s], derived[dc->ch_fri_betas + 2 * s + 1]);
-    old_eval = dev_fri_fold16(x, idx4, evals, beta, &fail);
-    x = gl_sqr(gl_sqr(gl_sqr(gl_sqr(x))));  // fri.go:486-488
-    idx >>= 4;
+    switch (ab) {
+      case 1: old_eval = dev_fri_fold<1>(x, idx_in, evals, beta, &fail); break;
+      case 2: old_eval = dev_fri_fold<2>(x, idx_in, evals, beta, &fail); break;
+      case 3: old_eval = dev_fri_fold<3>(x, idx_in, evals, beta, &fail); break;
+      default: old_eval = dev_fri_fold<4>(x, idx_in, evals, beta, &fail); break;
+    }
+#pragma unroll 1
+    for (u32 b = 0; b < ab; b++) x = gl_sqr(x);  // fri.go:486-488
+    idx >>= ab;
   }
   // final polynomial (fri.go:253-259, :493-497)
   Ext fin = ext_make(0, 0);

@@ -497,9 +497,9 @@ static int finish_layout(DevCircuit& c) {
   c.off_quot = (uint32_t)w; w += 2ull * c.num_challenges * c.qdf;
   c.off_queries = (uint32_t)w;
   c.leaf_len[0] = c.num_constants + c.num_routed;                 // fri_utils.go:60-72 numPreprocessedPolys
-  c.leaf_len[1] = c.num_wires;
-  c.leaf_len[2] = c.num_challenges * (1 + c.num_pp);               // :74-76
-  c.leaf_len[3] = c.num_challenges * c.qdf;                        // :78-80
+  c.leaf_len[1] = c.num_wires + c.leaf_salt[1];                    // (+ SALT_SIZE blinding elements when hiding)
+  c.leaf_len[2] = c.num_challenges * (1 + c.num_pp) + c.leaf_salt[2];  // :74-76
+  c.leaf_len[3] = c.num_challenges * c.qdf + c.leaf_salt[3];       // :78-80
   uint64_t qw = 0;
   for (int o = 0; o < 4; o++) { c.leaf_off[o] = (uint32_t)qw; qw += c.leaf_len[o]; }
   for (uint32_t s = 0; s < c.num_steps; s++) { c.step_evals_off[s] = (uint32_t)qw; qw += 2ull << c.arity_bits[s]; }
@@ -551,9 +551,21 @@ static int finish_layout(DevCircuit& c) {
   return GPV_OK;
 }
 
+static int circuit_from_json_impl(const char* common_json, size_t common_len, const char* verifier_only_json, size_t verifier_only_len,
+                                  unsigned flags, gpv_circuit** out);
 extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len, const char* verifier_only_json,
                                      size_t verifier_only_len, gpv_circuit** out) {
+  return circuit_from_json_impl(common_json, common_len, verifier_only_json, verifier_only_len, 0, out);
+}
+extern "C" int gpv_circuit_from_json_ex(const char* common_json, size_t common_len, const char* verifier_only_json,
+                                        size_t verifier_only_len, unsigned flags, gpv_circuit** out) {
+  if (flags & ~(unsigned)GPV_CIRCUIT_BEYOND_REFERENCE) return GPV_EINVAL;
+  return circuit_from_json_impl(common_json, common_len, verifier_only_json, verifier_only_len, flags, out);
+}
+static int circuit_from_json_impl(const char* common_json, size_t common_len, const char* verifier_only_json, size_t verifier_only_len,
+                                  unsigned flags, gpv_circuit** out) {
   if (!common_json || !verifier_only_json || !out) return GPV_EINVAL;
+  const bool beyond = (flags & GPV_CIRCUIT_BEYOND_REFERENCE) != 0;  // shapes the reference panics on
   *out = nullptr;
   JDoc pc(common_json, common_len);
   const JValue* common = pc.parse();
@@ -578,17 +590,21 @@ extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len,
               j_u32(fpc->get("proof_of_work_bits"), &c.pow_bits) && j_u32(fpc->get("num_query_rounds"), &c.num_queries);
   if (!good) { gpv_set_global_error("common_circuit_data: missing or malformed scalar field"); return GPV_ESHAPE; }
   const JValue* hiding = fp->get("hiding");
+  bool salted = false;
   if (hiding && hiding->kind == JValue::Bool && hiding->b) {  // common_data.go:121-124
-    gpv_set_global_error("Circuit has hiding enabled, which is not supported");
-    return GPV_ECONFIG;
+    if (!beyond) {
+      gpv_set_global_error("Circuit has hiding enabled, which is not supported");
+      return GPV_ECONFIG;
+    }
+    salted = true;  // plonky2: the wires / Zs+partial products / quotient leaves end in SALT_SIZE blinding elements
   }
   const JValue* rab = fp->get("reduction_arity_bits");
   if (!rab || rab->kind != JValue::Array || rab->size() > GPV_MAX_STEPS) { gpv_set_global_error("reduction_arity_bits"); return GPV_ESHAPE; }
   c.num_steps = (uint32_t)rab->size();
   for (uint32_t s = 0; s < c.num_steps; s++) {
     if (!j_u32(rab->child(s), &c.arity_bits[s])) return GPV_ESHAPE;
-    if (c.arity_bits[s] != 4) {  // fri.go:431-433 "assuming arity bits is 4"
-      gpv_set_global_error("reduction arity bits %u != 4 is not supported", c.arity_bits[s]);
+    if (beyond ? (c.arity_bits[s] < 1 || c.arity_bits[s] > 4) : c.arity_bits[s] != 4) {  // fri.go:431-433 "assuming arity bits is 4"
+      gpv_set_global_error("reduction arity bits %u != 4 is not supported%s", c.arity_bits[s], beyond ? " (1..4 with GPV_CIRCUIT_BEYOND_REFERENCE)" : "");
       return GPV_ECONFIG;
     }
   }
@@ -602,10 +618,11 @@ extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len,
       return GPV_ECONFIG;
     }
   }
-  if (c.cap_height != 4) {  // fri.go:118-126
-    gpv_set_global_error("cap_height %u != 4 is not supported", c.cap_height);
+  if (beyond ? c.cap_height > GPV_MAX_CAP_HEIGHT : c.cap_height != 4) {  // fri.go:118-126
+    gpv_set_global_error("cap_height %u != 4 is not supported%s", c.cap_height, beyond ? " (0..6 with GPV_CIRCUIT_BEYOND_REFERENCE)" : "");
     return GPV_ECONFIG;
   }
+  for (int o = 1; o < 4; o++) c.leaf_salt[o] = salted ? GPV_SALT_SIZE : 0;
   if (c.num_challenges < 1 || c.num_challenges > GPV_MAX_CHALLENGES || c.num_routed > GPV_MAX_ROUTED || c.num_routed > c.num_wires ||
       c.qdf == 0 || c.num_routed != c.qdf * (c.num_pp + 1) || c.degree_bits + c.rate_bits > 32 || c.pow_bits > 63 || c.num_queries == 0) {
     gpv_set_global_error("unsupported circuit dimensions");
@@ -692,15 +709,16 @@ extern "C" int gpv_circuit_from_json(const char* common_json, size_t common_len,
     }
   }
   const JValue* cap = vo->get("constants_sigmas_cap");
-  if (!cap || cap->kind != JValue::Array || cap->size() != 16) { gpv_set_global_error("constants_sigmas_cap"); return GPV_ESHAPE; }
+  const uint32_t cap_entries = 1u << c.cap_height;
+  if (!cap || cap->kind != JValue::Array || cap->size() != cap_entries) { gpv_set_global_error("constants_sigmas_cap"); return GPV_ESHAPE; }
   // Which hash the circuit was built with shows in the shape of its hashes: a decimal string is a BN254 scalar (the
   // reference's PoseidonBN254GoldilocksConfig), {"elements": [4 x u64]} a Poseidon-Goldilocks HashOut.
   c.hash_kind = cap->child(0)->kind == JValue::String ? GPV_HASH_POSEIDON_BN254 : GPV_HASH_POSEIDON_GOLDILOCKS;
-  for (int i = 0; i < 16; i++)
-    if (!j_hash(cap->child(i), c.hash_kind, c.sigmas_cap[i])) { gpv_set_global_error("constants_sigmas_cap[%d]", i); return GPV_ESHAPE; }
+  for (uint32_t i = 0; i < cap_entries; i++)
+    if (!j_hash(cap->child(i), c.hash_kind, c.sigmas_cap[i])) { gpv_set_global_error("constants_sigmas_cap[%u]", i); return GPV_ESHAPE; }
   if (!j_hash(vo->get("circuit_digest"), c.hash_kind, c.digest)) { gpv_set_global_error("circuit_digest"); return GPV_ESHAPE; }
   if (c.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS) {  // plonky2 refuses to deserialise a non-canonical field element
-    for (int i = 0; i < 16; i++)
+    for (uint32_t i = 0; i < cap_entries; i++)
       for (int k = 0; k < 4; k++)
         if (c.sigmas_cap[i][k] >= 0xFFFFFFFF00000001ULL) { gpv_set_global_error("constants_sigmas_cap: non-canonical element"); return GPV_ESHAPE; }
     for (int k = 0; k < 4; k++)
@@ -730,7 +748,7 @@ extern "C" size_t gpv_circuit_describe(const gpv_circuit* circ, uint64_t* blob, 
   if (!circ) return 0;
   const DevCircuit& c = circ->dc;
   std::vector<uint64_t> b(32, 0);
-  b[0] = 0x0001435650470000ULL | c.hash_kind;  // low byte: GPV_HASH_*
+  b[0] = 0x0001435650470000ULL | c.hash_kind | (c.leaf_salt[1] ? 0x100u : 0u);  // low byte: GPV_HASH_*; bit 8: salted leaves (hiding)
   b[1] = c.num_wires; b[2] = c.num_routed; b[3] = c.num_constants; b[4] = c.num_challenges; b[5] = c.num_pp; b[6] = c.qdf;
   b[7] = c.num_gate_constraints; b[8] = c.num_pi; b[9] = c.degree_bits; b[10] = c.rate_bits; b[11] = c.cap_height;
   b[12] = c.pow_bits; b[13] = c.num_queries; b[14] = c.num_steps;
@@ -756,7 +774,7 @@ extern "C" size_t gpv_circuit_describe(const gpv_circuit* circ, uint64_t* blob, 
   b[28] = b.size();
   for (uint32_t g = 0; g < c.n_groups; g++) { b.push_back(c.group_start[g]); b.push_back(c.group_end[g]); }
   b[29] = b.size();
-  for (int i = 0; i < 16; i++)
+  for (uint32_t i = 0; i < (1u << c.cap_height); i++)
     for (int k = 0; k < 4; k++) b.push_back(c.sigmas_cap[i][k]);
   b[30] = b.size();
   for (int k = 0; k < 4; k++) b.push_back(c.digest[k]);

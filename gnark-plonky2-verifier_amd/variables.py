@@ -29,12 +29,16 @@ def DeserializeVerifierOnlyCircuitData(raw):
 class Circuit:
     """gpv_circuit: CommonCircuitData + VerifierOnlyCircuitData, immutable, shared by every proof of a batch."""
 
-    def __init__(self, common, verifier_only):
+    def __init__(self, common, verifier_only, beyond_reference=False):
+        """beyond_reference: admit shapes the reference panics on (arity 2/4/8, cap height != 4, hiding)."""
         assert isinstance(common, CommonCircuitData)
         vo = verifier_only.raw if isinstance(verifier_only, VerifierOnlyCircuitData) else verifier_only
         h = ctypes.c_void_p()
         L = _lib.lib()
-        _lib.check(L.gpv_circuit_from_json(common.text, len(common.text), vo.text, len(vo.text), ctypes.byref(h)))
+        if beyond_reference:
+            _lib.check(L.gpv_circuit_from_json_ex(common.text, len(common.text), vo.text, len(vo.text), 1, ctypes.byref(h)))
+        else:
+            _lib.check(L.gpv_circuit_from_json(common.text, len(common.text), vo.text, len(vo.text), ctypes.byref(h)))
         self.h = h.value
         self.proof_nbytes = L.gpv_proof_nbytes(h)
         self.num_challenge_words = L.gpv_num_challenge_words(h)

@@ -130,6 +130,14 @@ typedef struct gpv_circuit gpv_circuit; /* CommonCircuitData + VerifierOnlyCircu
  * (variables/deserialize.go:149-156); gate ids parsed like gates.GateInstanceFromId (gates/gates.go:37-54). */
 int gpv_circuit_from_json(const char* common_json, size_t common_len, const char* verifier_only_json,
                           size_t verifier_only_len, gpv_circuit** out);
+/* The same with flags. GPV_CIRCUIT_BEYOND_REFERENCE admits shapes the reference PANICS on (gpv_circuit_from_json keeps
+ * answering them with GPV_ECONFIG, exactly like the reference): reduction arities 2 / 4 / 8 besides 16 (fri/fri.go:431-433), cap
+ * heights 0..6 besides 4 (fri/fri.go:118-126), hiding circuits (types/common_data.go:121-124: the wires / Zs / quotient leaves end
+ * in 4 blinding elements that are hashed but not evaluated). No reference implementation or fixture exists for them: parity is
+ * UNPINNED (checked against the oracle's literal restatement and an independent Python construction). */
+enum { GPV_CIRCUIT_BEYOND_REFERENCE = 1 };
+int gpv_circuit_from_json_ex(const char* common_json, size_t common_len, const char* verifier_only_json, size_t verifier_only_len,
+                             unsigned flags, gpv_circuit** out);
 int gpv_circuit_destroy(gpv_circuit* c);
 size_t gpv_proof_nbytes(const gpv_circuit* c);         /* packed record size: 127256 / 133416 for the fixtures */
 size_t gpv_num_challenge_words(const gpv_circuit* c);  /* 43 for the fixtures */

@@ -52,11 +52,17 @@ struct Circuit {
   std::vector<u64> selector_indices;
   std::vector<u64> group_start, group_end;
   // variables/circuit.go:21-24 (VerifierOnlyCircuitData)
-  u64 constants_sigmas_cap[16][4];
+  u64 constants_sigmas_cap[64][4];  // 2^cap_height entries (16 in the reference, fri.go:118-126)
   u64 circuit_digest[4];
   // HASH_POSEIDON_BN254: the reference (poseidon/bn254.go). HASH_POSEIDON_GOLDILOCKS: plonky2's default configuration, restated
   // from plonky2's published algorithm -- the reference has no such path, so that branch is PARITY UNPINNED.
   int hash_kind = HASH_POSEIDON_BN254;
+  // Shapes beyond the reference (all UNPINNED): `salted` = plonky2 hiding -- the wires / Zs+partial-products / quotient
+  // leaves end in 4 blinding elements (SALT_SIZE) that are part of the Merkle leaf but of no polynomial; the reference panics
+  // (types/common_data.go:121-124). Arities other than 16 and cap heights other than 4 need no flag: the restatement of
+  // fri.go:314-384 below is written for any arity, and caps are indexed by cap_height bits.
+  bool salted = false;
+  u64 salt(int oracle) const { return salted && oracle >= 1 ? 4 : 0; }
 
   // ---- derived shape
   u64 lde_bits() const { return degree_bits + rate_bits; }                     // types.go:47
@@ -70,9 +76,9 @@ struct Circuit {
   u64 leaf_len(int oracle) const {  // fri_utils.go:123-142
     switch (oracle) {
       case 0: return num_constants + num_routed_wires;
-      case 1: return num_wires;
-      case 2: return num_challenges * (1 + num_partial_products);
-      default: return num_challenges * quotient_degree_factor;
+      case 1: return num_wires + salt(1);
+      case 2: return num_challenges * (1 + num_partial_products) + salt(2);
+      default: return num_challenges * quotient_degree_factor + salt(3);
     }
   }
   // GL section offsets (in u64 words)
@@ -135,9 +141,10 @@ struct Circuit {
 };
 
 static inline Circuit circuit_from_blob(const u64* b, size_t n) {
-  if (n < (size_t)BLOB_HEADER_WORDS || (b[0] & ~(u64)0xFF) != BLOB_MAGIC || (b[0] & 0xFF) > 1) throw std::runtime_error("bad circuit blob");
+  if (n < (size_t)BLOB_HEADER_WORDS || (b[0] & ~(u64)0x1FF) != BLOB_MAGIC || (b[0] & 0xFF) > 1) throw std::runtime_error("bad circuit blob");
   Circuit c;
   c.hash_kind = (int)(b[0] & 0xFF);
+  c.salted = (b[0] & 0x100) != 0;
   c.num_wires = b[1]; c.num_routed_wires = b[2]; c.num_constants = b[3]; c.num_challenges = b[4];
   c.num_partial_products = b[5]; c.quotient_degree_factor = b[6]; c.num_gate_constraints = b[7];
   c.num_public_inputs = b[8]; c.degree_bits = b[9]; c.rate_bits = b[10]; c.cap_height = b[11];
@@ -161,8 +168,8 @@ static inline Circuit circuit_from_blob(const u64* b, size_t n) {
     c.group_start.push_back(b[off_groups + 2 * g]);
     c.group_end.push_back(b[off_groups + 2 * g + 1]);
   }
-  if (c.cap_height != 4) throw std::runtime_error("cap_height must be 4 (fri/fri.go:118-126)");
-  memcpy(c.constants_sigmas_cap, b + off_cap, sizeof c.constants_sigmas_cap);
+  if (c.cap_height > 6) throw std::runtime_error("cap_height above 6 (the reference: exactly 4, fri/fri.go:118-126)");
+  memcpy(c.constants_sigmas_cap, b + off_cap, 32 * c.cap_len());
   memcpy(c.circuit_digest, b + off_digest, sizeof c.circuit_digest);
   return c;
 }

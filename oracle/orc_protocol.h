@@ -522,7 +522,7 @@ struct PolyInfo { u64 oracle, index; };  // fri_utils.go:9-12
 static inline std::vector<PolyInfo> fri_all_polys(const Circuit& c) {  // fri_utils.go:144-152
   std::vector<PolyInfo> r;
   for (int o = 0; o < 4; o++)
-    for (u64 i = 0; i < c.leaf_len(o); i++) r.push_back({(u64)o, i});
+    for (u64 i = 0; i < c.leaf_len(o) - c.salt(o); i++) r.push_back({(u64)o, i});  // a salt is hashed, never evaluated (plonky2 unsalted_evals)
   return r;
 }
 static inline std::vector<PolyInfo> fri_zs_polys(const Circuit& c) {  // fri_utils.go:114-121

@@ -77,8 +77,9 @@ class CircuitInfo:
     def __init__(self, common, verifier_only):
         cfg = common["config"]
         fp = common["fri_params"]
-        if fp["hiding"]:
-            raise ValueError("Circuit has hiding enabled, which is not supported")  # common_data.go:121-124
+        # hiding: the reference panics (common_data.go:121-124); beyond the reference the wires / Zs / quotient leaves
+        # end in 4 blinding elements
+        self.salted = bool(fp["hiding"])
         self.num_wires = cfg["num_wires"]
         self.num_routed_wires = cfg["num_routed_wires"]
         self.num_challenges = cfg["num_challenges"]
@@ -126,9 +127,10 @@ class CircuitInfo:
         return 1 << (self.degree_bits - sum(self.arity_bits))
 
     def leaf_len(self, oracle):
+        salt = 4 if self.salted and oracle >= 1 else 0
         return [self.num_constants + self.num_routed_wires, self.num_wires,
                 self.num_challenges * (1 + self.num_partial_products),
-                self.num_challenges * self.quotient_degree_factor][oracle]
+                self.num_challenges * self.quotient_degree_factor][oracle] + salt
 
     @property
     def n_challenge_words(self):
@@ -136,7 +138,7 @@ class CircuitInfo:
 
     def blob(self):
         hdr = [0] * BLOB_HEADER_WORDS
-        hdr[0] = BLOB_MAGIC | self.hash_kind
+        hdr[0] = BLOB_MAGIC | self.hash_kind | (0x100 if self.salted else 0)
         hdr[1:14] = [self.num_wires, self.num_routed_wires, self.num_constants, self.num_challenges,
                      self.num_partial_products, self.quotient_degree_factor, self.num_gate_constraints,
                      self.num_public_inputs, self.degree_bits, self.rate_bits, self.cap_height, self.pow_bits,
@@ -663,3 +665,231 @@ def poseidon_gl_config_fixture(name):
     assert ci.hash_kind == HASH_POSEIDON_GOLDILOCKS
     _fixture_cache[key] = (ci, pack_proof(ci, pj2), (common, vo2, pj2), ch.copy())
     return _fixture_cache[key]
+
+
+# ---------------------------------------------------------------- shapes beyond the reference: arity, cap height, hiding
+def _ext_mul(x, y):
+    return ((x[0] * y[0] + 7 * x[1] * y[1]) % GL_P, (x[0] * y[1] + x[1] * y[0]) % GL_P)
+
+
+def _ext_add(x, y):
+    return ((x[0] + y[0]) % GL_P, (x[1] + y[1]) % GL_P)
+
+
+def _ext_sub(x, y):
+    return ((x[0] - y[0]) % GL_P, (x[1] - y[1]) % GL_P)
+
+
+def _ext_inv(x):
+    n = pow((x[0] * x[0] - 7 * x[1] * x[1]) % GL_P, GL_P - 2, GL_P)
+    return (x[0] * n % GL_P, (-x[1]) * n % GL_P)
+
+
+def _ext_pow(x, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = _ext_mul(r, x)
+        x = _ext_mul(x, x)
+        e >>= 1
+    return r
+
+
+def _root_of_unity(n_log):  # goldilocks/base.go:445-454
+    return pow(1753635133440165772, 1 << (32 - n_log), GL_P)
+
+
+def _bitrev(v, n):
+    return int(format(v, "0%db" % n)[::-1], 2) if n else 0
+
+
+def _fri_fold_terms(x, idx_in, ab, beta):
+    """Literal barycentric interpolation of fri.go:261-384 for one coset: returns (coefficients c_i with P(beta) = sum c_i y_i over
+    the UNpermuted evals order) -- P(beta) is linear in the evaluations."""
+    a = 1 << ab
+    g = _root_of_unity(ab)
+    g_inv = pow(g, a - 1, GL_P)
+    s = pow(g_inv, _bitrev(idx_in, ab), GL_P) * x % GL_P
+    pts = [s * pow(g, i, GL_P) % GL_P for i in range(a)]
+    lx = (1, 0)
+    for p in pts:
+        lx = _ext_mul(lx, _ext_sub(beta, (p, 0)))
+    coef = [None] * a
+    for i in range(a):
+        w = 1
+        for j in range(a):
+            if i != j:
+                w = w * (pts[i] - pts[j]) % GL_P
+        w = pow(w, GL_P - 2, GL_P)
+        term = _ext_mul(lx, _ext_mul((w, 0), _ext_inv(_ext_sub(beta, (pts[i], 0)))))
+        coef[_bitrev(i, ab)] = term  # permuted[rev(i)] = evals[i]  <=>  point i carries evals[rev(i)]
+    return coef
+
+
+def _merkle_fill(orc, hash_kind, n_sib, cap_len, pos, leaves, rng):
+    """Partial Merkle tree through the given leaves (pos[q] = leaf index): returns (sibling lists per query, cap as a list of 4-word
+    hashes). Nodes no path computes are random."""
+    if hash_kind == HASH_POSEIDON_GOLDILOCKS:
+        leaf_hash, two = orc.poseidon_gl_hash_or_noop, orc.poseidon_gl_two_to_one
+        rand = lambda: [int(v) for v in rng.integers(0, GL_P, size=4, dtype=np.uint64)]  # noqa: E731
+    else:
+        leaf_hash, two = orc.poseidon_bn254_hash_or_noop, orc.poseidon_bn254_two_to_one
+        rand = lambda: fr_limbs(int.from_bytes(rng.bytes(32), "little") % BN_R)  # noqa: E731
+    nq = len(pos)
+    digests = leaf_hash(np.array(leaves, dtype=np.uint64))
+    level = {pos[q]: [int(w) for w in digests[q]] for q in range(nq)}
+    free, known = {}, []
+    for l in range(n_sib):
+        known.append(level)
+        todo = sorted({p >> 1 for p in level})
+        lefts, rights = [], []
+        for par in todo:
+            pair = []
+            for child in (2 * par, 2 * par + 1):
+                if child not in level and (l, child) not in free:
+                    free[(l, child)] = rand()
+                pair.append(level[child] if child in level else free[(l, child)])
+            lefts.append(pair[0])
+            rights.append(pair[1])
+        out = two(np.array(lefts, dtype=np.uint64), np.array(rights, dtype=np.uint64))
+        level = {par: [int(w) for w in out[i]] for i, par in enumerate(todo)}
+    sibs = [[(known[l][(pos[q] >> l) ^ 1] if ((pos[q] >> l) ^ 1) in known[l] else free[(l, (pos[q] >> l) ^ 1)]) for l in range(n_sib)]
+            for q in range(nq)]
+    return sibs, [level[i] if i in level else rand() for i in range(cap_len)]
+
+
+def synthetic_shape_fixture(name, arity_bits, cap_height, hiding, hash_kind=HASH_POSEIDON_BN254, seed=1):
+    """A record of a shape the reference PANICS on (other FRI arities, another cap height, salted leaves), valid under supplied
+    challenges -- built without a prover, by an implementation that shares nothing with the product or the oracle:
+      * openings, initial-tree leaves, public inputs and the plonk challenges are the fixture's (so plonk.Verify still holds: it
+        does not depend on the FRI shape); with `hiding`, 4 random blinding elements are appended to the wires / Zs / quotient leaves;
+      * per query, the reduction steps are filled forward with random evaluations, evals[idx] := the value the previous step yields
+        (exact-integer barycentric interpolation, the literal form of fri.go:261-384); one free evaluation of the last step is solved
+        so that the result equals the (random) final polynomial at the final point -- the fold is linear in the evaluations;
+      * all Merkle trees (initial and per step) are then built through the 28 opened leaves with the requested hash.
+    Returns (CircuitInfo, packed bytes, (common, verifier_only, proof) json dicts, challenges [ncw])."""
+    ci0, packed0, (common0, vo0, pj0) = load_fixture(name)
+    orc = oracle()
+    rng = np.random.default_rng(seed)
+    ch0 = [int(v) for v in orc.challenges(orc.circuit(ci0), np.frombuffer(packed0, dtype=np.uint8).reshape(1, -1))[0]]
+    common = json.loads(json.dumps(common0))
+    common["fri_params"]["reduction_arity_bits"] = list(arity_bits)
+    common["fri_params"]["config"]["cap_height"] = cap_height
+    common["fri_params"]["hiding"] = bool(hiding)
+    nc, nq = ci0.num_challenges, ci0.num_query_rounds
+    n_log, cap_len = ci0.lde_bits, 1 << cap_height
+    rg = lambda: int(rng.integers(0, GL_P, dtype=np.uint64))  # noqa: E731
+    # challenges: plonk part + fri alpha of the fixture, fresh betas, pow response 0, the fixture's query indices
+    betas, gammas, alphas = ch0[0:nc], ch0[nc:2 * nc], ch0[2 * nc:3 * nc]
+    zeta, fri_alpha = (ch0[3 * nc], ch0[3 * nc + 1]), (ch0[3 * nc + 2], ch0[3 * nc + 3])
+    fri_betas = [(rg(), rg()) for _ in arity_bits]
+    # query indices are chosen here (the challenges are supplied): distinct, a few of them neighbours so that paths share Merkle
+    # nodes and cosets, and no last-step coset completely opened (one evaluation there must stay free, see below)
+    shift_last, a_last = sum(arity_bits[:-1]), 1 << arity_bits[-1]
+    while True:
+        idxs = [int(v) for v in rng.integers(0, 1 << n_log, size=nq)]
+        for k in range(1, nq, 5):
+            idxs[k] = idxs[k - 1] ^ (1 << int(rng.integers(0, n_log)))
+        per = {}
+        for i in idxs:
+            per[i >> (shift_last + arity_bits[-1])] = per.get(i >> (shift_last + arity_bits[-1]), set()) | {(i >> shift_last) & (a_last - 1)}
+        if len(set(idxs)) == nq and all(len(v) < a_last for v in per.values()):
+            break
+    ch = betas + gammas + alphas + list(zeta) + list(fri_alpha) + [w for b in fri_betas for w in b] + [0] + idxs
+    # reduced openings (fri.go:82-95) in batch order
+    op = pj0["proof"]["openings"]
+    b0 = [tuple(e) for k in ("constants", "plonk_sigmas", "wires", "plonk_zs", "partial_products", "quotient_polys") for e in op[k]]
+    b1 = [tuple(e) for e in op["plonk_zs_next"]]
+
+    def reduce_with_powers(terms, a):
+        acc = (0, 0)
+        for t in reversed(terms):
+            acc = _ext_add(_ext_mul(acc, a), t)
+        return acc
+
+    ro = [reduce_with_powers(b0, fri_alpha), reduce_with_powers(b1, fri_alpha)]
+    zeta_next = _ext_mul((_root_of_unity(ci0.degree_bits), 0), zeta)
+    final_len = 1 << (ci0.degree_bits - sum(arity_bits))
+    final = [(rg(), rg()) for _ in range(final_len)]
+    pj = json.loads(json.dumps(pj0))
+    fp = pj["proof"]["opening_proof"]
+    fp["final_poly"]["coeffs"] = [list(c) for c in final]
+    fp["pow_witness"] = rg()
+    w_lde = _root_of_unity(n_log)
+    # per query: blinding elements, the point x and the value the initial combination yields (fri.go:208-251)
+    old, xs, cur = [], [], []
+    for q in range(nq):
+        eps = fp["query_round_proofs"][q]["initial_trees_proof"]["evals_proofs"]
+        vals = []
+        for o in range(4):
+            vals += [(int(v), 0) for v in eps[o][0]]
+            if hiding and o >= 1:
+                eps[o][0] = list(eps[o][0]) + [rg() for _ in range(4)]
+        idx = idxs[q]
+        x = 7 * pow(w_lde, _bitrev(idx, n_log), GL_P) % GL_P
+        red0 = reduce_with_powers(vals, fri_alpha)
+        red1 = reduce_with_powers([(int(v), 0) for v in eps[2][0][:nc]], fri_alpha)
+        o0 = _ext_mul(_ext_sub(red0, ro[0]), _ext_inv(_ext_sub((x, 0), zeta)))
+        old.append(_ext_add(_ext_mul(_ext_pow(fri_alpha, nc), o0), _ext_mul(_ext_sub(red1, ro[1]), _ext_inv(_ext_sub((x, 0), zeta_next)))))
+        xs.append(x)
+        cur.append(idx)
+        fp["query_round_proofs"][q]["steps"] = []
+    # reduction steps, coset by coset: queries whose indices agree above the arity bits open the SAME coset and must carry the same
+    # evaluations (their fold is then the same value at the same next point -- which is what keeps later steps consistent)
+    for s_, ab in enumerate(arity_bits):
+        a = 1 << ab
+        last = s_ == len(arity_bits) - 1
+        cosets = {}
+        for q in range(nq):
+            cosets.setdefault(cur[q] >> ab, []).append(q)
+        for members in cosets.values():
+            evals = [(rg(), rg()) for _ in range(a)]
+            used = set()
+            for q in members:
+                evals[cur[q] & (a - 1)] = old[q]
+                used.add(cur[q] & (a - 1))
+            q0 = members[0]
+            coef = _fri_fold_terms(xs[q0], cur[q0] & (a - 1), ab, fri_betas[s_])
+            x_next = pow(xs[q0], a, GL_P)
+            if last:  # solve one evaluation nobody opens so that the fold lands on the final polynomial
+                k = next(i for i in range(a) if i not in used)
+                target = (0, 0)
+                for c in reversed(final):
+                    target = _ext_add(_ext_mul(target, (x_next, 0)), c)
+                rest = (0, 0)
+                for i in range(a):
+                    if i != k:
+                        rest = _ext_add(rest, _ext_mul(coef[i], evals[i]))
+                evals[k] = _ext_mul(_ext_sub(target, rest), _ext_inv(coef[k]))
+            new = (0, 0)
+            for i in range(a):
+                new = _ext_add(new, _ext_mul(coef[i], evals[i]))
+            for q in members:
+                fp["query_round_proofs"][q]["steps"].append({"evals": [list(e) for e in evals], "merkle_proof": {"siblings": []}})
+                old[q], xs[q], cur[q] = new, x_next, cur[q] >> ab
+    # ---- Merkle trees through the opened leaves
+    H = (lambda v: {"elements": [int(w) for w in v]}) if hash_kind == HASH_POSEIDON_GOLDILOCKS else (lambda v: str(fr_from_limbs(v)))
+    full = idxs
+    caps = []
+    for t in range(4 + len(arity_bits)):
+        if t < 4:
+            shift = 0
+            leaves = [fp["query_round_proofs"][q]["initial_trees_proof"]["evals_proofs"][t][0] for q in range(nq)]
+        else:
+            shift = sum(arity_bits[:t - 4 + 1])
+            leaves = [[w for e in fp["query_round_proofs"][q]["steps"][t - 4]["evals"] for w in e] for q in range(nq)]
+        n_sib = n_log - cap_height - shift
+        sibs, cap = _merkle_fill(orc, hash_kind, n_sib, cap_len, [i >> shift for i in full], leaves, rng)
+        for q in range(nq):
+            hs = [H(v) for v in sibs[q]]
+            if t < 4:
+                fp["query_round_proofs"][q]["initial_trees_proof"]["evals_proofs"][t][1] = {"siblings": hs}
+            else:
+                fp["query_round_proofs"][q]["steps"][t - 4]["merkle_proof"]["siblings"] = hs
+        caps.append([H(v) for v in cap])
+    rand_hash = caps[0][0]
+    vo = {"constants_sigmas_cap": caps[0], "circuit_digest": rand_hash}
+    pj["proof"]["wires_cap"], pj["proof"]["plonk_zs_partial_products_cap"], pj["proof"]["quotient_polys_cap"] = caps[1:4]
+    fp["commit_phase_merkle_caps"] = caps[4:]
+    ci = CircuitInfo(common, vo)
+    return ci, pack_proof(ci, pj), (common, vo, pj), np.array(ch, dtype=np.uint64)

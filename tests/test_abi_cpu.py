@@ -120,6 +120,56 @@ def test_ingest_poseidon_goldilocks_configuration(gpv, name):
         _circuit(gpv, common, bad)
 
 
+BEYOND_SHAPES = [  # (fixture, reduction arity bits, cap height, hiding, hash kind) -- SURVEY 8f.2; shared with the GPU parity test
+    ("step", [3, 3, 2], 4, False, 0),
+    ("decode_block", [2, 4, 1, 2], 2, False, 1),
+    ("step", [4, 4], 4, True, 0),
+    ("step", [1, 2, 3, 4], 6, True, 1),
+    ("decode_block", [4, 3], 0, False, 0),
+    ("decode_block", [4, 4, 2], 5, False, 1),   # the last step tree has no siblings at all: its leaves sit directly under the cap
+    ("decode_block", [1, 1, 1, 1, 1, 1, 1, 1], 5, True, 1),
+]
+
+
+@pytest.mark.parametrize("shape", BEYOND_SHAPES, ids=lambda s: "%s-%s-cap%d%s-%s" % (s[0], "".join(map(str, s[1])), s[2], "-salted" if s[3] else "", "gl" if s[4] else "bn"))
+def test_shapes_beyond_the_reference_are_opt_in(gpv, shape):
+    """FRI arities 2 / 4 / 8, cap heights != 4 and hiding circuits make the reference panic (fri.go:431-433, :118-126,
+    common_data.go:121-124). gpv_circuit_from_json keeps answering GPV_ECONFIG; gpv_circuit_from_json_ex(..., BEYOND_REFERENCE)
+    admits them, lays the record out like the independent Python packer, and the oracle accepts the synthetic record built for
+    the shape (tests/gpv_testlib.synthetic_shape_fixture) under its supplied challenges."""
+    name, arity, cap, hiding, hk = shape
+    ci, packed, (common, vo, pj), ch = T.synthetic_shape_fixture(name, arity, cap, hiding, hk)
+    cj, vj = gpv.types.CommonCircuitData(json.dumps(common)), gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo))
+    with pytest.raises(gpv.ConfigError):
+        gpv.variables.Circuit(cj, vj)
+    circuit = gpv.variables.Circuit(cj, vj, beyond_reference=True)
+    assert circuit.proof_nbytes == len(packed) and circuit.hash_kind == hk
+    assert circuit.num_merkle_trees == 4 + len(arity) and circuit.num_challenge_words == len(ch)
+    assert (circuit.describe() == ci.blob()).all()
+    got = gpv.variables.DeserializeProofWithPublicInputs(gpv.types.ProofWithPublicInputsRaw(json.dumps(pj)), circuit)
+    assert got.data.tobytes() == packed
+    orc = T.oracle()
+    oc = orc.circuit(ci)
+    one = np.frombuffer(packed, dtype=np.uint8).reshape(1, -1)
+    assert orc.fri_verify(oc, one, ch.reshape(1, -1)).tolist() == [0] and orc.plonk_verify(oc, one, ch.reshape(1, -1)).tolist() == [0]
+    assert orc.merkle_chains(oc, one, ch.reshape(1, -1)).all()
+
+
+def test_beyond_reference_limits(gpv):
+    _, _, (common, vo, _), _ = T.synthetic_shape_fixture("step", [4, 4], 4, False, 0)
+    for mutate in (lambda c: c["fri_params"].__setitem__("reduction_arity_bits", [5, 3]),       # arity 32: not built
+                   lambda c: c["fri_params"].__setitem__("reduction_arity_bits", [0, 4]),
+                   lambda c: c["fri_params"]["config"].__setitem__("cap_height", 7)):
+        bad = json.loads(json.dumps(common))
+        mutate(bad)
+        with pytest.raises(gpv.ConfigError):
+            gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(bad)), gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)), beyond_reference=True)
+    bad = json.loads(json.dumps(common))
+    bad["fri_params"]["config"]["cap_height"] = 3   # the cap in the verifier data has 16 entries, not 8
+    with pytest.raises(gpv.ShapeError):
+        gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(bad)), gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)), beyond_reference=True)
+
+
 def _circuit(gpv, common_obj, vo_obj):
     return gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(common_obj)),
                                  gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo_obj)))

@@ -971,6 +971,68 @@ def test_poseidon_goldilocks_merkle_primitives(gpv, api, orc):
     assert orc.poseidon_gl_hash_or_noop(np.array([[7, 8, 9]], dtype=np.uint64)).tolist() == [[7, 8, 9, 0]]
 
 
+# ---------------------------------------------------------------- shapes beyond the reference
+from test_abi_cpu import BEYOND_SHAPES  # noqa: E402
+
+
+@pytest.mark.parametrize("shape", BEYOND_SHAPES, ids=lambda s: "%s-%s-cap%d%s-%s" % (s[0], "".join(map(str, s[1])), s[2], "-salted" if s[3] else "", "gl" if s[4] else "bn"))
+def test_shapes_beyond_the_reference(gpv, api, orc, shape):
+    """PARITY UNPINNED (the reference panics on all of these). The synthetic record of the shape -- reduction steps filled by an
+    exact-integer Python interpolation, Merkle trees built with the oracle's hash -- must be ACCEPTED by the GPU path under its
+    supplied challenges (the closed-form arity-A fold == the literal barycentric form, salts hashed but not evaluated, caps of
+    2^h entries), and on tampered copies accept / failure mask / per-chain Merkle bits must equal the oracle's, with the shared
+    upper Merkle levels forced on and off (trees with fewer than three levels, or none, under the cap included)."""
+    name, arity, cap, hiding, hk = shape
+    ci, packed, (common, vo, pj), ch0 = T.synthetic_shape_fixture(name, arity, cap, hiding, hk)
+    cj = gpv.types.CommonCircuitData(json.dumps(common))
+    circuit = gpv.variables.Circuit(cj, gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)), beyond_reference=True)
+    oc = orc.circuit(ci)
+    chip = gpv.verifier.NewVerifierChip(api, cj)
+    n = 96
+    rng = np.random.default_rng(31)
+    words = np.tile(np.frombuffer(packed, dtype=np.uint64), (n, 1)).copy()
+    q0, qwords, f0, qfr, n_gl = T.query_section_layout(ci)
+    chs = np.tile(ch0.reshape(1, -1), (n, 1)).copy()
+    tampered = np.zeros(n, dtype=bool)
+    step_off = sum(ci.leaf_len(o) for o in range(4))
+    for i in range(1, n, 2):
+        site = (i // 2) % 5
+        if site == 0:
+            words[i, q0 + int(rng.integers(0, ci.num_query_rounds)) * qwords + int(rng.integers(0, step_off))] ^= np.uint64(1)   # leaf word (or salt)
+        elif site == 1:
+            words[i, q0 + int(rng.integers(0, ci.num_query_rounds)) * qwords + step_off + int(rng.integers(0, qwords - step_off))] ^= np.uint64(1)
+        elif site == 2:
+            words[i, n_gl + 4 * f0 + 4 * int(rng.integers(0, ci.num_query_rounds * qfr))] ^= np.uint64(1 << 9)           # a sibling
+        elif site == 3:
+            words[i, q0 + ci.num_query_rounds * qwords + int(rng.integers(0, 2 * ci.final_poly_len))] ^= np.uint64(2)     # final polynomial
+        else:
+            chs[i, 3 * ci.num_challenges + 4 + int(rng.integers(0, 2 * len(arity)))] ^= np.uint64(4)                      # a fri beta
+        tampered[i] = True
+    batch = words.view(np.uint8).reshape(n, -1)
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    noncanon = (words[:, :n_gl - ci.num_public_inputs] >= np.uint64(P)).any(axis=1)
+    if hk == 1:
+        noncanon |= (words[:, n_gl:] >= np.uint64(P)).any(axis=1)
+    expect = orc.plonk_verify(oc, batch, chs).astype(np.int64) | orc.fri_verify(oc, batch, chs).astype(np.int64) | noncanon.astype(np.int64)
+    assert expect[0] == 0 and ((expect != 0) == tampered).all()
+    chains = gpv.fri.NewChip(api).VerifyMerkleProofsToCap(pb, chs)
+    assert (chains == orc.merkle_chains(oc, batch, chs).reshape(chains.shape)).all()
+    for shared in (2, 0):
+        api.set_option(2, shared)
+        try:
+            acc, mask = chip.VerifyWithChallenges(pb, chs)
+        finally:
+            api.set_option(2, 1)
+        assert acc.tolist() == (~tampered).astype(np.uint8).tolist(), shared
+        clean = ~noncanon
+        assert mask[clean].tolist() == expect[clean].tolist(), shared
+    # own transcript: the challenges differ from the supplied ones, so the record is rejected -- with the oracle's challenges and masks
+    accept, fmask, fch = chip.Verify(pb, None, detail=True)
+    oacc, ofail, och = orc.verify(oc, batch, n_threads=8)
+    assert accept.tolist() == oacc.tolist() and (fch.flat == och).all()
+    assert fmask[clean].tolist() == [int(x) for x in ofail[clean]]
+
+
 # ---------------------------------------------------------------- hint functions (witness generation, SURVEY 8f.3)
 def test_gl_hint_functions(gpv, api, orc):
     """gpv_gl_hints == exact integers == oracle: MulAddHint (incl. base_test.go:97-116), ReduceHint on Fr-sized inputs,
