@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>  // types only; every function is resolved with dlsym
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <condition_variable>
@@ -199,8 +200,11 @@ static int group_alloc(gpv_group** out, const int* device_ids, int n_local, int 
       gpv_set_global_error("device id %d out of range (0..%d)", device_ids[i], n_dev - 1);
       return GPV_EINVAL;
     }
+    // Two ranks on one device cannot form an RCCL clique ("Duplicate GPU detected"). GPV_GROUP_ALLOW_DUPLICATE_DEVICES=1 admits
+    // it for the peer-copy exchange (GPV_GROUP_OPT_COLLECTIVE = 2): that is how the worker threads, the shard arithmetic and the
+    // pack / gather / unpack sequence of a multi-rank group are exercised on a one-GPU box.
     for (int j = 0; j < i; j++)
-      if (device_ids[j] == device_ids[i]) {
+      if (device_ids[j] == device_ids[i] && !(getenv("GPV_GROUP_ALLOW_DUPLICATE_DEVICES") && getenv("GPV_GROUP_ALLOW_DUPLICATE_DEVICES")[0] == '1')) {
         gpv_set_global_error("device id %d listed twice", device_ids[i]);
         return GPV_EINVAL;
       }
@@ -283,7 +287,8 @@ extern "C" gpv_ctx* gpv_group_ctx(gpv_group* g, int local_index) {
 extern "C" int gpv_group_set_option(gpv_group* g, int option, int value) {
   if (!g) return GPV_EINVAL;
   std::lock_guard<std::mutex> lk(g->call_mu);
-  if (option == GPV_GROUP_OPT_COLLECTIVE && (value == 0 || value == 1)) {
+  if (option == GPV_GROUP_OPT_COLLECTIVE && value >= 0 && value <= 2) {
+    if (value == 2 && !g->in_process) { group_error(g, "the peer-copy exchange needs every rank in this process"); return GPV_EINVAL; }
     g->collective = value;
     return GPV_OK;
   }
@@ -301,7 +306,8 @@ extern "C" int gpv_group_last_error_message(gpv_group* g, char* buf, size_t buf_
   return GPV_OK;
 }
 
-static bool wants_collective(const gpv_group* g) { return g->world > 1 || g->collective == 1; }
+static bool peer_copies(const gpv_group* g) { return g->collective == 2; }
+static bool wants_collective(const gpv_group* g) { return !peer_copies(g) && (g->world > 1 || g->collective == 1); }
 
 // communicator(s), created at the first call that needs them
 static int ensure_comm(gpv_group* g) {
@@ -341,9 +347,32 @@ static void exchange(gpv_group* g, Worker& w, const uint8_t* accept_local_dev, s
     w.bits_cap = need;
   }
   gpvk_pack_accept_bits(st, accept_local_dev, hi - lo, w.bits + (size_t)w.rank * slot, slot);
+  if (peer_copies(g)) {  // phase 1 ends here: the slot must be complete before any other rank copies it
+    W_GPV(w, gpvi_take_launch_error(w.ctx));
+    W_HIP(w, hipStreamSynchronize(st));
+    return;
+  }
   if (wants_collective(g)) {
     ncclResult_t e = g_rccl.AllGather(w.bits + (size_t)w.rank * slot, w.bits, slot, ncclUint8, w.comm, st);
     if (e != ncclSuccess) { worker_fail(w, GPV_EDEVICE, "ncclAllGather: %s", g_rccl.GetErrorString(e)); return; }
+  }
+  gpvk_unpack_accept_bits(st, w.bits, slot, n_total, (u32)g->world, accept_all_dev);
+  W_GPV(w, gpvi_take_launch_error(w.ctx));
+}
+// Phase 2 of the peer-copy exchange (GPV_GROUP_OPT_COLLECTIVE = 2, every rank in this process): each rank pulls the other ranks'
+// slots with device-to-device copies (hipMemcpyPeerAsync between devices) and unpacks. Same result as the all-gather; no RCCL.
+static void gather_by_peer_copies(gpv_group* g, Worker& w, size_t n_total, uint8_t* accept_all_dev) {
+  const size_t slot = gpv_accept_slot_bytes(n_total, g->world);
+  hipStream_t st = gpvi_ctx_stream(w.ctx);
+  W_HIP(w, hipSetDevice(w.device));
+  for (auto& o : g->w) {
+    if (o.rank == w.rank) continue;
+    const uint8_t* src = o.bits + (size_t)o.rank * slot;
+    uint8_t* dst = w.bits + (size_t)o.rank * slot;
+    if (o.device == w.device)
+      W_HIP(w, hipMemcpyAsync(dst, src, slot, hipMemcpyDeviceToDevice, st));
+    else
+      W_HIP(w, hipMemcpyPeerAsync(dst, w.device, src, o.device, slot, st));
   }
   gpvk_unpack_accept_bits(st, w.bits, slot, n_total, (u32)g->world, accept_all_dev);
   W_GPV(w, gpvi_take_launch_error(w.ctx));
@@ -359,7 +388,7 @@ extern "C" int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const vo
     if (rc != GPV_OK) return rc;
   }
   const size_t first = g->w[0].rank;
-  return run_all(g, [&](Worker& w) {
+  int rc = run_all(g, [&](Worker& w) {
     const size_t i = (size_t)w.rank - first;
     W_HIP(w, hipSetDevice(w.device));
     size_t lo, hi;
@@ -370,6 +399,12 @@ extern "C" int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const vo
     uint8_t* mine = accept_all_dev[i] + lo;
     if (hi > lo) W_GPV(w, gpv_verify_dev(w.ctx, c, shard_dev[i], hi - lo, mine));
     exchange(g, w, mine, n_total, accept_all_dev[i]);
+    if (w.rc != GPV_OK) return;
+    W_HIP(w, hipStreamSynchronize(gpvi_ctx_stream(w.ctx)));
+  });
+  if (rc != GPV_OK || !peer_copies(g)) return rc;
+  return run_all(g, [&](Worker& w) {
+    gather_by_peer_copies(g, w, n_total, accept_all_dev[(size_t)w.rank - first]);
     if (w.rc != GPV_OK) return;
     W_HIP(w, hipStreamSynchronize(gpvi_ctx_stream(w.ctx)));
   });
@@ -386,7 +421,7 @@ extern "C" int gpv_group_verify(gpv_group* g, const gpv_circuit* c, const void* 
   const size_t rec = gpv_proof_nbytes(c);
   size_t first_lo, tmp;
   gpv_shard_bounds(n_total, g->w[0].rank, g->world, &first_lo, &tmp);  // `proofs` starts at the first local rank's block
-  return run_all(g, [&](Worker& w) {
+  int rc = run_all(g, [&](Worker& w) {
     W_HIP(w, hipSetDevice(w.device));
     size_t lo, hi;
     gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
@@ -399,8 +434,16 @@ extern "C" int gpv_group_verify(gpv_group* g, const gpv_circuit* c, const void* 
     uint8_t* acc_local = w.accept_all + lo;  // unused when the block is empty
     if (hi > lo) W_GPV(w, gpvi_verify_host_batch(w.ctx, c, (const uint8_t*)proofs + (lo - first_lo) * rec, hi - lo, &acc_local));
     exchange(g, w, acc_local, n_total, w.accept_all);
-    if (w.rc != GPV_OK) return;
+    if (w.rc != GPV_OK || peer_copies(g)) return;
     // every rank holds the whole verdict on its device; the lowest local rank hands it to the caller
+    if (w.rank == g->w[0].rank) W_HIP(w, hipMemcpyAsync(accept, w.accept_all, n_total, hipMemcpyDeviceToHost, st));
+    W_HIP(w, hipStreamSynchronize(st));
+  });
+  if (rc != GPV_OK || !peer_copies(g)) return rc;
+  return run_all(g, [&](Worker& w) {
+    hipStream_t st = gpvi_ctx_stream(w.ctx);
+    gather_by_peer_copies(g, w, n_total, w.accept_all);
+    if (w.rc != GPV_OK) return;
     if (w.rank == g->w[0].rank) W_HIP(w, hipMemcpyAsync(accept, w.accept_all, n_total, hipMemcpyDeviceToHost, st));
     W_HIP(w, hipStreamSynchronize(st));
   });

@@ -283,7 +283,10 @@ int gpv_group_local(const gpv_group* g);           /* ranks driven by this proce
 int gpv_group_rank(const gpv_group* g, int local_index);
 gpv_ctx* gpv_group_ctx(gpv_group* g, int local_index); /* the rank's context (timing, options, primitives) */
 /* GPV_GROUP_OPT_COLLECTIVE: 0 (default) = the RCCL all-gather runs only when world > 1, 1 = always (exercises the RCCL
- * path on a single GPU). Any other option id is forwarded to every rank's context (gpv_ctx_set_option). */
+ * path on a single GPU), 2 = no RCCL: every rank pulls the other ranks' slots with device-to-device / peer copies (only for
+ * gpv_group_create, where all ranks live in this process; also the only exchange that works with two ranks on one device,
+ * which GPV_GROUP_ALLOW_DUPLICATE_DEVICES=1 in the environment admits for testing). Any other option id is forwarded to
+ * every rank's context (gpv_ctx_set_option). */
 enum { GPV_GROUP_OPT_COLLECTIVE = 100 };
 int gpv_group_set_option(gpv_group* g, int option, int value);
 int gpv_group_last_error_message(gpv_group* g, char* buf, size_t buf_len);

@@ -860,6 +860,41 @@ def test_group_world1_with_rccl_collective(gpv, orc, mode):
         grp.close()
 
 
+def test_group_several_ranks_on_one_gpu_peer_copy_exchange(gpv, orc, monkeypatch):
+    """The multi-rank machinery of gpv_group_create on the one GPU of this box: three ranks (three worker threads, three contexts,
+    ONE shared circuit) on device 0, exchange by device-to-device copies instead of RCCL (an RCCL clique cannot hold two ranks of
+    one device). Ragged batch sizes incl. fewer proofs than ranks; every rank must end with the whole verdict."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("GPV_GROUP_ALLOW_DUPLICATE_DEVICES", "1")
+    common, vo, circuit, proofs = _load(gpv, "decode_block")
+    ci, packed, _ = T.load_fixture("decode_block")
+    grp = gpv.Group(device_ids=[0, 0, 0])
+    try:
+        assert (grp.world, grp.local, grp.ranks) == (3, 3, [0, 1, 2])
+        grp.set_option(gpv._lib.GROUP_OPT_COLLECTIVE, 2)
+        for n in (1, 2, 3, 10, 1000, 3001):
+            batch, tampered = T.synthetic_batch(ci, packed, n, seed=500 + n, tamper_every=3)
+            expect = (~tampered).astype(np.uint8).tolist()
+            acc = grp.verify(circuit, batch, n)
+            assert acc.tolist() == expect, n
+            for r in range(3):
+                assert grp.read_rank_accept(r, n).tolist() == expect, (n, r)
+            t = torch.from_numpy(batch.copy()).to("cuda:0")
+            rec = circuit.proof_nbytes
+            bounds = [gpv.shard_bounds(n, r, 3) for r in range(3)]
+            outs = [torch.full((n,), 9, dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+            grp.verify_dev(circuit, [t.data_ptr() + lo * rec if hi > lo else 0 for lo, hi in bounds], n, [o.data_ptr() for o in outs])
+            for o in outs:
+                assert o.cpu().numpy().tolist() == expect, n
+        oacc, _, _ = orc.verify(orc.circuit(ci), batch[:32], n_threads=8)
+        assert acc[:32].tolist() == oacc.tolist()
+    finally:
+        grp.close()
+    monkeypatch.delenv("GPV_GROUP_ALLOW_DUPLICATE_DEVICES")
+    with pytest.raises(gpv.GpvError):
+        gpv.Group(device_ids=[0, 0])
+
+
 def test_group_multi_device_if_present(gpv, orc):
     """With more than one GPU visible: one process, one worker thread per device, ONE shared circuit, ncclCommInitAll clique;
     every rank must end with the whole verdict on its own device. (The 1-GPU test box skips this; the arithmetic and the
@@ -969,6 +1004,35 @@ def test_poseidon_goldilocks_merkle_primitives(gpv, api, orc):
     st = np.concatenate([l, r, np.zeros((64, 4), dtype=np.uint64)], axis=1)
     assert (pg.Poseidon(st)[:, :4] == orc.poseidon_gl_two_to_one(l, r)).all()
     assert orc.poseidon_gl_hash_or_noop(np.array([[7, 8, 9]], dtype=np.uint64)).tolist() == [[7, 8, 9, 0]]
+
+
+# ---------------------------------------------------------------- fri.Chip with the reference's full argument list
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_fri_chip_surface_like_fri_test_go(gpv, api, orc, name):
+    """fri_test.go:106-133 builds GetInstance(zeta), ToOpenings(openings), the four initial Merkle caps and calls
+    VerifyFriProof(instance, openings, friChallenges, initialMerkleCaps, friProof). The mirror offers the same surface."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, (cj, voj, pj) = T.load_fixture(name)
+    chip = gpv.fri.NewChip(api, common)
+    ch = gpv.verifier.NewVerifierChip(api, common).GetChallenges(proofs)
+    inst = chip.GetInstance(circuit, ch.PlonkZeta)
+    assert [o.NumPolys for o in inst.Oracles] == [ci.leaf_len(o) for o in range(4)] and not any(o.Blinding for o in inst.Oracles)
+    assert len(inst.Batches[0].Polynomials) == sum(ci.leaf_len(o) for o in range(4)) and len(inst.Batches[1].Polynomials) == ci.num_challenges
+    assert inst.Batches[1].Polynomials[0] == gpv.fri.PolynomialInfo(2, 0) and inst.Batches[0].Polynomials[ci.leaf_len(0)] == gpv.fri.PolynomialInfo(1, 0)
+    g = pow(1753635133440165772, 1 << (32 - ci.degree_bits), P)
+    z = [int(v) for v in ch.PlonkZeta[0]]
+    assert inst.Batches[1].Point[0].tolist() == [g * z[0] % P, g * z[1] % P]
+    op = chip.ToOpenings(proofs)
+    o = pj["proof"]["openings"]
+    expect0 = o["constants"] + o["plonk_sigmas"] + o["wires"] + o["plonk_zs"] + o["partial_products"] + o["quotient_polys"]
+    assert op.Batches[0].Values[0].tolist() == expect0 and op.Batches[1].Values[0].tolist() == o["plonk_zs_next"]
+    caps = [np.array([T.fr_limbs(int(x) % R) for x in cap], dtype=np.uint64) for cap in
+            (voj["constants_sigmas_cap"], pj["proof"]["wires_cap"], pj["proof"]["plonk_zs_partial_products_cap"], pj["proof"]["quotient_polys_cap"])]
+    assert chip.VerifyFriProofWithCaps(inst, op, ch, caps, proofs).tolist() == [0]
+    caps[2] = caps[2].copy()
+    caps[2][3, 0] ^= np.uint64(1)
+    with pytest.raises(gpv.GpvError):
+        chip.VerifyFriProofWithCaps(inst, op, ch, caps, proofs)
 
 
 # ---------------------------------------------------------------- shapes beyond the reference (SURVEY 8f.2)
