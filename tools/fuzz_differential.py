@@ -1,66 +1,110 @@
-"""Long differential run: corrupted copies of the fixtures through libgpv (shared Merkle levels on and off) against the CPU
-oracle -- accept bits and failure masks must agree on every record.   python tools/fuzz_differential.py [n_per_fixture] [seed]
+"""Long differential run: corrupted copies of valid records through libgpv (shared Merkle levels on and off) against the CPU
+oracle -- accept bits and failure masks must agree on every record. Covers the two reference fixtures (full Verify, own
+transcript), the same fixtures with supplied challenges, the Poseidon-Goldilocks configuration and a set of shapes beyond the
+reference (the latter three through gpv_verify_given_challenges).   python tools/fuzz_differential.py [n_per_case] [seed]
 (Test infrastructure, like tests/: it is the only reason this script touches oracle/.)"""
-import importlib, sys, time
+import importlib
+import json
+import sys
+import time
+
 import numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import gpv_testlib as T
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import gpv_testlib as T  # noqa: E402
 
 gpv = importlib.import_module("gnark-plonky2-verifier_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = gpv.default_context()
 orc = T.oracle()
+P = T.GL_P
+KINDS = ["one bit anywhere", "one bit in the hash section", "a hash replaced by its neighbour", "a query-section word", "two corruptions",
+         "a hash replaced by random 256 bits", "one bit of a supplied challenge"]
+
+
+def mutate(ci, packed, ch0, rng, gl_hashes):
+    words = np.tile(np.frombuffer(packed, dtype=np.uint64), (n, 1)).copy()
+    nw = words.shape[1]
+    q0, qwords, f0, qfr, n_gl = T.query_section_layout(ci)
+    chs = None if ch0 is None else np.tile(np.asarray(ch0, dtype=np.uint64).reshape(1, -1), (n, 1)).copy()
+    kinds = np.zeros(n, dtype=int)
+    for i in range(1, n):
+        k = int(rng.integers(0, 7 if chs is not None else 6))
+        kinds[i] = k
+        if k == 0:
+            words[i, int(rng.integers(0, nw))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 64)))
+        elif k == 1:
+            words[i, int(rng.integers(n_gl, nw))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 62)))
+        elif k == 2:
+            w = n_gl + 4 * int(rng.integers(0, (nw - n_gl) // 4 - 1))
+            words[i, w:w + 4] = words[i, w + 4:w + 8]
+        elif k == 3:
+            words[i, q0 + int(rng.integers(0, ci.num_query_rounds * qwords))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 33)))
+        elif k == 4:
+            for _ in range(2):
+                words[i, int(rng.integers(q0, nw))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 60)))
+        elif k == 5:
+            w = n_gl + 4 * int(rng.integers(0, (nw - n_gl) // 4))
+            words[i, w:w + 4] = rng.integers(0, 2**63, 4, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 4, dtype=np.uint64)
+        else:
+            chs[i, int(rng.integers(0, chs.shape[1]))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 40)))
+    noncanon = (words[:, :n_gl - ci.num_public_inputs] >= np.uint64(P)).any(axis=1)
+    if gl_hashes:
+        noncanon |= (words[:, n_gl:] >= np.uint64(P)).any(axis=1)
+    return words.reshape(-1).view(np.uint8), chs, kinds, noncanon
+
+
+def run(label, circuit, common, ci, packed, ch0, gl_hashes, vo=None):
+    rng = np.random.default_rng(seed)
+    oc = orc.circuit(ci)
+    batch, chs, kinds, noncanon = mutate(ci, packed, ch0, rng, gl_hashes)
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    chip = gpv.verifier.NewVerifierChip(ctx, common)
+    b2 = batch.reshape(n, -1)
+    t = time.time()
+    if chs is None:
+        oacc, ofail, och = orc.verify(oc, b2, n_threads=32)
+        ofail = ofail.astype(np.int64)
+    else:
+        ofail = orc.plonk_verify(oc, b2, chs).astype(np.int64) | orc.fri_verify(oc, b2, chs).astype(np.int64) | noncanon.astype(np.int64)
+        oacc = (ofail == 0).astype(np.uint8)
+    t_or = time.time() - t
+    clean = ~noncanon
+    for mode in (2, 0):
+        ctx.set_option(2, mode)
+        if chs is None:
+            acc, mask, ch = chip.Verify(pb, vo, detail=True)
+            assert (ch.flat == och).all(), (label, mode, "challenges")
+        else:
+            acc, mask = chip.VerifyWithChallenges(pb, chs)
+        assert acc.tolist() == oacc.tolist(), (label, mode, "accept", np.nonzero(acc != oacc)[0][:5], kinds[np.nonzero(acc != oacc)[0][:5]])
+        bad = np.nonzero(mask[clean].astype(np.int64) != ofail[clean])[0]
+        assert bad.size == 0, (label, mode, "mask", bad[:5], kinds[clean][bad[:5]])
+        assert ((mask[noncanon] & 1) == 1).all()
+    ctx.set_option(2, 1)
+    print("%-58s %5d records (%4d accepted; by kind %s) agree with the oracle, shared levels on and off; oracle %.1f s"
+          % (label, n, int(oacc.sum()), np.bincount(kinds, minlength=7).tolist(), t_or), flush=True)
+
+
 for name in ("decode_block", "step"):
     d = T.GOLDEN / name
     common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
     vo = gpv.variables.DeserializeVerifierOnlyCircuitData(gpv.types.ReadVerifierOnlyCircuitData(d / "verifier_only_circuit_data.json"))
     circuit = gpv.variables.circuit_for(common, vo)
     ci, packed, _ = T.load_fixture(name)
-    oc = orc.circuit(ci)
-    base = np.frombuffer(packed, dtype=np.uint64)
-    words = np.tile(base, (n, 1)).copy()
-    nw = words.shape[1]
-    rng = np.random.default_rng(seed)
-    n_gl = nw - 4 * ((len(packed) - 8 * 0) // 32 - 0) if False else None
-    # Goldilocks words come first; the Fr section is the tail of 4-word elements. Its start is where the packer put it:
-    n_open = 2 * (ci.num_constants + ci.num_routed_wires + ci.num_wires + 2 * ci.num_challenges
-                  + ci.num_challenges * ci.num_partial_products + ci.num_challenges * ci.quotient_degree_factor)
-    qwords = sum(ci.leaf_len(o) for o in range(4)) + sum(2 << a for a in ci.arity_bits)
-    n_gl = n_open + ci.num_query_rounds * qwords + 2 * ci.final_poly_len + 1 + ci.num_public_inputs
-    kinds = np.zeros(n, dtype=int)
-    for i in range(1, n):
-        k = int(rng.integers(0, 6))
-        kinds[i] = k
-        if k == 0:      # one bit anywhere
-            words[i, int(rng.integers(0, nw))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 64)))
-        elif k == 1:    # one bit in the Fr section (caps, siblings)
-            words[i, int(rng.integers(n_gl, nw))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 62)))
-        elif k == 2:    # an Fr element replaced by its neighbour
-            w = n_gl + 4 * int(rng.integers(0, (nw - n_gl) // 4 - 1))
-            words[i, w:w + 4] = words[i, w + 4:w + 8]
-        elif k == 3:    # a query-section word
-            words[i, n_open + int(rng.integers(0, ci.num_query_rounds * qwords))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 33)))
-        elif k == 4:    # two independent corruptions
-            for _ in range(2):
-                words[i, int(rng.integers(n_open, nw))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 60)))
-        else:           # an Fr element replaced by a random value (possibly >= r: taken mod r)
-            w = n_gl + 4 * int(rng.integers(0, (nw - n_gl) // 4))
-            words[i, w:w + 4] = rng.integers(0, 2**63, 4, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 4, dtype=np.uint64)
-    batch = words.reshape(-1).view(np.uint8)
-    pb = gpv.variables.ProofBatch(circuit, batch)
-    chip = gpv.verifier.NewVerifierChip(ctx, common)
-    t = time.time()
-    oacc, ofail, och = orc.verify(oc, batch, n_threads=64)
-    t_or = time.time() - t
-    for mode in (2, 0):
-        ctx.set_option(2, mode)
-        acc, mask, ch = chip.Verify(pb, vo, detail=True)
-        assert acc.tolist() == oacc.tolist(), (name, mode, "accept")
-        clean = (ofail & 1) == 0
-        bad = np.nonzero(mask[clean] != ofail[clean].astype(np.uint32))[0]
-        assert bad.size == 0, (name, mode, "mask", bad[:5], kinds[clean][bad[:5]])
-        assert (ch.flat == och).all(), (name, mode, "challenges")
-    ctx.set_option(2, 1)
-    print("%s: %d records (%d accepted, %d rejected; by kind %s) agree with the oracle, shared levels on and off; oracle %.1f s"
-          % (name, n, int(oacc.sum()), n - int(oacc.sum()), np.bincount(kinds, minlength=6).tolist(), t_or))
+    run("%s: Verify (own transcript)" % name, circuit, common, ci, packed, None, False, vo)
+    ch0 = orc.challenges(orc.circuit(ci), np.frombuffer(packed, dtype=np.uint8).reshape(1, -1))[0]
+    run("%s: Verify with supplied challenges" % name, circuit, common, ci, packed, ch0, False)
+    ci2, packed2, (cj, voj, pj), ch2 = T.poseidon_gl_config_fixture(name)
+    cc = gpv.types.CommonCircuitData(json.dumps(cj))
+    run("%s: Poseidon-Goldilocks configuration" % name, gpv.variables.Circuit(cc, gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(voj))), cc, ci2, packed2, ch2, True)
+for name, arity, cap, hiding, hk in (("step", [3, 3, 2], 4, False, 0), ("decode_block", [2, 4, 1, 2], 2, True, 1), ("step", [1, 2, 3, 4], 6, True, 0),
+                                     ("decode_block", [4, 4, 2], 5, False, 1)):
+    ci3, packed3, (cj, voj, pj), ch3 = T.synthetic_shape_fixture(name, arity, cap, hiding, hk)
+    cc = gpv.types.CommonCircuitData(json.dumps(cj))
+    circuit = gpv.variables.Circuit(cc, gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(voj)), beyond_reference=True)
+    run("%s: arity bits %s, cap height %d%s, %s" % (name, arity, cap, ", salted" if hiding else "", "Poseidon-GL" if hk else "Poseidon-BN254"), circuit, cc,
+        ci3, packed3, ch3, hk == 1)
+print("kinds: " + "; ".join("%d %s" % (i, k) for i, k in enumerate(KINDS)))
