@@ -106,7 +106,7 @@ enum {
 };
 
 /* ------------------------------------------------------------------ context */
-typedef struct gpv_ctx gpv_ctx; /* one per process: device, stream, scratch (gl.New(api), base.go:112) */
+typedef struct gpv_ctx gpv_ctx; /* one per GPU (and per host thread that wants parallelism): device, stream pair, scratch (gl.New(api), base.go:112) */
 int gpv_ctx_create(gpv_ctx** out, int device_id);
 int gpv_ctx_destroy(gpv_ctx* ctx);
 /* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own. */
