@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "gpv_poseidon_bn254_two_to_one", "gpv_poseidon_bn254_to_vec", "gpv_gate_eval_unfiltered",
     "gpv_public_inputs_hash", "gpv_challenges", "gpv_plonk_verify", "gpv_gate_constraints", "gpv_fri_verify",
     "gpv_merkle_verify", "gpv_verify", "gpv_verify_detail", "gpv_verify_dev", "gpv_challenges_dev",
-    "gpv_merkle_verify_dev", "gpv_timing_enable", "gpv_timing_reset", "gpv_timing_get", "gpv_microbench", "gpv_mfma_probe",
+    "gpv_merkle_verify_dev", "gpv_timing_enable", "gpv_timing_reset", "gpv_timing_get", "gpv_microbench", "gpv_mfma_probe", "gpv_mfma_probe_permute", "gpv_mfma_probe_overlap",
     "gpv_verify_given_challenges", "gpv_verify_given_challenges_dev",
     "gpv_shard_bounds", "gpv_accept_slot_bytes", "gpv_group_create", "gpv_group_unique_id", "gpv_group_create_rank", "gpv_group_destroy",
     "gpv_group_world", "gpv_group_local", "gpv_group_rank", "gpv_group_set_option", "gpv_group_last_error_message",
@@ -129,6 +129,8 @@ def lib():
         L.gpv_verify_given_challenges.argtypes = [vp, vp, vp, vp, sz, vp, vp]
         L.gpv_verify_given_challenges_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.gpv_mfma_probe.argtypes = [vp, i32, vp, vp, vp, vp, sz, i32, ctypes.POINTER(ctypes.c_double)]
+        L.gpv_mfma_probe_permute.argtypes = [vp, i32, vp, vp, sz, vp, sz, i32, ctypes.POINTER(ctypes.c_double)]
+        L.gpv_mfma_probe_overlap.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), vp, sz]
         L.gpv_shard_bounds.argtypes = [sz, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
         L.gpv_accept_slot_bytes.argtypes = [sz, i32]
         L.gpv_accept_slot_bytes.restype = sz

@@ -1219,3 +1219,71 @@ extern "C" int gpv_mfma_probe(gpv_ctx* ctx, int which, const uint32_t* x, const 
   HIP_TRY(ctx, hipMemcpy(out, dout.p, 8 * 18 * n, hipMemcpyDeviceToHost));
   return GPV_OK;
 }
+
+// Whole Poseidon-BN254 permutation with the partial-round rows on the matrix pipe (probe, stage 2). images: 28 x 18 Toeplitz register
+// images of 2 KB (tools/mfma_probe.py). which = 0: the product's kernel, 1: the MFMA variant. states / out [n][16] canonical words.
+extern "C" int gpv_mfma_probe_permute(gpv_ctx* ctx, int which, const uint64_t* states, uint64_t* out, size_t n, const uint8_t* images,
+                                      size_t images_bytes, int reps, double* ms) {
+  REQUIRE(ctx, ctx && states && out && ms && n >= 1 && reps >= 1 && (which == 0 || ((which >= 1 && which <= 3) && images && images_bytes >= 28 * 18 * 2048)));
+  ENTER(ctx);
+  DevBuf<u64> din, dout;
+  DevBuf<uint8_t> dimg;
+  HIP_TRY(ctx, din.alloc(16 * n));
+  HIP_TRY(ctx, dout.alloc(16 * n));
+  HIP_TRY(ctx, dimg.alloc(images_bytes ? images_bytes : 16));
+  HIP_TRY(ctx, hipMemcpy(din.p, states, 128 * n, hipMemcpyHostToDevice));
+  if (images_bytes) HIP_TRY(ctx, hipMemcpy(dimg.p, images, images_bytes, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIP_TRY(ctx, hipEventCreate(&e0));
+  HIP_TRY(ctx, hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep <= reps; rep++) {
+    hipEventRecord(e0, ctx->stream);
+    if (which == 0) gpvk_poseidon_bn254_permute(ctx->stream, din.p, dout.p, n);
+    else gpvk_poseidon_bn254_permute_mfma(ctx->stream, din.p, dout.p, n, dimg.p, which == 1 ? 31u : which == 3 ? (31u | 0x100u) : 0u);
+    hipEventRecord(e1, ctx->stream);
+    if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); ctx_error(ctx, "probe launch failed"); return GPV_EDEVICE; }
+    float t = 0;
+    hipEventElapsedTime(&t, e0, e1);
+    if (rep > 0 && t < best) best = t;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  CHECK_LAUNCH(ctx);
+  *ms = best;
+  HIP_TRY(ctx, hipMemcpy(out, dout.p, 128 * n, hipMemcpyDeviceToHost));
+  return GPV_OK;
+}
+
+// Probe, stage 3: do MFMA and VALU work of the two waves of a SIMD overlap? ms[mode] for mode 0 (all MFMA), 1 (all VALU), 2 (odd wave
+// slots MFMA, even slots VALU); hw_ids receives HW_ID of the first `n_ids` blocks of the mode-2 launch.
+extern "C" int gpv_mfma_probe_overlap(gpv_ctx* ctx, int iters, double* ms3, uint32_t* hw_ids, size_t n_ids) {
+  REQUIRE(ctx, ctx && ms3 && iters >= 1);
+  ENTER(ctx);
+  const int blocks = 256 * 4 * 2;  // two waves per SIMD, one round
+  DevBuf<u64> dout;
+  DevBuf<u32> dslots;
+  HIP_TRY(ctx, dout.alloc((size_t)blocks * 64));
+  HIP_TRY(ctx, dslots.alloc(blocks));
+  hipEvent_t e0, e1;
+  HIP_TRY(ctx, hipEventCreate(&e0));
+  HIP_TRY(ctx, hipEventCreate(&e1));
+  for (int mode = 0; mode < 3; mode++) {
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+      hipEventRecord(e0, ctx->stream);
+      gpvk_probe_overlap(ctx->stream, mode, iters, dout.p, dslots.p, blocks);
+      hipEventRecord(e1, ctx->stream);
+      if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); ctx_error(ctx, "probe launch failed"); return GPV_EDEVICE; }
+      float t = 0;
+      hipEventElapsedTime(&t, e0, e1);
+      if (rep > 0 && t < best) best = t;
+    }
+    ms3[mode] = best;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  CHECK_LAUNCH(ctx);
+  if (hw_ids && n_ids) HIP_TRY(ctx, hipMemcpy(hw_ids, dslots.p, 4 * (n_ids < (size_t)blocks ? n_ids : (size_t)blocks), hipMemcpyDeviceToHost));
+  return GPV_OK;
+}

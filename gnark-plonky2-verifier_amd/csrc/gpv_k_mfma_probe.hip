@@ -18,7 +18,7 @@
 // constants change from row to row).
 #include "../../include/gpv.h"
 #include "gpv_launch.h"
-#include "gpv_fr.cuh"
+#include "gpv_poseidon.cuh"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -248,4 +248,205 @@ void gpvk_probe_row_mfma(hipStream_t st, const u32* x, const uint8_t* q, u64* ou
     GPVK_LAUNCH(k_probe_row_convert_fold_only, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, x, q, out, iters, n);
   else
     GPVK_LAUNCH(k_probe_row_mfma, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, x, q, out, iters, n);
+}
+
+// ================================================================ a whole Poseidon-BN254 permutation with the partial rounds' rows on the matrix pipe
+// Second stage of the probe: not one row in isolation but the real permutation (bn254.go:39-45), bit-exact against the product's
+// kernel, with the 28 two-round windows of the partial rounds evaluated as
+//   t_A  = s_0^5 + c                      VALU (three multiplications, as in the product)
+//   s_0' = row(S_A ; t_A, s_1, s_2, s_3)  16 MFMAs + fold + Montgomery reduction
+//   t_B  = s_0'^5 + c                     VALU
+//   s_0  = row(S_B, X ; t_B, s_1, s_2, s_3, t_A)          20 MFMAs + fold + reduction
+//   s_k  = row(R', U_A, U_B ; s_k, t_A, t_B), k = 1..3    3 x 12 MFMAs + fold + reduction   (R' = R mod r keeps s_k below ~1.1 r, so
+//                                                          that its 32 balanced digits exist; the product lets it grow to 60 r)
+// s_1..s_3 live as MFMA operands (signed bytes, both N tiles) between windows. The Toeplitz register images of the 18 constants of
+// every window (1 MB in all) are built by tools/mfma_probe.py from csrc/poseidon_tables.inc and read from global memory, 2 KB per
+// constant and row -- the realistic operand traffic the single-row probe did not have.
+struct ProbeBOp {
+  v4i t[2];  // operand B for N tile 0 (values of lanes 0..31) and N tile 1 (lanes 32..63)
+};
+GPV_DEV ProbeBOp probe_to_bop(const Fr& x) {
+  u32 w[8];
+  probe_signed_bytes(x, w);
+  ProbeBOp b;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    auto r = __builtin_amdgcn_permlane32_swap(w[k], w[4 + k], false, false);
+    b.t[0][k] = (int)r[0];
+    b.t[1][k] = (int)r[1];
+  }
+  return b;
+}
+// Montgomery reduction of 18 SIGNED carry-free columns whose total is non-negative (frc_reduce with arithmetic shifts)
+GPV_DEV Fr probe_reduce_signed(long long (&t)[18]) {
+  const u32 n[FR_LIMBS] = FR29_N_INIT;
+#pragma unroll
+  for (int i = 0; i < FR_LIMBS; i++) {
+    u32 m = ((u32)t[i] * FR29_NINV) & FR_MASK;
+#pragma unroll
+    for (int j = 0; j < FR_LIMBS; j++) t[i + j] += (long long)((u64)m * n[j]);
+    t[i + 1] += t[i] >> FR_BITS;  // arithmetic: the low 29 bits are zero now
+  }
+  Fr r;
+  long long carry = 0;
+#pragma unroll
+  for (int i = 0; i < FR_LIMBS - 1; i++) {
+    long long v = t[FR_LIMBS + i] + carry;
+    r.l[i] = (u32)v & FR_MASK;
+    carry = v >> FR_BITS;
+  }
+  r.l[FR_LIMBS - 1] = (u32)(t[2 * FR_LIMBS - 1] + carry);
+  return r;
+}
+template <int K>
+GPV_DEV Fr probe_mfma_row(const uint8_t* __restrict__ img, const ProbeBOp (&b)[K], u32 lane) {
+  v16i acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[mt][nt][e] = 0;
+#pragma unroll
+  for (int j = 0; j < K; j++)
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+      const v4i a = *(const v4i*)(img + ((size_t)(j * 2 + mt) * 64 + lane) * 16);
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[j].t[nt], acc[mt][nt], 0, 0, 0);
+    }
+  long long t[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) t[k] = 0;
+  probe_fold<0, 0>(t, acc);
+  return probe_reduce_signed(t);
+}
+#define PROBE_IMG_BYTES 2048  // one constant: [2 M tiles][64 lanes][16 B]
+#define PROBE_IMGS_PER_WINDOW 18
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_poseidon_bn254_permute_mfma(const u64* __restrict__ in,
+                                                                                                            u64* __restrict__ out, size_t n,
+                                                                                                            const uint8_t* __restrict__ images,
+                                                                                                            u32 window_mask) {
+  const u32 lane = threadIdx.x;
+  size_t i = (size_t)blockIdx.x * 64 + lane;
+  const bool live = i < n;
+  const size_t src = live ? i : 0;  // idle lanes of the last wave compute on a copy: every lane takes part in the MFMAs
+  Fr s[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) s[k] = fr_from_canonical64(in + 16 * src + 4 * k);
+  PbnState st;
+  st.s0 = fr_add_lazy(s[0], pbn_load(PBN_C, 0));
+  st.s1 = fr_add_lazy(s[1], pbn_load(PBN_C, 1));
+  st.s2 = fr_add_lazy(s[2], pbn_load(PBN_C, 2));
+  st.s3 = fr_add_lazy(s[3], pbn_load(PBN_C, 3));
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+    pbn_sbox_ark(st, (r + 1) * 4);
+    pbn_mix<false>(st, r < 3 ? PBN_MT : PBN_PT);
+  }
+  ProbeBOp b1 = probe_to_bop(st.s1), b2 = probe_to_bop(st.s2), b3 = probe_to_bop(st.s3);
+  // Two waves share a SIMD and run the same code: left alone they stay in lockstep (both in the VALU phase, then both queueing for
+  // the matrix pipe), which is a stable equilibrium under fair arbitration and overlaps nothing. The wave in the odd slot starts
+  // the partial rounds about half a window late, so that one wave's MFMA phase falls into the other's VALU phase.
+  if (window_mask & 0x100) {
+    const u32 wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID.WAVE_ID
+    if (wave_slot & 1) {
+      __builtin_amdgcn_s_sleep(100);
+    }
+  }
+  window_mask &= 31;
+#pragma unroll 1
+  for (int w = 0; w < 28; w++) {
+    // window_mask = 31: every window its own constants (the real permutation); 0: all windows read window 0's images (wrong results,
+    // 36 KB working set instead of 1 MB: separates operand-fetch latency from the rest)
+    const uint8_t* img = images + (size_t)(w & window_mask) * PROBE_IMGS_PER_WINDOW * PROBE_IMG_BYTES;
+    const int a = 2 * w, b = 2 * w + 1;
+    Fr ta = pbn_exp5_add(st.s0, pbn_load(PBN_C, 20 + a));
+    ProbeBOp bta = probe_to_bop(ta);
+    Fr s0a;
+    {
+      const ProbeBOp ops[4] = {bta, b1, b2, b3};
+      s0a = probe_mfma_row<4>(img, ops, lane);
+    }
+    Fr tb = pbn_exp5_add(s0a, pbn_load(PBN_C, 20 + b));
+    ProbeBOp btb = probe_to_bop(tb);
+    {
+      const ProbeBOp ops[5] = {btb, b1, b2, b3, bta};
+      st.s0 = probe_mfma_row<5>(img + 4 * PROBE_IMG_BYTES, ops, lane);
+    }
+    {
+      const ProbeBOp ops[3] = {b1, bta, btb};
+      st.s1 = probe_mfma_row<3>(img + 9 * PROBE_IMG_BYTES, ops, lane);
+    }
+    {
+      const ProbeBOp ops[3] = {b2, bta, btb};
+      st.s2 = probe_mfma_row<3>(img + 12 * PROBE_IMG_BYTES, ops, lane);
+    }
+    {
+      const ProbeBOp ops[3] = {b3, bta, btb};
+      st.s3 = probe_mfma_row<3>(img + 15 * PROBE_IMG_BYTES, ops, lane);
+    }
+    b1 = probe_to_bop(st.s1);
+    b2 = probe_to_bop(st.s2);
+    b3 = probe_to_bop(st.s3);
+  }
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+    pbn_sbox_ark(st, r < 3 ? 20 + 56 + 4 * r : -1);
+    pbn_mix<false>(st, PBN_MT);
+  }
+  if (!live) return;
+  fr_to_canonical64(st.s0, out + 16 * i);
+  fr_to_canonical64(st.s1, out + 16 * i + 4);
+  fr_to_canonical64(st.s2, out + 16 * i + 8);
+  fr_to_canonical64(st.s3, out + 16 * i + 12);
+}
+void gpvk_poseidon_bn254_permute_mfma(hipStream_t st, const u64* in, u64* out, size_t n, const uint8_t* images, u32 window_mask) {
+  GPVK_LAUNCH(k_poseidon_bn254_permute_mfma, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, out, n, images, window_mask);
+}
+
+// ================================================================ do the matrix pipe and the vector ALU overlap across the two waves of a SIMD?
+// mode 0: every wave runs `iters` independent-accumulator MFMAs; mode 1: every wave runs a VALU multiply-add chain of about the same
+// length; mode 2: the wave in the odd hardware slot runs the MFMAs, the one in the even slot the VALU chain. If the pipes overlap,
+// mode 2 takes about max(mode 0, mode 1) / 2 ... i.e. as long as ONE wave's loop; if they serialise, the sum of the two.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_probe_overlap(int mode, int iters, u64* __restrict__ out,
+                                                                                             u32* __restrict__ slots) {
+  const u32 lane = threadIdx.x;
+  const u32 slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID.WAVE_ID
+  if (lane == 0) slots[blockIdx.x] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);  // WAVE_ID, SIMD_ID, PIPE_ID, CU_ID ...
+  const bool do_mfma = mode == 0 || (mode == 2 && (slot & 1));
+  u64 acc = 0;
+  if (do_mfma) {
+    v16i c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) c[k][e] = (int)lane;
+    v4i a = {(int)lane, 1, 2, 3}, b = {4, 5, (int)lane, 7};
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) c[k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c[k], 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc += (u32)c[k][0] + (u32)c[k][7];
+  } else {
+    u64 x0 = lane, x1 = lane + 1, x2 = lane + 2, x3 = lane + 3;
+    const u32 m = 0x9E3779B9u + lane;
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) {  // 4 x 16 = 64 multiply-adds per trip (= 256+ VALU cycles, the length of 4 MFMAs)
+        x0 = (u64)(u32)x0 * m + x0;
+        x1 = (u64)(u32)x1 * m + x1;
+        x2 = (u64)(u32)x2 * m + x2;
+        x3 = (u64)(u32)x3 * m + x3;
+      }
+    }
+    acc = x0 ^ x1 ^ x2 ^ x3;
+  }
+  out[(size_t)blockIdx.x * 64 + lane] = acc;
+}
+void gpvk_probe_overlap(hipStream_t st, int mode, int iters, u64* out, u32* slots, int blocks) {
+  GPVK_LAUNCH(k_probe_overlap, dim3(blocks), dim3(64), 0, st, mode, iters, out, slots);
 }

@@ -81,6 +81,8 @@ void gpvk_gather_pih(hipStream_t st, const u64* derived, u64* out, u32 ncw, size
 // gpv_k_mfma_probe.hip (measurement only)
 void gpvk_probe_row_valu(hipStream_t st, const u32* x, const u32* c_limbs, u64* out, int iters, size_t n);
 void gpvk_probe_row_mfma(hipStream_t st, const u32* x, const uint8_t* q, u64* out, int iters, size_t n, int parts);
+void gpvk_poseidon_bn254_permute_mfma(hipStream_t st, const u64* in, u64* out, size_t n, const uint8_t* images, u32 window_mask);
+void gpvk_probe_overlap(hipStream_t st, int mode, int iters, u64* out, u32* slots, int blocks);
 // gpv_k_plonk.hip
 void gpvk_gate_eval_unfiltered(hipStream_t st, DevGate g, const u64* weights, const u64* constants, u32 n_constants, const u64* wires,
                                u32 n_wires, const u64* pih, u64* out, u32 max_out, size_t n);

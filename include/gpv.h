@@ -327,6 +327,14 @@ int gpv_microbench(gpv_ctx* ctx, int which, double* lane_ops_per_sec);
  * constants, then their Toeplitz images; built by tools/mfma_probe.py), out [n][18] normalised 29-bit limbs of the exact integer. *ms = duration of the timed launch(es). */
 int gpv_mfma_probe(gpv_ctx* ctx, int which, const uint32_t* x, const uint32_t* c_limbs, const uint8_t* q, uint64_t* out, size_t n,
                    int iters, double* ms);
+/* Stage 2 of the probe: the whole Poseidon-BN254 permutation (poseidon/bn254.go:39-45) with the rows of its 56 partial rounds on the
+ * matrix pipe (which = 1; images = 28 x 18 Toeplitz register images of 2 KB built by tools/mfma_probe.py from the round constants)
+ * against the product's kernel (which = 0). states / out [n][4][4] canonical; *ms = best of `reps` launches. Evidence only. */
+int gpv_mfma_probe_permute(gpv_ctx* ctx, int which, const uint64_t* states, uint64_t* out, size_t n, const uint8_t* images,
+                           size_t images_bytes, int reps, double* ms);
+/* Stage 3 of the probe: ms3[0] = every wave runs 4 x iters MFMAs, ms3[1] = every wave runs a VALU multiply-add chain of similar
+ * length, ms3[2] = per SIMD one wave does the MFMAs and the other the VALU chain (2 waves per SIMD, one round of waves). */
+int gpv_mfma_probe_overlap(gpv_ctx* ctx, int iters, double* ms3, uint32_t* hw_ids, size_t n_ids);
 
 #ifdef __cplusplus
 }

@@ -100,3 +100,83 @@ for which, name in ((0, "VALU row alone"), (1, "MFMA row, unaligned window opera
 for alone, both, nm in ((1, 2, "window"), (5, 7, "image")):
     print("%s: VALU row + MFMA row alone %.2f ms, side by side %.2f ms -> overlap factor %.2f (1.0 = none, %.2f = perfect)"
           % (nm, res[0] + res[alone], res[both], (res[0] + res[alone]) / res[both], (res[0] + res[alone]) / max(res[0], res[alone])))
+
+
+# ================================================================ stage 2: the whole permutation, partial-round rows on the matrix pipe
+def parse_table(name):
+    import re
+    text = (ROOT / "gnark-plonky2-verifier_amd" / "csrc" / "poseidon_tables.inc").read_text()
+    m = re.search(r"GPV_TABLE_U32\(%s, (\d+)\) = \{(.*?)\};" % name, text, re.S)
+    vals = [int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]+)u", m.group(2))]
+    assert len(vals) == int(m.group(1))
+    return [sum(v << (29 * k) for k, v in enumerate(vals[i:i + 9])) for i in range(0, len(vals), 9)]
+
+
+def toeplitz_image(c):
+    d = signed_digits(c)
+    im = np.zeros((2, 64, 16), dtype=np.int8)
+    for mt in range(2):
+        for l in range(64):
+            m, k0 = 32 * mt + (l & 31), 16 * (l >> 5)
+            for k in range(16):
+                i = m - (k0 + k)
+                if 0 <= i < 32:
+                    im[mt, l, k] = d[i]
+    return im
+
+
+S, X = parse_table("PBN_S"), parse_table("PBN_X")
+ONE = pow(2, 261, R)  # Montgomery form of 1
+assert len(S) == 392 and len(X) == 28 and all(v < R for v in S + X)
+cache = {}
+
+
+def image(c):
+    if c not in cache:
+        cache[c] = toeplitz_image(c)
+    return cache[c]
+
+
+imgs = []
+for w in range(28):
+    a, b = 2 * w, 2 * w + 1
+    row_a = [S[7 * a + k] for k in range(4)]                       # (t_A, s_1, s_2, s_3)
+    row_b = [S[7 * b + k] for k in range(4)] + [X[w]]              # (t_B, s_1, s_2, s_3, t_A)
+    upd = [[ONE, S[7 * a + 3 + k], S[7 * b + 3 + k]] for k in (1, 2, 3)]   # (s_k, t_A, t_B)
+    for c in row_a + row_b + [c for u in upd for c in u]:
+        imgs.append(image(c))
+images = np.stack(imgs).reshape(-1).view(np.uint8).copy()
+assert images.size == 28 * 18 * 2048
+orc = T.oracle()
+n_chk = 1000
+st = np.array([[T.fr_limbs(int.from_bytes(rng.bytes(32), "little") % R) for _ in range(4)] for _ in range(n_chk)], dtype=np.uint64).reshape(n_chk, 16)
+st[0] = 0
+expect = orc.poseidon_bn254_permute(st)
+
+
+def permute(which, states, reps):
+    out = np.zeros_like(states)
+    ms = ctypes.c_double()
+    gpv._lib.check(L.gpv_mfma_probe_permute(ctx.h, which, gpv._lib.ptr(states), gpv._lib.ptr(out), states.shape[0], gpv._lib.ptr(images), images.size,
+                                            reps, ctypes.byref(ms)), ctx.h)
+    return out, ms.value
+
+
+for which, name in ((0, "product kernel"), (1, "MFMA-row kernel"), (3, "MFMA-row kernel, staggered waves")):
+    out, _ = permute(which, st, 1)
+    bad = np.nonzero((out != expect.reshape(out.shape)).any(axis=1))[0]
+    print("Poseidon-BN254 permutation, %s == oracle: %s" % (name, "yes (%d states)" % n_chk if bad.size == 0 else "NO (%d of %d states differ, first %d)" % (bad.size, n_chk, bad[0])), flush=True)
+big = np.tile(st, ((1 << 20) // n_chk + 1, 1))[:1 << 20].copy()
+for which, name in ((0, "product kernel (VALU only)"), (1, "partial-round rows on the matrix pipe"), (2, "  the same, all windows on one window's images"), (3, "  the same, odd wave slots start half a window late")):
+    _, ms = permute(which, big, 3)
+    print("2^20 permutations, %-40s %8.2f ms  %6.1f M perms/s" % (name, ms, (1 << 20) / ms / 1e3), flush=True)
+
+
+# ================================================================ stage 3: do the two pipes overlap across the two waves of a SIMD?
+ms3 = (ctypes.c_double * 3)()
+ids = np.zeros(2048, dtype=np.uint32)
+gpv._lib.check(L.gpv_mfma_probe_overlap(ctx.h, 2000, ms3, gpv._lib.ptr(ids), ids.size), ctx.h)
+slot = ids & 0xF
+simd = (ids >> 4) & 0x3
+print("2 waves per SIMD, one round: all MFMA %.3f ms, all VALU %.3f ms, one of each per SIMD %.3f ms  (wave slots seen: %s)"
+      % (ms3[0], ms3[1], ms3[2], sorted(set(int(v) for v in slot))), flush=True)
