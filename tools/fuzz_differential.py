@@ -68,7 +68,11 @@ def run(label, circuit, common, ci, packed, ch0, gl_hashes, vo=None):
         oacc, ofail, och = orc.verify(oc, b2, n_threads=32)
         ofail = ofail.astype(np.int64)
     else:
-        ofail = orc.plonk_verify(oc, b2, chs).astype(np.int64) | orc.fri_verify(oc, b2, chs).astype(np.int64) | noncanon.astype(np.int64)
+        from concurrent.futures import ThreadPoolExecutor  # the oracle's stage entry points are single-threaded; ctypes drops the GIL
+        parts = np.array_split(np.arange(n), 16)
+        with ThreadPoolExecutor(16) as ex:
+            res = list(ex.map(lambda ix: orc.plonk_verify(oc, b2[ix], chs[ix]).astype(np.int64) | orc.fri_verify(oc, b2[ix], chs[ix]).astype(np.int64), parts))
+        ofail = np.concatenate(res) | noncanon.astype(np.int64)
         oacc = (ofail == 0).astype(np.uint8)
     t_or = time.time() - t
     clean = ~noncanon
