@@ -25,7 +25,7 @@ class ProofChallenges:
         self.PlonkAlphas = flat[:, k:k + nc]; k += nc
         self.PlonkZeta = flat[:, k:k + 2]; k += 2
         self.FriAlpha = flat[:, k:k + 2]; k += 2
-        self.FriBetas = flat[:, k:k + 2 * ns].reshape(-1, ns, 2); k += 2 * ns
+        self.FriBetas = flat[:, k:k + 2 * ns].reshape(flat.shape[0], ns, 2); k += 2 * ns
         self.FriPowResponse = flat[:, k]; k += 1
         self.FriQueryIndices = flat[:, k:k + nq]
 

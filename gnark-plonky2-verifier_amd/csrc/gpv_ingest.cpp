@@ -517,7 +517,10 @@ static int finish_layout(DevCircuit& c) {
   c.fr_quot_cap = 2 * cap_len;
   c.fr_commit_caps = 3 * cap_len;
   c.fr_queries = (3 + c.num_steps) * cap_len;
-  if (c.lde_bits < c.cap_height + total_arity) return GPV_ECONFIG;
+  if (c.lde_bits < c.cap_height + total_arity) {
+    gpv_set_global_error("reduction arities (sum %u) leave no room for a cap of height %u in a domain of 2^%u points", total_arity, c.cap_height, c.lde_bits);
+    return GPV_ECONFIG;
+  }
   c.init_siblings = c.lde_bits - c.cap_height;
   uint32_t qf = 4 * c.init_siblings, bits = c.init_siblings;
   for (uint32_t s = 0; s < c.num_steps; s++) {

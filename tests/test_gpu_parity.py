@@ -486,6 +486,48 @@ def test_random_records_differential(gpv, api, orc, name):
     assert (fri.VerifyMerkleProofsToCap(pb, rch) == orc.merkle_chains(oc, recs.tobytes(), rch)).all()
 
 
+@pytest.mark.parametrize("name,arity", [("decode_block", []), ("decode_block", [4]), ("step", [4, 4, 4])])
+def test_other_numbers_of_reduction_steps_differential(gpv, api, orc, name, arity):
+    """The reference accepts any number of arity-16 reduction steps (fri.go:421-491 loops over friParams.ReductionArityBits); the
+    fixtures have two. Zero, one and three steps on random records: challenges, failure masks, per-chain Merkle bits == oracle
+    (zero steps: a 4096-coefficient final polynomial, no step trees; three on `step`: the last step tree has no siblings; three on
+    `decode_block` would leave a step tree above the cap: GPV_ECONFIG)."""
+    if name == "step":
+        _, _, (c_db, vo_db, _) = T.load_fixture("decode_block")
+        bad = json.loads(json.dumps(c_db))
+        bad["fri_params"]["reduction_arity_bits"] = [4, 4, 4]
+        with pytest.raises(gpv.ConfigError):
+            gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(bad)), gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo_db)))
+    ci0, packed0, (common, vo, pj) = T.load_fixture(name)
+    cj = json.loads(json.dumps(common))
+    cj["fri_params"]["reduction_arity_bits"] = arity
+    ci = T.CircuitInfo(cj, vo)
+    ccd = gpv.types.CommonCircuitData(json.dumps(cj))
+    circuit = gpv.variables.Circuit(ccd, gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)))   # plain entry point: arity 16 only
+    oc = orc.circuit(ci)
+    assert circuit.num_merkle_trees == 4 + len(arity) and (circuit.describe() == ci.blob()).all()
+    rng = np.random.default_rng(77 + len(arity))
+    n = 40
+    recs = _random_records(ci, circuit.proof_nbytes, n, rng)
+    pb = gpv.variables.ProofBatch(circuit, recs.tobytes())
+    chip = gpv.verifier.NewVerifierChip(api, ccd)
+    accept, mask, ch = chip.Verify(pb, None, detail=True)
+    oacc, ofail, och = orc.verify(oc, recs.tobytes(), n_threads=8)
+    assert (ch.flat == och).all() and accept.tolist() == oacc.tolist() and mask.tolist() == [int(x) for x in ofail]
+    rch = rand_gl(rng, och.shape)
+    fri = gpv.fri.NewChip(api, ccd)
+    assert fri.VerifyFriProof(pb, rch).tolist() == [int(x) for x in orc.fri_verify(oc, recs.tobytes(), rch)]
+    assert (fri.VerifyMerkleProofsToCap(pb, rch) == orc.merkle_chains(oc, recs.tobytes(), rch)).all()
+    for shared in (2, 0):
+        api.set_option(2, shared)
+        try:
+            a2, m2 = chip.VerifyWithChallenges(pb, rch)
+        finally:
+            api.set_option(2, 1)
+        expect = orc.plonk_verify(oc, recs.tobytes(), rch).astype(np.int64) | orc.fri_verify(oc, recs.tobytes(), rch).astype(np.int64)
+        assert m2.tolist() == expect.tolist() and a2.sum() == 0, shared
+
+
 def test_circuit_variant_differential(gpv, api, orc):
     """A different circuit shape (gate list without PoseidonMdsGate/CosetInterpolationGate, 3 selector groups re-cut,
     20 query rounds, pow bits 10): ingest, layout and every kernel must follow the circuit description, not the fixtures."""
