@@ -1162,6 +1162,37 @@ def test_gl_hint_functions(gpv, api, orc):
     assert (inv[g] == gl.Inverse(np.array(single, dtype=np.uint64)[g])[0]).all()
 
 
+def test_config4_whole_batch_65536_on_one_gpu(gpv, api):
+    """BASELINE config 4 is 65 536 `step` proofs; sharded it is 8 x 8192 (test above). Here the WHOLE batch sits on one GPU (8.7 GB of
+    288 GB) and goes through one gpv_verify_dev call -- the largest size the configs name: accept == tamper mask for all 65 536,
+    and the verdict of the first 8192 equals what the 8192-proof call gives for the same records (no dependence on batch size)."""
+    torch = pytest.importorskip("torch")
+    common, vo, circuit, proofs = _load(gpv, "step")
+    ci, packed, _ = T.load_fixture("step")
+    n = 65536
+    dev = torch.device("cuda:0")
+    rec = torch.from_numpy(np.frombuffer(packed, dtype=np.int64).copy()).to(dev)
+    batch = rec.repeat(n, 1).contiguous()
+    q0, qwords, f0, qfr, n_gl = T.query_section_layout(ci)
+    tampered = np.array([T.splitmix64(1 + i) % 16 == 0 for i in range(n)])
+    rows = torch.tensor(np.nonzero(tampered)[0], device=dev)
+    cols = torch.tensor([q0 + T.splitmix64(2 + int(i)) % (ci.num_query_rounds * qwords) for i in np.nonzero(tampered)[0]], device=dev)
+    batch[rows, cols] = batch[rows, cols] ^ 1
+    acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    chip = gpv.verifier.NewVerifierChip(api, common)
+    chip.VerifyDevice(circuit, batch.data_ptr(), n, acc.data_ptr())
+    api.synchronize()
+    got = acc.cpu().numpy()
+    assert (got == (~tampered).astype(np.uint8)).all()
+    acc2 = torch.zeros(8192, dtype=torch.uint8, device=dev)
+    chip.VerifyDevice(circuit, batch.data_ptr(), 8192, acc2.data_ptr())
+    api.synchronize()
+    assert (acc2.cpu().numpy() == got[:8192]).all()
+    del batch
+    torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------- Verify with caller-supplied challenges; heterogeneous batches
 @pytest.mark.parametrize("name", ["decode_block", "step"])
 def test_verify_given_challenges_on_permuted_query_rounds(gpv, api, orc, name):
