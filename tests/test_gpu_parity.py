@@ -215,6 +215,43 @@ def test_gates_without_reference_kat(gpv, api, orc):
             assert got[i].shape == exp.shape and (got[i] == exp).all(), kind
 
 
+def test_gate_parameter_sweep(gpv, api, orc):
+    """Every parametrised gate over the range of parameters that fit 136 wires (the fixtures and gates_test.go pin one parameter
+    set each): ArithmeticGate / ArithmeticExtensionGate / MulExtensionGate num_ops, BaseSumGate limbs x base, ConstantGate,
+    ReducingGate / ReducingExtensionGate num_coeffs, ExponentiationGate num_power_bits, RandomAccessGate bits x copies x extra
+    constants, CosetInterpolationGate subgroup_bits x degree with arbitrary barycentric weights -- constraint by constraint == oracle."""
+    rng = np.random.default_rng(99)
+    W = 136
+    cases = []
+    cases += [(4, [k, 0, 0], []) for k in (1, 7, 34)]                        # arithmetic: 4 wires per op
+    cases += [(5, [k, 0, 0], []) for k in (1, 5, 17)]                        # arithmetic extension: 8 per op
+    cases += [(6, [k, 0, 0], []) for k in (1, 9, 22)]                        # mul extension: 6 per op
+    cases += [(3, [l, b, 0], []) for l, b in ((1, 2), (8, 3), (20, 16), (63, 2), (135, 2), (4, 200))]
+    cases += [(1, [k, 0, 0], []) for k in (1, 3, 4)]                         # constant (4 constants are supplied)
+    cases += [(7, [k, 0, 0], []) for k in (1, 2, 20, 43)]                    # reducing: 6 + k + 2 (k - 1) wires
+    cases += [(8, [k, 0, 0], []) for k in (1, 2, 16, 32)]                    # reducing extension: 6 + 2 k + 2 (k - 1)
+    cases += [(9, [k, 0, 0], []) for k in (1, 2, 33, 67)]                    # exponentiation: 2 + 2 k wires
+    for bits in range(0, 7):
+        for copies, extra in ((1, 0), (2, 2), (3, 1)):
+            if (2 + (1 << bits)) * copies + extra + copies * bits <= W and extra <= 4:
+                cases.append((10, [bits, copies, extra], []))
+    for sb, deg in ((1, 2), (2, 2), (2, 3), (3, 2), (3, 4), (4, 6), (4, 2), (4, 15), (5, 3)):
+        npnt = 1 << sb
+        if 1 + 2 * npnt + 4 + 4 * ((npnt - 2) // (deg - 1)) + 2 <= W:
+            cases.append((11, [sb, deg, 0], [int(v) for v in rand_gl(rng, npnt)]))
+    assert len(cases) > 50
+    n = 6
+    for kind, params, weights in cases:
+        wires = rand_gl(rng, (n, W, 2))
+        wires[0, :, 1] = 0                                                   # a base-field row too
+        cst = rand_gl(rng, (n, 4, 2))
+        ph = rand_gl(rng, (n, 4))
+        got = gpv.plonk.Gate(kind, *params, weights=weights).EvalUnfiltered(cst, wires, ph, api, max_out=512)
+        for i in range(n):
+            exp = orc.gate_eval_unfiltered(kind, params, weights, cst[i], wires[i], ph[i])
+            assert got[i].shape == exp.shape and (got[i] == exp).all(), (kind, params, i)
+
+
 # ---------------------------------------------------------------- protocol stages on the fixtures
 def _load(gpv, name):
     d = T.GOLDEN / name
