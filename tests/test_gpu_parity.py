@@ -438,6 +438,29 @@ def test_merkle_full_size_config5(gpv, api, orc):
     assert (ok[idx] == orc.merkle_chains(oc, batch[idx], chs[idx])).all()
 
 
+def test_verify_json_tool_on_the_reference_files(tmp_path):
+    """tools/verify_json.py: the reference's three JSON files in, verdict out (exit status 0 = all accepted); a tampered proof
+    file makes it exit 1."""
+    import os
+    import subprocess
+    import sys
+    for name in ("decode_block", "step"):
+        d = T.GOLDEN / name
+        cmd = [sys.executable, str(T.ROOT / "tools" / "verify_json.py"), "--common", str(d / "common_circuit_data.json"), "--verifier-only",
+               str(d / "verifier_only_circuit_data.json"), str(d / "proof_with_public_inputs.json"), "--repeat", "3"]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ))
+        assert out.returncode == 0 and "accepted: 3, rejected: 0" in out.stdout, out.stdout + out.stderr
+    pj = json.loads((T.GOLDEN / "step" / "proof_with_public_inputs.json").read_text())
+    pj["proof"]["openings"]["wires"][5][0] ^= 1
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps(pj))
+    d = T.GOLDEN / "step"
+    out = subprocess.run([sys.executable, str(T.ROOT / "tools" / "verify_json.py"), "--common", str(d / "common_circuit_data.json"), "--verifier-only",
+                          str(d / "verifier_only_circuit_data.json"), str(d / "proof_with_public_inputs.json"), str(bad)], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 1 and "accepted: 1, rejected: 1" in out.stdout, out.stdout + out.stderr
+
+
 def test_bench_collective_path_single_rank():
     """bench.py's multi-GPU code path (RCCL init, barrier, packed-bit all_gather, max-reduce of the time) on one rank."""
     import json as _json
