@@ -39,7 +39,7 @@ extern "C" int gpv_shard_bounds(size_t n, int rank, int world, size_t* lo, size_
 extern "C" size_t gpv_accept_slot_bytes(size_t n, int world) {
   if (world <= 0) return 0;
   const size_t max_block = (n + (size_t)world - 1) / (size_t)world;
-  return (max_block + 7) / 8;
+  return ((max_block + 7) / 8 + 15) & ~(size_t)15;  // whole 16-byte units: every rank's slot of the gather buffer stays 16-byte aligned
 }
 
 namespace {
@@ -411,7 +411,7 @@ extern "C" int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const vo
 }
 
 extern "C" int gpv_group_verify(gpv_group* g, const gpv_circuit* c, const void* proofs, size_t n_total, uint8_t* accept) {
-  if (!g || !c || !accept || (n_total && !proofs)) return GPV_EINVAL;
+  if (!g || !c || !accept) return GPV_EINVAL;  // `proofs` may be NULL when none of this process's blocks holds a proof (n_total < world)
   std::lock_guard<std::mutex> lk(g->call_mu);
   if (n_total == 0) return GPV_OK;
   if (wants_collective(g)) {
@@ -432,6 +432,7 @@ extern "C" int gpv_group_verify(gpv_group* g, const gpv_circuit* c, const void* 
       w.accept_all_cap = n_total;
     }
     uint8_t* acc_local = w.accept_all + lo;  // unused when the block is empty
+    if (hi > lo && !proofs) { worker_fail(w, GPV_EINVAL, "proofs is NULL but rank %d owns %zu proofs", w.rank, hi - lo); return; }
     if (hi > lo) W_GPV(w, gpvi_verify_host_batch(w.ctx, c, (const uint8_t*)proofs + (lo - first_lo) * rec, hi - lo, &acc_local));
     exchange(g, w, acc_local, n_total, w.accept_all);
     if (w.rc != GPV_OK || peer_copies(g)) return;

@@ -267,7 +267,7 @@ int gpv_merkle_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs
  * verdict of the whole batch. RCCL is dlopen'ed on first use; a group of one device never needs it. */
 /* Block of rank `rank`: sizes differ by at most one, lower ranks get the extra proof. Pure host arithmetic. */
 int gpv_shard_bounds(size_t n, int rank, int world, size_t* lo, size_t* hi);
-/* Bytes every rank contributes to the all-gather: ceil(ceil(n / world) / 8). */
+/* Bytes every rank contributes to the all-gather: ceil(ceil(n / world) / 8), rounded up to a multiple of 16 (zero padding). */
 size_t gpv_accept_slot_bytes(size_t n, int world);
 typedef struct gpv_group gpv_group;
 /* One process drives n_devices GPUs: a worker thread and a gpv_ctx per device, RCCL clique via ncclCommInitAll. Rank i runs

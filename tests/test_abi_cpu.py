@@ -72,7 +72,7 @@ def test_group_shard_arithmetic_matches_distributed(gpv):
                 prev = hi
                 sizes.append(hi - lo)
             assert prev == n and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
-            assert L.gpv_accept_slot_bytes(n, world) == (max(sizes) + 7) // 8
+            assert L.gpv_accept_slot_bytes(n, world) == ((max(sizes) + 7) // 8 + 15) // 16 * 16
     lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
     for bad in ((8, -1, 2), (8, 2, 2), (8, 0, 0)):
         assert L.gpv_shard_bounds(bad[0], bad[1], bad[2], ctypes.byref(lo), ctypes.byref(hi)) == gpv._lib.GPV_EINVAL
