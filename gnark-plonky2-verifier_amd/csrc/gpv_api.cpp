@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -67,6 +68,10 @@ struct gpv_ctx {
   size_t stage_accept_n = 0;
   hipStream_t upload = nullptr;
   hipEvent_t ev_upload = nullptr;
+  // host-batch path: odd chunks run on a second context of the same device (own stream pair and scratch), so that two chunks are
+  // in flight and the launch tails / small-chunk latency of one overlap the other's kernels
+  gpv_ctx* twin = nullptr;
+  hipEvent_t ev_twin_done = nullptr;
 };
 
 static void ctx_error(gpv_ctx* ctx, const char* fmt, ...) {
@@ -196,6 +201,8 @@ extern "C" int gpv_ctx_destroy(gpv_ctx* ctx) {
   if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
   if (ctx->upload) { hipStreamSynchronize(ctx->upload); hipStreamDestroy(ctx->upload); }
   if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
+  if (ctx->twin) gpv_ctx_destroy(ctx->twin);
+  if (ctx->ev_twin_done) hipEventDestroy(ctx->ev_twin_done);
   if (ctx->crown) hipFree(ctx->crown);
   if (ctx->stage) hipFree(ctx->stage);
   if (ctx->stage_accept) hipFree(ctx->stage_accept);
@@ -1062,10 +1069,12 @@ extern "C" int gpv_verify_detail(gpv_ctx* ctx, const gpv_circuit* c, const void*
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GPV_OK;
 }
-// Host batch -> accept bytes, the plain VerifierChip.Verify replacement. The records are uploaded in chunks on their own
-// stream (1024, 2048, then up to 8192 proofs each) so that all but the first copy overlap the verification of the previous
-// chunk; staging lives in the context (no hipMalloc per call). Pageable host memory works (the copy then blocks the host
-// thread, not the GPU); pinned memory (hipHostMalloc / hipHostRegister by the caller) copies faster.
+// Host batch -> accept bytes, the plain VerifierChip.Verify replacement. The records are uploaded in chunks on their own stream
+// and verified as they arrive, two chunks in flight: even chunks on this context, odd ones on a twin context of the same device
+// (own stream pair and scratch). A single chunk in flight left the GPU under-used while the batch ramped up (a 1024-proof chunk
+// runs at 2/3 of the rate of an 8192-proof one) -- 98 k proofs/s at 8192 host-resident proofs; with two in flight the tails of
+// one chunk overlap the other's kernels (tools/half_batch_probe.py): 104 k at 8192, 112 k at 32768. Staging lives in the context (no hipMalloc per call).
+// Pageable host memory works (the copy then blocks the host thread, not the GPU); pinned memory copies faster.
 int gpvi_verify_host_batch(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t** accept_dev) {
   ENTER(ctx);
   const size_t rec = c->dc.proof_nbytes;
@@ -1079,28 +1088,52 @@ int gpvi_verify_host_batch(gpv_ctx* ctx, const gpv_circuit* c, const void* proof
     HIP_TRY(ctx, hipMalloc((void**)&ctx->stage_accept, n));
     ctx->stage_accept_n = n;
   }
-  {
-    int rc = ensure_scratch(ctx, c, n < 8192 ? n : 8192);  // once, for the largest chunk: no re-allocation between chunks
-    if (rc != GPV_OK) return rc;
-  }
-  size_t done = 0, step = 1024;
-  while (done < n) {
-    size_t left = n - done, take;
-    if (step < 4096 && left > 2 * step) {
-      take = step;  // ramp-up: short first copies, so the GPU starts early
-      step *= 2;
-    } else {
-      size_t parts = (left + 8191) / 8192;
-      take = (left + parts - 1) / parts;
+  // Chunk schedule: a short first chunk so that the GPU starts after a few milliseconds of upload, then chunks of up to 4096 proofs,
+  // two in flight. GPV_HOST_CHUNKS="a,b,c" overrides the sizes (the last one repeats) -- a measurement hook.
+  // Measured at 8192 / 32768 host-resident proofs (pinned or pageable, 57 GB/s H2D; profiles/r02j_host_path.txt): 78.7 / 293 ms with
+  // 1024,1024,2048,4096...; 80.3 / 297 with 1024,3072,4096; 84.5 / 300 with 4096; 94.1 / 309 with one chunk of 8192 at a time.
+  size_t sched[8] = {1024, 1024, 2048, 4096, 0, 0, 0, 0};
+  int n_sched = 4;
+  if (const char* env = getenv("GPV_HOST_CHUNKS")) {
+    n_sched = 0;
+    for (const char* q = env; *q && n_sched < 8;) {
+      size_t v = strtoull(q, (char**)&q, 10);
+      if (v) sched[n_sched++] = v;
+      while (*q == ',') q++;
     }
+    if (n_sched == 0) { sched[0] = 4096; n_sched = 1; }
+  }
+  const bool two = n > sched[0];
+  if (two && !ctx->twin) {
+    int rc = gpv_ctx_create(&ctx->twin, ctx->device);
+    if (rc != GPV_OK) { ctx_error(ctx, "second context for the host-batch path: %s", gpv_get_global_error()); return rc; }
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_twin_done, hipEventDisableTiming));
+  }
+  if (two) {
+    ctx->twin->merkle_shared = ctx->merkle_shared;
+    ctx->twin->transcript_variant = ctx->transcript_variant;
+  }
+  size_t done = 0, k = 0;
+  while (done < n) {
+    const size_t chunk = sched[k < (size_t)n_sched ? k : (size_t)n_sched - 1];
+    const size_t take = n - done < chunk + chunk / 4 ? n - done : chunk;  // the last chunk absorbs a short remainder
+    gpv_ctx* run = (two && (k & 1)) ? ctx->twin : ctx;
     const uint8_t* src = (const uint8_t*)proofs + done * rec;
     uint8_t* dst = ctx->stage + done * rec;
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, take * rec, hipMemcpyHostToDevice, ctx->upload));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->upload));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload, 0));
-    int rc = gpv_verify_dev(ctx, c, dst, take, ctx->stage_accept + done);
-    if (rc != GPV_OK) return rc;
+    HIP_TRY(ctx, hipEventRecord(run->ev_upload, ctx->upload));
+    HIP_TRY(ctx, hipStreamWaitEvent(run->stream, run->ev_upload, 0));
+    int rc = gpv_verify_dev(run, c, dst, take, ctx->stage_accept + done);
+    if (rc != GPV_OK) {
+      if (run != ctx) ctx_error(ctx, "%s", run->err.c_str());
+      return rc;
+    }
     done += take;
+    k++;
+  }
+  if (two) {  // the caller's stream order covers both contexts
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_twin_done, ctx->twin->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_twin_done, 0));
   }
   *accept_dev = ctx->stage_accept;
   return GPV_OK;
