@@ -42,7 +42,7 @@ struct gpv_ctx {
   hipStream_t own_stream = nullptr;
   // side stream + events: the latency-bound transcript (and plonk / FRI field work) overlaps the Merkle leaf hashing
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_transcript = nullptr, ev_side_done = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_cleared = nullptr, ev_transcript = nullptr, ev_side_done = nullptr;
   u32* digests = nullptr;
   size_t digest_words = 0;
   int transcript_variant = 0;  // GPV_OPT_TRANSCRIPT_VARIANT
@@ -179,6 +179,7 @@ extern "C" int gpv_ctx_create(gpv_ctx** out, int device_id) {
   hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_cleared, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_transcript, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_side_done, hipEventDisableTiming) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->upload, hipStreamNonBlocking) != hipSuccess ||
@@ -207,6 +208,7 @@ extern "C" int gpv_ctx_destroy(gpv_ctx* ctx) {
   if (ctx->stage) hipFree(ctx->stage);
   if (ctx->stage_accept) hipFree(ctx->stage_accept);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_cleared) hipEventDestroy(ctx->ev_cleared);
   if (ctx->ev_transcript) hipEventDestroy(ctx->ev_transcript);
   if (ctx->ev_side_done) hipEventDestroy(ctx->ev_side_done);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -419,13 +421,17 @@ static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* p
   rc = ensure_scratch(ctx, c, n);
   if (rc != GPV_OK) return rc;
   hipStream_t main_st = ctx->stream, side = ctx->side;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), main_st));
-  launch_range_check(ctx, main_st, dcd, proofs_dev, n);
+  // The transcript goes first: its few waves (one lane per proof, a long dependent chain) must be resident before the leaf
+  // hashing fills every wave slot of the chip, or they wait for the first Merkle waves to retire (milliseconds).
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_st));
   HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
   launch_transcript(ctx, side, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_transcript, side));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), main_st));
+  launch_range_check(ctx, main_st, dcd, proofs_dev, n);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_cleared, main_st));
   launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n);
+  HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_cleared, 0));  // plonk and the FRI queries OR into the fail masks
   launch_plonk(ctx, side, dcd, proofs_dev, n);
   launch_fri_query(ctx, side, c, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));

@@ -51,6 +51,8 @@ GPV_DEV Fr fr_load(const u32* tab, int idx) {  // Montgomery-form table entry, i
 }
 
 // ---------------------------------------------------------------- 64-bit column accumulators
+// Operand-scanning form (rounds 1b - 2f). The product path uses the column-scanning rows further down (fr_row); these stay
+// as the reference form of the arithmetic for the MFMA feasibility probe (gpv_k_mfma_probe.hip) and for A/B runs.
 struct FrCols {
   u64 t[2 * FR_LIMBS];
 };
@@ -110,27 +112,136 @@ GPV_DEV Fr frc_reduce(FrCols& c) {
   return r;
 }
 
+// ---------------------------------------------------------------- column-scanning rows (the product path's form)
+// (sum_t a[t] * b[t]  [+ x * R]) / R mod r, up to a multiple of r -- the same value frc_mac x K + frc_reduce returns, bit
+// for bit, evaluated COLUMN BY COLUMN: column k's multiply-add chain starts from the carry of column k-1, takes the K * 9
+// operand products and the m_i * n_j products of the Montgomery step that land on it, and leaves as one masked limb and
+// one shifted carry. Against the operand-scanning form above this removes the 16 64-bit "column += carry" additions of
+// every reduction (205 instead of 220 instructions for a single product, measured on the ISA) and the 18 live 64-bit
+// columns (36 VGPRs): only the chain accumulator and the nine m_i are live besides the operands.
+// Bounds are those of frc_reduce: a column holds <= 9 K products < 2^58 (2^60 with lazy-sum operands), 9 products
+// m * n_j < 2^58 and one carry < 2^36; K <= 5 normalised products keep it below 2^63.8.
+struct FrRowAcc {
+  u32 m[FR_LIMBS];
+  u64 acc;
+  Fr r;
+};
+// One multiply-add of the chain, pinned: the empty asm makes the running sum opaque, so the compiler cannot re-associate
+// the chain into "products from zero, carry added last" (which is what brings the 64-bit additions back).
+GPV_DEV void frr_mad(u64& acc, u32 a, u32 b) {
+  acc += (u64)a * b;
+  asm("" : "+v"(acc));
+}
+// finish column K_: add the Montgomery products, emit m / the result limb, shift the carry out
+template <int COL>
+GPV_DEV void frr_finish_column(FrRowAcc& w) {
+  const u32 n[FR_LIMBS] = FR29_N_INIT;
+  if (COL < FR_LIMBS) {
+#pragma unroll
+    for (int i = 0; i < COL; i++) frr_mad(w.acc, w.m[i], n[COL - i]);
+    w.m[COL] = ((u32)w.acc * FR29_NINV) & FR_MASK;
+    frr_mad(w.acc, w.m[COL], n[0]);
+    w.acc >>= FR_BITS;  // low 29 bits are zero now
+  } else {
+#pragma unroll
+    for (int i = COL - FR_LIMBS + 1; i < FR_LIMBS; i++) frr_mad(w.acc, w.m[i], n[COL - i]);
+    if (COL < 2 * FR_LIMBS - 1) {
+      w.r.l[COL - FR_LIMBS] = (u32)w.acc & FR_MASK;
+      w.acc >>= FR_BITS;
+    } else {
+      w.r.l[FR_LIMBS - 1] = (u32)w.acc;
+    }
+  }
+}
+template <int COL>
+GPV_DEV void frr_mac_column(FrRowAcc& w, const Fr& a, const Fr& b) {
+#pragma unroll
+  for (int i = (COL < FR_LIMBS ? 0 : COL - FR_LIMBS + 1); i <= (COL < FR_LIMBS ? COL : FR_LIMBS - 1); i++)
+    frr_mad(w.acc, a.l[i], b.l[COL - i]);
+}
+// a * a with the cross terms doubled (d = 2 a limb-wise): 45 multiply-adds over the 17 columns
+template <int COL>
+GPV_DEV void frr_sqr_column(FrRowAcc& w, const Fr& a, const u32 (&d)[FR_LIMBS]) {
+#pragma unroll
+  for (int i = (COL < FR_LIMBS ? 0 : COL - FR_LIMBS + 1); 2 * i < COL; i++) frr_mad(w.acc, a.l[i], d[COL - i]);
+  if (COL % 2 == 0) frr_mad(w.acc, a.l[COL / 2], a.l[COL / 2]);
+}
+// + x * R: limb COL - 9 of x enters column COL (one multiply-add by an opaque 1: a 64-bit add of a zero-extended
+// register would need a second, zeroed register and an instruction to make it)
+GPV_DEV u32 frr_one() {
+  u32 r;
+  asm("s_mov_b32 %0, 1" : "=s"(r));
+  return r;
+}
+template <int COL>
+GPV_DEV void frr_add_column(FrRowAcc& w, const Fr& x, u32 one) {
+  if (COL >= FR_LIMBS) frr_mad(w.acc, x.l[COL - FR_LIMBS], one);
+}
+template <int K, bool ADD, int COL>
+struct FrRowStep {
+  static GPV_DEV void run(FrRowAcc& w, const Fr* a, const Fr* b, const Fr& x, u32 one) {
+#pragma unroll
+    for (int t = 0; t < K; t++) frr_mac_column<COL>(w, a[t], b[t]);
+    if (ADD) frr_add_column<COL>(w, x, one);
+    frr_finish_column<COL>(w);
+    FrRowStep<K, ADD, COL + 1>::run(w, a, b, x, one);
+  }
+};
+template <int K, bool ADD>
+struct FrRowStep<K, ADD, 2 * FR_LIMBS> {
+  static GPV_DEV void run(FrRowAcc&, const Fr*, const Fr*, const Fr&, u32) {}
+};
+// `one`: the multiplier of the addend -- frr_one(), or a wave-uniform 0 / 1 when one code path serves rows with and without
+// an addend (the last full round of Poseidon has no round constants)
+template <int K, bool ADD>
+GPV_DEV Fr fr_row(const Fr* a, const Fr* b, const Fr& x, u32 one) {
+  FrRowAcc w;
+  w.acc = 0;
+  FrRowStep<K, ADD, 0>::run(w, a, b, x, one);
+  return w.r;
+}
+template <int COL>
+struct FrSqrStep {
+  static GPV_DEV void run(FrRowAcc& w, const Fr& a, const u32 (&d)[FR_LIMBS]) {
+    frr_sqr_column<COL>(w, a, d);
+    frr_finish_column<COL>(w);
+    FrSqrStep<COL + 1>::run(w, a, d);
+  }
+};
+template <>
+struct FrSqrStep<2 * FR_LIMBS> {
+  static GPV_DEV void run(FrRowAcc&, const Fr&, const u32 (&)[FR_LIMBS]) {}
+};
+
 // ---------------------------------------------------------------- composite operations
 // a * b / R (mod r). Operands: normalised or lazy sums of two normalised values, any value < 2^261; the result is
 // < a*b/R + r (e.g. < 2 r when a*b < 168 r^2).
-GPV_DEV Fr fr_mul(const Fr& a, const Fr& b) {
-  FrCols c;
-  frc_zero(c);
-  frc_mac(c, a, b);
-  return frc_reduce(c);
-}
+GPV_DEV Fr fr_mul(const Fr& a, const Fr& b) { return fr_row<1, false>(&a, &b, a, 0u); }
 GPV_DEV Fr fr_sqr(const Fr& a) {
-  FrCols c;
-  frc_zero(c);
-  frc_sqr(c, a);
-  return frc_reduce(c);
+  u32 d[FR_LIMBS];
+#pragma unroll
+  for (int i = 0; i < FR_LIMBS; i++) d[i] = a.l[i] << 1;
+  FrRowAcc w;
+  w.acc = 0;
+  FrSqrStep<0>::run(w, a, d);
+  return w.r;
 }
 // a * b / R + x
-GPV_DEV Fr fr_mul_add(const Fr& a, const Fr& b, const Fr& x) {
-  FrCols c;
-  frc_init_addend(c, x);
-  frc_mac(c, a, b);
-  return frc_reduce(c);
+GPV_DEV Fr fr_mul_add(const Fr& a, const Fr& b, const Fr& x, u32 one) { return fr_row<1, true>(&a, &b, x, one); }
+GPV_DEV Fr fr_mul_add(const Fr& a, const Fr& b, const Fr& x) { return fr_mul_add(a, b, x, frr_one()); }
+// a0 b0 + a1 b1 (+ x), ... : K products, one reduction
+GPV_DEV Fr fr_dot2_add(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& x) {
+  const Fr a[2] = {a0, a1}, b[2] = {b0, b1};
+  return fr_row<2, true>(a, b, x, frr_one());
+}
+GPV_DEV Fr fr_dot4(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& a2, const Fr& b2, const Fr& a3, const Fr& b3) {
+  const Fr a[4] = {a0, a1, a2, a3}, b[4] = {b0, b1, b2, b3};
+  return fr_row<4, false>(a, b, a0, 0u);
+}
+GPV_DEV Fr fr_dot5(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& a2, const Fr& b2, const Fr& a3, const Fr& b3,
+                   const Fr& a4, const Fr& b4) {
+  const Fr a[5] = {a0, a1, a2, a3, a4}, b[5] = {b0, b1, b2, b3, b4};
+  return fr_row<5, false>(a, b, a0, 0u);
 }
 // ---------------------------------------------------------------- conversions
 // 256-bit little-endian words -> 9 limbs (no reduction: any value < 2^256 < 6 r is a legal operand)

@@ -3,8 +3,9 @@
 #include "gpv_launch.h"
 #include "gpv_fri.cuh"
 
-__global__ __launch_bounds__(64) void k_fri_query(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+__global__ __launch_bounds__(64) GPVK_SIDE_STREAM_KERNEL void k_fri_query(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                   const u64* __restrict__ derived, size_t n, u32* __restrict__ fail) {
+  gpvk_side_stream_priority();
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries;
   if (item >= n * nq) return;

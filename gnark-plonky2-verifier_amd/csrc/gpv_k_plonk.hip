@@ -27,9 +27,10 @@ __global__ __launch_bounds__(GPV_PLONK_BLOCK) void k_gate_eval_unfiltered(DevGat
   gate_eval_unfiltered(g, v, weights, lds + threadIdx.x, GPV_PLONK_BLOCK, sink);
 }
 
-__global__ __launch_bounds__(GPV_PLONK_BLOCK) void k_plonk(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+__global__ __launch_bounds__(GPV_PLONK_BLOCK) GPVK_SIDE_STREAM_KERNEL void k_plonk(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                            const u64* __restrict__ derived, size_t n, u32* __restrict__ fail) {
   __shared__ u64 lds[GPV_PLONK_BLOCK * GPV_PLONK_LDS_PER_LANE];
+  gpvk_side_stream_priority();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64* rec = proofs + i * (dc->proof_nbytes / 8);

@@ -20,8 +20,9 @@ __global__ __launch_bounds__(256) void k_range_check(const DevCircuit* __restric
     if (x >= GLP) atomicOr(&fail[p], (u32)GPV_FAIL_RANGE);
   }
 }
-__global__ __launch_bounds__(64) void k_transcript(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+__global__ __launch_bounds__(64) GPVK_SIDE_STREAM_KERNEL void k_transcript(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
                                                    u64* __restrict__ derived) {
+  gpvk_side_stream_priority();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64* rec = proofs + i * (dc->proof_nbytes / 8);
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(64) void k_transcript(const DevCircuit* __restrict_
 __global__ __launch_bounds__(64) void k_transcript_coop(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
                                                         u64* __restrict__ derived) {
   __shared__ u64 lds_rc[360];
+  gpvk_side_stream_priority();
   pgl_coop_stage_constants(lds_rc);
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PGL_COOP_LANES;
   if (i >= n) return;  // whole 16-lane groups leave together; the others only exchange data inside their own group
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(64) void k_transcript_coop(const DevCircuit* __rest
 // challenges supplied by the caller: fill in the public-inputs hash and the reduced openings only
 __global__ __launch_bounds__(64) void k_derive_extra(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
                                                      u64* __restrict__ derived) {
+  gpvk_side_stream_priority();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64* rec = proofs + i * (dc->proof_nbytes / 8);

@@ -20,6 +20,15 @@ void gpvk_note_launch(hipError_t e, const char* what);
     gpvk_note_launch(hipGetLastError(), #kernel);                  \
   } while (0)
 
+// The kernels of the side stream (transcript, plonk, FRI query arithmetic) are short dependent chains on few waves; the
+// Merkle kernels next to them on the same SIMDs issue a VALU instruction in every slot. Raising the wave's issue priority
+// lets the side-stream wave take a slot whenever its next instruction is ready, so its latency-bound critical path stays
+// hidden under the hashing instead of being stretched by the round-robin share (s_setprio: 0 = default .. 3 = highest).
+#define GPVK_SIDE_STREAM_KERNEL __attribute__((amdgpu_waves_per_eu(4, 4)))
+#if defined(__HIPCC__)
+__device__ __forceinline__ void gpvk_side_stream_priority() { __builtin_amdgcn_s_setprio(3); }
+#endif
+
 // gpv_k_prim.hip
 void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n);
 void gpvk_gl_hints(hipStream_t st, int hint, const u64* in, u64* out, uint8_t* ok, size_t n);

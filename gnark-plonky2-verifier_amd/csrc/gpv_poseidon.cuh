@@ -165,21 +165,24 @@ GPV_DEV Fr pbn_exp5(const Fr& x) {
   Fr x4 = fr_sqr(x2);
   return fr_mul(x4, x);
 }
-GPV_DEV Fr pbn_exp5_add(const Fr& x, const Fr& c) {
+GPV_DEV Fr pbn_exp5_add(const Fr& x, const Fr& c, u32 one) {
   Fr x2 = fr_sqr(x);
   Fr x4 = fr_sqr(x2);
-  return fr_mul_add(x4, x, c);
+  return fr_mul_add(x4, x, c, one);
 }
+GPV_DEV Fr pbn_exp5_add(const Fr& x, const Fr& c) { return pbn_exp5_add(x, c, frr_one()); }
 struct PbnState {
   Fr s0, s1, s2, s3;
 };
-// s_k <- s_k^5 + C[it + k] for k = 0..3  (exp5state then ark, bn254.go:136-143); it < 0: no constants.
+// s_k <- s_k^5 + C[it + k] for k = 0..3  (exp5state then ark, bn254.go:136-143); it < 0: no constants (the same code with the
+// addend multiplied by a wave-uniform 0: one copy of the S-box serves all eight full rounds, which keeps the permutation
+// inside the 64 KB instruction cache).
 // `count` < 4 (TwoToOne's first round) applies it to the first `count` elements of the rotating state only, with the
 // constants C[it + 4 - count + j]: started from (s_2, s_3, *, *) two trips leave (*, *, f(s_2), f(s_3)).
 GPV_DEV void pbn_sbox_ark(PbnState& st, int it, int count = 4) {
 #pragma unroll 1
   for (int k = 4 - count; k < 4; k++) {
-    Fr t = it >= 0 ? pbn_exp5_add(st.s0, pbn_load(PBN_C, it + k)) : pbn_exp5(st.s0);
+    Fr t = pbn_exp5_add(st.s0, pbn_load(PBN_C, it >= 0 ? it + k : 0), it >= 0 ? 1u : 0u);
     st.s0 = st.s1;
     st.s1 = st.s2;
     st.s2 = st.s3;
@@ -188,13 +191,7 @@ GPV_DEV void pbn_sbox_ark(PbnState& st, int it, int count = 4) {
 }
 // sum_j tab[base + j] * s_j, one reduction. Inputs normalised and < 2.2 r, table entries < r: result < 1.1 r.
 GPV_DEV Fr pbn_dot4(const u32* tab, int base, const Fr& a0, const Fr& a1, const Fr& a2, const Fr& a3) {
-  FrCols c;
-  frc_zero(c);
-  frc_mac(c, a0, pbn_load(tab, base));
-  frc_mac(c, a1, pbn_load(tab, base + 1));
-  frc_mac(c, a2, pbn_load(tab, base + 2));
-  frc_mac(c, a3, pbn_load(tab, base + 3));
-  return frc_reduce(c);
+  return fr_dot4(a0, pbn_load(tab, base), a1, pbn_load(tab, base + 1), a2, pbn_load(tab, base + 2), a3, pbn_load(tab, base + 3));
 }
 // mix (bn254.go:194-208): out_i = sum_j m[j][i] s_j; tab holds the transposed matrix, tab[4 i + j] = m[j][i].
 // HALF (TwoToOne's first round, wave-uniform): s_0 and s_1 are constants whose share of row i is the precomputed PBN_KK[i],
@@ -204,17 +201,11 @@ GPV_DEV void pbn_mix(PbnState& st, const u32* tab, bool half = false) {
   Fr r0 = fr_zero(), r1 = fr_zero(), r2 = fr_zero(), r3 = fr_zero();
 #pragma unroll 1
   for (int i = 0; i < 4; i++) {
-    FrCols c;
-    if (HALF_POSSIBLE && half) {
-      frc_init_addend(c, pbn_load(PBN_KK, i));
-    } else {
-      frc_zero(c);
-      frc_mac(c, st.s0, pbn_load(tab, 4 * i));
-      frc_mac(c, st.s1, pbn_load(tab, 4 * i + 1));
-    }
-    frc_mac(c, st.s2, pbn_load(tab, 4 * i + 2));
-    frc_mac(c, st.s3, pbn_load(tab, 4 * i + 3));
-    Fr acc = frc_reduce(c);
+    Fr acc;
+    if (HALF_POSSIBLE && half)
+      acc = fr_dot2_add(st.s2, pbn_load(tab, 4 * i + 2), st.s3, pbn_load(tab, 4 * i + 3), pbn_load(PBN_KK, i));
+    else
+      acc = pbn_dot4(tab, 4 * i, st.s0, st.s1, st.s2, st.s3);
     r0 = r1;
     r1 = r2;
     r2 = r3;
@@ -244,63 +235,38 @@ GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
     st.s2 = fr_add_lazy(s[2], pbn_load(PBN_C, 2));
     st.s3 = fr_add_lazy(s[3], pbn_load(PBN_C, 3));
   }
-  // first half of the full rounds (bn254.go:130-150, isFirst): 3 x {x^5, ark, mix M}, then x^5, ark(16), mix P
+  // The eight full rounds share ONE copy of their code (loop over the two halves, the 56 partial rounds sit between them):
+  // first half (bn254.go:130-150, isFirst): 3 x {x^5, ark, mix M}, then x^5, ark(16), mix P;
+  // second half (!isFirst): 3 x {x^5, ark, mix M}, then x^5, mix M.
 #pragma unroll 1
-  for (int i = 0; i < 4; i++) {
-    const bool head = ZERO_HEAD && i == 0;
-    pbn_sbox_ark(st, (i + 1) * 4, head ? 2 : 4);
-    pbn_mix<ZERO_HEAD>(st, i < 3 ? PBN_MT : PBN_PT, head);
-  }
-  // 56 partial rounds (bn254.go:152-169), evaluated two at a time. The reference updates s_k += t * S[7i+3+k] every round
-  // (three Montgomery reductions); here rounds A = 2w and B = 2w + 1 share them: round B's row uses the window's base
-  // values b_k and the precomputed cross constant X_w = sum_k S[7B+k] S[7A+3+k] (tools/gen_constants.py), and
-  // b_k <- b_k + t_A S[7A+3+k] + t_B S[7B+3+k] is reduced once. 11 instead of 14 reductions per two rounds, exact in F_r.
-  // Bounds: s_1..s_3 are never reduced below their running bound -- each round adds < 1.02 r, so after 56 rounds they are
-  // < 60 r < 2^260 (R = 2^261 = 168.9 r); limbs are normalised by every reduction; the 5-product row stays below
-  // (2 * 2.2 + 3 * 60) r^2 / R + r < 2.1 r and its columns below 45 * 2^58 + 9 * 2^58 < 2^63.8.
+  for (int half = 0; half < 2; half++) {
 #pragma unroll 1
-  for (int w = 0; w < 28; w++) {
-    const int a = 2 * w, b = 2 * w + 1;
-    Fr ta = pbn_exp5_add(st.s0, pbn_load(PBN_C, 20 + a));
-    Fr s0a = pbn_dot4(PBN_S, 7 * a, ta, st.s1, st.s2, st.s3);
-    Fr tb = pbn_exp5_add(s0a, pbn_load(PBN_C, 20 + b));
-    {
-      FrCols c;
-      frc_zero(c);
-      frc_mac(c, tb, pbn_load(PBN_S, 7 * b));
-      frc_mac(c, st.s1, pbn_load(PBN_S, 7 * b + 1));
-      frc_mac(c, st.s2, pbn_load(PBN_S, 7 * b + 2));
-      frc_mac(c, st.s3, pbn_load(PBN_S, 7 * b + 3));
-      frc_mac(c, ta, pbn_load(PBN_X, w));
-      st.s0 = frc_reduce(c);
+    for (int i = 0; i < 4; i++) {
+      const bool head = ZERO_HEAD && half == 0 && i == 0;
+      const int it = half == 0 ? (i + 1) * 4 : (i < 3 ? 20 + 56 + 4 * i : -1);
+      pbn_sbox_ark(st, it, head ? 2 : 4);
+      pbn_mix<ZERO_HEAD>(st, (half == 0 && i == 3) ? PBN_PT : PBN_MT, head);
     }
-    {
-      FrCols c;
-      frc_init_addend(c, st.s1);
-      frc_mac(c, ta, pbn_load(PBN_S, 7 * a + 4));
-      frc_mac(c, tb, pbn_load(PBN_S, 7 * b + 4));
-      st.s1 = frc_reduce(c);
-    }
-    {
-      FrCols c;
-      frc_init_addend(c, st.s2);
-      frc_mac(c, ta, pbn_load(PBN_S, 7 * a + 5));
-      frc_mac(c, tb, pbn_load(PBN_S, 7 * b + 5));
-      st.s2 = frc_reduce(c);
-    }
-    {
-      FrCols c;
-      frc_init_addend(c, st.s3);
-      frc_mac(c, ta, pbn_load(PBN_S, 7 * a + 6));
-      frc_mac(c, tb, pbn_load(PBN_S, 7 * b + 6));
-      st.s3 = frc_reduce(c);
-    }
-  }
-  // second half (bn254.go:130-150, !isFirst): 3 x {x^5, ark, mix M}, then x^5, mix M
+    if (half == 1) break;
+    // 56 partial rounds (bn254.go:152-169), evaluated two at a time. The reference updates s_k += t * S[7i+3+k] every round
+    // (three Montgomery reductions); here rounds A = 2w and B = 2w + 1 share them: round B's row uses the window's base
+    // values b_k and the precomputed cross constant X_w = sum_k S[7B+k] S[7A+3+k] (tools/gen_constants.py), and
+    // b_k <- b_k + t_A S[7A+3+k] + t_B S[7B+3+k] is reduced once. 11 instead of 14 reductions per two rounds, exact in F_r.
+    // Bounds: s_1..s_3 are never reduced below their running bound -- each round adds < 1.02 r, so after 56 rounds they are
+    // < 60 r < 2^260 (R = 2^261 = 168.9 r); limbs are normalised by every reduction; the 5-product row stays below
+    // (2 * 2.2 + 3 * 60) r^2 / R + r < 2.1 r and its columns below 45 * 2^58 + 9 * 2^58 < 2^63.8.
 #pragma unroll 1
-  for (int i = 0; i < 4; i++) {
-    pbn_sbox_ark(st, i < 3 ? 20 + 56 + 4 * i : -1);
-    pbn_mix<false>(st, PBN_MT);
+    for (int w = 0; w < 28; w++) {
+      const int a = 2 * w, b = 2 * w + 1;
+      Fr ta = pbn_exp5_add(st.s0, pbn_load(PBN_C, 20 + a));
+      Fr s0a = pbn_dot4(PBN_S, 7 * a, ta, st.s1, st.s2, st.s3);
+      Fr tb = pbn_exp5_add(s0a, pbn_load(PBN_C, 20 + b));
+      st.s0 = fr_dot5(tb, pbn_load(PBN_S, 7 * b), st.s1, pbn_load(PBN_S, 7 * b + 1), st.s2, pbn_load(PBN_S, 7 * b + 2), st.s3,
+                      pbn_load(PBN_S, 7 * b + 3), ta, pbn_load(PBN_X, w));
+      st.s1 = fr_dot2_add(ta, pbn_load(PBN_S, 7 * a + 4), tb, pbn_load(PBN_S, 7 * b + 4), st.s1);
+      st.s2 = fr_dot2_add(ta, pbn_load(PBN_S, 7 * a + 5), tb, pbn_load(PBN_S, 7 * b + 5), st.s2);
+      st.s3 = fr_dot2_add(ta, pbn_load(PBN_S, 7 * a + 6), tb, pbn_load(PBN_S, 7 * b + 6), st.s3);
+    }
   }
   s[0] = st.s0;
   s[1] = st.s1;
