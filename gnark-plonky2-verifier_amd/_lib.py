@@ -245,6 +245,7 @@ class _BorrowedContext(Context):
         self.h = None
 
 
+OPT_TRANSCRIPT_VARIANT, OPT_MERKLE_SHARED_LEVELS, OPT_FR_EVALUATION = 1, 2, 3  # gpv_ctx_set_option / gpv_group_set_option
 GROUP_OPT_COLLECTIVE = 100
 
 

@@ -60,6 +60,7 @@ struct gpv_ctx {
   // the copy of chunk k+1 runs while chunk k is being verified
   // shared upper Merkle levels (gpv_k_crown.hip)
   int merkle_shared = 1;  // GPV_OPT_MERKLE_SHARED_LEVELS: 0 off, 1 from GPV_MERKLE_SHARED_FROM proofs up, 2 always
+  int fr_form = 0;        // GPV_OPT_FR_EVALUATION: 0 by launch size, 1 column scanning, 2 operand scanning (gpv_fr.cuh)
   void* crown = nullptr;
   size_t crown_bytes = 0;
   uint8_t* stage = nullptr;
@@ -232,6 +233,10 @@ extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
     ctx->merkle_shared = value;
     return GPV_OK;
   }
+  if (option == GPV_OPT_FR_EVALUATION && value >= 0 && value <= 2) {
+    ctx->fr_form = value;
+    return GPV_OK;
+  }
   ctx->err = "unknown option or value";
   return GPV_EINVAL;
 }
@@ -371,7 +376,7 @@ static void launch_plonk(gpv_ctx* ctx, hipStream_t st, const DevCircuit* dcd, co
 }
 static void launch_merkle_leaves(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n) {
   Timed t(ctx, TK_LEAVES, st);
-  gpvk_merkle_leaves(st, dcd, c->dc, (const u64*)proofs, n, ctx->digests);
+  gpvk_merkle_leaves(st, dcd, c->dc, (const u64*)proofs, n, ctx->digests, ctx->fr_form);
 }
 static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n,
                                 uint8_t* ok_dev) {
@@ -381,12 +386,12 @@ static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit*
     CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown);
     {
       Timed tl(ctx, TK_LOWER, st);
-      gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS);
+      gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS, ctx->fr_form);
     }
-    gpvk_crown(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, b, ctx->fail);
+    gpvk_crown(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, b, ctx->fail, ctx->fr_form);
     return;
   }
-  gpvk_merkle_climb(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, ctx->fail, ok_dev);
+  gpvk_merkle_climb(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, ctx->fail, ok_dev, ctx->fr_form);
 }
 // both Merkle phases back to back on one stream (entry points with caller-supplied challenges)
 static void launch_merkle(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, uint8_t* ok_dev) {
@@ -656,7 +661,7 @@ extern "C" int gpv_poseidon_bn254_permute_dev(gpv_ctx* ctx, const uint64_t* stat
   if (n == 0) return GPV_OK;
   {
     Timed t(ctx, TK_PBN);
-    gpvk_poseidon_bn254_permute(ctx->stream, states, out, n);
+    gpvk_poseidon_bn254_permute(ctx->stream, states, out, n, ctx->fr_form);
   }
   CHECK_LAUNCH(ctx);
   return GPV_OK;
@@ -714,7 +719,7 @@ extern "C" int gpv_poseidon_bn254_hash_or_noop(gpv_ctx* ctx, const uint64_t* in,
     return GPV_OK;
   }
   return map_host(ctx, in, len, out, 4, n, [&](u64* i, u64* o) {
-    gpvk_poseidon_bn254_hash_or_noop(ctx->stream, i, (u32)len, o, n);
+    gpvk_poseidon_bn254_hash_or_noop(ctx->stream, i, (u32)len, o, n, ctx->fr_form);
     return GPV_OK;
   });
 }
@@ -729,7 +734,7 @@ extern "C" int gpv_poseidon_bn254_two_to_one(gpv_ctx* ctx, const uint64_t* left,
   HIP_TRY(ctx, dout.alloc(4 * n));
   HIP_TRY(ctx, hipMemcpyAsync(dl.p, left, 32 * n, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(dr.p, right, 32 * n, hipMemcpyHostToDevice, ctx->stream));
-  gpvk_poseidon_bn254_two_to_one(ctx->stream, dl.p, dr.p, dout.p, n);
+  gpvk_poseidon_bn254_two_to_one(ctx->stream, dl.p, dr.p, dout.p, n, ctx->fr_form);
   CHECK_LAUNCH(ctx);
   HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1118,6 +1123,7 @@ int gpvi_verify_host_batch(gpv_ctx* ctx, const gpv_circuit* c, const void* proof
   if (two) {
     ctx->twin->merkle_shared = ctx->merkle_shared;
     ctx->twin->transcript_variant = ctx->transcript_variant;
+    ctx->twin->fr_form = ctx->fr_form;
   }
   size_t done = 0, k = 0;
   while (done < n) {
@@ -1278,7 +1284,7 @@ extern "C" int gpv_mfma_probe_permute(gpv_ctx* ctx, int which, const uint64_t* s
   float best = 1e30f;
   for (int rep = 0; rep <= reps; rep++) {
     hipEventRecord(e0, ctx->stream);
-    if (which == 0) gpvk_poseidon_bn254_permute(ctx->stream, din.p, dout.p, n);
+    if (which == 0) gpvk_poseidon_bn254_permute(ctx->stream, din.p, dout.p, n, 2);
     else gpvk_poseidon_bn254_permute_mfma(ctx->stream, din.p, dout.p, n, dimg.p, which == 1 ? 31u : which == 3 ? (31u | 0x100u) : 0u);
     hipEventRecord(e1, ctx->stream);
     if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); ctx_error(ctx, "probe launch failed"); return GPV_EDEVICE; }

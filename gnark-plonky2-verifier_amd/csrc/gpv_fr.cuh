@@ -214,35 +214,95 @@ struct FrSqrStep<2 * FR_LIMBS> {
 };
 
 // ---------------------------------------------------------------- composite operations
-// a * b / R (mod r). Operands: normalised or lazy sums of two normalised values, any value < 2^261; the result is
-// < a*b/R + r (e.g. < 2 r when a*b < 168 r^2).
-GPV_DEV Fr fr_mul(const Fr& a, const Fr& b) { return fr_row<1, false>(&a, &b, a, 0u); }
-GPV_DEV Fr fr_sqr(const Fr& a) {
-  u32 d[FR_LIMBS];
+// Two evaluation orders of the same rows, bit-identical results, chosen by how much of the chip a launch fills
+// (gpvk_fr_chain_pays, gpv_launch.h):
+//   FrChain  column scanning (fr_row): fewest instructions, but a row is one serial chain -- the kernels need four waves per
+//            SIMD to keep the VALU busy. The throughput form: launches that fill the chip.
+//   FrWide   operand scanning (frc_*): 18 independent column chains per row, 15-16 more instructions per reduction. A single
+//            wave issues back to back, so a permutation's LATENCY is ~1.5x lower: small batches (a few waves per SIMD or
+//            fewer), where the Merkle kernels are a dependent chain of permutations on a mostly idle chip.
+// Operands: normalised or lazy sums of two normalised values, any value < 2^261; a product row returns < sum a_t b_t / R + r.
+// `one` (0 or 1, wave-uniform) multiplies the addend.
+struct FrChain {
+  GPV_DEV static u32 one() { return frr_one(); }
+  GPV_DEV static Fr mul(const Fr& a, const Fr& b) { return fr_row<1, false>(&a, &b, a, 0u); }
+  GPV_DEV static Fr sqr(const Fr& a) {
+    u32 d[FR_LIMBS];
 #pragma unroll
-  for (int i = 0; i < FR_LIMBS; i++) d[i] = a.l[i] << 1;
-  FrRowAcc w;
-  w.acc = 0;
-  FrSqrStep<0>::run(w, a, d);
-  return w.r;
-}
-// a * b / R + x
-GPV_DEV Fr fr_mul_add(const Fr& a, const Fr& b, const Fr& x, u32 one) { return fr_row<1, true>(&a, &b, x, one); }
-GPV_DEV Fr fr_mul_add(const Fr& a, const Fr& b, const Fr& x) { return fr_mul_add(a, b, x, frr_one()); }
-// a0 b0 + a1 b1 (+ x), ... : K products, one reduction
-GPV_DEV Fr fr_dot2_add(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& x) {
-  const Fr a[2] = {a0, a1}, b[2] = {b0, b1};
-  return fr_row<2, true>(a, b, x, frr_one());
-}
-GPV_DEV Fr fr_dot4(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& a2, const Fr& b2, const Fr& a3, const Fr& b3) {
-  const Fr a[4] = {a0, a1, a2, a3}, b[4] = {b0, b1, b2, b3};
-  return fr_row<4, false>(a, b, a0, 0u);
-}
-GPV_DEV Fr fr_dot5(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& a2, const Fr& b2, const Fr& a3, const Fr& b3,
-                   const Fr& a4, const Fr& b4) {
-  const Fr a[5] = {a0, a1, a2, a3, a4}, b[5] = {b0, b1, b2, b3, b4};
-  return fr_row<5, false>(a, b, a0, 0u);
-}
+    for (int i = 0; i < FR_LIMBS; i++) d[i] = a.l[i] << 1;
+    FrRowAcc w;
+    w.acc = 0;
+    FrSqrStep<0>::run(w, a, d);
+    return w.r;
+  }
+  GPV_DEV static Fr mul_add(const Fr& a, const Fr& b, const Fr& x, u32 one) { return fr_row<1, true>(&a, &b, x, one); }
+  GPV_DEV static Fr dot2_add(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& x) {
+    const Fr a[2] = {a0, a1}, b[2] = {b0, b1};
+    return fr_row<2, true>(a, b, x, frr_one());
+  }
+  GPV_DEV static Fr dot4(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& a2, const Fr& b2, const Fr& a3, const Fr& b3) {
+    const Fr a[4] = {a0, a1, a2, a3}, b[4] = {b0, b1, b2, b3};
+    return fr_row<4, false>(a, b, a0, 0u);
+  }
+  GPV_DEV static Fr dot5(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& a2, const Fr& b2, const Fr& a3, const Fr& b3,
+                         const Fr& a4, const Fr& b4) {
+    const Fr a[5] = {a0, a1, a2, a3, a4}, b[5] = {b0, b1, b2, b3, b4};
+    return fr_row<5, false>(a, b, a0, 0u);
+  }
+};
+struct FrWide {
+  GPV_DEV static u32 one() { return 1u; }
+  GPV_DEV static Fr mul(const Fr& a, const Fr& b) {
+    FrCols c;
+    frc_zero(c);
+    frc_mac(c, a, b);
+    return frc_reduce(c);
+  }
+  GPV_DEV static Fr sqr(const Fr& a) {
+    FrCols c;
+    frc_zero(c);
+    frc_sqr(c, a);
+    return frc_reduce(c);
+  }
+  GPV_DEV static Fr mul_add(const Fr& a, const Fr& b, const Fr& x, u32 one) {
+    FrCols c;
+    Fr xm;
+#pragma unroll
+    for (int i = 0; i < FR_LIMBS; i++) xm.l[i] = x.l[i] & (0u - one);
+    frc_init_addend(c, xm);
+    frc_mac(c, a, b);
+    return frc_reduce(c);
+  }
+  GPV_DEV static Fr dot2_add(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& x) {
+    FrCols c;
+    frc_init_addend(c, x);
+    frc_mac(c, a0, b0);
+    frc_mac(c, a1, b1);
+    return frc_reduce(c);
+  }
+  GPV_DEV static Fr dot4(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& a2, const Fr& b2, const Fr& a3, const Fr& b3) {
+    FrCols c;
+    frc_zero(c);
+    frc_mac(c, a0, b0);
+    frc_mac(c, a1, b1);
+    frc_mac(c, a2, b2);
+    frc_mac(c, a3, b3);
+    return frc_reduce(c);
+  }
+  GPV_DEV static Fr dot5(const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1, const Fr& a2, const Fr& b2, const Fr& a3, const Fr& b3,
+                         const Fr& a4, const Fr& b4) {
+    FrCols c;
+    frc_zero(c);
+    frc_mac(c, a0, b0);
+    frc_mac(c, a1, b1);
+    frc_mac(c, a2, b2);
+    frc_mac(c, a3, b3);
+    frc_mac(c, a4, b4);
+    return frc_reduce(c);
+  }
+};
+// conversions and one-off products (not on a hot path): the compact form
+GPV_DEV Fr fr_mul(const Fr& a, const Fr& b) { return FrChain::mul(a, b); }
 // ---------------------------------------------------------------- conversions
 // 256-bit little-endian words -> 9 limbs (no reduction: any value < 2^256 < 6 r is a legal operand)
 GPV_DEV Fr fr_limbs_from_words(const u64 x[4]) {

@@ -29,11 +29,13 @@
 //           BN254 only): hash_or_noop = the elements themselves padded with zeros when there are at most 4, else the
 //           rate-8 overwrite sponge (poseidon/goldilocks.go:72-86); two_to_one = first four words of
 //           permute([left, right, 0, 0, 0, 0])
-struct HashBN {
+// FA: the evaluation order of the Fr rows (gpv_fr.cuh) -- FrChain for launches that fill the chip, FrWide for small ones
+template <class FA>
+struct HashBNOf {
   typedef Fr Node;
   static constexpr u32 kind = 0;
-  GPV_DEV static Node leaf(const u64* __restrict__ leaf, u32 len) { return poseidon_bn254_hash_or_noop(leaf, len); }  // fri.go:104
-  GPV_DEV static Node two_to_one(const Node& l, const Node& r) { return poseidon_bn254_two_to_one(l, r); }
+  GPV_DEV static Node leaf(const u64* __restrict__ leaf, u32 len) { return poseidon_bn254_hash_or_noop<FA>(leaf, len); }  // fri.go:104
+  GPV_DEV static Node two_to_one(const Node& l, const Node& r) { return poseidon_bn254_two_to_one<FA>(l, r); }
   GPV_DEV static Node from_words(const u64* __restrict__ w) { return fr_from_canonical64(w); }
   GPV_DEV static void to_words(const Node& a, u64 out[4]) { fr_to_canonical64(a, out); }
   GPV_DEV static void words_reduce(u64 w[4]) { fr_words_reduce(w); }  // a supplied 256-bit value is taken mod r like a gnark witness
@@ -54,6 +56,8 @@ struct HashBN {
     return r;
   }
 };
+typedef HashBNOf<FrChain> HashBN;
+typedef HashBNOf<FrWide> HashBNWide;
 struct GlNode {
   u64 w[4];
 };

@@ -5,27 +5,50 @@
 #include "gpv_fri.cuh"
 #include "gpv_transcript.cuh"
 
-__global__ __launch_bounds__(64) void k_poseidon_bn254_permute(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+// Every BN254 kernel exists in the two evaluation orders of gpv_fr.cuh: the plain name is the column-scanning (throughput)
+// form, `_wide` the operand-scanning (latency) form; the launch wrappers pick by the number of lanes (gpvk_fr_chain_pays).
+template <class FA>
+GPV_DEV void poseidon_bn254_permute_body(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fr s[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) s[k] = fr_from_canonical64(in + 16 * i + 4 * k);
-  poseidon_bn254_permute(s);
+  poseidon_bn254_permute<false, FA>(s);
 #pragma unroll
   for (int k = 0; k < 4; k++) fr_to_canonical64(s[k], out + 16 * i + 4 * k);
 }
-__global__ __launch_bounds__(64) void k_poseidon_bn254_hash_or_noop(const u64* __restrict__ in, u32 len, u64* __restrict__ out, size_t n) {
+template <class FA>
+GPV_DEV void poseidon_bn254_hash_or_noop_body(const u64* __restrict__ in, u32 len, u64* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fr h = poseidon_bn254_hash_or_noop(in + (size_t)len * i, len);
+  Fr h = poseidon_bn254_hash_or_noop<FA>(in + (size_t)len * i, len);
   fr_to_canonical64(h, out + 4 * i);
 }
-__global__ __launch_bounds__(64) void k_poseidon_bn254_two_to_one(const u64* __restrict__ l, const u64* __restrict__ r, u64* __restrict__ out, size_t n) {
+template <class FA>
+GPV_DEV void poseidon_bn254_two_to_one_body(const u64* __restrict__ l, const u64* __restrict__ r, u64* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fr h = poseidon_bn254_two_to_one(fr_from_canonical64(l + 4 * i), fr_from_canonical64(r + 4 * i));
+  Fr h = poseidon_bn254_two_to_one<FA>(fr_from_canonical64(l + 4 * i), fr_from_canonical64(r + 4 * i));
   fr_to_canonical64(h, out + 4 * i);
+}
+__global__ __launch_bounds__(64) void k_poseidon_bn254_permute(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+  poseidon_bn254_permute_body<FrChain>(in, out, n);
+}
+__global__ __launch_bounds__(64) void k_poseidon_bn254_permute_wide(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+  poseidon_bn254_permute_body<FrWide>(in, out, n);
+}
+__global__ __launch_bounds__(64) void k_poseidon_bn254_hash_or_noop(const u64* __restrict__ in, u32 len, u64* __restrict__ out, size_t n) {
+  poseidon_bn254_hash_or_noop_body<FrChain>(in, len, out, n);
+}
+__global__ __launch_bounds__(64) void k_poseidon_bn254_hash_or_noop_wide(const u64* __restrict__ in, u32 len, u64* __restrict__ out, size_t n) {
+  poseidon_bn254_hash_or_noop_body<FrWide>(in, len, out, n);
+}
+__global__ __launch_bounds__(64) void k_poseidon_bn254_two_to_one(const u64* __restrict__ l, const u64* __restrict__ r, u64* __restrict__ out, size_t n) {
+  poseidon_bn254_two_to_one_body<FrChain>(l, r, out, n);
+}
+__global__ __launch_bounds__(64) void k_poseidon_bn254_two_to_one_wide(const u64* __restrict__ l, const u64* __restrict__ r, u64* __restrict__ out, size_t n) {
+  poseidon_bn254_two_to_one_body<FrWide>(l, r, out, n);
 }
 __global__ void k_poseidon_bn254_to_vec(const u64* __restrict__ h, u64* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,17 +140,33 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_leaves(const DevCir
                                                                     size_t n, MerkleOrder order, u32* __restrict__ digests) {
   merkle_leaves_body<HashBN>(dc, proofs, n, order, digests);
 }
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_leaves_wide(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                    size_t n, MerkleOrder order, u32* __restrict__ digests) {
+  merkle_leaves_body<HashBNWide>(dc, proofs, n, order, digests);
+}
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                                    const u64* __restrict__ derived, size_t n, MerkleOrder order,
                                                                    const u32* __restrict__ digests, u32* __restrict__ fail,
                                                                    uint8_t* __restrict__ ok_out) {
   merkle_climb_body<HashBN>(dc, proofs, derived, n, order, digests, fail, ok_out);
 }
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_wide(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                   const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                                   const u32* __restrict__ digests, u32* __restrict__ fail,
+                                                                   uint8_t* __restrict__ ok_out) {
+  merkle_climb_body<HashBNWide>(dc, proofs, derived, n, order, digests, fail, ok_out);
+}
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_lower(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                                          const u64* __restrict__ derived, size_t n, MerkleOrder order,
                                                                          const u32* __restrict__ digests, u64* __restrict__ mid,
                                                                          u32 crown_levels) {
   merkle_climb_lower_body<HashBN>(dc, proofs, derived, n, order, digests, mid, crown_levels);
+}
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_lower_wide(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                         const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                                         const u32* __restrict__ digests, u64* __restrict__ mid,
+                                                                         u32 crown_levels) {
+  merkle_climb_lower_body<HashBNWide>(dc, proofs, derived, n, order, digests, mid, crown_levels);
 }
 // Poseidon-Goldilocks configuration: ~20x less arithmetic per hash, so 256-lane blocks
 #define GPV_MERKLE_BLOCK_GL 256
@@ -166,45 +205,63 @@ static MerkleOrder merkle_order(const DevCircuit& c, bool leaves) {
   return o;
 }
 
-void gpvk_poseidon_bn254_permute(hipStream_t st, const u64* in, u64* out, size_t n) {
-  GPVK_LAUNCH(k_poseidon_bn254_permute, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, out, n);
+void gpvk_poseidon_bn254_permute(hipStream_t st, const u64* in, u64* out, size_t n, int form) {
+  if (gpvk_fr_chain_pays(n, form))
+    GPVK_LAUNCH(k_poseidon_bn254_permute, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, out, n);
+  else
+    GPVK_LAUNCH(k_poseidon_bn254_permute_wide, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, out, n);
 }
-void gpvk_poseidon_bn254_hash_or_noop(hipStream_t st, const u64* in, u32 len, u64* out, size_t n) {
-  GPVK_LAUNCH(k_poseidon_bn254_hash_or_noop, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
+void gpvk_poseidon_bn254_hash_or_noop(hipStream_t st, const u64* in, u32 len, u64* out, size_t n, int form) {
+  if (gpvk_fr_chain_pays(n, form))
+    GPVK_LAUNCH(k_poseidon_bn254_hash_or_noop, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
+  else
+    GPVK_LAUNCH(k_poseidon_bn254_hash_or_noop_wide, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
 }
-void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, u64* out, size_t n) {
-  GPVK_LAUNCH(k_poseidon_bn254_two_to_one, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, l, r, out, n);
+void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, u64* out, size_t n, int form) {
+  if (gpvk_fr_chain_pays(n, form))
+    GPVK_LAUNCH(k_poseidon_bn254_two_to_one, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, l, r, out, n);
+  else
+    GPVK_LAUNCH(k_poseidon_bn254_two_to_one_wide, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, l, r, out, n);
 }
 void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n) {
   GPVK_LAUNCH(k_poseidon_bn254_to_vec, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, h, out, n);
 }
 size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n) { return n * hc.num_queries * hc.n_trees * FR_LIMBS; }
-void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests) {
+void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, int form) {
   size_t items = n * hc.num_queries;
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH(k_merkle_leaves_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs, n,
                 merkle_order(hc, true), digests);
-  else
+  else if (gpvk_fr_chain_pays(items * hc.n_trees, form))
     GPVK_LAUNCH(k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
+                merkle_order(hc, true), digests);
+  else
+    GPVK_LAUNCH(k_merkle_leaves_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
                 merkle_order(hc, true), digests);
 }
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                       const u32* digests, u32* fail, uint8_t* ok_out) {
+                       const u32* digests, u32* fail, uint8_t* ok_out, int form) {
   size_t items = n * hc.num_queries;
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH(k_merkle_climb_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs,
                 derived, n, merkle_order(hc, false), digests, fail, ok_out);
-  else
+  else if (gpvk_fr_chain_pays(items * hc.n_trees, form))
     GPVK_LAUNCH(k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
+                merkle_order(hc, false), digests, fail, ok_out);
+  else
+    GPVK_LAUNCH(k_merkle_climb_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
                 merkle_order(hc, false), digests, fail, ok_out);
 }
 void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                             const u32* digests, u64* mid, u32 crown_levels) {
+                             const u32* digests, u64* mid, u32 crown_levels, int form) {
   size_t items = n * hc.num_queries;
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH(k_merkle_climb_lower_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd,
                 proofs, derived, n, merkle_order(hc, false), digests, mid, crown_levels);
-  else
+  else if (gpvk_fr_chain_pays(items * hc.n_trees, form))
     GPVK_LAUNCH(k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
+                derived, n, merkle_order(hc, false), digests, mid, crown_levels);
+  else
+    GPVK_LAUNCH(k_merkle_climb_lower_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
                 derived, n, merkle_order(hc, false), digests, mid, crown_levels);
 }

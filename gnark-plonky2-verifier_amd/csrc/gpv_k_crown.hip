@@ -204,6 +204,10 @@ __global__ __launch_bounds__(64) void k_crown_level(const DevCircuit* __restrict
                                                     const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
   crown_level_body<HashBN>(dc, proofs, derived, n, b, k);
 }
+__global__ __launch_bounds__(64) void k_crown_level_wide(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                         const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
+  crown_level_body<HashBNWide>(dc, proofs, derived, n, b, k);
+}
 __global__ __launch_bounds__(256) void k_crown_level_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                         const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
   crown_level_body<HashGL>(dc, proofs, derived, n, b, k);
@@ -340,7 +344,7 @@ CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base) {
 }
 // after gpvk_merkle_climb_lower has filled b.mid on the same stream
 void gpvk_crown(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, CrownBufs b,
-                u32* fail) {
+                u32* fail, int form) {
   size_t groups = n * hc.n_trees, items = n * hc.num_queries, cap = groups * hc.num_queries;
   gpvk_note_launch(hipMemsetAsync(b.count, 0, 4 * GPV_CROWN_LEVELS, st), "memset(crown counters)");
   gpvk_note_launch(hipMemsetAsync(b.gflag, 0, 4 * groups, st), "memset(crown flags)");
@@ -352,7 +356,11 @@ void gpvk_crown(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, con
       GPVK_LAUNCH(k_crown_level_gl, dim3(gpvk_blocks_for(cap, 256)), dim3(256), 0, st, dcd, proofs, derived, n, b, k);
     } else {
       GPVK_LAUNCH(k_crown_reconcile, dim3(gpvk_blocks_for(groups, 2)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
-      GPVK_LAUNCH(k_crown_level, dim3(gpvk_blocks_for(cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
+      // ~22 / 19 / 13 distinct nodes per tree on the three shared levels (28 uniform indices)
+      if (gpvk_fr_chain_pays(groups * 22, form))
+        GPVK_LAUNCH(k_crown_level, dim3(gpvk_blocks_for(cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
+      else
+        GPVK_LAUNCH(k_crown_level_wide, dim3(gpvk_blocks_for(cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
     }
   }
   if (gl)

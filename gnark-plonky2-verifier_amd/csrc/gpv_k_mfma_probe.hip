@@ -341,8 +341,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   st.s3 = fr_add_lazy(s[3], pbn_load(PBN_C, 3));
 #pragma unroll 1
   for (int r = 0; r < 4; r++) {
-    pbn_sbox_ark(st, (r + 1) * 4);
-    pbn_mix<false>(st, r < 3 ? PBN_MT : PBN_PT);
+    pbn_sbox_ark<FrWide>(st, (r + 1) * 4);
+    pbn_mix<false, FrWide>(st, r < 3 ? PBN_MT : PBN_PT);
   }
   ProbeBOp b1 = probe_to_bop(st.s1), b2 = probe_to_bop(st.s2), b3 = probe_to_bop(st.s3);
   // Two waves share a SIMD and run the same code: left alone they stay in lockstep (both in the VALU phase, then both queueing for
@@ -361,14 +361,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // 36 KB working set instead of 1 MB: separates operand-fetch latency from the rest)
     const uint8_t* img = images + (size_t)(w & window_mask) * PROBE_IMGS_PER_WINDOW * PROBE_IMG_BYTES;
     const int a = 2 * w, b = 2 * w + 1;
-    Fr ta = pbn_exp5_add(st.s0, pbn_load(PBN_C, 20 + a));
+    Fr ta = pbn_exp5_add<FrWide>(st.s0, pbn_load(PBN_C, 20 + a), 1u);
     ProbeBOp bta = probe_to_bop(ta);
     Fr s0a;
     {
       const ProbeBOp ops[4] = {bta, b1, b2, b3};
       s0a = probe_mfma_row<4>(img, ops, lane);
     }
-    Fr tb = pbn_exp5_add(s0a, pbn_load(PBN_C, 20 + b));
+    Fr tb = pbn_exp5_add<FrWide>(s0a, pbn_load(PBN_C, 20 + b), 1u);
     ProbeBOp btb = probe_to_bop(tb);
     {
       const ProbeBOp ops[5] = {btb, b1, b2, b3, bta};
@@ -392,8 +392,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 #pragma unroll 1
   for (int r = 0; r < 4; r++) {
-    pbn_sbox_ark(st, r < 3 ? 20 + 56 + 4 * r : -1);
-    pbn_mix<false>(st, PBN_MT);
+    pbn_sbox_ark<FrWide>(st, r < 3 ? 20 + 56 + 4 * r : -1);
+    pbn_mix<false, FrWide>(st, PBN_MT);
   }
   if (!live) return;
   fr_to_canonical64(st.s0, out + 16 * i);

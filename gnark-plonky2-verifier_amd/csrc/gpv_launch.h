@@ -29,6 +29,14 @@ void gpvk_note_launch(hipError_t e, const char* what);
 __device__ __forceinline__ void gpvk_side_stream_priority() { __builtin_amdgcn_s_setprio(3); }
 #endif
 
+// Which evaluation order of the BN254 Fr rows a launch of `lanes` hashing lanes gets (gpv_fr.cuh: FrChain / FrWide). The
+// column-scanning kernels need four resident waves per SIMD (262 144 lanes fill the chip once) and win from about two chip
+// fills on; below that the operand-scanning kernels finish sooner (step fixture, ms per batch, wide / chain: 8.0 / 11.7 at
+// 1 proof, 13.3 / 14.8 at 1024, 21.2 / 21.8 at 2048, 37.1 / 36.8 at 4096, 72.3 / 69.6 at 8192 -- profiles/r02l_batch_sweep.txt).
+#define GPV_FR_CHAIN_MIN_LANES ((size_t)1 << 19)
+// form: GPV_OPT_FR_EVALUATION -- 0 by size, 1 column scanning, 2 operand scanning
+static inline bool gpvk_fr_chain_pays(size_t lanes, int form) { return form == 1 || (form == 0 && lanes >= GPV_FR_CHAIN_MIN_LANES); }
+
 // gpv_k_prim.hip
 void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n);
 void gpvk_gl_hints(hipStream_t st, int hint, const u64* in, u64* out, uint8_t* ok, size_t n);
@@ -45,12 +53,12 @@ void gpvk_poseidon_gl_hash_no_pad(hipStream_t st, const u64* in, u32 len, u64* o
 void gpvk_microbench(hipStream_t st, int which, u64* out, int blocks, int threads, int iters);
 int gpvk_microbench_ops_per_iter();
 // gpv_k_bn254.hip
-void gpvk_poseidon_bn254_permute(hipStream_t st, const u64* in, u64* out, size_t n);
-void gpvk_poseidon_bn254_hash_or_noop(hipStream_t st, const u64* in, u32 len, u64* out, size_t n);
-void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, u64* out, size_t n);
+void gpvk_poseidon_bn254_permute(hipStream_t st, const u64* in, u64* out, size_t n, int form);
+void gpvk_poseidon_bn254_hash_or_noop(hipStream_t st, const u64* in, u32 len, u64* out, size_t n, int form);
+void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, u64* out, size_t n, int form);
 void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n);
 size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n);  // u32 words of leaf-digest scratch for n proofs
-void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests);
+void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, int form);
 // shared upper Merkle levels (gpv_k_crown.hip)
 // 3 measured best on MI355X at 8192 proofs: sibling walk 42.5 / 41.9 / 42.4 / 42.8 ms for 2 / 3 / 4 / 5 levels (each level saves fewer
 // hashes than the one above it and costs one more launch tail)
@@ -71,11 +79,11 @@ size_t gpvk_crown_bytes(const DevCircuit& hc, size_t n);
 bool gpvk_crown_supported(const DevCircuit& hc, size_t n);
 CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base);
 void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                             const u32* digests, u64* mid, u32 crown_levels);
+                             const u32* digests, u64* mid, u32 crown_levels, int form);
 void gpvk_crown(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, CrownBufs b,
-                u32* fail);
+                u32* fail, int form);
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                       const u32* digests, u32* fail, uint8_t* ok_out);
+                       const u32* digests, u32* fail, uint8_t* ok_out, int form);
 // gpv_k_transcript.hip
 void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u32* fail);
 void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);

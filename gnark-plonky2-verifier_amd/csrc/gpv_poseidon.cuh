@@ -159,18 +159,13 @@ GPV_DEV void poseidon_gl_permute(u64 s[12]) {
 // four trips return the state to its original order, every register index stays static (no scratch) and the loops stay
 // inside the instruction cache.
 GPV_DEV Fr pbn_load(const u32* tab, int idx) { return fr_load(tab, idx); }
-// x^5 (+ c)  (bn254.go:181-185): two squarings and one multiplication
-GPV_DEV Fr pbn_exp5(const Fr& x) {
-  Fr x2 = fr_sqr(x);
-  Fr x4 = fr_sqr(x2);
-  return fr_mul(x4, x);
-}
+// x^5 + one * c  (bn254.go:181-185): two squarings and one multiplication. FA = FrChain / FrWide (gpv_fr.cuh).
+template <class FA>
 GPV_DEV Fr pbn_exp5_add(const Fr& x, const Fr& c, u32 one) {
-  Fr x2 = fr_sqr(x);
-  Fr x4 = fr_sqr(x2);
-  return fr_mul_add(x4, x, c, one);
+  Fr x2 = FA::sqr(x);
+  Fr x4 = FA::sqr(x2);
+  return FA::mul_add(x4, x, c, one);
 }
-GPV_DEV Fr pbn_exp5_add(const Fr& x, const Fr& c) { return pbn_exp5_add(x, c, frr_one()); }
 struct PbnState {
   Fr s0, s1, s2, s3;
 };
@@ -179,10 +174,11 @@ struct PbnState {
 // inside the 64 KB instruction cache).
 // `count` < 4 (TwoToOne's first round) applies it to the first `count` elements of the rotating state only, with the
 // constants C[it + 4 - count + j]: started from (s_2, s_3, *, *) two trips leave (*, *, f(s_2), f(s_3)).
+template <class FA>
 GPV_DEV void pbn_sbox_ark(PbnState& st, int it, int count = 4) {
 #pragma unroll 1
   for (int k = 4 - count; k < 4; k++) {
-    Fr t = pbn_exp5_add(st.s0, pbn_load(PBN_C, it >= 0 ? it + k : 0), it >= 0 ? 1u : 0u);
+    Fr t = pbn_exp5_add<FA>(st.s0, pbn_load(PBN_C, it >= 0 ? it + k : 0), it >= 0 ? FA::one() : 0u);
     st.s0 = st.s1;
     st.s1 = st.s2;
     st.s2 = st.s3;
@@ -190,22 +186,23 @@ GPV_DEV void pbn_sbox_ark(PbnState& st, int it, int count = 4) {
   }
 }
 // sum_j tab[base + j] * s_j, one reduction. Inputs normalised and < 2.2 r, table entries < r: result < 1.1 r.
+template <class FA>
 GPV_DEV Fr pbn_dot4(const u32* tab, int base, const Fr& a0, const Fr& a1, const Fr& a2, const Fr& a3) {
-  return fr_dot4(a0, pbn_load(tab, base), a1, pbn_load(tab, base + 1), a2, pbn_load(tab, base + 2), a3, pbn_load(tab, base + 3));
+  return FA::dot4(a0, pbn_load(tab, base), a1, pbn_load(tab, base + 1), a2, pbn_load(tab, base + 2), a3, pbn_load(tab, base + 3));
 }
 // mix (bn254.go:194-208): out_i = sum_j m[j][i] s_j; tab holds the transposed matrix, tab[4 i + j] = m[j][i].
 // HALF (TwoToOne's first round, wave-uniform): s_0 and s_1 are constants whose share of row i is the precomputed PBN_KK[i],
 // so a row is that addend + two products.
-template <bool HALF_POSSIBLE>
+template <bool HALF_POSSIBLE, class FA>
 GPV_DEV void pbn_mix(PbnState& st, const u32* tab, bool half = false) {
   Fr r0 = fr_zero(), r1 = fr_zero(), r2 = fr_zero(), r3 = fr_zero();
 #pragma unroll 1
   for (int i = 0; i < 4; i++) {
     Fr acc;
     if (HALF_POSSIBLE && half)
-      acc = fr_dot2_add(st.s2, pbn_load(tab, 4 * i + 2), st.s3, pbn_load(tab, 4 * i + 3), pbn_load(PBN_KK, i));
+      acc = FA::dot2_add(st.s2, pbn_load(tab, 4 * i + 2), st.s3, pbn_load(tab, 4 * i + 3), pbn_load(PBN_KK, i));
     else
-      acc = pbn_dot4(tab, 4 * i, st.s0, st.s1, st.s2, st.s3);
+      acc = pbn_dot4<FA>(tab, 4 * i, st.s0, st.s1, st.s2, st.s3);
     r0 = r1;
     r1 = r2;
     r2 = r3;
@@ -220,7 +217,7 @@ GPV_DEV void pbn_mix(PbnState& st, const u32* tab, bool half = false) {
 // ZERO_HEAD: the caller guarantees s[0] = s[1] = 0 (TwoToOne, bn254.go:96-104). Then the first S-box layer of those two
 // elements and their share of the first mix are constants (PBN_KK, tools/gen_constants.py): the first round costs two
 // S-boxes and four two-product rows instead of four and four four-product rows -- exact, 1.6 % fewer multiply-adds.
-template <bool ZERO_HEAD = false>
+template <bool ZERO_HEAD = false, class FA = FrChain>
 GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
   PbnState st;
   // ark(0): lazy limb-wise sums (< 2^30 per limb) feed the first squaring directly
@@ -244,8 +241,8 @@ GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
     for (int i = 0; i < 4; i++) {
       const bool head = ZERO_HEAD && half == 0 && i == 0;
       const int it = half == 0 ? (i + 1) * 4 : (i < 3 ? 20 + 56 + 4 * i : -1);
-      pbn_sbox_ark(st, it, head ? 2 : 4);
-      pbn_mix<ZERO_HEAD>(st, (half == 0 && i == 3) ? PBN_PT : PBN_MT, head);
+      pbn_sbox_ark<FA>(st, it, head ? 2 : 4);
+      pbn_mix<ZERO_HEAD, FA>(st, (half == 0 && i == 3) ? PBN_PT : PBN_MT, head);
     }
     if (half == 1) break;
     // 56 partial rounds (bn254.go:152-169), evaluated two at a time. The reference updates s_k += t * S[7i+3+k] every round
@@ -258,14 +255,14 @@ GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
 #pragma unroll 1
     for (int w = 0; w < 28; w++) {
       const int a = 2 * w, b = 2 * w + 1;
-      Fr ta = pbn_exp5_add(st.s0, pbn_load(PBN_C, 20 + a));
-      Fr s0a = pbn_dot4(PBN_S, 7 * a, ta, st.s1, st.s2, st.s3);
-      Fr tb = pbn_exp5_add(s0a, pbn_load(PBN_C, 20 + b));
-      st.s0 = fr_dot5(tb, pbn_load(PBN_S, 7 * b), st.s1, pbn_load(PBN_S, 7 * b + 1), st.s2, pbn_load(PBN_S, 7 * b + 2), st.s3,
+      Fr ta = pbn_exp5_add<FA>(st.s0, pbn_load(PBN_C, 20 + a), FA::one());
+      Fr s0a = pbn_dot4<FA>(PBN_S, 7 * a, ta, st.s1, st.s2, st.s3);
+      Fr tb = pbn_exp5_add<FA>(s0a, pbn_load(PBN_C, 20 + b), FA::one());
+      st.s0 = FA::dot5(tb, pbn_load(PBN_S, 7 * b), st.s1, pbn_load(PBN_S, 7 * b + 1), st.s2, pbn_load(PBN_S, 7 * b + 2), st.s3,
                       pbn_load(PBN_S, 7 * b + 3), ta, pbn_load(PBN_X, w));
-      st.s1 = fr_dot2_add(ta, pbn_load(PBN_S, 7 * a + 4), tb, pbn_load(PBN_S, 7 * b + 4), st.s1);
-      st.s2 = fr_dot2_add(ta, pbn_load(PBN_S, 7 * a + 5), tb, pbn_load(PBN_S, 7 * b + 5), st.s2);
-      st.s3 = fr_dot2_add(ta, pbn_load(PBN_S, 7 * a + 6), tb, pbn_load(PBN_S, 7 * b + 6), st.s3);
+      st.s1 = FA::dot2_add(ta, pbn_load(PBN_S, 7 * a + 4), tb, pbn_load(PBN_S, 7 * b + 4), st.s1);
+      st.s2 = FA::dot2_add(ta, pbn_load(PBN_S, 7 * a + 5), tb, pbn_load(PBN_S, 7 * b + 5), st.s2);
+      st.s3 = FA::dot2_add(ta, pbn_load(PBN_S, 7 * a + 6), tb, pbn_load(PBN_S, 7 * b + 6), st.s3);
     }
   }
   s[0] = st.s0;
@@ -274,14 +271,16 @@ GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
   s[3] = st.s3;
 }
 // TwoToOne (bn254.go:96-104)
+template <class FA = FrChain>
 GPV_DEV Fr poseidon_bn254_two_to_one(const Fr& l, const Fr& r) {
   Fr s[4] = {fr_zero(), fr_zero(), l, r};
-  poseidon_bn254_permute<true>(s);
+  poseidon_bn254_permute<true, FA>(s);
   return s[0];
 }
 // HashOrNoop / HashNoPad over a leaf of Goldilocks words (bn254.go:47-94); `leaf` may be strided.
 // The nine words of the NEXT absorption are loaded before the current permutation starts, so their HBM latency (each lane
 // walks its own leaf: uncoalesced 8-byte loads) hides under ~100 k instructions instead of stalling the wave 16 times.
+template <class FA = FrChain>
 GPV_DEV Fr poseidon_bn254_hash_or_noop(const u64* leaf, u32 len) {
   if (len <= 3) {
     u64 x0 = len > 0 ? leaf[0] : 0, x1 = len > 1 ? leaf[1] : 0, x2 = len > 2 ? leaf[2] : 0;
@@ -299,7 +298,7 @@ GPV_DEV Fr poseidon_bn254_hash_or_noop(const u64* leaf, u32 len) {
     const u32 nx = i + 9;
 #pragma unroll
     for (u32 k = 0; k < 9; k++) w[k] = nx + k < len ? leaf[nx + k] : 0;
-    poseidon_bn254_permute(s);
+    poseidon_bn254_permute<false, FA>(s);
   }
   return s[0];
 }

@@ -118,8 +118,12 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
  * GPV_OPT_MERKLE_SHARED_LEVELS: 1 (default) = for batches of 1024 proofs or more (2 = for every batch) the last three levels of every Merkle tree are hashed once per distinct
  * node instead of once per query path (the paths of a proof's queries meet near the cap; inputs are compared word for
  * word and a proof whose paths disagree is re-hashed path by path, so accept bits are identical); 0 = every path on its
- * own, literally fri/fri.go:97-144. */
-enum { GPV_OPT_TRANSCRIPT_VARIANT = 1, GPV_OPT_MERKLE_SHARED_LEVELS = 2 };
+ * own, literally fri/fri.go:97-144.
+ * GPV_OPT_FR_EVALUATION: the BN254 kernels exist in two evaluation orders of the same Montgomery rows with bit-identical
+ * results -- column scanning (fewest instructions, needs a launch that fills the chip about twice) and operand scanning
+ * (lower latency per permutation). 0 (default) = chosen per launch by its number of hashing lanes, 1 = always column
+ * scanning, 2 = always operand scanning. */
+enum { GPV_OPT_TRANSCRIPT_VARIANT = 1, GPV_OPT_MERKLE_SHARED_LEVELS = 2, GPV_OPT_FR_EVALUATION = 3 };
 int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value);
 /* Copies the last error text of this context (or of context-free calls when ctx == NULL). */
 int gpv_last_error_message(gpv_ctx* ctx, char* buf, size_t buf_len);

@@ -183,6 +183,56 @@ def test_poseidon_bn254_hashes(gpv, api, orc):
     assert (chip.ToVec(h) == orc.poseidon_bn254_to_vec(h)).all()
 
 
+@pytest.mark.parametrize("form", [1, 2])
+def test_fr_evaluation_orders_are_identical(gpv, api, orc, form):
+    """GPV_OPT_FR_EVALUATION: the BN254 kernels exist as column-scanning (1) and operand-scanning (2) forms of the same Montgomery
+    rows, chosen per launch by its size. Forced either way, at sizes where the automatic choice would pick the other one, every
+    primitive, every Merkle chain (per-path and with the shared upper levels) and the whole verification still match the oracle."""
+    chip = gpv.poseidon.NewBN254Chip(api)
+    rng = np.random.default_rng(60 + form)
+    api.set_option(3, form)
+    try:
+        for inp, exp in PBN_KATS:  # poseidon/bn254_test.go:31-97
+            out = chip.Poseidon([[T.fr_limbs(int(x)) for x in inp]])[0]
+            assert [T.fr_from_limbs(l) for l in out] == [int(x) for x in exp]
+        states = rand_fr(rng, 4 * 700).reshape(700, 4, 4)
+        states[0] = 0
+        states[1, :] = T.fr_limbs(R - 1)
+        states[2, 0] = [2**64 - 1] * 4
+        assert (chip.Poseidon(states) == orc.poseidon_bn254_permute(states)).all()
+        for ln in (1, 3, 4, 9, 10, 27, 85, 136):
+            x = rand_gl(rng, (70, ln))
+            assert (chip.HashOrNoop(x) == orc.poseidon_bn254_hash_or_noop(x)).all(), ln
+        l, r = rand_fr(rng, 300), rand_fr(rng, 300)
+        l[0] = T.fr_limbs(R - 1)
+        r[0] = T.fr_limbs(R - 1)
+        assert (chip.TwoToOne(l, r) == orc.poseidon_bn254_two_to_one(l, r)).all()
+        for name in ("step", "decode_block"):
+            common, vo, circuit, proofs = _load(gpv, name)
+            ci, packed, _ = T.load_fixture(name)
+            oc = orc.circuit(ci)
+            n = 24
+            recs = _random_records(ci, len(packed), n, rng)
+            recs[:6] = np.frombuffer(packed, dtype=np.uint64)            # valid proofs ...
+            recs[3, T.query_section_layout(ci)[0] + 5] ^= np.uint64(1)   # ... one of them with a flipped leaf word
+            pb = gpv.variables.ProofBatch(circuit, recs.tobytes())
+            vchip = gpv.verifier.NewVerifierChip(api, common)
+            for shared in (2, 0):
+                api.set_option(2, shared)
+                try:
+                    accept, mask, ch = vchip.Verify(pb, vo, detail=True)
+                finally:
+                    api.set_option(2, 1)
+                oacc, ofail, och = orc.verify(oc, recs.tobytes(), n_threads=8)
+                assert (ch.flat == och).all() and accept.tolist() == oacc.tolist() and mask.tolist() == [int(x) for x in ofail], (name, shared)
+                assert accept[:3].all() and not accept[3] and accept[4:6].all()
+            fri = gpv.fri.NewChip(api, common)
+            rch = rand_gl(rng, och.shape)
+            assert (fri.VerifyMerkleProofsToCap(pb, rch) == orc.merkle_chains(oc, recs.tobytes(), rch)).all(), name
+    finally:
+        api.set_option(3, 0)
+
+
 # ---------------------------------------------------------------- gates (plonk/gates/gates_test.go:712-768)
 def test_gate_kats(gpv, api, orc):
     kat = json.loads((T.GOLDEN / "gates_kat.json").read_text())
