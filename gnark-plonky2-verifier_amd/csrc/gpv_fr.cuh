@@ -8,9 +8,11 @@
 // absorb every product that ever lands on it (<= 45 of them, < 2^63.5) WITHOUT a carry, so a multiplication is a
 // block of back-to-back `v_mad_u64_u32 col, a_i, b_j, col` plus one carry sweep at the end:
 //     81 (a x b) + 9 (m) + 81 (m x n) multiply-adds, ~45 cheap ops of normalisation.
-// The redundancy also buys lazy reduction: several products are summed in the columns and reduced once
-// (`frc_mac` x K then `frc_reduce`), which is how the Poseidon mix rows (4 products) and the "+ round constant" /
-// "+ s_k" additions are fused.
+// The redundancy also buys lazy reduction: several products are summed in the columns and reduced once, which is how the
+// Poseidon mix rows (4 products) and the "+ round constant" / "+ s_k" additions are fused.
+// Two evaluation orders of such a row live here, with identical results (policies FrWide / FrChain at the end of the
+// arithmetic section): operand scanning into 18 column accumulators (`frc_mac` x K then `frc_reduce`, 220 instructions for
+// one product) and, since round 2k, column scanning (`fr_row`, 205 instructions and 36 fewer live VGPRs, one serial chain).
 //
 // Representation: value = sum l[i] 2^(29 i); "normalised" means l[0..7] < 2^29 and l[8] small. Values are only kept
 // below a small multiple of r (never canonical inside a permutation); every bound is stated at the function that

@@ -150,7 +150,7 @@ GPV_DEV void poseidon_gl_permute(u64 s[12]) {
 // ================================================================ Poseidon-BN254
 // State elements are Montgomery residues in the redundant radix-2^29 form of gpv_fr.cuh (values < ~10 r, never
 // canonical inside the permutation). Fusions relative to the reference's op-by-op form (bn254.go:130-208):
-//   * x^5 + round constant: the constant enters the column accumulators of the last multiplication (C * R) -- free;
+//   * x^5 + round constant: the constant enters the column accumulators of the last multiplication (C * R);
 //   * mix row out_i = sum_j m[j][i] s_j: four products in one set of columns, ONE Montgomery reduction;
 //   * partial round: new s_0 likewise (4 products, 1 reduction); s_k += s_0 * S is a multiply with addend.
 // Per permutation: 264 single multiplications/squarings, 60 four-product rows, 28 five-product rows and 84 two-product
