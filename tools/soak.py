@@ -51,6 +51,7 @@ def work(tid):
             torch.cuda.synchronize()
             chip = gpv.verifier.NewVerifierChip(ctx, common)
             ctx.set_option(2, int(rng.choice([0, 1, 2])))
+            ctx.set_option(3, int(rng.choice([0, 1, 2])))  # GPV_OPT_FR_EVALUATION: by size / column scanning / operand scanning
             reps = int(rng.integers(2, 6))
             for _ in range(reps):
                 if ch is None:
