@@ -1084,7 +1084,7 @@ extern "C" int gpv_verify_detail(gpv_ctx* ctx, const gpv_circuit* c, const void*
 // and verified as they arrive, two chunks in flight: even chunks on this context, odd ones on a twin context of the same device
 // (own stream pair and scratch). A single chunk in flight left the GPU under-used while the batch ramped up (a 1024-proof chunk
 // runs at 2/3 of the rate of an 8192-proof one) -- 98 k proofs/s at 8192 host-resident proofs; with two in flight the tails of
-// one chunk overlap the other's kernels (tools/half_batch_probe.py): 104 k at 8192, 112 k at 32768. Staging lives in the context (no hipMalloc per call).
+// one chunk overlap the other's kernels (tools/half_batch_probe.py): 104 k at 8192, 112 k at 32768 (108 k / 117 k with the round-2k kernels). Staging lives in the context (no hipMalloc per call).
 // Pageable host memory works (the copy then blocks the host thread, not the GPU); pinned memory copies faster.
 int gpvi_verify_host_batch(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t** accept_dev) {
   ENTER(ctx);
@@ -1099,12 +1099,13 @@ int gpvi_verify_host_batch(gpv_ctx* ctx, const gpv_circuit* c, const void* proof
     HIP_TRY(ctx, hipMalloc((void**)&ctx->stage_accept, n));
     ctx->stage_accept_n = n;
   }
-  // Chunk schedule: a short first chunk so that the GPU starts after a few milliseconds of upload, then chunks of up to 4096 proofs,
-  // two in flight. GPV_HOST_CHUNKS="a,b,c" overrides the sizes (the last one repeats) -- a measurement hook.
-  // Measured at 8192 / 32768 host-resident proofs (pinned or pageable, 57 GB/s H2D; profiles/r02j_host_path.txt): 78.7 / 293 ms with
-  // 1024,1024,2048,4096...; 80.3 / 297 with 1024,3072,4096; 84.5 / 300 with 4096; 94.1 / 309 with one chunk of 8192 at a time.
-  size_t sched[8] = {1024, 1024, 2048, 4096, 0, 0, 0, 0};
-  int n_sched = 4;
+  // Chunk schedule: a short first chunk so that the GPU starts after a few milliseconds of upload, then growing chunks (from 4096
+  // proofs on the Merkle kernels run in their throughput form), two in flight. GPV_HOST_CHUNKS="a,b,c" overrides the sizes (the
+  // last one repeats) -- a measurement hook.
+  // Measured at 8192 / 32768 host-resident proofs (pinned or pageable, 57 GB/s H2D; profiles/r02l_host_path.txt): 75.9 / 280.5 ms with
+  // 1024,1024,2048,4096,8192...; 76.3 / 285.4 with 1024,1024,2048,4096...; 77.9 / 283.8 with 1024,3072,4096; 83.0 / 289.8 with 4096.
+  size_t sched[8] = {1024, 1024, 2048, 4096, 8192, 0, 0, 0};
+  int n_sched = 5;
   if (const char* env = getenv("GPV_HOST_CHUNKS")) {
     n_sched = 0;
     for (const char* q = env; *q && n_sched < 8;) {
