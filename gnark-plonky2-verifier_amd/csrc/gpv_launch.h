@@ -30,10 +30,11 @@ __device__ __forceinline__ void gpvk_side_stream_priority() { __builtin_amdgcn_s
 #endif
 
 // Which evaluation order of the BN254 Fr rows a launch of `lanes` hashing lanes gets (gpv_fr.cuh: FrChain / FrWide). The
-// column-scanning kernels need four resident waves per SIMD (262 144 lanes fill the chip once) and win from about two chip
-// fills on; below that the operand-scanning kernels finish sooner (step fixture, ms per batch, wide / chain: 8.0 / 11.7 at
-// 1 proof, 13.3 / 14.8 at 1024, 21.2 / 21.8 at 2048, 37.1 / 36.8 at 4096, 72.3 / 69.6 at 8192 -- profiles/r02l_batch_sweep.txt).
-#define GPV_FR_CHAIN_MIN_LANES ((size_t)1 << 19)
+// column-scanning kernels need four resident waves per SIMD (262 144 lanes fill the chip once) and win from about three chip
+// fills on; below that the operand-scanning kernels finish sooner. Step fixture (168 lanes per proof), ms per batch, column /
+// operand scanning: 21.6 / 20.4 at 2048 proofs, 30.0 / 29.0 at 3072, 37.3 / 36.7 at 4096, 45.2 / 45.5 at 5120, 69.1 / 71.5 at 8192,
+// 136.3 / 142.0 at 16384 (profiles/r02l_batch_sweep.txt); a single proof: 11.7 / 8.6.
+#define GPV_FR_CHAIN_MIN_LANES ((size_t)3 << 18)
 // form: GPV_OPT_FR_EVALUATION -- 0 by size, 1 column scanning, 2 operand scanning
 static inline bool gpvk_fr_chain_pays(size_t lanes, int form) { return form == 1 || (form == 0 && lanes >= GPV_FR_CHAIN_MIN_LANES); }
 

@@ -120,7 +120,7 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
  * word and a proof whose paths disagree is re-hashed path by path, so accept bits are identical); 0 = every path on its
  * own, literally fri/fri.go:97-144.
  * GPV_OPT_FR_EVALUATION: the BN254 kernels exist in two evaluation orders of the same Montgomery rows with bit-identical
- * results -- column scanning (fewest instructions, needs a launch that fills the chip about twice) and operand scanning
+ * results -- column scanning (fewest instructions, needs a launch that fills the chip about three times) and operand scanning
  * (lower latency per permutation). 0 (default) = chosen per launch by its number of hashing lanes, 1 = always column
  * scanning, 2 = always operand scanning. */
 enum { GPV_OPT_TRANSCRIPT_VARIANT = 1, GPV_OPT_MERKLE_SHARED_LEVELS = 2, GPV_OPT_FR_EVALUATION = 3 };
