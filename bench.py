@@ -172,6 +172,7 @@ def main():
 
     # ---- contexts: a plain context (single GPU / torch exchange) or the ranks of a gpv_group (C-ABI exchange)
     group, exchange, exchange_note = None, "none", ""
+    hard_exit = False  # a probe thread is stuck inside RCCL: leave with os._exit after the result line is out
     if in_process:
         group = gpv.Group(device_ids=list(range(args.gpus)))
         exchange = "abi"
@@ -190,7 +191,7 @@ def main():
         dist.broadcast(flag, src=0)
         dist.broadcast(uid, src=0)
         ok = int(flag.item())
-        if ok:
+        if ok:  # stage 1: every rank builds its group object (no communicator yet); nobody enters RCCL unless all succeeded
             try:
                 group = gpv.Group(rank=rank, world=world, unique_id=bytes(uid.cpu().numpy().tobytes()), device_id=local_rank)
                 group.set_option(gpv._lib.GROUP_OPT_COLLECTIVE, 1)
@@ -198,15 +199,36 @@ def main():
                 pb, _ = probe_wl.cloned_batch(rank, rank + 1, world)  # one proof per rank
                 pa = torch.zeros(world, dtype=torch.uint8, device=dev)
                 torch.cuda.synchronize()
-                group.verify_dev(probe_wl.circuit, [pb.data_ptr()], world, [pa.data_ptr()])  # forms the communicator (ncclCommInitRank)
             except Exception as e:  # noqa: BLE001
                 ok, why = 0, str(e)[:160]
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item()) and ok
+        if ok:  # stage 2: one tiny collective verify forms the communicator (ncclCommInitRank); a rank that does not come back
+            # within the time limit votes for the fallback and leaves its probe thread behind (see hard_exit below)
+            import threading
+            res = {}
+
+            def probe():
+                try:
+                    group.verify_dev(probe_wl.circuit, [pb.data_ptr()], world, [pa.data_ptr()])
+                    res["ok"] = True
+                except Exception as e:  # noqa: BLE001
+                    res["why"] = str(e)[:160]
+
+            th = threading.Thread(target=probe, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("GPV_BENCH_GROUP_TIMEOUT", "180")))
+            if th.is_alive():
+                ok, why, hard_exit = 0, "communicator formation did not finish in time", True
+            elif not res.get("ok"):
+                ok, why = 0, res.get("why", "probe failed")
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()):
             exchange = "abi"
         else:
-            if group is not None:
+            if group is not None and not hard_exit:
                 group.close()
             group, exchange, exchange_note = None, "torch", " (gpv_group could not be formed on every rank%s)" % (": " + why if why else "")
     elif use_collective:
@@ -391,6 +413,8 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
+    if hard_exit:
+        os._exit(0)
 
 
 def bench_poseidon_gl(gpv, T, ctx, dev):
