@@ -134,7 +134,7 @@ GPV_DEV void frr_mad(u64& acc, u32 a, u32 b) {
   acc += (u64)a * b;
   asm("" : "+v"(acc));
 }
-// finish column K_: add the Montgomery products, emit m / the result limb, shift the carry out
+// finish column COL: add the Montgomery products, emit m / the result limb, shift the carry out
 template <int COL>
 GPV_DEV void frr_finish_column(FrRowAcc& w) {
   const u32 n[FR_LIMBS] = FR29_N_INIT;
