@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Probe: does keeping two half-batches in flight on two contexts / stream pairs beat one
 full batch on one context? The launch tails of one half (crown levels, leaves -> walk hand-off) would overlap the other's
-kernels. Prints proofs/s for 1 x 8192, 2 x 4096 and 4 x 2048 in flight."""
+kernels. Prints proofs/s for 1 x N, 2 x N/2 and 4 x N/4 in flight (N = argv[1], default 8192)."""
 import importlib
 import sys
 import time
@@ -20,7 +20,7 @@ bench = importlib.import_module("bench")
 
 dev = torch.device("cuda", 0)
 wl = bench.Workload(gpv, T, "step", dev)
-N = 8192
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 batch, tam = wl.cloned_batch(0, N, N)
 acc = torch.zeros(N, dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
