@@ -46,12 +46,27 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # v_mad_u64_u32 issues on half of the SIMD-32 lanes per clock (measured: half the v_add_u32 rate, profiles/r01a_microbench.txt):
-# 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz (max clock, MI355X_MICROARCH.md). The in-run microbenchmark is reported next to it;
-# it is DVFS-sensitive (a pure multiply stream throttles harder than the kernel does), so it is not used as the denominator.
-MAD_PEAK_MODEL = 256 * 4 * 16 * 2.4e9
-MADS_PER_FR_MUL = 136  # 8x8 product + 8x8 reduction + 8 "m" multiplies (CIOS, 32-bit limbs)
+# 256 CUs x 4 SIMDs x 16 lanes/clk, at 2.4 GHz (max clock, MI355X_MICROARCH.md) for the model peak and at the shader clock sampled
+# DURING the timed steps (tools/probe: s_memtime / s_memrealtime of one spinning wave) for the peak at the measured clock.
+MAD_LANES_PER_CLK = 256 * 4 * 16
+MAD_PEAK_MODEL = MAD_LANES_PER_CLK * 2.4e9
+MADS_PER_FR_MUL = 136  # SURVEY 8d's algorithmic figure: 8x8 product + 8x8 reduction + 8 "m" multiplies (CIOS, 32-bit limbs)
 FR_MULS_PER_PERM = 784  # poseidon/bn254.go: 8 full rounds x 28 + 56 partial rounds x 10
 CROWN_LEVELS = 3  # GPV_CROWN_LEVELS (csrc/gpv_launch.h)
+
+
+def executed_mads_per_perm(zero_head):
+    """v_mad_u64_u32 the radix-2^29 kernels EXECUTE per Poseidon-BN254 permutation -- exact by construction: every frr_mad of
+    csrc/gpv_fr.cuh is one pinned v_mad_u64_u32, and a column-scanning row of K products costs 81 K (+ 9 with an addend) + 81 for
+    the Montgomery step (a squaring 45 + 81). Per permutation (csrc/gpv_poseidon.cuh): 88 S-boxes = 176 squarings + 88
+    multiply-with-addend, 60 four-product rows (32 mix rows + 28 partial-round rows), 28 five-product rows, 84 two-product updates;
+    TwoToOne (zero_head) saves two S-boxes and turns four four-product rows into two-product ones. tools/isa_count.py counts the
+    same numbers in the shipped code object (profiles/r03_isa_counts.json)."""
+    sqr, mul_add, dot4, dot5, dot2_add = 45 + 81, 81 + 9 + 81, 4 * 81 + 81, 5 * 81 + 81, 2 * 81 + 9 + 81
+    total = 176 * sqr + 88 * mul_add + 60 * dot4 + 28 * dot5 + 84 * dot2_add
+    if zero_head:
+        total += -2 * (2 * sqr + mul_add) - 4 * dot4 + 4 * dot2_add
+    return total
 
 
 def perms_per_proof(ci):
@@ -141,6 +156,7 @@ def main():
     ap.add_argument("--no-poseidon-gl", action="store_true")
     ap.add_argument("--no-heterogeneous", action="store_true")
     ap.add_argument("--no-poseidon-gl-config", action="store_true")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the BASELINE config 3 / config 5 legs (fri_verify_4096, merkle_only_4096)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the accept all-gather even at world size 1 (test hook)")
     args = ap.parse_args()
 
@@ -280,16 +296,35 @@ def main():
 
     barrier()  # the batches were written on torch's stream; a group's contexts run on their own
     full = None
+    est_step_s = None
     for _ in range(args.warmup):
+        barrier()
+        tw = time.perf_counter()
         full = step()
+        barrier()
+        est_step_s = time.perf_counter() - tw
     barrier()
     ctx.timing_enable(True)
     ctx.timing_reset()
+    # shader clock under THIS load: a one-wave sampler (tools/probe) spins on its own stream through most of the timed region
+    probe, clock_ghz = None, None
+    if rank == 0 and est_step_s:
+        try:
+            sys.path.insert(0, str(ROOT / "tools" / "probe"))
+            import gpv_probe as probe
+            probe.clock_sample_begin(int(min(0.8 * est_step_s * args.steps, 2.0) * 1e6), device=local_rank)
+        except Exception:
+            probe = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if probe is not None:
+        try:
+            clock_ghz = probe.clock_sample_end()
+        except Exception:
+            clock_ghz = None
     if torch_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -378,20 +413,48 @@ def main():
                             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_proof": alg_bytes_per_proof,
                             "other_kernels_ms": {k: v[0] for k, v in cand.items() if k != dom},
                             "note": "integer-VALU bound workload; see valu_roofline"}
-        mad_measured = max(ctx.microbench(0) for _ in range(3))
-        mad_peak = MAD_PEAK_MODEL
-        per_perm = FR_MULS_PER_PERM * MADS_PER_FR_MUL
-        rate = lambda perms, ms: float(perms) * per_perm * n_local / (ms * 1e-3) if ms > 0 else 0.0  # noqa: E731
-        # the sibling walk as a whole: the reference hashes climb_perms times per proof; the shared upper levels execute fewer,
-        # so this is an effective rate
-        line["valu_roofline"] = {"bound": "valu_int32_mad", "kernel": dom, "achieved": rate(dom_perms, dom_ms) / 1e12,
-                                 "peak": mad_peak / 1e12, "unit": "T v_mad_u64_u32 lane-ops/s", "frac": rate(dom_perms, dom_ms) / mad_peak,
-                                 "peak_definition": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz", "peak_microbench_this_run": mad_measured / 1e12,
-                                 "algorithmic_mads_per_proof": float(dom_perms) * per_perm, "bn254_perms_per_proof": dom_perms,
-                                 "per_kernel_frac": {k: rate(v[2], v[0]) / mad_peak for k, v in cand.items()},
-                                 "bn254_leaf_perms_per_proof": leaf_perms, "bn254_sibling_perms_per_proof_reference": climb_perms,
-                                 "sibling_walk_effective_frac": rate(climb_perms, merkle_ms) / mad_peak, "sibling_walk_ms": merkle_ms}
+        # VALU roofline, two numerators and two denominators, every one recomputable from this line + profiles/:
+        #   algorithmic   permutations x 784 Fr mults x 136 multiply-adds (SURVEY 8d's radix-2^32 CIOS count -- what the reference's
+        #                 arithmetic costs in 32-bit multiply-adds, independent of this implementation)
+        #   executed      permutations x the v_mad_u64_u32 the radix-2^29 kernels actually issue (executed_mads_per_perm: fewer,
+        #                 thanks to the fused rows -- 436 instead of 784 reductions)
+        #   peak_model            16 384 lanes/clk x 2.4 GHz
+        #   peak_at_measured_clock  16 384 lanes/clk x the shader clock sampled during the timed steps of this run
+        per_perm_alg = FR_MULS_PER_PERM * MADS_PER_FR_MUL
+        # leaves hash with the general permutation, the sibling walk with TwoToOne (zero head)
+        per_perm_exec = {"k_merkle_leaves": executed_mads_per_perm(False), "k_merkle_climb": executed_mads_per_perm(True),
+                         "k_merkle_climb_lower": executed_mads_per_perm(True)}
+        rate = lambda perms, ms, per_perm: float(perms) * per_perm * n_local / (ms * 1e-3) if ms > 0 else 0.0  # noqa: E731
+        peak_meas = MAD_LANES_PER_CLK * clock_ghz * 1e9 if clock_ghz else None
+        isa = {}
+        try:
+            isa = json.loads((ROOT / "profiles" / "r03_isa_counts.json").read_text())
+        except Exception:
+            pass
+        a_alg, a_exec = rate(dom_perms, dom_ms, per_perm_alg), rate(dom_perms, dom_ms, per_perm_exec[dom])
+        line["valu_roofline"] = {
+            "bound": "valu_int32_mad", "kernel": dom, "unit": "T v_mad_u64_u32 lane-ops/s",
+            "achieved": a_exec / 1e12, "peak": MAD_PEAK_MODEL / 1e12, "frac": a_exec / MAD_PEAK_MODEL,
+            "numerator": "executed multiply-adds (frac_algorithmic counts SURVEY 8d's 784 x 136 per permutation instead)",
+            "peak_definition": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (model: max clock)",
+            "executed_mads_per_perm": per_perm_exec[dom], "algorithmic_mads_per_perm": per_perm_alg,
+            "executed_mads_source": "exact by construction of the Fr rows (bench.py executed_mads_per_perm); static count of the shipped code object: profiles/r03_isa_counts.json (tools/isa_count.py)",
+            "executed_valu_per_perm": isa.get("pmc_valu_per_perm"), "executed_valu_source": isa.get("pmc_source"),
+            "achieved_algorithmic": a_alg / 1e12, "frac_algorithmic": a_alg / MAD_PEAK_MODEL,
+            "achieved_executed": a_exec / 1e12, "frac_executed": a_exec / MAD_PEAK_MODEL,
+            "shader_clock_ghz_during_steps": clock_ghz,
+            "peak_at_measured_clock": peak_meas / 1e12 if peak_meas else None,
+            "frac_executed_at_measured_clock": a_exec / peak_meas if peak_meas else None,
+            "frac_algorithmic_at_measured_clock": a_alg / peak_meas if peak_meas else None,
+            "bn254_perms_per_proof": dom_perms,
+            "per_kernel_frac_executed": {k: rate(v[2], v[0], per_perm_exec[k]) / MAD_PEAK_MODEL for k, v in cand.items()},
+            "per_kernel_frac_algorithmic": {k: rate(v[2], v[0], per_perm_alg) / MAD_PEAK_MODEL for k, v in cand.items()},
+            "bn254_leaf_perms_per_proof": leaf_perms, "bn254_sibling_perms_per_proof_reference": climb_perms,
+            "sibling_walk_effective_frac_algorithmic": rate(climb_perms, merkle_ms, per_perm_alg) / MAD_PEAK_MODEL, "sibling_walk_ms": merkle_ms}
         line["stage_ms"] = stage_ms
+        if not args.no_config_legs and n_ranks == 1:
+            line["fri_verify_4096"] = bench_fri_verify(gpv, T, ctx, dev, max(2, min(args.steps, 5)))
+            line["merkle_only_4096"] = bench_merkle_only(gpv, T, ctx, dev, max(2, min(args.steps, 5)))
         if not args.no_poseidon_gl:
             line["poseidon_gl"] = bench_poseidon_gl(gpv, T, ctx, dev)
         if not args.no_heterogeneous and n_ranks == 1:
@@ -437,6 +500,55 @@ def bench_poseidon_gl(gpv, T, ctx, dev):
     return {"metric": "poseidon_goldilocks_perms_per_sec", "value": n_states / (pgl_ms * 1e-3), "states": n_states,
             "launch_ms": pgl_ms, "hbm_GBs": n_states * 192 / (pgl_ms * 1e-3) / 1e9,
             "hbm_frac": n_states * 192 / (pgl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
+def bench_fri_verify(gpv, T, ctx, dev, steps, n=4096):
+    """BASELINE config 3: fri.VerifyFriProof on testdata/step, 28 queries x 4096 proofs, challenges supplied (precomputed once by
+    GetChallenges), everything resident in HBM: gpv_fri_verify_dev = Merkle paths + query-round field work + PoW. 1 in 16 tampered in
+    the query-round section; the failure masks of the timed run must be zero exactly for the untampered proofs."""
+    wl = Workload(gpv, T, "step", dev)
+    batch, tam = wl.cloned_batch(0, n, n)
+    chip = gpv.verifier.NewVerifierChip(ctx, wl.common)
+    ch0 = chip.GetChallenges(wl.proof).flat[0]
+    chs = torch.from_numpy(np.asarray(ch0, dtype=np.uint64).view(np.int64).copy()).to(dev).repeat(n, 1).contiguous()
+    mask = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    fchip = gpv.fri.NewChip(ctx, wl.common)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    dt = _time_steps(ctx, lambda: fchip.VerifyFriProofDevice(wl.circuit, batch.data_ptr(), chs.data_ptr(), n, mask.data_ptr()), steps)
+    stage = {nm: ctx.timing_get(k)[0] for nm, k in (("merkle_walk", 0), ("merkle_leaves", 7), ("fri_query", 4))}
+    ctx.timing_enable(False)
+    got = mask.cpu().numpy()
+    if not ((got == 0) == ~tam).all():
+        raise SystemExit("fri_verify_4096: failure masks do not match the tamper mask")
+    return {"config": "BASELINE config 3: fri.VerifyFriProof on testdata/step, 28 queries x %d proofs, challenges supplied" % n,
+            "entry_point": "gpv_fri_verify_dev", "proofs": n, "steps": steps, "proofs_per_s": n / dt, "ms_per_step": 1e3 * dt,
+            "query_rounds_per_s": n * wl.ci.num_query_rounds / dt, "stage_ms": stage, "checked": "mask == 0 exactly for the untampered proofs"}
+
+
+def bench_merkle_only(gpv, T, ctx, dev, steps, n=4096):
+    """BASELINE config 5: the Poseidon-BN254 Merkle-cap variant alone, 4096 testdata/decode_block proofs x 168 Merkle chains
+    (2 604 permutations per proof, literally one walk per path: gpv_merkle_verify_dev reports a bit per (proof, query, tree))."""
+    wl = Workload(gpv, T, "decode_block", dev)
+    ci = wl.ci
+    batch, tam = wl.cloned_batch(0, n, n)
+    chip = gpv.verifier.NewVerifierChip(ctx, wl.common)
+    ch0 = chip.GetChallenges(wl.proof).flat[0]
+    chs = torch.from_numpy(np.asarray(ch0, dtype=np.uint64).view(np.int64).copy()).to(dev).repeat(n, 1).contiguous()
+    n_chains = ci.num_query_rounds * (4 + len(ci.arity_bits))
+    ok = torch.zeros((n, n_chains), dtype=torch.uint8, device=dev)
+    fchip = gpv.fri.NewChip(ctx, wl.common)
+    dt = _time_steps(ctx, lambda: fchip.VerifyMerkleProofsToCapDevice(wl.circuit, batch.data_ptr(), chs.data_ptr(), n, ok.data_ptr()), steps)
+    good = ok.min(dim=1).values.cpu().numpy().astype(bool)
+    if not (good == ~tam).all():
+        raise SystemExit("merkle_only_4096: per-path bits do not match the tamper mask")
+    leaf_perms, climb_perms = perms_per_proof(ci)
+    perms = leaf_perms + climb_perms
+    return {"config": "BASELINE config 5: Poseidon-BN254 Merkle-cap paths only, testdata/decode_block, %d proofs x %d chains" % (n, n_chains),
+            "entry_point": "gpv_merkle_verify_dev", "proofs": n, "steps": steps, "proofs_per_s": n / dt, "ms_per_step": 1e3 * dt,
+            "bn254_perms_per_proof": perms, "bn254_perms_per_s": n * perms / dt, "fr_muls_per_s_algorithmic": n * perms * FR_MULS_PER_PERM / dt,
+            "valu_frac_algorithmic": n * perms * FR_MULS_PER_PERM * MADS_PER_FR_MUL / dt / MAD_PEAK_MODEL,
+            "checked": "all 168 path bits set exactly for the untampered proofs"}
 
 
 def _time_steps(ctx, fn, steps):
@@ -521,7 +633,7 @@ def bench_poseidon_gl_config(gpv, T, ctx, fixture, dev, n, steps):
     copies verified with the original challenges (gpv_verify_given_challenges_dev). Shows what the engine does when the hash is
     ~20x cheaper: the Merkle kernels stop dominating."""
     ci, packed, (common, vo, pj), ch = T.poseidon_gl_config_fixture(fixture)
-    circuit = gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(common)), gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)))
+    circuit = gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(common)), gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)), beyond_reference=True)
     rec = torch.from_numpy(np.frombuffer(packed, dtype=np.int64).copy()).to(dev)
     batch = rec.repeat(n, 1).contiguous()
     q0, qwords, f0, qfr, n_gl = T.query_section_layout(ci)

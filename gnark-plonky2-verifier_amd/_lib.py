@@ -11,7 +11,7 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libgpv.so"
 
-GPV_OK, GPV_ESHAPE, GPV_ECONFIG, GPV_EDEVICE, GPV_EINVAL, GPV_ENOMEM = 0, -1, -2, -3, -4, -5
+GPV_OK, GPV_ESHAPE, GPV_ECONFIG, GPV_EDEVICE, GPV_EINVAL, GPV_ENOMEM, GPV_EPEER = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/gpv.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "gpv_poseidon_bn254_two_to_one", "gpv_poseidon_bn254_to_vec", "gpv_gate_eval_unfiltered",
     "gpv_public_inputs_hash", "gpv_challenges", "gpv_plonk_verify", "gpv_gate_constraints", "gpv_fri_verify",
     "gpv_merkle_verify", "gpv_verify", "gpv_verify_detail", "gpv_verify_dev", "gpv_challenges_dev",
-    "gpv_merkle_verify_dev", "gpv_timing_enable", "gpv_timing_reset", "gpv_timing_get", "gpv_microbench", "gpv_mfma_probe", "gpv_mfma_probe_permute", "gpv_mfma_probe_overlap",
+    "gpv_merkle_verify_dev", "gpv_fri_verify_dev", "gpv_timing_enable", "gpv_timing_reset", "gpv_timing_get",
     "gpv_verify_given_challenges", "gpv_verify_given_challenges_dev",
     "gpv_shard_bounds", "gpv_accept_slot_bytes", "gpv_group_create", "gpv_group_unique_id", "gpv_group_create_rank", "gpv_group_destroy",
     "gpv_group_world", "gpv_group_local", "gpv_group_rank", "gpv_group_set_option", "gpv_group_last_error_message",
@@ -122,15 +122,12 @@ def lib():
         L.gpv_verify_dev.argtypes = [vp, vp, vp, sz, vp]
         L.gpv_challenges_dev.argtypes = [vp, vp, vp, sz, vp]
         L.gpv_merkle_verify_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.gpv_fri_verify_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.gpv_timing_enable.argtypes = [vp, i32]
         L.gpv_timing_reset.argtypes = [vp]
         L.gpv_timing_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
-        L.gpv_microbench.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double)]
         L.gpv_verify_given_challenges.argtypes = [vp, vp, vp, vp, sz, vp, vp]
         L.gpv_verify_given_challenges_dev.argtypes = [vp, vp, vp, vp, sz, vp]
-        L.gpv_mfma_probe.argtypes = [vp, i32, vp, vp, vp, vp, sz, i32, ctypes.POINTER(ctypes.c_double)]
-        L.gpv_mfma_probe_permute.argtypes = [vp, i32, vp, vp, sz, vp, sz, i32, ctypes.POINTER(ctypes.c_double)]
-        L.gpv_mfma_probe_overlap.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), vp, sz]
         L.gpv_shard_bounds.argtypes = [sz, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
         L.gpv_accept_slot_bytes.argtypes = [sz, i32]
         L.gpv_accept_slot_bytes.restype = sz
@@ -221,11 +218,6 @@ class Context:
         check(lib().gpv_timing_get(ctypes.c_void_p(self.h), kind, ctypes.byref(ms), ctypes.byref(n)), self.h)
         return ms.value, n.value
 
-    def microbench(self, which):
-        v = ctypes.c_double()
-        check(lib().gpv_microbench(ctypes.c_void_p(self.h), which, ctypes.byref(v)), self.h)
-        return v.value
-
 
 def shard_bounds(n, rank, world):
     """gpv_shard_bounds: contiguous block [lo, hi) of rank `rank` (host arithmetic, no GPU needed)."""
@@ -245,7 +237,7 @@ class _BorrowedContext(Context):
         self.h = None
 
 
-OPT_TRANSCRIPT_VARIANT, OPT_MERKLE_SHARED_LEVELS, OPT_FR_EVALUATION = 1, 2, 3  # gpv_ctx_set_option / gpv_group_set_option
+OPT_TRANSCRIPT_VARIANT, OPT_MERKLE_SHARED_LEVELS, OPT_FR_EVALUATION, OPT_HOST_CHUNK_FIRST, OPT_HOST_CHUNK_MAX = 1, 2, 3, 4, 5  # gpv_ctx_set_option / gpv_group_set_option
 GROUP_OPT_COLLECTIVE = 100
 
 

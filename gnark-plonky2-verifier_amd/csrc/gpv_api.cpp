@@ -54,8 +54,9 @@ struct gpv_ctx {
   // grow-only scratch for the verify pipeline
   u64* derived = nullptr;
   size_t derived_words = 0;
-  u32* fail = nullptr;
+  u32* fail = nullptr;  // [fail_n] failure masks, then [fail_n][GPV_DONE_STRIDE] visit counters (one allocation, one memset)
   size_t fail_n = 0;
+  u32 crown_gen = 0;  // generation of the last run that used the crown scratch (stamps of older runs do not count)
   // host-batch path (gpv_verify): grow-only staging for the packed records and the accept bytes, and an upload stream so
   // the copy of chunk k+1 runs while chunk k is being verified
   // shared upper Merkle levels (gpv_k_crown.hip)
@@ -73,6 +74,8 @@ struct gpv_ctx {
   // in flight and the launch tails / small-chunk latency of one overlap the other's kernels
   gpv_ctx* twin = nullptr;
   hipEvent_t ev_twin_done = nullptr;
+  // chunk schedule of the host-batch path: first, first, 2 first, 4 first, ... capped at max (GPV_OPT_HOST_CHUNK_FIRST / _MAX)
+  size_t host_chunk_first = 1024, host_chunk_max = 8192;
 };
 
 static void ctx_error(gpv_ctx* ctx, const char* fmt, ...) {
@@ -85,20 +88,52 @@ static void ctx_error(gpv_ctx* ctx, const char* fmt, ...) {
   else gpv_set_global_error("%s", buf);
 }
 
-#define ENTER(ctx)                                        \
-  std::lock_guard<std::recursive_mutex> enter_lock_(ctx->mu); \
-  HIP_TRY(ctx, hipSetDevice(ctx->device))
-
 // First failed kernel launch (or async memset) of this host thread since the last CHECK_LAUNCH: every launch wrapper in the
 // gpv_k_*.hip files reports hipGetLastError() right after its launch (GPVK_LAUNCH, gpv_launch.h), so a stage that never
 // started cannot be overwritten by the status of later API calls and leave fail[] == 0 ("accept") behind.
 static thread_local hipError_t g_launch_err = hipSuccess;
 static thread_local const char* g_launch_what = "";
+static thread_local int g_entry_depth = 0;
+struct EntryDepth {  // entry points nest (gpv_verify -> gpv_verify_dev): only the outermost one resets the latch
+  EntryDepth() {
+    if (g_entry_depth++ == 0) g_launch_err = hipSuccess;
+  }
+  ~EntryDepth() { g_entry_depth--; }
+};
 void gpvk_note_launch(hipError_t e, const char* what) {
   if (e != hipSuccess && g_launch_err == hipSuccess) {
     g_launch_err = e;
     g_launch_what = what;
   }
+}
+
+// A failed launch that an earlier call on this thread left latched (it returned through HIP_TRY before its CHECK_LAUNCH) must not
+// be blamed on this call: the outermost entry point of a thread starts from a clean slate.
+#define ENTER(ctx)                                        \
+  std::lock_guard<std::recursive_mutex> enter_lock_(ctx->mu); \
+  EntryDepth enter_depth_;                                \
+  HIP_TRY(ctx, hipSetDevice(ctx->device))
+
+// Fault injection for the fail-closed tests (gpv_testhooks.h): process-wide, armed only by tests.
+#include <atomic>
+static std::atomic<int> g_fault_stage{0}, g_fault_nth{-1}, g_fault_seen{0};
+static std::atomic<unsigned> g_fault_num{1}, g_fault_den{1};
+unsigned gpvk_fault_blocks(int stage, unsigned blocks) {
+  if (g_fault_stage.load(std::memory_order_relaxed) != stage) return blocks;
+  const int nth = g_fault_nth.load(), seen = g_fault_seen.fetch_add(1);
+  if (nth >= 0 && seen != nth) return blocks;
+  return (unsigned)((unsigned long long)blocks * g_fault_num.load() / g_fault_den.load());
+}
+// stage GPV_STAGE_GROUP_RANK: rank `nth` of a gpv_group reports a failed verification (exercises the failure path of the exchange)
+bool gpvi_fault_rank(int rank) { return g_fault_stage.load() == GPV_STAGE_GROUP_RANK && g_fault_nth.load() == rank; }
+extern "C" int gpvi_test_set_fault(int stage, int nth, unsigned num, unsigned den) {
+  if (den == 0) return GPV_EINVAL;
+  g_fault_num = num;
+  g_fault_den = den;
+  g_fault_nth = nth;
+  g_fault_seen = 0;
+  g_fault_stage = stage;
+  return GPV_OK;
 }
 
 #define HIP_TRY(ctx, expr)                                                                      \
@@ -237,6 +272,16 @@ extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
     ctx->fr_form = value;
     return GPV_OK;
   }
+  if (option == GPV_OPT_HOST_CHUNK_FIRST && value >= 1 && value <= (1 << 24)) {
+    ctx->host_chunk_first = (size_t)value;
+    if (ctx->host_chunk_max < ctx->host_chunk_first) ctx->host_chunk_max = ctx->host_chunk_first;
+    return GPV_OK;
+  }
+  if (option == GPV_OPT_HOST_CHUNK_MAX && value >= 1 && value <= (1 << 24)) {
+    ctx->host_chunk_max = (size_t)value;
+    if (ctx->host_chunk_first > ctx->host_chunk_max) ctx->host_chunk_first = ctx->host_chunk_max;
+    return GPV_OK;
+  }
   ctx->err = "unknown option or value";
   return GPV_EINVAL;
 }
@@ -263,6 +308,10 @@ extern "C" int gpv_timing_reset(gpv_ctx* ctx) {
   ENTER(ctx);
   int rc = drain_timing(ctx);
   for (int i = 0; i < TK_COUNT; i++) { ctx->acc_ms[i] = 0; ctx->acc_n[i] = 0; }
+  if (ctx->twin) {
+    drain_timing(ctx->twin);
+    for (int i = 0; i < TK_COUNT; i++) { ctx->twin->acc_ms[i] = 0; ctx->twin->acc_n[i] = 0; }
+  }
   return rc;
 }
 extern "C" int gpv_timing_get(gpv_ctx* ctx, int kind, double* avg_ms, uint64_t* launches) {
@@ -270,8 +319,16 @@ extern "C" int gpv_timing_get(gpv_ctx* ctx, int kind, double* avg_ms, uint64_t* 
   ENTER(ctx);
   int rc = drain_timing(ctx);
   if (rc != GPV_OK) return rc;
-  if (avg_ms) *avg_ms = ctx->acc_n[kind] ? ctx->acc_ms[kind] / (double)ctx->acc_n[kind] : 0.0;
-  if (launches) *launches = ctx->acc_n[kind];
+  double ms = ctx->acc_ms[kind];
+  uint64_t cnt = ctx->acc_n[kind];
+  if (ctx->twin) {  // odd chunks of host batches run on the twin context
+    rc = drain_timing(ctx->twin);
+    if (rc != GPV_OK) { ctx->err = ctx->twin->err; return rc; }
+    ms += ctx->twin->acc_ms[kind];
+    cnt += ctx->twin->acc_n[kind];
+  }
+  if (avg_ms) *avg_ms = cnt ? ms / (double)cnt : 0.0;
+  if (launches) *launches = cnt;
   return GPV_OK;
 }
 
@@ -325,6 +382,44 @@ static bool merkle_shared_for(const gpv_ctx* ctx, const gpv_circuit* c, size_t n
   if (ctx->merkle_shared == 0 || !gpvk_crown_supported(c->dc, n)) return false;
   return ctx->merkle_shared == 2 || n >= GPV_MERKLE_SHARED_FROM;
 }
+// ---- fail-closed verdict plumbing (gpv_launch.h)
+static Verdict verdict_of(gpv_ctx* ctx) { return Verdict{ctx->fail, ctx->fail + ctx->fail_n}; }
+static size_t verdict_bytes(size_t n) { return n * (1 + GPV_DONE_STRIDE) * sizeof(u32); }
+// clears the failure masks and the visit counters of the first n proofs (the counter rows start at fail + fail_n)
+static hipError_t verdict_clear(gpv_ctx* ctx, size_t n, hipStream_t st) {
+  if (n == ctx->fail_n) return hipMemsetAsync(ctx->fail, 0, verdict_bytes(n), st);
+  hipError_t e = hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), st);
+  if (e != hipSuccess) return e;
+  return hipMemsetAsync(ctx->fail + ctx->fail_n, 0, n * GPV_DONE_STRIDE * sizeof(u32), st);
+}
+// what every counter must read for a proof of circuit `c` once the stages of `mask` have run
+static DoneExpect done_expect(const gpv_ctx* ctx, const gpv_circuit* c, size_t n, u32 mask, bool per_path_merkle) {
+  const DevCircuit& d = c->dc;
+  DoneExpect e;
+  memset(&e, 0, sizeof e);
+  const u32 paths = d.num_queries * d.n_trees;
+  const bool shared = !per_path_merkle && merkle_shared_for(ctx, c, n);
+  u32 levels = 0;
+  for (u32 t = 0; t < d.n_trees; t++) {
+    const u32 sib = t < 4 ? d.init_siblings : d.step_siblings[t - 4];
+    levels += sib < GPV_CROWN_LEVELS ? sib : GPV_CROWN_LEVELS;
+  }
+  e.v[GPV_DONE_RANGE] = gpvk_range_words(d);
+  e.v[GPV_DONE_DERIVED] = 1;
+  e.v[GPV_DONE_PLONK] = 1;
+  e.v[GPV_DONE_FRI] = d.num_queries;
+  e.v[GPV_DONE_LEAVES] = paths;
+  e.v[GPV_DONE_CLIMB] = paths;
+  e.v[GPV_DONE_PLAN] = shared ? paths : 0;
+  e.v[GPV_DONE_RECON] = shared ? d.num_queries * levels : 0;
+  e.v[GPV_DONE_CAP] = paths;
+  e.mask = mask;
+  return e;
+}
+#define DONE_BIT(s) (1u << (s))
+#define DONE_MERKLE (DONE_BIT(GPV_DONE_LEAVES) | DONE_BIT(GPV_DONE_CLIMB) | DONE_BIT(GPV_DONE_PLAN) | DONE_BIT(GPV_DONE_RECON) | DONE_BIT(GPV_DONE_CAP))
+#define DONE_ALL ((1u << GPV_DONE_COUNT) - 1)
+
 static int ensure_scratch(gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
   size_t need = n * (c->dc.n_challenge_words + GPV_DERIVED_EXTRA);
   if (need > ctx->derived_words) {
@@ -334,7 +429,7 @@ static int ensure_scratch(gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
   }
   if (n > ctx->fail_n) {
     if (ctx->fail) { hipStreamSynchronize(ctx->stream); hipFree(ctx->fail); ctx->fail = nullptr; ctx->fail_n = 0; }
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->fail, n * sizeof(u32)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->fail, verdict_bytes(n)));
     ctx->fail_n = n;
   }
   size_t dw = gpvk_merkle_digest_words(c->dc, n);
@@ -348,15 +443,17 @@ static int ensure_scratch(gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
     if (cb > ctx->crown_bytes) {
       if (ctx->crown) { hipStreamSynchronize(ctx->stream); hipFree(ctx->crown); ctx->crown = nullptr; ctx->crown_bytes = 0; }
       HIP_TRY(ctx, hipMalloc(&ctx->crown, cb));
+      HIP_TRY(ctx, hipMemset(ctx->crown, 0, cb));  // no stamp of an earlier life of this memory may look current
       ctx->crown_bytes = cb;
+      ctx->crown_gen = 0;
     }
   }
   return GPV_OK;
 }
 
-static void launch_range_check(gpv_ctx* ctx, hipStream_t st, const DevCircuit* dcd, const void* proofs, size_t n) {
+static void launch_range_check(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n) {
   Timed t(ctx, TK_RANGE, st);
-  gpvk_range_check(st, dcd, (const u64*)proofs, n, ctx->fail);
+  gpvk_range_check(st, dcd, c->dc, (const u64*)proofs, n, verdict_of(ctx));
 }
 // One lane per proof costs the least total work and hides under the leaf hashing for large batches; below
 // GPV_TRANSCRIPT_COOP_BELOW proofs its ~10 ms latency is exposed and the 16-lane cooperative kernel wins
@@ -366,17 +463,17 @@ static void launch_transcript(gpv_ctx* ctx, hipStream_t st, const DevCircuit* dc
   Timed t(ctx, TK_TRANSCRIPT, st);
   bool coop = ctx->transcript_variant == 2 || (ctx->transcript_variant == 0 && n < GPV_TRANSCRIPT_COOP_BELOW);
   if (coop)
-    gpvk_transcript_coop(st, dcd, (const u64*)proofs, n, ctx->derived);
+    gpvk_transcript_coop(st, dcd, (const u64*)proofs, n, ctx->derived, verdict_of(ctx));
   else
-    gpvk_transcript(st, dcd, (const u64*)proofs, n, ctx->derived);
+    gpvk_transcript(st, dcd, (const u64*)proofs, n, ctx->derived, verdict_of(ctx));
 }
 static void launch_plonk(gpv_ctx* ctx, hipStream_t st, const DevCircuit* dcd, const void* proofs, size_t n) {
   Timed t(ctx, TK_PLONK, st);
-  gpvk_plonk(st, dcd, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->fail);
+  gpvk_plonk(st, dcd, (const u64*)proofs, (const u64*)ctx->derived, n, verdict_of(ctx));
 }
 static void launch_merkle_leaves(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n) {
   Timed t(ctx, TK_LEAVES, st);
-  gpvk_merkle_leaves(st, dcd, c->dc, (const u64*)proofs, n, ctx->digests, ctx->fr_form);
+  gpvk_merkle_leaves(st, dcd, c->dc, (const u64*)proofs, n, ctx->digests, verdict_of(ctx), ctx->fr_form);
 }
 static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n,
                                 uint8_t* ok_dev) {
@@ -386,12 +483,17 @@ static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit*
     CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown);
     {
       Timed tl(ctx, TK_LOWER, st);
-      gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS, ctx->fr_form);
+      gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS, verdict_of(ctx),
+                              ctx->fr_form);
     }
-    gpvk_crown(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, b, ctx->fail, ctx->fr_form);
+    if (++ctx->crown_gen >= (1u << 30)) {  // generations are 30-bit stamps: start over on a clean scratch
+      gpvk_note_launch(hipMemsetAsync(ctx->crown, 0, ctx->crown_bytes, st), "memset(crown scratch)");
+      ctx->crown_gen = 1;
+    }
+    gpvk_crown(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, b, verdict_of(ctx), ctx->crown_gen, ctx->fr_form);
     return;
   }
-  gpvk_merkle_climb(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, ctx->fail, ok_dev, ctx->fr_form);
+  gpvk_merkle_climb(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, verdict_of(ctx), ok_dev, ctx->fr_form);
 }
 // both Merkle phases back to back on one stream (entry points with caller-supplied challenges)
 static void launch_merkle(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, uint8_t* ok_dev) {
@@ -400,7 +502,7 @@ static void launch_merkle(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* 
 }
 static void launch_fri_query(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n) {
   Timed t(ctx, TK_FRI, st);
-  gpvk_fri_query(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->fail);
+  gpvk_fri_query(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, verdict_of(ctx));
 }
 #define CHECK_LAUNCH(ctx)                                                                              \
   do {                                                                                                 \
@@ -414,8 +516,8 @@ static void launch_fri_query(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c,
 
 // Full pipeline on device-resident proofs; leaves the failure masks in ctx->fail and the derived values in ctx->derived.
 //
-//   main stream : memset(fail) -> range check -> [fork] -> Merkle leaf digests ------------> [wait T] -> Merkle climb -> [join]
-//   side stream :                              [wait fork] -> transcript -> [T] -> plonk -> FRI queries -> [done]
+//   main stream : clear(fail, done) -> [fork] -> range check -> [C] -> Merkle leaf digests ---> [wait T] -> Merkle climb -> [join]
+//   side stream :                 [wait fork] -> transcript -> [T] -> [wait C] -> plonk -> FRI queries -> [done]
 //
 // The leaf digests (39 % of the Poseidon-BN254 work) need only the proof bytes, so the latency-bound transcript (one lane
 // per proof, ~130 dependent permutations) and the small field kernels run underneath them instead of in front of them.
@@ -428,12 +530,12 @@ static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* p
   hipStream_t main_st = ctx->stream, side = ctx->side;
   // The transcript goes first: its few waves (one lane per proof, a long dependent chain) must be resident before the leaf
   // hashing fills every wave slot of the chip, or they wait for the first Merkle waves to retire (milliseconds).
+  HIP_TRY(ctx, verdict_clear(ctx, n, main_st));  // before the fork: the transcript reports into the visit counters
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_st));
   HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
   launch_transcript(ctx, side, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_transcript, side));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), main_st));
-  launch_range_check(ctx, main_st, dcd, proofs_dev, n);
+  launch_range_check(ctx, main_st, c, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_cleared, main_st));
   launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_cleared, 0));  // plonk and the FRI queries OR into the fail masks
@@ -823,7 +925,7 @@ static int upload_challenges(gpv_ctx* ctx, const gpv_circuit* c, const DevCircui
     src = tmp.p;
   }
   gpvk_scatter_challenges(ctx->stream, src, ctx->derived, ncw, n);
-  gpvk_derive_extra(ctx->stream, dcd, (const u64*)proofs_dev, n, ctx->derived);
+  gpvk_derive_extra(ctx->stream, dcd, (const u64*)proofs_dev, n, ctx->derived, verdict_of(ctx));
   CHECK_LAUNCH(ctx);
   if (!challenges_on_device) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // tmp is freed on return
   return GPV_OK;
@@ -895,7 +997,7 @@ struct StageSetup {
     if (rc != GPV_OK) return rc;
     rc = ensure_scratch(ctx, c, n);
     if (rc != GPV_OK) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), ctx->stream));
+    HIP_TRY(ctx, verdict_clear(ctx, n, ctx->stream));
     return upload_challenges(ctx, c, dcd, hb.proofs.p, challenges, n, false);
   }
 };
@@ -909,6 +1011,7 @@ extern "C" int gpv_plonk_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* 
   int rc = st.run(ctx, c, proofs, challenges, n);
   if (rc != GPV_OK) return rc;
   launch_plonk(ctx, ctx->stream, st.dcd, st.hb.proofs.p, n);
+  gpvk_finalize(ctx->stream, verdict_of(ctx), done_expect(ctx, c, n, DONE_BIT(GPV_DONE_DERIVED) | DONE_BIT(GPV_DONE_PLONK), false), nullptr, n);
   CHECK_LAUNCH(ctx);
   HIP_TRY(ctx, hipMemcpyAsync(fail_mask, ctx->fail, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -937,18 +1040,46 @@ extern "C" int gpv_gate_constraints(gpv_ctx* ctx, const gpv_circuit* c, const vo
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GPV_OK;
 }
+// fri.Chip.VerifyFriProof on a device-resident batch with device-resident challenges (BASELINE config 3's timed form): Merkle paths
+// (leaf digests + sibling walk, shared upper levels as configured), the field part of every query round and the PoW check; the
+// per-proof failure masks land in fail_mask_dev. Enqueued on the context's stream, no host synchronisation.
+extern "C" int gpv_fri_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, const uint64_t* challenges_dev, size_t n,
+                                  uint32_t* fail_mask_dev) {
+  REQUIRE(ctx, ctx && c && proofs_dev && challenges_dev && fail_mask_dev);
+  ENTER(ctx);
+  if (n == 0) return GPV_OK;
+  const DevCircuit* dcd;
+  int rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  rc = ensure_scratch(ctx, c, n);
+  if (rc != GPV_OK) return rc;
+  HIP_TRY(ctx, verdict_clear(ctx, n, ctx->stream));
+  rc = upload_challenges(ctx, c, dcd, proofs_dev, challenges_dev, n, true);
+  if (rc != GPV_OK) return rc;
+  launch_merkle(ctx, c, dcd, proofs_dev, n, nullptr);
+  launch_fri_query(ctx, ctx->stream, c, dcd, proofs_dev, n);
+  gpvk_finalize(ctx->stream, verdict_of(ctx), done_expect(ctx, c, n, DONE_BIT(GPV_DONE_DERIVED) | DONE_BIT(GPV_DONE_FRI) | DONE_MERKLE, false), nullptr, n);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(fail_mask_dev, ctx->fail, 4 * n, hipMemcpyDeviceToDevice, ctx->stream));
+  return GPV_OK;
+}
 extern "C" int gpv_fri_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n,
                               uint32_t* fail_mask) {
   REQUIRE(ctx, ctx && c && proofs && challenges && fail_mask);
   ENTER(ctx);
   if (n == 0) return GPV_OK;
-  StageSetup st;
-  int rc = st.run(ctx, c, proofs, challenges, n);
+  HostBatch hb;
+  int rc = hb.upload(ctx, c, proofs, n);
   if (rc != GPV_OK) return rc;
-  launch_merkle(ctx, c, st.dcd, st.hb.proofs.p, n, nullptr);
-  launch_fri_query(ctx, ctx->stream, c, st.dcd, st.hb.proofs.p, n);
-  CHECK_LAUNCH(ctx);
-  HIP_TRY(ctx, hipMemcpyAsync(fail_mask, ctx->fail, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+  DevBuf<u64> dch;
+  DevBuf<u32> dmask;
+  const size_t ncw = c->dc.n_challenge_words;
+  HIP_TRY(ctx, dch.alloc(ncw * n));
+  HIP_TRY(ctx, dmask.alloc(n));
+  HIP_TRY(ctx, hipMemcpyAsync(dch.p, challenges, 8 * ncw * n, hipMemcpyHostToDevice, ctx->stream));
+  rc = gpv_fri_verify_dev(ctx, c, hb.proofs.p, dch.p, n, dmask.p);
+  if (rc != GPV_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(fail_mask, dmask.p, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GPV_OK;
 }
@@ -962,7 +1093,8 @@ extern "C" int gpv_merkle_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const v
   if (rc != GPV_OK) return rc;
   rc = ensure_scratch(ctx, c, n);
   if (rc != GPV_OK) return rc;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), ctx->stream));
+  HIP_TRY(ctx, verdict_clear(ctx, n, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ok_dev, 0, n * c->dc.num_queries * c->dc.n_trees, ctx->stream));  // a path nobody walked is not "ok"
   const u32 ncw = c->dc.n_challenge_words;
   gpvk_scatter_challenges(ctx->stream, (const u64*)challenges_dev,
                      ctx->derived, ncw, n);
@@ -980,6 +1112,7 @@ extern "C" int gpv_merkle_verify(gpv_ctx* ctx, const gpv_circuit* c, const void*
   DevBuf<uint8_t> dok;
   const size_t items = n * c->dc.num_queries * c->dc.n_trees;
   HIP_TRY(ctx, dok.alloc(items));
+  HIP_TRY(ctx, hipMemsetAsync(dok.p, 0, items, ctx->stream));  // a path nobody walked is not "ok"
   launch_merkle(ctx, c, st.dcd, st.hb.proofs.p, n, dok.p);
   CHECK_LAUNCH(ctx);
   HIP_TRY(ctx, hipMemcpyAsync(ok, dok.p, items, hipMemcpyDeviceToHost, ctx->stream));
@@ -993,7 +1126,7 @@ extern "C" int gpv_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* pr
   if (n == 0) return GPV_OK;
   int rc = verify_pipeline_dev(ctx, c, proofs_dev, n);
   if (rc != GPV_OK) return rc;
-  gpvk_finalize(ctx->stream, (const u32*)ctx->fail, accept_dev, n);
+  gpvk_finalize(ctx->stream, verdict_of(ctx), done_expect(ctx, c, n, DONE_ALL, false), accept_dev, n);
   CHECK_LAUNCH(ctx);
   return GPV_OK;
 }
@@ -1007,8 +1140,8 @@ static int verify_given_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const v
   rc = ensure_scratch(ctx, c, n);
   if (rc != GPV_OK) return rc;
   hipStream_t main_st = ctx->stream, side = ctx->side;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->fail, 0, n * sizeof(u32), main_st));
-  launch_range_check(ctx, main_st, dcd, proofs_dev, n);
+  HIP_TRY(ctx, verdict_clear(ctx, n, main_st));
+  launch_range_check(ctx, main_st, c, dcd, proofs_dev, n);
   rc = upload_challenges(ctx, c, dcd, proofs_dev, challenges_dev, n, true);
   if (rc != GPV_OK) return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_st));
@@ -1029,7 +1162,7 @@ extern "C" int gpv_verify_given_challenges_dev(gpv_ctx* ctx, const gpv_circuit* 
   if (n == 0) return GPV_OK;
   int rc = verify_given_pipeline_dev(ctx, c, proofs_dev, challenges_dev, n);
   if (rc != GPV_OK) return rc;
-  gpvk_finalize(ctx->stream, (const u32*)ctx->fail, accept_dev, n);
+  gpvk_finalize(ctx->stream, verdict_of(ctx), done_expect(ctx, c, n, DONE_ALL, false), accept_dev, n);
   CHECK_LAUNCH(ctx);
   return GPV_OK;
 }
@@ -1100,20 +1233,16 @@ int gpvi_verify_host_batch(gpv_ctx* ctx, const gpv_circuit* c, const void* proof
     ctx->stage_accept_n = n;
   }
   // Chunk schedule: a short first chunk so that the GPU starts after a few milliseconds of upload, then growing chunks (from 4096
-  // proofs on the Merkle kernels run in their throughput form), two in flight. GPV_HOST_CHUNKS="a,b,c" overrides the sizes (the
-  // last one repeats) -- a measurement hook.
+  // proofs on the Merkle kernels run in their throughput form), two in flight: first, first, 2 first, 4 first, ... capped at max
+  // (GPV_OPT_HOST_CHUNK_FIRST / GPV_OPT_HOST_CHUNK_MAX, defaults 1024 / 8192).
   // Measured at 8192 / 32768 host-resident proofs (pinned or pageable, 57 GB/s H2D; profiles/r02l_host_path.txt): 75.9 / 280.5 ms with
   // 1024,1024,2048,4096,8192...; 76.3 / 285.4 with 1024,1024,2048,4096...; 77.9 / 283.8 with 1024,3072,4096; 83.0 / 289.8 with 4096.
-  size_t sched[8] = {1024, 1024, 2048, 4096, 8192, 0, 0, 0};
-  int n_sched = 5;
-  if (const char* env = getenv("GPV_HOST_CHUNKS")) {
-    n_sched = 0;
-    for (const char* q = env; *q && n_sched < 8;) {
-      size_t v = strtoull(q, (char**)&q, 10);
-      if (v) sched[n_sched++] = v;
-      while (*q == ',') q++;
-    }
-    if (n_sched == 0) { sched[0] = 4096; n_sched = 1; }
+  size_t sched[32];
+  int n_sched = 0;
+  sched[n_sched++] = ctx->host_chunk_first;
+  for (size_t v = ctx->host_chunk_first; n_sched < 32; v *= 2) {
+    sched[n_sched++] = v < ctx->host_chunk_max ? v : ctx->host_chunk_max;
+    if (v >= ctx->host_chunk_max) break;
   }
   const bool two = n > sched[0];
   if (two && !ctx->twin) {
@@ -1125,6 +1254,7 @@ int gpvi_verify_host_batch(gpv_ctx* ctx, const gpv_circuit* c, const void* proof
     ctx->twin->merkle_shared = ctx->merkle_shared;
     ctx->twin->transcript_variant = ctx->transcript_variant;
     ctx->twin->fr_form = ctx->fr_form;
+    ctx->twin->timing = ctx->timing;  // kernels of odd chunks are timed in the twin's accumulators; gpv_timing_get merges them
   }
   size_t done = 0, k = 0;
   while (done < n) {
@@ -1170,166 +1300,5 @@ void gpvi_ctx_set_error(gpv_ctx* ctx, const char* msg) { ctx->err = msg; }
 const char* gpvi_ctx_get_error(const gpv_ctx* ctx) { return ctx->err.c_str(); }
 int gpvi_take_launch_error(gpv_ctx* ctx) {
   CHECK_LAUNCH(ctx);
-  return GPV_OK;
-}
-
-// ================================================================ instruction-rate microbenchmark (kernels: gpv_k_prim.hip)
-extern "C" int gpv_microbench(gpv_ctx* ctx, int which, double* lane_ops_per_sec) {
-  REQUIRE(ctx, ctx && lane_ops_per_sec && which >= 0 && which <= 7);
-  ENTER(ctx);
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const int blocks = 256 * 8, threads = 256, iters = 4096;
-  DevBuf<u64> out;
-  HIP_TRY(ctx, out.alloc((size_t)blocks * threads));
-  hipEvent_t e0, e1;
-  HIP_TRY(ctx, hipEventCreate(&e0));
-  HIP_TRY(ctx, hipEventCreate(&e1));
-  float best = 1e30f;
-  for (int rep = 0; rep < 4; rep++) {
-    hipEventRecord(e0, ctx->stream);
-    gpvk_microbench(ctx->stream, which, out.p, blocks, threads, iters);
-    hipEventRecord(e1, ctx->stream);
-    if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); ctx_error(ctx, "microbench launch failed"); return GPV_EDEVICE; }
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    if (rep > 0 && ms < best) best = ms;
-  }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  double ops = (double)blocks * threads * (double)iters * (double)gpvk_microbench_ops_per_iter();
-  *lane_ops_per_sec = ops / (best * 1e-3);
-  return GPV_OK;
-}
-
-// ================================================================ MFMA feasibility probe (kernels: gpv_k_mfma_probe.hip)
-extern "C" int gpv_mfma_probe(gpv_ctx* ctx, int which, const uint32_t* x, const uint32_t* c_limbs, const uint8_t* q, uint64_t* out, size_t n,
-                              int iters, double* ms) {
-  REQUIRE(ctx, ctx && x && c_limbs && q && out && ms && which >= 0 && which <= 7 && iters >= 1 && n >= 1);
-  ENTER(ctx);
-  DevBuf<u32> dx, dc;
-  DevBuf<uint8_t> dq;
-  DevBuf<u64> dout, dout2;
-  HIP_TRY(ctx, dx.alloc(36 * n));
-  HIP_TRY(ctx, dc.alloc(36));
-  const size_t q_bytes = 4 * 96 + 4 * 2 * 64 * 16;  // digit strings, then the Toeplitz register images
-  HIP_TRY(ctx, dq.alloc(q_bytes));
-  HIP_TRY(ctx, dout.alloc(18 * n));
-  HIP_TRY(ctx, dout2.alloc(18 * n));
-  HIP_TRY(ctx, hipMemcpy(dx.p, x, 4 * 36 * n, hipMemcpyHostToDevice));
-  HIP_TRY(ctx, hipMemcpy(dc.p, c_limbs, 4 * 36, hipMemcpyHostToDevice));
-  HIP_TRY(ctx, hipMemcpy(dq.p, q, q_bytes, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  HIP_TRY(ctx, hipEventCreate(&e0));
-  HIP_TRY(ctx, hipEventCreate(&e1));
-  float best = 1e30f;
-  for (int rep = 0; rep < 3; rep++) {
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    hipEventRecord(e0, ctx->stream);
-    if (which == 0) {
-      gpvk_probe_row_valu(ctx->stream, dx.p, dc.p, dout.p, iters, n);
-    } else if (which == 1) {
-      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 7);
-    } else if (which == 3) {
-      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 2);
-    } else if (which == 4) {
-      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 5);
-    } else if (which == 5) {
-      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 7 + 8);
-    } else if (which == 6) {
-      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 2 + 8);
-    } else if (which == 7) {  // VALU row beside the image-operand MFMA row
-      hipEventRecord(ctx->ev_fork, ctx->stream);
-      hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
-      gpvk_probe_row_valu(ctx->side, dx.p, dc.p, dout2.p, iters, n);
-      hipEventRecord(ctx->ev_side_done, ctx->side);
-      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 7 + 8);
-      hipStreamWaitEvent(ctx->stream, ctx->ev_side_done, 0);
-    } else {  // both at once: the VALU kernel on the side stream, the MFMA kernel on the main one
-      hipEventRecord(ctx->ev_fork, ctx->stream);
-      hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
-      gpvk_probe_row_valu(ctx->side, dx.p, dc.p, dout2.p, iters, n);
-      hipEventRecord(ctx->ev_side_done, ctx->side);
-      gpvk_probe_row_mfma(ctx->stream, dx.p, dq.p, dout.p, iters, n, 7);
-      hipStreamWaitEvent(ctx->stream, ctx->ev_side_done, 0);
-    }
-    hipEventRecord(e1, ctx->stream);
-    if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); ctx_error(ctx, "probe launch failed"); return GPV_EDEVICE; }
-    float t = 0;
-    hipEventElapsedTime(&t, e0, e1);
-    if (rep > 0 && t < best) best = t;
-  }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  CHECK_LAUNCH(ctx);
-  *ms = best;
-  HIP_TRY(ctx, hipMemcpy(out, dout.p, 8 * 18 * n, hipMemcpyDeviceToHost));
-  return GPV_OK;
-}
-
-// Whole Poseidon-BN254 permutation with the partial-round rows on the matrix pipe (probe, stage 2). images: 28 x 18 Toeplitz register
-// images of 2 KB (tools/mfma_probe.py). which = 0: the product's kernel, 1: the MFMA variant. states / out [n][16] canonical words.
-extern "C" int gpv_mfma_probe_permute(gpv_ctx* ctx, int which, const uint64_t* states, uint64_t* out, size_t n, const uint8_t* images,
-                                      size_t images_bytes, int reps, double* ms) {
-  REQUIRE(ctx, ctx && states && out && ms && n >= 1 && reps >= 1 && (which == 0 || ((which >= 1 && which <= 3) && images && images_bytes >= 28 * 18 * 2048)));
-  ENTER(ctx);
-  DevBuf<u64> din, dout;
-  DevBuf<uint8_t> dimg;
-  HIP_TRY(ctx, din.alloc(16 * n));
-  HIP_TRY(ctx, dout.alloc(16 * n));
-  HIP_TRY(ctx, dimg.alloc(images_bytes ? images_bytes : 16));
-  HIP_TRY(ctx, hipMemcpy(din.p, states, 128 * n, hipMemcpyHostToDevice));
-  if (images_bytes) HIP_TRY(ctx, hipMemcpy(dimg.p, images, images_bytes, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  HIP_TRY(ctx, hipEventCreate(&e0));
-  HIP_TRY(ctx, hipEventCreate(&e1));
-  float best = 1e30f;
-  for (int rep = 0; rep <= reps; rep++) {
-    hipEventRecord(e0, ctx->stream);
-    if (which == 0) gpvk_poseidon_bn254_permute(ctx->stream, din.p, dout.p, n, 2);
-    else gpvk_poseidon_bn254_permute_mfma(ctx->stream, din.p, dout.p, n, dimg.p, which == 1 ? 31u : which == 3 ? (31u | 0x100u) : 0u);
-    hipEventRecord(e1, ctx->stream);
-    if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); ctx_error(ctx, "probe launch failed"); return GPV_EDEVICE; }
-    float t = 0;
-    hipEventElapsedTime(&t, e0, e1);
-    if (rep > 0 && t < best) best = t;
-  }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  CHECK_LAUNCH(ctx);
-  *ms = best;
-  HIP_TRY(ctx, hipMemcpy(out, dout.p, 128 * n, hipMemcpyDeviceToHost));
-  return GPV_OK;
-}
-
-// Probe, stage 3: do MFMA and VALU work of the two waves of a SIMD overlap? ms[mode] for mode 0 (all MFMA), 1 (all VALU), 2 (odd wave
-// slots MFMA, even slots VALU); hw_ids receives HW_ID of the first `n_ids` blocks of the mode-2 launch.
-extern "C" int gpv_mfma_probe_overlap(gpv_ctx* ctx, int iters, double* ms3, uint32_t* hw_ids, size_t n_ids) {
-  REQUIRE(ctx, ctx && ms3 && iters >= 1);
-  ENTER(ctx);
-  const int blocks = 256 * 4 * 2;  // two waves per SIMD, one round
-  DevBuf<u64> dout;
-  DevBuf<u32> dslots;
-  HIP_TRY(ctx, dout.alloc((size_t)blocks * 64));
-  HIP_TRY(ctx, dslots.alloc(blocks));
-  hipEvent_t e0, e1;
-  HIP_TRY(ctx, hipEventCreate(&e0));
-  HIP_TRY(ctx, hipEventCreate(&e1));
-  for (int mode = 0; mode < 3; mode++) {
-    float best = 1e30f;
-    for (int rep = 0; rep < 4; rep++) {
-      hipEventRecord(e0, ctx->stream);
-      gpvk_probe_overlap(ctx->stream, mode, iters, dout.p, dslots.p, blocks);
-      hipEventRecord(e1, ctx->stream);
-      if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); ctx_error(ctx, "probe launch failed"); return GPV_EDEVICE; }
-      float t = 0;
-      hipEventElapsedTime(&t, e0, e1);
-      if (rep > 0 && t < best) best = t;
-    }
-    ms3[mode] = best;
-  }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  CHECK_LAUNCH(ctx);
-  if (hw_ids && n_ids) HIP_TRY(ctx, hipMemcpy(hw_ids, dslots.p, 4 * (n_ids < (size_t)blocks ? n_ids : (size_t)blocks), hipMemcpyDeviceToHost));
   return GPV_OK;
 }

@@ -29,6 +29,12 @@
 #include "gpv_internal.h"
 #include "gpv_launch.h"
 
+// Last 16 bytes of a rank's slot: byte 0 = 0 when the rank verified its block, else non-zero. A rank whose verification FAILED (HIP
+// error, out of memory ...) still takes part in the exchange with a zeroed slot and this flag raised, so that no other rank waits
+// for it inside the collective; every rank then returns GPV_EPEER instead of a verdict (a failing rank used to skip the
+// all-gather and leave the others blocked in it).
+#define GPV_SLOT_TRAILER 16
+
 extern "C" int gpv_shard_bounds(size_t n, int rank, int world, size_t* lo, size_t* hi) {
   if (world <= 0 || rank < 0 || rank >= world || !lo || !hi) return GPV_EINVAL;
   const size_t base = n / (size_t)world, rem = n % (size_t)world, r = (size_t)rank;
@@ -39,7 +45,8 @@ extern "C" int gpv_shard_bounds(size_t n, int rank, int world, size_t* lo, size_
 extern "C" size_t gpv_accept_slot_bytes(size_t n, int world) {
   if (world <= 0) return 0;
   const size_t max_block = (n + (size_t)world - 1) / (size_t)world;
-  return ((max_block + 7) / 8 + 15) & ~(size_t)15;  // whole 16-byte units: every rank's slot of the gather buffer stays 16-byte aligned
+  // whole 16-byte units (every rank's slot of the gather buffer stays 16-byte aligned), then a 16-byte status trailer
+  return (((max_block + 7) / 8 + 15) & ~(size_t)15) + GPV_SLOT_TRAILER;
 }
 
 namespace {
@@ -96,6 +103,8 @@ struct Worker {
   size_t bits_cap = 0;
   uint8_t* accept_all = nullptr;  // [n_total] unpacked, for the host-batch entry point
   size_t accept_all_cap = 0;
+  uint8_t* peer_status = nullptr;  // [world] pinned host: the status bytes of every rank's slot after the exchange
+  int status = 0;                  // this rank's own status for the current call (0 = block verified)
   int rc = GPV_OK;
   std::string err;
 };
@@ -149,9 +158,15 @@ static void worker_loop(gpv_group* g, size_t idx) {
     }
   }
 }
-// runs `job` once per local rank (on the rank's own thread when there are several) and returns the first failure
+// runs `job` once per local rank (on the rank's own thread when there are several) and returns the first failure; run_all_keep does
+// not clear the ranks' errors first (second phase of a call: a rank that failed in the first keeps its error)
+struct gpv_group;
+static int run_all_keep(gpv_group* g, const std::function<void(Worker&)>& job);
 static int run_all(gpv_group* g, const std::function<void(Worker&)>& job) {
   for (auto& w : g->w) { w.rc = GPV_OK; w.err.clear(); }
+  return run_all_keep(g, job);
+}
+static int run_all_keep(gpv_group* g, const std::function<void(Worker&)>& job) {
   if (g->w.size() == 1) {
     job(g->w[0]);
   } else {
@@ -271,6 +286,7 @@ extern "C" int gpv_group_destroy(gpv_group* g) {
     if (r && w.comm) r->CommDestroy(w.comm);
     if (w.bits) hipFree(w.bits);
     if (w.accept_all) hipFree(w.accept_all);
+    if (w.peer_status) hipHostFree(w.peer_status);
     gpv_ctx_destroy(w.ctx);
   }
   delete g;
@@ -332,32 +348,72 @@ static int ensure_comm(gpv_group* g) {
   return GPV_OK;
 }
 
-// Exchange step of one rank, enqueued on its context's stream: accept bytes of its block -> bits in its slot of the gather
-// buffer -> in-place ncclAllGather (world == 1 without the collective option: the slot is already the whole buffer) ->
-// accept bytes of the whole batch in `accept_all_dev`.
-static void exchange(gpv_group* g, Worker& w, const uint8_t* accept_local_dev, size_t n_total, uint8_t* accept_all_dev) {
-  size_t lo, hi;
-  gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
+// After the gathered buffer is complete in stream order: unpack it and fetch every rank's status byte (checked by
+// exchange_check once the stream has been synchronised).
+static void exchange_finish(gpv_group* g, Worker& w, size_t n_total, uint8_t* accept_all_dev) {
   const size_t slot = gpv_accept_slot_bytes(n_total, g->world);
-  const size_t need = slot * (size_t)g->world;
+  hipStream_t st = gpvi_ctx_stream(w.ctx);
+  gpvk_unpack_accept_bits(st, w.bits, slot, n_total, (u32)g->world, accept_all_dev);
+  if (gpvi_take_launch_error(w.ctx) != GPV_OK) { worker_fail(w, GPV_EDEVICE, "unpack_accept_bits: %s", gpvi_ctx_get_error(w.ctx)); return; }
+  W_HIP(w, hipMemcpy2DAsync(w.peer_status, 1, w.bits + slot - GPV_SLOT_TRAILER, slot, 1, (size_t)g->world, hipMemcpyDeviceToHost, st));
+}
+// After hipStreamSynchronize: the verdict is valid only if every rank verified its block.
+static void exchange_check(gpv_group* g, Worker& w) {
+  if (w.rc != GPV_OK) return;  // this rank's own error is the more specific one
+  for (int r = 0; r < g->world; r++)
+    if (w.peer_status[r]) { worker_fail(w, GPV_EPEER, "rank %d of the group failed to verify its block; the batch has no verdict", r); return; }
+}
+// Buffers of the exchange, allocated BEFORE any rank starts verifying: a rank that cannot allocate fails here, while no collective
+// has been enqueued by anybody yet.
+static void exchange_prepare(gpv_group* g, Worker& w, size_t n_total, bool need_accept_all) {
+  W_HIP(w, hipSetDevice(w.device));
+  const size_t need = gpv_accept_slot_bytes(n_total, g->world) * (size_t)g->world;
   hipStream_t st = gpvi_ctx_stream(w.ctx);
   if (need > w.bits_cap) {
     if (w.bits) { W_HIP(w, hipStreamSynchronize(st)); hipFree(w.bits); w.bits = nullptr; w.bits_cap = 0; }
     W_HIP(w, hipMalloc((void**)&w.bits, need));
     w.bits_cap = need;
   }
-  gpvk_pack_accept_bits(st, accept_local_dev, hi - lo, w.bits + (size_t)w.rank * slot, slot);
+  if (need_accept_all && n_total > w.accept_all_cap) {
+    if (w.accept_all) { W_HIP(w, hipStreamSynchronize(st)); hipFree(w.accept_all); w.accept_all = nullptr; w.accept_all_cap = 0; }
+    W_HIP(w, hipMalloc((void**)&w.accept_all, n_total));
+    w.accept_all_cap = n_total;
+  }
+  if (!w.peer_status) W_HIP(w, hipHostMalloc((void**)&w.peer_status, GPV_MAX_DEVICES > g->world ? GPV_MAX_DEVICES : g->world, hipHostMallocDefault));
+  w.status = 0;
+}
+// A rank whose block could not be verified: record the error, keep going to the exchange with the flag raised.
+static void rank_failed(Worker& w, int rc, const char* what) {
+  worker_fail(w, rc, "%s: %s", what, gpvi_ctx_get_error(w.ctx));
+  w.status = 1;
+}
+// Exchange step of one rank, enqueued on its context's stream: accept bytes of its block -> bits in its slot of the gather
+// buffer -> in-place ncclAllGather (world == 1 without the collective option: the slot is already the whole buffer) ->
+// accept bytes of the whole batch in `accept_all_dev`. Never returns before the collective has been enqueued: the other ranks
+// are waiting in it.
+static void exchange(gpv_group* g, Worker& w, const uint8_t* accept_local_dev, size_t n_total, uint8_t* accept_all_dev) {
+  size_t lo, hi;
+  gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
+  const size_t slot = gpv_accept_slot_bytes(n_total, g->world);
+  hipStream_t st = gpvi_ctx_stream(w.ctx);
+  uint8_t* mine = w.bits + (size_t)w.rank * slot;
+  if (w.status == 0) {
+    gpvk_pack_accept_bits(st, accept_local_dev, hi - lo, mine, slot);  // writes the whole slot: bits, zero padding, zero trailer
+    if (gpvi_take_launch_error(w.ctx) != GPV_OK) rank_failed(w, GPV_EDEVICE, "pack_accept_bits");
+  }
+  if (w.status != 0) {  // no verdict from this rank: all-zero bits, flag raised (best effort: a dead device fails these too)
+    hipMemsetAsync(mine, 0, slot, st);
+    hipMemsetAsync(mine + slot - GPV_SLOT_TRAILER, 1, 1, st);
+  }
   if (peer_copies(g)) {  // phase 1 ends here: the slot must be complete before any other rank copies it
-    W_GPV(w, gpvi_take_launch_error(w.ctx));
-    W_HIP(w, hipStreamSynchronize(st));
+    if (hipStreamSynchronize(st) != hipSuccess) rank_failed(w, GPV_EDEVICE, "hipStreamSynchronize");
     return;
   }
   if (wants_collective(g)) {
-    ncclResult_t e = g_rccl.AllGather(w.bits + (size_t)w.rank * slot, w.bits, slot, ncclUint8, w.comm, st);
+    ncclResult_t e = g_rccl.AllGather(mine, w.bits, slot, ncclUint8, w.comm, st);
     if (e != ncclSuccess) { worker_fail(w, GPV_EDEVICE, "ncclAllGather: %s", g_rccl.GetErrorString(e)); return; }
   }
-  gpvk_unpack_accept_bits(st, w.bits, slot, n_total, (u32)g->world, accept_all_dev);
-  W_GPV(w, gpvi_take_launch_error(w.ctx));
+  exchange_finish(g, w, n_total, accept_all_dev);
 }
 // Phase 2 of the peer-copy exchange (GPV_GROUP_OPT_COLLECTIVE = 2, every rank in this process): each rank pulls the other ranks'
 // slots with device-to-device copies (hipMemcpyPeerAsync between devices) and unpacks. Same result as the all-gather; no RCCL.
@@ -374,8 +430,7 @@ static void gather_by_peer_copies(gpv_group* g, Worker& w, size_t n_total, uint8
     else
       W_HIP(w, hipMemcpyPeerAsync(dst, w.device, src, o.device, slot, st));
   }
-  gpvk_unpack_accept_bits(st, w.bits, slot, n_total, (u32)g->world, accept_all_dev);
-  W_GPV(w, gpvi_take_launch_error(w.ctx));
+  exchange_finish(g, w, n_total, accept_all_dev);
 }
 
 extern "C" int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const void* const* shard_dev, size_t n_total,
@@ -388,26 +443,40 @@ extern "C" int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const vo
     if (rc != GPV_OK) return rc;
   }
   const size_t first = g->w[0].rank;
-  int rc = run_all(g, [&](Worker& w) {
+  for (auto& w : g->w) {  // argument checks before any rank starts: a rank that bailed out later would strand the others in the collective
     const size_t i = (size_t)w.rank - first;
-    W_HIP(w, hipSetDevice(w.device));
     size_t lo, hi;
     gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
-    if (hi > lo && !shard_dev[i]) { worker_fail(w, GPV_EINVAL, "shard pointer %zu is NULL", i); return; }
-    if (!accept_all_dev[i]) { worker_fail(w, GPV_EINVAL, "accept pointer %zu is NULL", i); return; }
+    if (hi > lo && !shard_dev[i]) { group_error(g, "shard pointer %zu is NULL", i); return GPV_EINVAL; }
+    if (!accept_all_dev[i]) { group_error(g, "accept pointer %zu is NULL", i); return GPV_EINVAL; }
+  }
+  int rc = run_all(g, [&](Worker& w) { exchange_prepare(g, w, n_total, false); });
+  if (rc != GPV_OK) return rc;
+  rc = run_all(g, [&](Worker& w) {
+    const size_t i = (size_t)w.rank - first;
+    size_t lo, hi;
+    gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
     // the block's own accept bytes land directly in its range of the full-batch buffer, then are packed from there
     uint8_t* mine = accept_all_dev[i] + lo;
-    if (hi > lo) W_GPV(w, gpv_verify_dev(w.ctx, c, shard_dev[i], hi - lo, mine));
+    if (hipSetDevice(w.device) != hipSuccess) rank_failed(w, GPV_EDEVICE, "hipSetDevice");
+    else if (hi > lo) {
+      int vrc = gpv_verify_dev(w.ctx, c, shard_dev[i], hi - lo, mine);
+      if (vrc == GPV_OK && gpvi_fault_rank(w.rank)) { vrc = GPV_EDEVICE; gpvi_ctx_set_error(w.ctx, "injected fault (gpv_testhooks.h)"); }
+      if (vrc != GPV_OK) rank_failed(w, vrc, "gpv_verify_dev");
+    }
     exchange(g, w, mine, n_total, accept_all_dev[i]);
-    if (w.rc != GPV_OK) return;
-    W_HIP(w, hipStreamSynchronize(gpvi_ctx_stream(w.ctx)));
+    if (peer_copies(g)) return;
+    if (hipStreamSynchronize(gpvi_ctx_stream(w.ctx)) != hipSuccess) { worker_fail(w, GPV_EDEVICE, "hipStreamSynchronize after the exchange"); return; }
+    exchange_check(g, w);
   });
-  if (rc != GPV_OK || !peer_copies(g)) return rc;
-  return run_all(g, [&](Worker& w) {
+  if (!peer_copies(g)) return rc;
+  // phase 2 runs even when a rank failed phase 1: its slot carries the flag, and every rank must learn about it
+  int rc2 = run_all_keep(g, [&](Worker& w) {
     gather_by_peer_copies(g, w, n_total, accept_all_dev[(size_t)w.rank - first]);
-    if (w.rc != GPV_OK) return;
-    W_HIP(w, hipStreamSynchronize(gpvi_ctx_stream(w.ctx)));
+    if (hipStreamSynchronize(gpvi_ctx_stream(w.ctx)) != hipSuccess) { worker_fail(w, GPV_EDEVICE, "hipStreamSynchronize after the exchange"); return; }
+    exchange_check(g, w);
   });
+  return rc != GPV_OK ? rc : rc2;
 }
 
 extern "C" int gpv_group_verify(gpv_group* g, const gpv_circuit* c, const void* proofs, size_t n_total, uint8_t* accept) {
@@ -421,33 +490,40 @@ extern "C" int gpv_group_verify(gpv_group* g, const gpv_circuit* c, const void* 
   const size_t rec = gpv_proof_nbytes(c);
   size_t first_lo, tmp;
   gpv_shard_bounds(n_total, g->w[0].rank, g->world, &first_lo, &tmp);  // `proofs` starts at the first local rank's block
-  int rc = run_all(g, [&](Worker& w) {
-    W_HIP(w, hipSetDevice(w.device));
+  for (auto& w : g->w) {  // argument checks before any rank starts
+    size_t lo, hi;
+    gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
+    if (hi > lo && !proofs) { group_error(g, "proofs is NULL but rank %d owns %zu proofs", w.rank, hi - lo); return GPV_EINVAL; }
+  }
+  int rc = run_all(g, [&](Worker& w) { exchange_prepare(g, w, n_total, true); });
+  if (rc != GPV_OK) return rc;
+  rc = run_all(g, [&](Worker& w) {
     size_t lo, hi;
     gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
     hipStream_t st = gpvi_ctx_stream(w.ctx);
-    if (n_total > w.accept_all_cap) {
-      if (w.accept_all) { W_HIP(w, hipStreamSynchronize(st)); hipFree(w.accept_all); w.accept_all = nullptr; w.accept_all_cap = 0; }
-      W_HIP(w, hipMalloc((void**)&w.accept_all, n_total));
-      w.accept_all_cap = n_total;
-    }
     uint8_t* acc_local = w.accept_all + lo;  // unused when the block is empty
-    if (hi > lo && !proofs) { worker_fail(w, GPV_EINVAL, "proofs is NULL but rank %d owns %zu proofs", w.rank, hi - lo); return; }
-    if (hi > lo) W_GPV(w, gpvi_verify_host_batch(w.ctx, c, (const uint8_t*)proofs + (lo - first_lo) * rec, hi - lo, &acc_local));
+    if (hipSetDevice(w.device) != hipSuccess) rank_failed(w, GPV_EDEVICE, "hipSetDevice");
+    else if (hi > lo) {
+      int vrc = gpvi_verify_host_batch(w.ctx, c, (const uint8_t*)proofs + (lo - first_lo) * rec, hi - lo, &acc_local);
+      if (vrc == GPV_OK && gpvi_fault_rank(w.rank)) { vrc = GPV_EDEVICE; gpvi_ctx_set_error(w.ctx, "injected fault (gpv_testhooks.h)"); }
+      if (vrc != GPV_OK) rank_failed(w, vrc, "gpv_verify (host batch)");
+    }
     exchange(g, w, acc_local, n_total, w.accept_all);
-    if (w.rc != GPV_OK || peer_copies(g)) return;
+    if (peer_copies(g)) return;
     // every rank holds the whole verdict on its device; the lowest local rank hands it to the caller
-    if (w.rank == g->w[0].rank) W_HIP(w, hipMemcpyAsync(accept, w.accept_all, n_total, hipMemcpyDeviceToHost, st));
-    W_HIP(w, hipStreamSynchronize(st));
+    if (w.rc == GPV_OK && w.rank == g->w[0].rank) hipMemcpyAsync(accept, w.accept_all, n_total, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) { worker_fail(w, GPV_EDEVICE, "hipStreamSynchronize after the exchange"); return; }
+    exchange_check(g, w);
   });
-  if (rc != GPV_OK || !peer_copies(g)) return rc;
-  return run_all(g, [&](Worker& w) {
+  if (!peer_copies(g)) return rc;
+  int rc2 = run_all_keep(g, [&](Worker& w) {
     hipStream_t st = gpvi_ctx_stream(w.ctx);
     gather_by_peer_copies(g, w, n_total, w.accept_all);
-    if (w.rc != GPV_OK) return;
-    if (w.rank == g->w[0].rank) W_HIP(w, hipMemcpyAsync(accept, w.accept_all, n_total, hipMemcpyDeviceToHost, st));
-    W_HIP(w, hipStreamSynchronize(st));
+    if (w.rc == GPV_OK && w.rank == g->w[0].rank) hipMemcpyAsync(accept, w.accept_all, n_total, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) { worker_fail(w, GPV_EDEVICE, "hipStreamSynchronize after the exchange"); return; }
+    exchange_check(g, w);
   });
+  return rc != GPV_OK ? rc : rc2;
 }
 
 // Test / diagnostics: the gathered accept bytes as rank `local_index` holds them on ITS device after the last

@@ -717,6 +717,18 @@ static int circuit_from_json_impl(const char* common_json, size_t common_len, co
   // Which hash the circuit was built with shows in the shape of its hashes: a decimal string is a BN254 scalar (the
   // reference's PoseidonBN254GoldilocksConfig), {"elements": [4 x u64]} a Poseidon-Goldilocks HashOut.
   c.hash_kind = cap->child(0)->kind == JValue::String ? GPV_HASH_POSEIDON_BN254 : GPV_HASH_POSEIDON_GOLDILOCKS;
+  // The reference cannot deserialise Poseidon-Goldilocks verifier data (its caps and digest are decimal strings,
+  // variables/deserialize.go:149-156): on the drop-in entry point that configuration is refused like every other shape beyond the
+  // reference, and admitted -- parity unpinned -- only with the opt-in flag.
+  if (c.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS && !beyond) {
+    gpv_set_global_error("Poseidon-Goldilocks hashes ({\"elements\": [...]}) are not the reference's configuration (GPV_CIRCUIT_BEYOND_REFERENCE admits them)");
+    return GPV_ECONFIG;
+  }
+  const JValue* dg = vo->get("circuit_digest");
+  if (dg && (dg->kind == JValue::String) != (c.hash_kind == GPV_HASH_POSEIDON_BN254)) {
+    gpv_set_global_error("circuit_digest and constants_sigmas_cap use different hash encodings");
+    return GPV_ESHAPE;
+  }
   for (uint32_t i = 0; i < cap_entries; i++)
     if (!j_hash(cap->child(i), c.hash_kind, c.sigmas_cap[i])) { gpv_set_global_error("constants_sigmas_cap[%u]", i); return GPV_ESHAPE; }
   if (!j_hash(vo->get("circuit_digest"), c.hash_kind, c.digest)) { gpv_set_global_error("circuit_digest"); return GPV_ESHAPE; }

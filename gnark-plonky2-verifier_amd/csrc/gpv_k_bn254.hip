@@ -69,9 +69,12 @@ struct MerkleOrder {
 // (9 redundant limbs for Poseidon-BN254, 4 x u64 for Poseidon-Goldilocks). The bodies are written over the hasher policy
 // (gpv_fri.cuh); the __global__ entry points keep one name per configuration so profiles stay comparable across rounds.
 #define GPV_MERKLE_BLOCK 64
+// Visit counters (fail-closed verdict, gpv_launch.h): a lane reports its unit right after its bounds check, where the proof index is
+// at hand -- from there on it has no exit but the end of its hash chain, and reporting at the end instead would keep the index and
+// the counter pointer live across ~100 k instructions (it cost k_merkle_leaves its fourth wave per SIMD: 126 -> 157 VGPRs).
 template <class H>
 GPV_DEV void merkle_leaves_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n, const MerkleOrder& order,
-                                u32* __restrict__ digests) {
+                                u32* __restrict__ digests, const Verdict& v) {
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries;
   const size_t items = n * nq;
@@ -79,6 +82,7 @@ GPV_DEV void merkle_leaves_body(const DevCircuit* __restrict__ dc, const u64* __
   size_t p = item / nq;
   u32 q = (u32)(item - p * nq);
   u32 tree = order.cls[blockIdx.y];
+  atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_LEAVES], 1u);
   const u64* rec = proofs + p * (dc->proof_nbytes / 8);
   const u64* qrec = rec + dc->off_queries + (size_t)q * dc->query_words;
   const u64* leaf;
@@ -95,7 +99,7 @@ GPV_DEV void merkle_leaves_body(const DevCircuit* __restrict__ dc, const u64* __
 }
 template <class H>
 GPV_DEV void merkle_climb_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
-                               const MerkleOrder& order, const u32* __restrict__ digests, u32* __restrict__ fail,
+                               const MerkleOrder& order, const u32* __restrict__ digests, const Verdict& v,
                                uint8_t* __restrict__ ok_out) {
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries;
@@ -110,14 +114,16 @@ GPV_DEV void merkle_climb_body(const DevCircuit* __restrict__ dc, const u64* __r
   typename H::Node cur = H::load_digest(digests + ((size_t)tree * items + item) * FR_LIMBS);
   bool ok = dev_merkle_climb<H>(cur, m.sib, m.n_sib, m.bits, m.cap + 4 * m.cap_index);
   if (ok_out) ok_out[item * dc->n_trees + tree] = ok;
-  if (!ok) atomicOr(&fail[p], tree < 4 ? (u32)GPV_FAIL_MERKLE_INITIAL : (u32)GPV_FAIL_MERKLE_STEP);
+  if (!ok) atomicOr(&v.fail[p], tree < 4 ? (u32)GPV_FAIL_MERKLE_INITIAL : (u32)GPV_FAIL_MERKLE_STEP);
+  atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_CLIMB], 1u);  // the whole walk ...
+  atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_CAP], 1u);    // ... and its comparison with the cap entry
 }
 // The same walk, stopped `crown_levels` levels below the cap: the node reached there is stored as canonical words
 // ([tree][item][4]) and the shared upper levels are hashed once per distinct node by gpv_k_crown.hip.
 template <class H>
 GPV_DEV void merkle_climb_lower_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived,
                                      size_t n, const MerkleOrder& order, const u32* __restrict__ digests, u64* __restrict__ mid,
-                                     u32 crown_levels) {
+                                     u32 crown_levels, const Verdict& v) {
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries;
   const size_t items = n * nq;
@@ -127,6 +133,7 @@ GPV_DEV void merkle_climb_lower_body(const DevCircuit* __restrict__ dc, const u6
   u32 tree = order.cls[blockIdx.y];
   const u64* rec = proofs + p * (dc->proof_nbytes / 8);
   const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
+  atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_CLIMB], 1u);
   MerklePath m = dev_merkle_path(dc, rec, d, q, tree);
   typename H::Node cur = H::load_digest(digests + ((size_t)tree * items + item) * FR_LIMBS);
   u32 top = m.n_sib < crown_levels ? m.n_sib : crown_levels;
@@ -137,55 +144,55 @@ GPV_DEV void merkle_climb_lower_body(const DevCircuit* __restrict__ dc, const u6
   o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; o[3] = out[3];
 }
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_leaves(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                                    size_t n, MerkleOrder order, u32* __restrict__ digests) {
-  merkle_leaves_body<HashBN>(dc, proofs, n, order, digests);
+                                                                    size_t n, MerkleOrder order, u32* __restrict__ digests, Verdict v) {
+  merkle_leaves_body<HashBN>(dc, proofs, n, order, digests, v);
 }
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_leaves_wide(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                                    size_t n, MerkleOrder order, u32* __restrict__ digests) {
-  merkle_leaves_body<HashBNWide>(dc, proofs, n, order, digests);
+                                                                    size_t n, MerkleOrder order, u32* __restrict__ digests, Verdict v) {
+  merkle_leaves_body<HashBNWide>(dc, proofs, n, order, digests, v);
 }
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                                    const u64* __restrict__ derived, size_t n, MerkleOrder order,
-                                                                   const u32* __restrict__ digests, u32* __restrict__ fail,
+                                                                   const u32* __restrict__ digests, Verdict v,
                                                                    uint8_t* __restrict__ ok_out) {
-  merkle_climb_body<HashBN>(dc, proofs, derived, n, order, digests, fail, ok_out);
+  merkle_climb_body<HashBN>(dc, proofs, derived, n, order, digests, v, ok_out);
 }
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_wide(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                                    const u64* __restrict__ derived, size_t n, MerkleOrder order,
-                                                                   const u32* __restrict__ digests, u32* __restrict__ fail,
+                                                                   const u32* __restrict__ digests, Verdict v,
                                                                    uint8_t* __restrict__ ok_out) {
-  merkle_climb_body<HashBNWide>(dc, proofs, derived, n, order, digests, fail, ok_out);
+  merkle_climb_body<HashBNWide>(dc, proofs, derived, n, order, digests, v, ok_out);
 }
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_lower(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                                          const u64* __restrict__ derived, size_t n, MerkleOrder order,
                                                                          const u32* __restrict__ digests, u64* __restrict__ mid,
-                                                                         u32 crown_levels) {
-  merkle_climb_lower_body<HashBN>(dc, proofs, derived, n, order, digests, mid, crown_levels);
+                                                                         u32 crown_levels, Verdict v) {
+  merkle_climb_lower_body<HashBN>(dc, proofs, derived, n, order, digests, mid, crown_levels, v);
 }
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_lower_wide(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                                          const u64* __restrict__ derived, size_t n, MerkleOrder order,
                                                                          const u32* __restrict__ digests, u64* __restrict__ mid,
-                                                                         u32 crown_levels) {
-  merkle_climb_lower_body<HashBNWide>(dc, proofs, derived, n, order, digests, mid, crown_levels);
+                                                                         u32 crown_levels, Verdict v) {
+  merkle_climb_lower_body<HashBNWide>(dc, proofs, derived, n, order, digests, mid, crown_levels, v);
 }
 // Poseidon-Goldilocks configuration: ~20x less arithmetic per hash, so 256-lane blocks
 #define GPV_MERKLE_BLOCK_GL 256
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK_GL) void k_merkle_leaves_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                                          size_t n, MerkleOrder order, u32* __restrict__ digests) {
-  merkle_leaves_body<HashGL>(dc, proofs, n, order, digests);
+                                                                          size_t n, MerkleOrder order, u32* __restrict__ digests, Verdict v) {
+  merkle_leaves_body<HashGL>(dc, proofs, n, order, digests, v);
 }
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK_GL) void k_merkle_climb_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                                          const u64* __restrict__ derived, size_t n, MerkleOrder order,
-                                                                         const u32* __restrict__ digests, u32* __restrict__ fail,
+                                                                         const u32* __restrict__ digests, Verdict v,
                                                                          uint8_t* __restrict__ ok_out) {
-  merkle_climb_body<HashGL>(dc, proofs, derived, n, order, digests, fail, ok_out);
+  merkle_climb_body<HashGL>(dc, proofs, derived, n, order, digests, v, ok_out);
 }
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK_GL) void k_merkle_climb_lower_gl(const DevCircuit* __restrict__ dc,
                                                                                const u64* __restrict__ proofs,
                                                                                const u64* __restrict__ derived, size_t n, MerkleOrder order,
                                                                                const u32* __restrict__ digests, u64* __restrict__ mid,
-                                                                               u32 crown_levels) {
-  merkle_climb_lower_body<HashGL>(dc, proofs, derived, n, order, digests, mid, crown_levels);
+                                                                               u32 crown_levels, Verdict v) {
+  merkle_climb_lower_body<HashGL>(dc, proofs, derived, n, order, digests, mid, crown_levels, v);
 }
 static MerkleOrder merkle_order(const DevCircuit& c, bool leaves) {
   // cost of a phase-1 chain = ceil(leaf_len / 9) permutations, of a phase-2 chain = number of siblings;
@@ -227,41 +234,41 @@ void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n
   GPVK_LAUNCH(k_poseidon_bn254_to_vec, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, h, out, n);
 }
 size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n) { return n * hc.num_queries * hc.n_trees * FR_LIMBS; }
-void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, int form) {
+void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, Verdict v, int form) {
   size_t items = n * hc.num_queries;
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
-    GPVK_LAUNCH(k_merkle_leaves_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs, n,
-                merkle_order(hc, true), digests);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs, n,
+                merkle_order(hc, true), digests, v);
   else if (gpvk_fr_chain_pays(items * hc.n_trees, form))
-    GPVK_LAUNCH(k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
-                merkle_order(hc, true), digests);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
+                merkle_order(hc, true), digests, v);
   else
-    GPVK_LAUNCH(k_merkle_leaves_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
-                merkle_order(hc, true), digests);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
+                merkle_order(hc, true), digests, v);
 }
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                       const u32* digests, u32* fail, uint8_t* ok_out, int form) {
+                       const u32* digests, Verdict v, uint8_t* ok_out, int form) {
   size_t items = n * hc.num_queries;
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
-    GPVK_LAUNCH(k_merkle_climb_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs,
-                derived, n, merkle_order(hc, false), digests, fail, ok_out);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs,
+                derived, n, merkle_order(hc, false), digests, v, ok_out);
   else if (gpvk_fr_chain_pays(items * hc.n_trees, form))
-    GPVK_LAUNCH(k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
-                merkle_order(hc, false), digests, fail, ok_out);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
+                merkle_order(hc, false), digests, v, ok_out);
   else
-    GPVK_LAUNCH(k_merkle_climb_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
-                merkle_order(hc, false), digests, fail, ok_out);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
+                merkle_order(hc, false), digests, v, ok_out);
 }
 void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                             const u32* digests, u64* mid, u32 crown_levels, int form) {
+                             const u32* digests, u64* mid, u32 crown_levels, Verdict v, int form) {
   size_t items = n * hc.num_queries;
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
-    GPVK_LAUNCH(k_merkle_climb_lower_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd,
-                proofs, derived, n, merkle_order(hc, false), digests, mid, crown_levels);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd,
+                proofs, derived, n, merkle_order(hc, false), digests, mid, crown_levels, v);
   else if (gpvk_fr_chain_pays(items * hc.n_trees, form))
-    GPVK_LAUNCH(k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
-                derived, n, merkle_order(hc, false), digests, mid, crown_levels);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
+                derived, n, merkle_order(hc, false), digests, mid, crown_levels, v);
   else
-    GPVK_LAUNCH(k_merkle_climb_lower_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
-                derived, n, merkle_order(hc, false), digests, mid, crown_levels);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
+                derived, n, merkle_order(hc, false), digests, mid, crown_levels, v);
 }

@@ -13,17 +13,17 @@
 //                      Equal: the path follows the shared node. Different (a corrupted proof): the path gets a node of
 //                      its own, appended to the level's work list, and keeps to itself from there up
 //   k_crown_level      one lane per node of level k (dense, every lane hashes exactly once); the top level compares with
-//                      the cap entry of the path that owns the node
-//   k_crown_finish     any mismatching top node fails the proof -- the same verdict as AND-ing the reference's per-path
-//                      assertions, because every path's top node is either the shared one (identical inputs all the way)
-//                      or its own
+//                      the cap entry of the path that owns the node. Every node is STAMPED with the run's generation once it
+//                      has been hashed from inputs of this run (a computed child must carry this run's stamp)
+//   k_crown_finish     one lane per (proof, tree): every path looks up ITS top node (the shared one it followed all the way, or
+//                      its own); a mismatch with the cap fails the proof -- literally the AND of the reference's per-path
+//                      assertions -- and a top node without this run's stamp does not count as visited (fail-closed verdict)
 //
 // The per-path kernel (k_merkle_climb_lower) stops GPV_CROWN_LEVELS below the cap and hands over canonical words.
 #include "../../include/gpv.h"
 #include "gpv_launch.h"
 #include "gpv_fri.cuh"
 
-#define CROWN_FLAG_CAP_MISMATCH 2u
 #define CROWN_SRC_SIBLING 0x80000000u
 
 struct CrownItem {
@@ -92,11 +92,15 @@ GPV_DEV void load_words_reduced(const u64* __restrict__ p, u64 w[4]) {
 #define CROWN_PAIRS_PER_WAVE 8
 template <bool ASSIGN>
 GPV_DEV void crown_plan_pair(const DevCircuit* __restrict__ dc, const u64* __restrict__ derived, size_t n, const CrownBufs& b, size_t pair,
-                             u32 (&running)[GPV_CROWN_LEVELS]) {
+                             u32 (&running)[GPV_CROWN_LEVELS], const Verdict& v) {
   const CrownLane L = crown_lane(dc, n, pair);
   const u32 nq = dc->num_queries;
   const size_t items = n * nq;
   const bool path = L.live && L.q < nq;
+  if (ASSIGN) {  // visit counter: the paths of this group that were planned (one atomic per group)
+    const u32 planned = (u32)__popc((u32)(__ballot(path) >> L.base));
+    if (L.live && L.q == 0) atomicAdd(&v.done[L.p * GPV_DONE_STRIDE + GPV_DONE_PLAN], planned);
+  }
   const u64* d = derived + L.p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
   const CrownGeom geo = crown_geom(dc, L.tree);
   const u32 id = path ? crown_id(dc, d, geo, L.q) : 0xFFFFFFFFu;  // idle lanes carry a key no path has
@@ -138,14 +142,15 @@ GPV_DEV void crown_plan_pair(const DevCircuit* __restrict__ dc, const u64* __res
     running[k] += total;
   }
 }
-__global__ __launch_bounds__(64) void k_crown_plan(const DevCircuit* __restrict__ dc, const u64* __restrict__ derived, size_t n, CrownBufs b) {
+__global__ __launch_bounds__(64) void k_crown_plan(const DevCircuit* __restrict__ dc, const u64* __restrict__ derived, size_t n, CrownBufs b,
+                                                   Verdict v) {
   const size_t pairs = (n * dc->n_trees + 1) / 2;
   const size_t first_pair = (size_t)blockIdx.x * CROWN_PAIRS_PER_WAVE;
   u32 running[GPV_CROWN_LEVELS];
 #pragma unroll
   for (int k = 0; k < GPV_CROWN_LEVELS; k++) running[k] = 0;
   for (u32 j = 0; j < CROWN_PAIRS_PER_WAVE; j++)
-    if (first_pair + j < pairs) crown_plan_pair<false>(dc, derived, n, b, first_pair + j, running);
+    if (first_pair + j < pairs) crown_plan_pair<false>(dc, derived, n, b, first_pair + j, running, v);
 #pragma unroll
   for (int k = 0; k < GPV_CROWN_LEVELS; k++) {
     u32 base = 0;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(64) void k_crown_plan(const DevCircuit* __restrict_
     running[k] = (u32)__shfl((int)base, 0);
   }
   for (u32 j = 0; j < CROWN_PAIRS_PER_WAVE; j++)
-    if (first_pair + j < pairs) crown_plan_pair<true>(dc, derived, n, b, first_pair + j, running);
+    if (first_pair + j < pairs) crown_plan_pair<true>(dc, derived, n, b, first_pair + j, running, v);
 }
 
 // One lane per node of level k, grid-stride: the grid is sized for the node count of a valid batch (at most one shared node per
@@ -161,11 +166,12 @@ __global__ __launch_bounds__(64) void k_crown_plan(const DevCircuit* __restrict_
 // node. (A grid of 2 x paths, the worst case, launched 2.75 M lanes for ~0.9 M nodes: 8 % of the kernel's time, r02b PMC.)
 template <class H>
 GPV_DEV void crown_level_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
-                              const CrownBufs& b, u32 k) {
+                              const CrownBufs& b, u32 k, u32 gen) {
   const size_t total = b.count[k];
 #pragma unroll 1
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     typename H::Node in[2];
+    bool fresh = true;  // every computed child was hashed in THIS run (level 0's children are covered by GPV_DONE_CLIMB)
     {
       const CrownItem it = b.item[k][i];
       const u64* below = k == 0 ? b.mid : b.res[k - 1];
@@ -173,6 +179,7 @@ GPV_DEV void crown_level_body(const DevCircuit* __restrict__ dc, const u64* __re
       for (int side = 0; side < 2; side++) {
         u32 src = it.src[side];
         const u64* w = below + 4 * (size_t)(src & ~CROWN_SRC_SIBLING);
+        if (k != 0 && !(src & CROWN_SRC_SIBLING)) fresh &= (b.stamp[k - 1][src] >> 2) == gen;
         if (src & CROWN_SRC_SIBLING) {
           const size_t p = it.proof;
           MerklePath m = dev_merkle_path(dc, proofs + p * (dc->proof_nbytes / 8), derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA),
@@ -189,6 +196,7 @@ GPV_DEV void crown_level_body(const DevCircuit* __restrict__ dc, const u64* __re
     u64* o = b.res[k] + 4 * i;
     o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; o[3] = out[3];
     const u32 meta = b.item[k][i].meta;  // re-read after the hash: nothing of the item stays live across it
+    u32 code = GPV_STAMP_OK;
     if ((meta >> 16) & 1) {
       const size_t p = b.item[k][i].proof;
       const u32 tree = meta & 0xFF;
@@ -196,27 +204,28 @@ GPV_DEV void crown_level_body(const DevCircuit* __restrict__ dc, const u64* __re
                                      tree);
       u64 want[4];
       load_words_reduced<H>(m.cap + 4 * m.cap_index, want);
-      if (!fr_words_equal(out, want)) atomicOr(&b.gflag[p * dc->n_trees + tree], CROWN_FLAG_CAP_MISMATCH);
+      if (!fr_words_equal(out, want)) code = GPV_STAMP_CAP_MISMATCH;
     }
+    b.stamp[k][i] = fresh ? (gen << 2) | code : 0u;
   }
 }
 __global__ __launch_bounds__(64) void k_crown_level(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                    const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
-  crown_level_body<HashBN>(dc, proofs, derived, n, b, k);
+                                                    const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k, u32 gen) {
+  crown_level_body<HashBN>(dc, proofs, derived, n, b, k, gen);
 }
 __global__ __launch_bounds__(64) void k_crown_level_wide(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                         const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
-  crown_level_body<HashBNWide>(dc, proofs, derived, n, b, k);
+                                                         const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k, u32 gen) {
+  crown_level_body<HashBNWide>(dc, proofs, derived, n, b, k, gen);
 }
 __global__ __launch_bounds__(256) void k_crown_level_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                        const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
-  crown_level_body<HashGL>(dc, proofs, derived, n, b, k);
+                                                        const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k, u32 gen) {
+  crown_level_body<HashGL>(dc, proofs, derived, n, b, k, gen);
 }
 
 // Two groups per wave like the plan; run before level k.
 template <class H>
 GPV_DEV void crown_reconcile_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
-                                  const CrownBufs& b, u32 k) {
+                                  const CrownBufs& b, u32 k, const Verdict& v) {
   const CrownLane L = crown_lane(dc, n, blockIdx.x);
   const u32 nq = dc->num_queries;
   const size_t items = n * nq;
@@ -243,6 +252,10 @@ GPV_DEV void crown_reconcile_body(const DevCircuit* __restrict__ dc, const u64* 
   const u32 via = crown_first(child_key, on ? (child_key ^ 1u) : 0xFFFFFFFEu, L.base, nq);  // a path through the other child
   const u32 leader = crown_first(parent, parent, L.base, nq);
   const u32 via_shared_below = (u32)__shfl((int)shared_below, L.base + (int)(via < nq ? via : 0));
+  {  // visit counter: the (path, level) pairs of this group that are reconciled below (one atomic per group)
+    const u32 visited = (u32)__popc((u32)(__ballot(on) >> L.base));
+    if (L.live && L.q == 0 && visited) atomicAdd(&v.done[L.p * GPV_DONE_STRIDE + GPV_DONE_RECON], visited);
+  }
   if (!on) return;
   bool alone = k != 0 && (b.pstate[pq] & 1u);
   u32 child_src = own_below;
@@ -277,51 +290,69 @@ GPV_DEV void crown_reconcile_body(const DevCircuit* __restrict__ dc, const u64* 
   b.pslot[pq * GPV_CROWN_LEVELS + k] = slot;
 }
 __global__ __launch_bounds__(64) void k_crown_reconcile(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                        const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
-  crown_reconcile_body<HashBN>(dc, proofs, derived, n, b, k);
+                                                        const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k, Verdict v) {
+  crown_reconcile_body<HashBN>(dc, proofs, derived, n, b, k, v);
 }
 __global__ __launch_bounds__(64) void k_crown_reconcile_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                           const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k) {
-  crown_reconcile_body<HashGL>(dc, proofs, derived, n, b, k);
+                                                           const u64* __restrict__ derived, size_t n, CrownBufs b, u32 k, Verdict v) {
+  crown_reconcile_body<HashGL>(dc, proofs, derived, n, b, k, v);
 }
 
-// one lane per (proof, query), blockIdx.y = tree
+// One lane per (proof, tree). Every path of the group looks up the top node its own chain ended in (pslot of its last level: the
+// shared node it followed all the way up, or the node of its own it was given when it left the shared tree): a top node that differs
+// from the cap entry fails the proof (fri.go:135-143, per path), and only a top node hashed IN THIS RUN from inputs of this run counts
+// as a visited path.
 template <class H>
 GPV_DEV void crown_finish_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
-                               const CrownBufs& b, u32* __restrict__ fail) {
-  size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                               const CrownBufs& b, const Verdict& v, u32 gen) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries, nt = dc->n_trees;
+  if (g >= n * nt) return;
+  const size_t p = g / nt;
+  const u32 tree = (u32)(g - p * nt);
   const size_t items = n * nq;
-  if (item >= items) return;
-  const size_t p = item / nq;
-  const u32 q = (u32)(item - p * nq), tree = blockIdx.y;
   const u32 bit = tree < 4 ? (u32)GPV_FAIL_MERKLE_INITIAL : (u32)GPV_FAIL_MERKLE_STEP;
   const CrownGeom geo = crown_geom(dc, tree);
+  const size_t slots = 2 * items * nt;  // capacity of a level's work list (gpvk_crown_carve)
+  u32 visited = 0;
+  bool bad = false;
   if (geo.top != 0) {
-    if (q == 0 && (b.gflag[p * nt + tree] & CROWN_FLAG_CAP_MISMATCH)) atomicOr(&fail[p], bit);
-    return;
+#pragma unroll 4
+    for (u32 q = 0; q < nq; q++) {
+      const u32 slot = b.pslot[(g * nq + q) * GPV_CROWN_LEVELS + (geo.top - 1)];
+      const u32 st = slot < slots ? b.stamp[geo.top - 1][slot] : 0u;
+      const bool fresh = (st >> 2) == gen;
+      visited += fresh;
+      bad |= fresh && (st & 3u) != GPV_STAMP_OK;
+    }
+  } else {
+    // a tree whose leaves sit directly under the cap: nothing to hash (fri.go:135-143)
+    const u64* rec = proofs + p * (dc->proof_nbytes / 8);
+    const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
+    for (u32 q = 0; q < nq; q++) {
+      const MerklePath m = dev_merkle_path(dc, rec, d, q, tree);
+      u64 want[4];
+      load_words_reduced<H>(m.cap + 4 * m.cap_index, want);
+      bad |= !fr_words_equal(b.mid + 4 * ((size_t)tree * items + p * nq + q), want);
+      visited++;
+    }
   }
-  // a tree whose leaves sit directly under the cap: nothing to hash (fri.go:135-143)
-  const u64* rec = proofs + p * (dc->proof_nbytes / 8);
-  const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
-  const MerklePath m = dev_merkle_path(dc, rec, d, q, tree);
-  u64 want[4];
-  load_words_reduced<H>(m.cap + 4 * m.cap_index, want);
-  if (!fr_words_equal(b.mid + 4 * ((size_t)tree * items + item), want)) atomicOr(&fail[p], bit);
+  if (bad) atomicOr(&v.fail[p], bit);
+  atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_CAP], visited);
 }
 __global__ void k_crown_finish(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
-                               CrownBufs b, u32* __restrict__ fail) {
-  crown_finish_body<HashBN>(dc, proofs, derived, n, b, fail);
+                               CrownBufs b, Verdict v, u32 gen) {
+  crown_finish_body<HashBN>(dc, proofs, derived, n, b, v, gen);
 }
 __global__ void k_crown_finish_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ derived, size_t n,
-                                  CrownBufs b, u32* __restrict__ fail) {
-  crown_finish_body<HashGL>(dc, proofs, derived, n, b, fail);
+                                  CrownBufs b, Verdict v, u32 gen) {
+  crown_finish_body<HashGL>(dc, proofs, derived, n, b, v, gen);
 }
 
 // work lists hold the shared nodes (at most one per path and level) plus one node per path that left the shared tree
 size_t gpvk_crown_bytes(const DevCircuit& hc, size_t n) {
   size_t cap = n * hc.n_trees * hc.num_queries;
-  return 256 + 32 * cap + GPV_CROWN_LEVELS * (sizeof(CrownItem) + 32) * 2 * cap + 2 * 4 * GPV_CROWN_LEVELS * cap + 4 * cap + 4 * n * hc.n_trees;
+  return 256 + 32 * cap + GPV_CROWN_LEVELS * (sizeof(CrownItem) + 32 + 4) * 2 * cap + 2 * 4 * GPV_CROWN_LEVELS * cap + 4 * cap;
 }
 // slots and node indices travel as 31-bit numbers (bit 31 marks "sibling supplied by query ...")
 bool gpvk_crown_supported(const DevCircuit& hc, size_t n) {
@@ -339,32 +370,32 @@ CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base) {
   b.slot = (u32*)p; p += 4 * GPV_CROWN_LEVELS * cap;
   b.pslot = (u32*)p; p += 4 * GPV_CROWN_LEVELS * cap;
   b.pstate = (u32*)p; p += 4 * cap;
-  b.gflag = (u32*)p;
+  for (int k = 0; k < GPV_CROWN_LEVELS; k++) { b.stamp[k] = (u32*)p; p += 4 * 2 * cap; }
   return b;
 }
-// after gpvk_merkle_climb_lower has filled b.mid on the same stream
+// after gpvk_merkle_climb_lower has filled b.mid on the same stream. `gen`: the run's generation (unique per use of this scratch, never
+// 0; the scratch is zeroed when it is allocated), the value a stamp must carry to count.
 void gpvk_crown(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, CrownBufs b,
-                u32* fail, int form) {
-  size_t groups = n * hc.n_trees, items = n * hc.num_queries, cap = groups * hc.num_queries;
+                Verdict v, u32 gen, int form) {
+  size_t groups = n * hc.n_trees, cap = groups * hc.num_queries;
   gpvk_note_launch(hipMemsetAsync(b.count, 0, 4 * GPV_CROWN_LEVELS, st), "memset(crown counters)");
-  gpvk_note_launch(hipMemsetAsync(b.gflag, 0, 4 * groups, st), "memset(crown flags)");
-  GPVK_LAUNCH(k_crown_plan, dim3(gpvk_blocks_for(groups, 2 * CROWN_PAIRS_PER_WAVE)), dim3(64), 0, st, dcd, derived, n, b);
+  GPVK_LAUNCH_STAGE(GPV_STAGE_CROWN_PLAN, k_crown_plan, dim3(gpvk_blocks_for(groups, 2 * CROWN_PAIRS_PER_WAVE)), dim3(64), 0, st, dcd, derived, n, b, v);
   const bool gl = hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS;
   for (u32 k = 0; k < GPV_CROWN_LEVELS; k++) {
     if (gl) {
-      GPVK_LAUNCH(k_crown_reconcile_gl, dim3(gpvk_blocks_for(groups, 2)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
-      GPVK_LAUNCH(k_crown_level_gl, dim3(gpvk_blocks_for(cap, 256)), dim3(256), 0, st, dcd, proofs, derived, n, b, k);
+      GPVK_LAUNCH_STAGE(GPV_STAGE_CROWN_RECONCILE, k_crown_reconcile_gl, dim3(gpvk_blocks_for(groups, 2)), dim3(64), 0, st, dcd, proofs, derived, n, b, k, v);
+      GPVK_LAUNCH_STAGE(GPV_STAGE_CROWN_LEVEL, k_crown_level_gl, dim3(gpvk_blocks_for(cap, 256)), dim3(256), 0, st, dcd, proofs, derived, n, b, k, gen);
     } else {
-      GPVK_LAUNCH(k_crown_reconcile, dim3(gpvk_blocks_for(groups, 2)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
+      GPVK_LAUNCH_STAGE(GPV_STAGE_CROWN_RECONCILE, k_crown_reconcile, dim3(gpvk_blocks_for(groups, 2)), dim3(64), 0, st, dcd, proofs, derived, n, b, k, v);
       // ~22 / 19 / 13 distinct nodes per tree on the three shared levels (28 uniform indices)
       if (gpvk_fr_chain_pays(groups * 22, form))
-        GPVK_LAUNCH(k_crown_level, dim3(gpvk_blocks_for(cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
+        GPVK_LAUNCH_STAGE(GPV_STAGE_CROWN_LEVEL, k_crown_level, dim3(gpvk_blocks_for(cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k, gen);
       else
-        GPVK_LAUNCH(k_crown_level_wide, dim3(gpvk_blocks_for(cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k);
+        GPVK_LAUNCH_STAGE(GPV_STAGE_CROWN_LEVEL, k_crown_level_wide, dim3(gpvk_blocks_for(cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k, gen);
     }
   }
   if (gl)
-    GPVK_LAUNCH(k_crown_finish_gl, dim3(gpvk_blocks_for(items, 256), hc.n_trees), dim3(256), 0, st, dcd, proofs, derived, n, b, fail);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CROWN_FINISH, k_crown_finish_gl, dim3(gpvk_blocks_for(groups, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, v, gen);
   else
-    GPVK_LAUNCH(k_crown_finish, dim3(gpvk_blocks_for(items, 256), hc.n_trees), dim3(256), 0, st, dcd, proofs, derived, n, b, fail);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CROWN_FINISH, k_crown_finish, dim3(gpvk_blocks_for(groups, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, v, gen);
 }

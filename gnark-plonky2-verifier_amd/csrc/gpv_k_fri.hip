@@ -4,7 +4,7 @@
 #include "gpv_fri.cuh"
 
 __global__ __launch_bounds__(64) GPVK_SIDE_STREAM_KERNEL void k_fri_query(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                  const u64* __restrict__ derived, size_t n, u32* __restrict__ fail) {
+                                                  const u64* __restrict__ derived, size_t n, Verdict v) {
   gpvk_side_stream_priority();
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries;
@@ -16,11 +16,12 @@ __global__ __launch_bounds__(64) GPVK_SIDE_STREAM_KERNEL void k_fri_query(const 
   u32 f = dev_fri_query(dc, rec, d, q);
   // proof of work (fri.go:75-80): pow_response < 2^(64 - pow_bits)
   if (q == 0 && dc->pow_bits && (d[dc->ch_pow] >> (64 - dc->pow_bits)) != 0) f |= GPV_FAIL_POW;
-  if (f) atomicOr(&fail[p], f);
+  if (f) atomicOr(&v.fail[p], f);
+  atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_FRI], 1u);
 }
 
 void gpvk_fri_query(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                    u32* fail) {
+                    Verdict v) {
   size_t items = n * hc.num_queries;
-  GPVK_LAUNCH(k_fri_query, dim3(gpvk_blocks_for(items, 64)), dim3(64), 0, st, dcd, proofs, derived, n, fail);
+  GPVK_LAUNCH_STAGE(GPV_STAGE_FRI, k_fri_query, dim3(gpvk_blocks_for(items, 64)), dim3(64), 0, st, dcd, proofs, derived, n, v);
 }

@@ -28,14 +28,15 @@ __global__ __launch_bounds__(GPV_PLONK_BLOCK) void k_gate_eval_unfiltered(DevGat
 }
 
 __global__ __launch_bounds__(GPV_PLONK_BLOCK) GPVK_SIDE_STREAM_KERNEL void k_plonk(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
-                                                           const u64* __restrict__ derived, size_t n, u32* __restrict__ fail) {
+                                                           const u64* __restrict__ derived, size_t n, Verdict v) {
   __shared__ u64 lds[GPV_PLONK_BLOCK * GPV_PLONK_LDS_PER_LANE];
   gpvk_side_stream_priority();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64* rec = proofs + i * (dc->proof_nbytes / 8);
   u32 f = dev_plonk_verify(dc, rec, derived + i * (dc->n_challenge_words + GPV_DERIVED_EXTRA), lds + threadIdx.x, GPV_PLONK_BLOCK);
-  if (f) atomicOr(&fail[i], f);
+  if (f) atomicOr(&v.fail[i], f);
+  atomicAdd(&v.done[i * GPV_DONE_STRIDE + GPV_DONE_PLONK], 1u);
 }
 // EvaluateGateConstraints with materialised slots (parity/debug path; the verify path streams them, gpv_plonk.cuh)
 __global__ __launch_bounds__(GPV_PLONK_BLOCK) void k_gate_constraints(const DevCircuit* __restrict__ dc,
@@ -72,8 +73,8 @@ void gpvk_gate_eval_unfiltered(hipStream_t st, DevGate g, const u64* weights, co
   GPVK_LAUNCH(k_gate_eval_unfiltered, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, g, weights, constants,
                      n_constants, wires, n_wires, pih, out, max_out, n);
 }
-void gpvk_plonk(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u32* fail) {
-  GPVK_LAUNCH(k_plonk, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, dcd, proofs, derived, n, fail);
+void gpvk_plonk(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, Verdict v) {
+  GPVK_LAUNCH_STAGE(GPV_STAGE_PLONK, k_plonk, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, dcd, proofs, derived, n, v);
 }
 void gpvk_gate_constraints(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u64* out) {
   GPVK_LAUNCH(k_gate_constraints, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, dcd, proofs, derived, n,

@@ -1,5 +1,5 @@
 // Primitive kernels: chip-level Goldilocks operators, the batched Poseidon-Goldilocks permutation (BASELINE config 2)
-// and the instruction-rate microbenchmark that defines the VALU-integer roof.
+
 #include "../../include/gpv.h"
 #include "gpv_launch.h"
 #include "gpv_poseidon_coop.cuh"
@@ -253,45 +253,6 @@ __global__ __launch_bounds__(64) void k_challenger_run(const u32* __restrict__ s
   }
 }
 
-// ================================================================ instruction-rate microbenchmark
-// Eight independent dependency chains per lane, enough waves to fill every SIMD: measures issue rate, not latency.
-#define MB_CHAINS 8
-template <int WHICH>
-__global__ __launch_bounds__(256) void k_microbench(u64* out, int iters) {
-  u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 977u;
-  u64 acc64[MB_CHAINS];
-  u32 acc32[MB_CHAINS];
-  double accd[MB_CHAINS];
-#pragma unroll
-  for (int k = 0; k < MB_CHAINS; k++) {
-    acc64[k] = ((u64)a << 32) + b + k;
-    acc32[k] = a + k;
-    accd[k] = 1.0 + 1e-9 * (double)(a + k);
-  }
-  double da = 1.0000001, db = 1e-12 * (double)b;
-#pragma unroll 1
-  for (int it = 0; it < iters; it++) {
-#pragma unroll
-    for (int rep = 0; rep < 4; rep++) {
-#pragma unroll
-      for (int k = 0; k < MB_CHAINS; k++) {
-        if (WHICH == 0) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc64[k]) : "v"(a), "v"(b) : "vcc");
-        if (WHICH == 1) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(acc32[k]) : "v"(a));
-        if (WHICH == 2) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(acc32[k]) : "v"(a));
-        if (WHICH == 3) asm volatile("v_fma_f64 %0, %1, %0, %2" : "+v"(accd[k]) : "v"(da), "v"(db));
-        if (WHICH == 4) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(acc32[k]) : "v"(a) : "vcc");
-        if (WHICH == 5) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc32[k]) : "v"(a), "v"(b));
-        if (WHICH == 6) asm volatile("v_add_u32 %0, %0, %1" : "+v"(acc32[k]) : "v"(a));
-        if (WHICH == 7) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc64[k]) : "v"(acc64[(k + 1) % MB_CHAINS]));
-      }
-    }
-  }
-  u64 r = 0;
-#pragma unroll
-  for (int k = 0; k < MB_CHAINS; k++) r ^= acc64[k] ^ acc32[k] ^ (u64)__double_as_longlong(accd[k]);
-  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = r;
-}
-
 
 void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n) {
   GPVK_LAUNCH(k_gl_op, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, op, a, b, c, out, n);
@@ -329,17 +290,4 @@ void gpvk_poseidon_gl_permute_coop(hipStream_t st, const u64* in, u64* out, size
 }
 void gpvk_poseidon_gl_hash_no_pad(hipStream_t st, const u64* in, u32 len, u64* out, size_t n) {
   GPVK_LAUNCH(k_poseidon_gl_hash_no_pad, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
-}
-int gpvk_microbench_ops_per_iter() { return 4 * MB_CHAINS; }
-void gpvk_microbench(hipStream_t st, int which, u64* out, int blocks, int threads, int iters) {
-  switch (which) {
-    case 0: GPVK_LAUNCH(k_microbench<0>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 1: GPVK_LAUNCH(k_microbench<1>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 2: GPVK_LAUNCH(k_microbench<2>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 3: GPVK_LAUNCH(k_microbench<3>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 4: GPVK_LAUNCH(k_microbench<4>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 5: GPVK_LAUNCH(k_microbench<5>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 6: GPVK_LAUNCH(k_microbench<6>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-    case 7: GPVK_LAUNCH(k_microbench<7>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
-  }
 }

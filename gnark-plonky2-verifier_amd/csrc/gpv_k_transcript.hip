@@ -3,34 +3,53 @@
 #include "gpv_launch.h"
 #include "gpv_transcript.cuh"
 
-// Canonical-form check of every Goldilocks word except the public inputs: one coalesced pass over the batch.
-__global__ __launch_bounds__(256) void k_range_check(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
-                                                     u32* __restrict__ fail) {
+// Canonical-form check of every Goldilocks word except the public inputs: one coalesced pass over the batch. A block owns one chunk
+// of GPV_RANGE_CHUNK consecutive words of ONE record (consecutive lanes read consecutive words), so the number of words it checked
+// goes into that proof's visit counter with one atomic per wave -- the verdict later requires the counter to equal the record's
+// checked-word count (fail-closed: a word nobody looked at cannot pass).
+#define GPV_RANGE_CHUNK 2048
+#define GPV_RANGE_BLOCK 256
+GPV_DEV u32 range_words(const DevCircuit* __restrict__ dc) {
   // Poseidon-Goldilocks configuration: the hashes (caps, siblings) are Goldilocks elements of the proof too, so the words of
   // the hash section are checked as well; a BN254 hash is taken mod r like a gnark witness and has no canonical-form check
-  const u32 gl_part = dc->off_pi;
-  const u32 words = gl_part + (dc->hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS ? 4 * dc->n_fr : 0);
-  const size_t stride_words = dc->proof_nbytes / 8;
-  const size_t total = (size_t)words * n;
-  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
-    size_t p = w / words;
-    u32 k = (u32)(w - p * words);
-    if (k >= gl_part) k = dc->n_gl_words + (k - gl_part);
-    u64 x = proofs[p * stride_words + k];
-    if (x >= GLP) atomicOr(&fail[p], (u32)GPV_FAIL_RANGE);
+  return dc->off_pi + (dc->hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS ? 4 * dc->n_fr : 0);
+}
+__global__ __launch_bounds__(GPV_RANGE_BLOCK) void k_range_check(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+                                                                 u32 chunks_per_proof, Verdict v) {
+  const u32 gl_part = dc->off_pi, words = range_words(dc);
+  const size_t p = blockIdx.x / chunks_per_proof;
+  if (p >= n) return;
+  const u32 chunk = blockIdx.x - (u32)(p * chunks_per_proof);
+  const u32 w0 = chunk * GPV_RANGE_CHUNK, w1 = min(words, w0 + GPV_RANGE_CHUNK);
+  const u64* rec = proofs + p * (dc->proof_nbytes / 8);
+  u32 seen = 0;
+  bool bad = false;
+#pragma unroll 4
+  for (u32 w = w0 + threadIdx.x; w < w1; w += GPV_RANGE_BLOCK) {
+    const u32 k = w >= gl_part ? dc->n_gl_words + (w - gl_part) : w;
+    bad |= rec[k] >= GLP;
+    seen++;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) seen += (u32)__shfl_down((int)seen, off);
+  const bool any_bad = __ballot(bad) != 0;
+  if ((threadIdx.x & 63) == 0) {
+    if (seen) atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_RANGE], seen);
+    if (any_bad) atomicOr(&v.fail[p], (u32)GPV_FAIL_RANGE);
   }
 }
 __global__ __launch_bounds__(64) GPVK_SIDE_STREAM_KERNEL void k_transcript(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
-                                                   u64* __restrict__ derived) {
+                                                   u64* __restrict__ derived, Verdict v) {
   gpvk_side_stream_priority();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64* rec = proofs + i * (dc->proof_nbytes / 8);
   dev_transcript(dc, rec, derived + i * (dc->n_challenge_words + GPV_DERIVED_EXTRA));
+  atomicAdd(&v.done[i * GPV_DONE_STRIDE + GPV_DONE_DERIVED], 1u);
 }
 // cooperative variant: one 16-lane group per proof, four proofs per wave; round constants staged in LDS
 __global__ __launch_bounds__(64) void k_transcript_coop(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
-                                                        u64* __restrict__ derived) {
+                                                        u64* __restrict__ derived, Verdict v) {
   __shared__ u64 lds_rc[360];
   gpvk_side_stream_priority();
   pgl_coop_stage_constants(lds_rc);
@@ -38,10 +57,11 @@ __global__ __launch_bounds__(64) void k_transcript_coop(const DevCircuit* __rest
   if (i >= n) return;  // whole 16-lane groups leave together; the others only exchange data inside their own group
   const u64* rec = proofs + i * (dc->proof_nbytes / 8);
   dev_transcript_coop(dc, rec, derived + i * (dc->n_challenge_words + GPV_DERIVED_EXTRA), lds_rc);
+  if ((threadIdx.x & (PGL_COOP_LANES - 1)) == 0) atomicAdd(&v.done[i * GPV_DONE_STRIDE + GPV_DONE_DERIVED], 1u);
 }
 // challenges supplied by the caller: fill in the public-inputs hash and the reduced openings only
 __global__ __launch_bounds__(64) void k_derive_extra(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
-                                                     u64* __restrict__ derived) {
+                                                     u64* __restrict__ derived, Verdict v) {
   gpvk_side_stream_priority();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -66,10 +86,22 @@ __global__ __launch_bounds__(64) void k_derive_extra(const DevCircuit* __restric
   for (u32 w = orr.c1; w > orr.c0; w -= 2) sum = ext_muladd(sum, fri_alpha, ext_make(rec[w - 2], rec[w - 1]));
   extra[6] = sum.a;
   extra[7] = sum.b;
+  atomicAdd(&v.done[i * GPV_DONE_STRIDE + GPV_DONE_DERIVED], 1u);
 }
-__global__ void k_finalize(const u32* __restrict__ fail, uint8_t* __restrict__ accept, size_t n) {
+// The verdict (fail-closed, gpv_launch.h): a proof is accepted only if no assertion failed AND every stage of `expect.mask` visited
+// exactly the units the circuit prescribes. A failed range check reports GPV_FAIL_RANGE alone (include/gpv.h).
+__global__ void k_finalize(Verdict v, DoneExpect expect, uint8_t* __restrict__ accept, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) accept[i] = fail[i] == 0;
+  if (i >= n) return;
+  u32 f = v.fail[i];
+  bool incomplete = false;
+#pragma unroll
+  for (int s = 0; s < GPV_DONE_COUNT; s++)
+    if ((expect.mask >> s) & 1) incomplete |= v.done[i * GPV_DONE_STRIDE + s] != expect.v[s];
+  if (f & GPV_FAIL_RANGE) f = GPV_FAIL_RANGE;
+  if (incomplete) f |= (u32)GPV_FAIL_INCOMPLETE;
+  v.fail[i] = f;
+  if (accept) accept[i] = f == 0;
 }
 // Multi-GPU exchange: the accept bytes of one rank's block -> bits, 8 per byte (bit i of byte j = accept[8 j + i]),
 // zero-padded to the fixed slot size every rank contributes to the all-gather ...
@@ -122,20 +154,23 @@ __global__ void k_gather_pih(const u64* __restrict__ derived, u64* __restrict__ 
 }
 
 
-void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u32* fail) {
-  GPVK_LAUNCH(k_range_check, dim3(2048), dim3(256), 0, st, dcd, proofs, n, fail);
+u32 gpvk_range_words(const DevCircuit& hc) { return hc.off_pi + (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS ? 4 * hc.n_fr : 0); }
+void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, Verdict v) {
+  const u32 chunks = (gpvk_range_words(hc) + GPV_RANGE_CHUNK - 1) / GPV_RANGE_CHUNK;
+  if (!chunks) return;
+  GPVK_LAUNCH_STAGE(GPV_STAGE_RANGE, k_range_check, dim3((unsigned)(n * chunks)), dim3(GPV_RANGE_BLOCK), 0, st, dcd, proofs, n, chunks, v);
 }
-void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived) {
-  GPVK_LAUNCH(k_transcript, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
+void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived, Verdict v) {
+  GPVK_LAUNCH_STAGE(GPV_STAGE_TRANSCRIPT, k_transcript, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived, v);
 }
-void gpvk_transcript_coop(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived) {
-  GPVK_LAUNCH(k_transcript_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
+void gpvk_transcript_coop(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived, Verdict v) {
+  GPVK_LAUNCH_STAGE(GPV_STAGE_TRANSCRIPT, k_transcript_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 64)), dim3(64), 0, st, dcd, proofs, n, derived, v);
 }
-void gpvk_derive_extra(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived) {
-  GPVK_LAUNCH(k_derive_extra, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived);
+void gpvk_derive_extra(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived, Verdict v) {
+  GPVK_LAUNCH_STAGE(GPV_STAGE_DERIVE_EXTRA, k_derive_extra, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, derived, v);
 }
-void gpvk_finalize(hipStream_t st, const u32* fail, uint8_t* accept, size_t n) {
-  GPVK_LAUNCH(k_finalize, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, fail, accept, n);
+void gpvk_finalize(hipStream_t st, Verdict v, DoneExpect expect, uint8_t* accept, size_t n) {
+  GPVK_LAUNCH(k_finalize, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, v, expect, accept, n);
 }
 void gpvk_pack_accept_bits(hipStream_t st, const uint8_t* accept, size_t m, uint8_t* bits, size_t slot_bytes) {
   GPVK_LAUNCH(k_pack_accept_bits, dim3(gpvk_blocks_for(slot_bytes, 256)), dim3(256), 0, st, accept, m, bits, slot_bytes);

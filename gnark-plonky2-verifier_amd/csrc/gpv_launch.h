@@ -20,6 +20,47 @@ void gpvk_note_launch(hipError_t e, const char* what);
     gpvk_note_launch(hipGetLastError(), #kernel);                  \
   } while (0)
 
+// ---- fail-closed verdict (accept = conjunction of ALL assertions). Besides OR-ing assertion failures into
+// fail[proof], every protocol kernel reports that it has VISITED its units of a proof in a per-proof counter row; the verdict kernel
+// accepts only when every counter equals what the circuit prescribes. A stage whose grid under-covers the batch, a lane that returns
+// early, a launch that is skipped: the proofs concerned end as GPV_FAIL_INCOMPLETE = reject, never as "fail mask still zero".
+enum {
+  GPV_DONE_RANGE = 0,    // words whose canonical form was checked                       expected: every checked word of the record
+  GPV_DONE_DERIVED = 1,  // transcript (or, with supplied challenges, derive_extra)      1
+  GPV_DONE_PLONK = 2,    // vanishing-polynomial check                                   1
+  GPV_DONE_FRI = 3,      // query rounds (field part)                                    num_queries
+  GPV_DONE_LEAVES = 4,   // leaf digests                                                 num_queries * n_trees
+  GPV_DONE_CLIMB = 5,    // sibling walks (whole, or up to the shared levels)            num_queries * n_trees
+  GPV_DONE_PLAN = 6,     // shared levels: paths planned                                 num_queries * n_trees (0 without shared levels)
+  GPV_DONE_RECON = 7,    // shared levels: (path, level) reconciliations                 num_queries * sum_tree levels(tree)
+  GPV_DONE_CAP = 8,      // paths whose top node was computed IN THIS RUN and compared with the cap   num_queries * n_trees
+  GPV_DONE_COUNT = 9
+};
+#define GPV_DONE_STRIDE 12  // u32 words per proof (48 B)
+struct Verdict {
+  u32* fail;  // [n] assertion-failure bits (GPV_FAIL_*)
+  u32* done;  // [n][GPV_DONE_STRIDE] visit counters
+};
+struct DoneExpect {
+  u32 v[GPV_DONE_COUNT];
+  u32 mask;  // stages that were launched for this call (bit s = counter s is checked)
+};
+// Fault injection for tests (gpv_testhooks.h): the launch of `stage` (its nth launch of the call; -1 = every one) keeps only
+// blocks * num / den of its grid (0 = the launch is skipped). Identity unless a test armed it.
+enum {
+  GPV_STAGE_RANGE = 1, GPV_STAGE_TRANSCRIPT, GPV_STAGE_PLONK, GPV_STAGE_FRI, GPV_STAGE_LEAVES, GPV_STAGE_CLIMB, GPV_STAGE_CROWN_PLAN,
+  GPV_STAGE_CROWN_RECONCILE, GPV_STAGE_CROWN_LEVEL, GPV_STAGE_CROWN_FINISH, GPV_STAGE_DERIVE_EXTRA,
+  GPV_STAGE_GROUP_RANK = 100  // not a launch: rank `nth` of a gpv_group pretends its verification failed
+};
+bool gpvi_fault_rank(int rank);
+unsigned gpvk_fault_blocks(int stage, unsigned blocks);
+#define GPVK_LAUNCH_STAGE(stage, kernel, grid, block, lds, st, ...)  \
+  do {                                                               \
+    dim3 g_ = (grid);                                                \
+    g_.x = gpvk_fault_blocks(stage, g_.x);                           \
+    if (g_.x) GPVK_LAUNCH(kernel, g_, block, lds, st, __VA_ARGS__);  \
+  } while (0)
+
 // The kernels of the side stream (transcript, plonk, FRI query arithmetic) are short dependent chains on few waves; the
 // Merkle kernels next to them on the same SIMDs issue a VALU instruction in every slot. Raising the wave's issue priority
 // lets the side-stream wave take a slot whenever its next instruction is ready, so its latency-bound critical path stays
@@ -51,15 +92,13 @@ void gpvk_challenger_run(hipStream_t st, const u32* script, u32 n_ops, const u64
 void gpvk_poseidon_gl_permute(hipStream_t st, const u64* in, u64* out, size_t n);
 void gpvk_poseidon_gl_permute_coop(hipStream_t st, const u64* in, u64* out, size_t n);  // 16 lanes per state
 void gpvk_poseidon_gl_hash_no_pad(hipStream_t st, const u64* in, u32 len, u64* out, size_t n);
-void gpvk_microbench(hipStream_t st, int which, u64* out, int blocks, int threads, int iters);
-int gpvk_microbench_ops_per_iter();
 // gpv_k_bn254.hip
 void gpvk_poseidon_bn254_permute(hipStream_t st, const u64* in, u64* out, size_t n, int form);
 void gpvk_poseidon_bn254_hash_or_noop(hipStream_t st, const u64* in, u32 len, u64* out, size_t n, int form);
 void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, u64* out, size_t n, int form);
 void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n);
 size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n);  // u32 words of leaf-digest scratch for n proofs
-void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, int form);
+void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, Verdict v, int form);
 // shared upper Merkle levels (gpv_k_crown.hip)
 // 3 measured best on MI355X at 8192 proofs: sibling walk 42.5 / 41.9 / 42.4 / 42.8 ms for 2 / 3 / 4 / 5 levels (each level saves fewer
 // hashes than the one above it and costs one more launch tail)
@@ -74,40 +113,42 @@ struct CrownBufs {
   u32* slot;                        // [proof][tree][query][level] slot of the shared node at the path's position
   u32* pslot;                       // same shape: the node the path's own chain passes through (shared, or its own)
   u32* pstate;                      // [proof][tree][query] bit 0: the path has left the shared tree
-  u32* gflag;                       // [proof][tree] cap-mismatch flag
+  u32* stamp[GPV_CROWN_LEVELS];     // [slot] run generation << 2 | code, written when the node has been hashed from inputs of THIS run
 };
+// code of a stamp: a node whose inputs were all computed in this run (and, for a top node, equals its cap entry) / a top node that
+// differs from its cap entry
+#define GPV_STAMP_OK 1u
+#define GPV_STAMP_CAP_MISMATCH 2u
 size_t gpvk_crown_bytes(const DevCircuit& hc, size_t n);
 bool gpvk_crown_supported(const DevCircuit& hc, size_t n);
 CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base);
 void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                             const u32* digests, u64* mid, u32 crown_levels, int form);
+                             const u32* digests, u64* mid, u32 crown_levels, Verdict v, int form);
 void gpvk_crown(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, CrownBufs b,
-                u32* fail, int form);
+                Verdict v, u32 gen, int form);
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                       const u32* digests, u32* fail, uint8_t* ok_out, int form);
+                       const u32* digests, Verdict v, uint8_t* ok_out, int form);
 // gpv_k_transcript.hip
-void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u32* fail);
-void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);
-void gpvk_transcript_coop(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);  // 16 lanes per proof
-void gpvk_derive_extra(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived);
-void gpvk_finalize(hipStream_t st, const u32* fail, uint8_t* accept, size_t n);
+void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, Verdict v);
+u32 gpvk_range_words(const DevCircuit& hc);  // words per record whose canonical form is checked
+void gpvk_transcript(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived, Verdict v);
+void gpvk_transcript_coop(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived, Verdict v);  // 16 lanes per proof
+void gpvk_derive_extra(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* derived, Verdict v);
+// The verdict: fail[i] |= GPV_FAIL_INCOMPLETE where a counter of `expect.mask` differs from its expected value; a proof whose range
+// check failed reports GPV_FAIL_RANGE alone (include/gpv.h); accept[i] = (fail[i] == 0) when `accept` is given.
+void gpvk_finalize(hipStream_t st, Verdict v, DoneExpect expect, uint8_t* accept, size_t n);
 void gpvk_pack_accept_bits(hipStream_t st, const uint8_t* accept, size_t m, uint8_t* bits, size_t slot_bytes);
 void gpvk_unpack_accept_bits(hipStream_t st, const uint8_t* gathered, size_t slot_bytes, size_t n_total, u32 world, uint8_t* accept_all);
 void gpvk_scatter_challenges(hipStream_t st, const u64* ch, u64* derived, u32 ncw, size_t n);
 void gpvk_gather_challenges(hipStream_t st, const u64* derived, u64* ch, u32 ncw, size_t n);
 void gpvk_gather_pih(hipStream_t st, const u64* derived, u64* out, u32 ncw, size_t n);
-// gpv_k_mfma_probe.hip (measurement only)
-void gpvk_probe_row_valu(hipStream_t st, const u32* x, const u32* c_limbs, u64* out, int iters, size_t n);
-void gpvk_probe_row_mfma(hipStream_t st, const u32* x, const uint8_t* q, u64* out, int iters, size_t n, int parts);
-void gpvk_poseidon_bn254_permute_mfma(hipStream_t st, const u64* in, u64* out, size_t n, const uint8_t* images, u32 window_mask);
-void gpvk_probe_overlap(hipStream_t st, int mode, int iters, u64* out, u32* slots, int blocks);
 // gpv_k_plonk.hip
 void gpvk_gate_eval_unfiltered(hipStream_t st, DevGate g, const u64* weights, const u64* constants, u32 n_constants, const u64* wires,
                                u32 n_wires, const u64* pih, u64* out, u32 max_out, size_t n);
-void gpvk_plonk(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u32* fail);
+void gpvk_plonk(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, Verdict v);
 void gpvk_gate_constraints(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u64* out);
 // gpv_k_fri.hip
 void gpvk_fri_query(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                    u32* fail);
+                    Verdict v);
 
 static inline unsigned gpvk_blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }

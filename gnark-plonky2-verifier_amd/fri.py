@@ -129,6 +129,17 @@ class Chip:
         _lib.check(_lib.lib().gpv_fri_verify(self.ctx.h, c.h, _lib.ptr(proofs.data), _lib.ptr(flat), proofs.n, _lib.ptr(mask)), self.ctx.h)
         return mask
 
+    def VerifyFriProofDevice(self, circuit, proofs_dev_ptr, challenges_dev_ptr, n, fail_mask_dev_ptr):
+        """VerifyFriProof on device-resident proofs / challenges / masks (gpv_fri_verify_dev): enqueued on the context's stream."""
+        _lib.check(_lib.lib().gpv_fri_verify_dev(self.ctx.h, circuit.h, _lib.ptr(proofs_dev_ptr), _lib.ptr(challenges_dev_ptr), n,
+                                                 _lib.ptr(fail_mask_dev_ptr)), self.ctx.h)
+
+    def VerifyMerkleProofsToCapDevice(self, circuit, proofs_dev_ptr, challenges_dev_ptr, n, ok_dev_ptr):
+        """verifyMerkleProofToCapWithCapIndex for every (proof, query, tree) on device-resident data (gpv_merkle_verify_dev):
+        ok_dev [n][queries][trees] bytes."""
+        _lib.check(_lib.lib().gpv_merkle_verify_dev(self.ctx.h, circuit.h, _lib.ptr(proofs_dev_ptr), _lib.ptr(challenges_dev_ptr), n,
+                                                    _lib.ptr(ok_dev_ptr)), self.ctx.h)
+
     def VerifyMerkleProofsToCap(self, proofs, challenges):
         """verifyMerkleProofToCapWithCapIndex (fri.go:97-144) for every (proof, query, tree): ok[n][queries][trees]."""
         c = proofs.circuit

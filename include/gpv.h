@@ -47,7 +47,8 @@ enum {
   GPV_ECONFIG = -2, /* unsupported configuration (hiding, unknown gate, arity != 4, cap != 4) */
   GPV_EDEVICE = -3, /* HIP failure or no GPU                                                  */
   GPV_EINVAL = -4,  /* bad argument                                                           */
-  GPV_ENOMEM = -5
+  GPV_ENOMEM = -5,
+  GPV_EPEER = -6    /* gpv_group: another rank failed to verify its block; the batch has no verdict      */
 };
 
 /* gate kinds, in the order of the reference's registry (plonk/gates/gates.go:20-35) */
@@ -102,8 +103,15 @@ enum {
   GPV_FAIL_FRI_DENOM = 1 << 6,      /* fri/fri.go:241-242                            */
   GPV_FAIL_FRI_EVAL = 1 << 7,       /* fri/fri.go:460-461                            */
   GPV_FAIL_FRI_INTERP = 1 << 8,     /* fri/fri.go:378-379, :280-286                  */
-  GPV_FAIL_FRI_FINAL = 1 << 9       /* fri/fri.go:496-497                            */
+  GPV_FAIL_FRI_FINAL = 1 << 9,      /* fri/fri.go:496-497                            */
+  GPV_FAIL_INCOMPLETE = 1 << 30    /* a verification stage did not visit every unit of this proof (fail-closed verdict, below) */
 };
+/* The verdict is fail-closed: accept[i] = 1 only if no assertion failed AND every stage reported that it visited proof i (every
+ * checked word, the transcript, the plonk check, every query round, every leaf, sibling walk and cap comparison -- the conjunction of
+ * ALL of the reference's assertions). A proof some stage did not reach is rejected with GPV_FAIL_INCOMPLETE.
+ * Mask after a range-check failure: a proof with a non-canonical word (GPV_FAIL_RANGE) reports that bit ALONE from gpv_verify_detail /
+ * gpv_verify_given_challenges: the reference's circuit is already unsatisfiable at verifier/verifier.go:84-141 and it defines no
+ * arithmetic on non-canonical representatives, so the other bits would describe this implementation, not the reference. */
 
 /* ------------------------------------------------------------------ context */
 typedef struct gpv_ctx gpv_ctx; /* one per GPU (and per host thread that wants parallelism): device, stream pair, scratch (gl.New(api), base.go:112) */
@@ -122,8 +130,11 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
  * GPV_OPT_FR_EVALUATION: the BN254 kernels exist in two evaluation orders of the same Montgomery rows with bit-identical
  * results -- column scanning (fewest instructions, needs a launch that fills the chip about three times) and operand scanning
  * (lower latency per permutation). 0 (default) = chosen per launch by its number of hashing lanes, 1 = always column
- * scanning, 2 = always operand scanning. */
-enum { GPV_OPT_TRANSCRIPT_VARIANT = 1, GPV_OPT_MERKLE_SHARED_LEVELS = 2, GPV_OPT_FR_EVALUATION = 3 };
+ * scanning, 2 = always operand scanning.
+ * GPV_OPT_HOST_CHUNK_FIRST / GPV_OPT_HOST_CHUNK_MAX: gpv_verify uploads a host batch in chunks of first, first, 2 first, 4 first, ...
+ * proofs capped at max and verifies them as they arrive, two in flight (defaults 1024 / 8192; 1 .. 2^24). */
+enum { GPV_OPT_TRANSCRIPT_VARIANT = 1, GPV_OPT_MERKLE_SHARED_LEVELS = 2, GPV_OPT_FR_EVALUATION = 3, GPV_OPT_HOST_CHUNK_FIRST = 4,
+       GPV_OPT_HOST_CHUNK_MAX = 5 };
 int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value);
 /* Copies the last error text of this context (or of context-free calls when ctx == NULL). */
 int gpv_last_error_message(gpv_ctx* ctx, char* buf, size_t buf_len);
@@ -137,7 +148,8 @@ int gpv_circuit_from_json(const char* common_json, size_t common_len, const char
 /* The same with flags. GPV_CIRCUIT_BEYOND_REFERENCE admits shapes the reference PANICS on (gpv_circuit_from_json keeps
  * answering them with GPV_ECONFIG, exactly like the reference): reduction arities 2 / 4 / 8 besides 16 (fri/fri.go:431-433), cap
  * heights 0..6 besides 4 (fri/fri.go:118-126), hiding circuits (types/common_data.go:121-124: the wires / Zs / quotient leaves end
- * in 4 blinding elements that are hashed but not evaluated). No reference implementation or fixture exists for them: parity is
+ * in 4 blinding elements that are hashed but not evaluated), Poseidon-Goldilocks hashes in the verifier data (plonky2's default
+ * configuration; the reference cannot deserialise it, variables/deserialize.go:149-156). No reference implementation or fixture exists for them: parity is
  * UNPINNED (checked against the oracle's literal restatement and an independent Python construction). */
 enum { GPV_CIRCUIT_BEYOND_REFERENCE = 1 };
 int gpv_circuit_from_json_ex(const char* common_json, size_t common_len, const char* verifier_only_json, size_t verifier_only_len,
@@ -259,6 +271,10 @@ int gpv_verify_given_challenges_dev(gpv_ctx* ctx, const gpv_circuit* c, const vo
 /* Device-resident batch: proofs_dev [n][nbytes] and accept_dev [n] are device pointers; enqueued on the context's
  * stream, no host synchronisation (the caller owns ordering, e.g. torch stream semantics). */
 int gpv_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint8_t* accept_dev);
+/* fri.Chip.VerifyFriProof (fri/fri.go:500-548) on a device-resident batch (BASELINE config 3): challenges_dev [n][gpv_num_challenge_words]
+ * and fail_mask_dev [n] are device pointers; enqueued on the context's stream, no host synchronisation. */
+int gpv_fri_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, const uint64_t* challenges_dev, size_t n,
+                       uint32_t* fail_mask_dev);
 /* Merkle paths only (BASELINE config 5), device-resident: challenges_dev as produced by gpv_challenges_dev */
 int gpv_challenges_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint64_t* challenges_dev);
 int gpv_merkle_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, const uint64_t* challenges_dev,
@@ -271,7 +287,9 @@ int gpv_merkle_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs
  * verdict of the whole batch. RCCL is dlopen'ed on first use; a group of one device never needs it. */
 /* Block of rank `rank`: sizes differ by at most one, lower ranks get the extra proof. Pure host arithmetic. */
 int gpv_shard_bounds(size_t n, int rank, int world, size_t* lo, size_t* hi);
-/* Bytes every rank contributes to the all-gather: ceil(ceil(n / world) / 8), rounded up to a multiple of 16 (zero padding). */
+/* Bytes every rank contributes to the all-gather: ceil(ceil(n / world) / 8) rounded up to a multiple of 16 (zero padding), plus a
+ * 16-byte status trailer (byte 0 != 0: the rank could not verify its block -- it still takes part in the exchange, with all-zero
+ * bits, so that no rank waits for it inside the collective, and every rank's call returns GPV_EPEER). */
 size_t gpv_accept_slot_bytes(size_t n, int world);
 typedef struct gpv_group gpv_group;
 /* One process drives n_devices GPUs: a worker thread and a gpv_ctx per device, RCCL clique via ncclCommInitAll. Rank i runs
@@ -315,30 +333,6 @@ int gpv_group_read_rank_accept(gpv_group* g, int local_index, uint8_t* accept, s
 int gpv_timing_enable(gpv_ctx* ctx, int on);
 int gpv_timing_reset(gpv_ctx* ctx);
 int gpv_timing_get(gpv_ctx* ctx, int kind, double* avg_ms, uint64_t* launches);
-/* Integer-multiply issue-rate microbenchmark (the roof that binds this workload):
- * which: 0 = v_mad_u64_u32, 1 = v_mul_lo_u32, 2 = v_mul_hi_u32, 3 = v_fma_f64, 4 = v_add_co_u32 chain, 5 = v_mad_u32_u24.
- * Returns lane-operations per second over the whole chip. */
-int gpv_microbench(gpv_ctx* ctx, int which, double* lane_ops_per_sec);
-
-/* MFMA feasibility probe (evidence only, not on the product path; DESIGN.md "what next"): one mix row sum_j C_j * X_j (4 wave-
- * uniform 254-bit constants, one 254-bit X_j per lane) computed `iters` times per lane either the product's way (which = 0:
- * 4 x 81 v_mad_u64_u32 into carry-free columns) or as a byte-plane Toeplitz GEMM on v_mfma_i32_32x32x32_i8 including the digit
- * split, the lane-layout round trip and the recombination (which = 1); which = 2 runs both kernels concurrently on two streams;
- * which = 3 / 4 time the MFMA path's two halves alone (the 16 MFMAs / everything but the MFMAs; their outputs are meaningless);
- * which = 5 / 6 / 7 = 1 / 3 / 2 with the A operands read from precomputed Toeplitz register images (q then holds 4 x 96 bytes of
- * digit strings followed by [4][2][64][16] image bytes) instead of unaligned windows of the digit strings.
- * x [n][4][9] radix-2^29 limbs (values < 2^255), c_limbs [4][9], q = 384 + 8192 bytes (reversed zero-padded signed digits of the
- * constants, then their Toeplitz images; built by tools/mfma_probe.py), out [n][18] normalised 29-bit limbs of the exact integer. *ms = duration of the timed launch(es). */
-int gpv_mfma_probe(gpv_ctx* ctx, int which, const uint32_t* x, const uint32_t* c_limbs, const uint8_t* q, uint64_t* out, size_t n,
-                   int iters, double* ms);
-/* Stage 2 of the probe: the whole Poseidon-BN254 permutation (poseidon/bn254.go:39-45) with the rows of its 56 partial rounds on the
- * matrix pipe (which = 1; images = 28 x 18 Toeplitz register images of 2 KB built by tools/mfma_probe.py from the round constants)
- * against the product's kernel (which = 0). states / out [n][4][4] canonical; *ms = best of `reps` launches. Evidence only. */
-int gpv_mfma_probe_permute(gpv_ctx* ctx, int which, const uint64_t* states, uint64_t* out, size_t n, const uint8_t* images,
-                           size_t images_bytes, int reps, double* ms);
-/* Stage 3 of the probe: ms3[0] = every wave runs 4 x iters MFMAs, ms3[1] = every wave runs a VALU multiply-add chain of similar
- * length, ms3[2] = per SIMD one wave does the MFMAs and the other the VALU chain (2 waves per SIMD, one round of waves). */
-int gpv_mfma_probe_overlap(gpv_ctx* ctx, int iters, double* ms3, uint32_t* hw_ids, size_t n_ids);
 
 #ifdef __cplusplus
 }

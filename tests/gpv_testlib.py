@@ -19,6 +19,17 @@ from pathlib import Path
 import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
+FAIL_RANGE, FAIL_INCOMPLETE = 1, 1 << 30  # GPV_FAIL_RANGE / GPV_FAIL_INCOMPLETE (include/gpv.h)
+
+
+def reported_mask(oracle_mask):
+    """The failure mask libgpv reports for a proof whose reference-ordered assertion mask is `oracle_mask` (include/gpv.h, "mask
+    after a range-check failure"): a proof with a non-canonical word reports GPV_FAIL_RANGE alone -- the reference's circuit is
+    unsatisfiable at verifier.go:84-141 and defines no arithmetic on non-canonical representatives; every other mask is reported
+    as it is."""
+    import numpy as _np
+    m = _np.asarray(oracle_mask).astype(_np.int64)
+    return _np.where(m & FAIL_RANGE, FAIL_RANGE, m)
 GOLDEN = ROOT / "tests" / "golden"
 GL_P = 2**64 - 2**32 + 1
 BN_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617

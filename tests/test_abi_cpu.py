@@ -72,7 +72,7 @@ def test_group_shard_arithmetic_matches_distributed(gpv):
                 prev = hi
                 sizes.append(hi - lo)
             assert prev == n and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
-            assert L.gpv_accept_slot_bytes(n, world) == ((max(sizes) + 7) // 8 + 15) // 16 * 16
+            assert L.gpv_accept_slot_bytes(n, world) == ((max(sizes) + 7) // 8 + 15) // 16 * 16 + 16  # + the status trailer
     lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
     for bad in ((8, -1, 2), (8, 2, 2), (8, 0, 0)):
         assert L.gpv_shard_bounds(bad[0], bad[1], bad[2], ctypes.byref(lo), ctypes.byref(hi)) == gpv._lib.GPV_EINVAL
@@ -100,7 +100,10 @@ def test_ingest_poseidon_goldilocks_configuration(gpv, name):
     form) is recognised by the shape of its hashes; the C++ ingest packs it exactly like the independent Python packer, same
     record size as the BN254 form (a hash is 4 x u64 either way). Non-canonical circuit hashes are refused."""
     ci, packed, (common, vo, pj), _ = T.poseidon_gl_config_fixture(name)
-    circuit = _circuit(gpv, common, vo)
+    # not the reference's configuration (it cannot deserialise such verifier data): refused on the drop-in entry point, opt-in only
+    with pytest.raises(gpv.ConfigError):
+        _circuit(gpv, common, vo)
+    circuit = _circuit(gpv, common, vo, beyond_reference=True)
     assert circuit.hash_kind == 1 and circuit.proof_nbytes == len(packed) == {"decode_block": 127256, "step": 133416}[name]
     assert (circuit.describe() == ci.blob()).all()
     got = gpv.variables.DeserializeProofWithPublicInputs(gpv.types.ProofWithPublicInputsRaw(json.dumps(pj)), circuit)
@@ -113,11 +116,15 @@ def test_ingest_poseidon_goldilocks_configuration(gpv, name):
     bad = json.loads(json.dumps(vo))
     bad["constants_sigmas_cap"][3]["elements"][1] = 2**64 - 1
     with pytest.raises(gpv.ShapeError):
-        _circuit(gpv, common, bad)
+        _circuit(gpv, common, bad, beyond_reference=True)
     bad = json.loads(json.dumps(vo))
     bad["circuit_digest"] = {"elements": [1, 2, 3]}
     with pytest.raises(gpv.ShapeError):
-        _circuit(gpv, common, bad)
+        _circuit(gpv, common, bad, beyond_reference=True)
+    bad = json.loads(json.dumps(vo))  # mixed encodings: a BN254 digest beside Poseidon-Goldilocks caps
+    bad["circuit_digest"] = vo0["circuit_digest"]
+    with pytest.raises(gpv.ShapeError):
+        _circuit(gpv, common, bad, beyond_reference=True)
 
 
 BEYOND_SHAPES = [  # (fixture, reduction arity bits, cap height, hiding, hash kind) -- SURVEY 8f.2; shared with the GPU parity test
@@ -170,9 +177,9 @@ def test_beyond_reference_limits(gpv):
         gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(bad)), gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)), beyond_reference=True)
 
 
-def _circuit(gpv, common_obj, vo_obj):
+def _circuit(gpv, common_obj, vo_obj, beyond_reference=False):
     return gpv.variables.Circuit(gpv.types.CommonCircuitData(json.dumps(common_obj)),
-                                 gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo_obj)))
+                                 gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo_obj)), beyond_reference=beyond_reference)
 
 
 def test_config_errors(gpv):

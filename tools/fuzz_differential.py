@@ -103,7 +103,7 @@ for name in ("decode_block", "step"):
     run("%s: Verify with supplied challenges" % name, circuit, common, ci, packed, ch0, False)
     ci2, packed2, (cj, voj, pj), ch2 = T.poseidon_gl_config_fixture(name)
     cc = gpv.types.CommonCircuitData(json.dumps(cj))
-    run("%s: Poseidon-Goldilocks configuration" % name, gpv.variables.Circuit(cc, gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(voj))), cc, ci2, packed2, ch2, True)
+    run("%s: Poseidon-Goldilocks configuration" % name, gpv.variables.Circuit(cc, gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(voj)), beyond_reference=True), cc, ci2, packed2, ch2, True)
 for name, arity, cap, hiding, hk in (("step", [3, 3, 2], 4, False, 0), ("decode_block", [2, 4, 1, 2], 2, True, 1), ("step", [1, 2, 3, 4], 6, True, 0),
                                      ("decode_block", [4, 4, 2], 5, False, 1)):
     ci3, packed3, (cj, voj, pj), ch3 = T.synthetic_shape_fixture(name, arity, cap, hiding, hk)

@@ -16,8 +16,11 @@ sys.path.insert(0, str(ROOT / "tests"))
 import gpv_testlib as T  # noqa: E402
 
 gpv = importlib.import_module("gnark-plonky2-verifier_amd")
-L = gpv._lib.lib()
-ctx = gpv.default_context()
+sys.path.insert(0, str(ROOT / "tools" / "probe"))
+import gpv_probe as P  # noqa: E402  (tools/probe/libgpvprobe.so: the probe is not part of libgpv.so)
+
+L = P.lib()
+DEV = 0
 R = T.BN_R
 MASK = (1 << 29) - 1
 
@@ -60,8 +63,8 @@ def run(which, xs, iters):
     x = np.array([[limbs29(v) for v in row] for row in xs], dtype=np.uint32)
     out = np.zeros((n, 18), dtype=np.uint64)
     ms = ctypes.c_double()
-    gpv._lib.check(L.gpv_mfma_probe(ctx.h, which, gpv._lib.ptr(x), gpv._lib.ptr(c_limbs), gpv._lib.ptr(qbuf), gpv._lib.ptr(out), n,
-                                    iters, ctypes.byref(ms)), ctx.h)
+    P.check(L.gpvp_mfma_probe(DEV, which, gpv._lib.ptr(x), gpv._lib.ptr(c_limbs), gpv._lib.ptr(qbuf), gpv._lib.ptr(out), n,
+                                    iters, ctypes.byref(ms)))
     return out, ms.value
 
 
@@ -90,8 +93,8 @@ for which, name in ((0, "VALU row alone"), (1, "MFMA row, unaligned window opera
                     (4, "  of which: split + swaps + fold"), (5, "MFMA row, Toeplitz image operands"), (6, "  of which: the 16 MFMAs + operand loads"),
                     (2, "VALU row beside the window MFMA row"), (7, "VALU row beside the image MFMA row")):
     ms = ctypes.c_double()
-    gpv._lib.check(L.gpv_mfma_probe(ctx.h, which, gpv._lib.ptr(xbig), gpv._lib.ptr(c_limbs), gpv._lib.ptr(qbuf), gpv._lib.ptr(out), n, iters,
-                                    ctypes.byref(ms)), ctx.h)
+    P.check(L.gpvp_mfma_probe(DEV, which, gpv._lib.ptr(xbig), gpv._lib.ptr(c_limbs), gpv._lib.ptr(qbuf), gpv._lib.ptr(out), n, iters,
+                                    ctypes.byref(ms)))
     rows = n * iters * (2 if which in (2, 7) else 1)
     res[which] = ms.value
     # a wave takes rows/64 row-evaluations; per SIMD: time * clock / (wave-rows per SIMD)
@@ -157,8 +160,8 @@ expect = orc.poseidon_bn254_permute(st)
 def permute(which, states, reps):
     out = np.zeros_like(states)
     ms = ctypes.c_double()
-    gpv._lib.check(L.gpv_mfma_probe_permute(ctx.h, which, gpv._lib.ptr(states), gpv._lib.ptr(out), states.shape[0], gpv._lib.ptr(images), images.size,
-                                            reps, ctypes.byref(ms)), ctx.h)
+    P.check(L.gpvp_mfma_probe_permute(DEV, which, gpv._lib.ptr(states), gpv._lib.ptr(out), states.shape[0], gpv._lib.ptr(images), images.size,
+                                            reps, ctypes.byref(ms)))
     return out, ms.value
 
 
@@ -175,7 +178,7 @@ for which, name in ((0, "product kernel (VALU only)"), (1, "partial-round rows o
 # ================================================================ stage 3: do the two pipes overlap across the two waves of a SIMD?
 ms3 = (ctypes.c_double * 3)()
 ids = np.zeros(2048, dtype=np.uint32)
-gpv._lib.check(L.gpv_mfma_probe_overlap(ctx.h, 2000, ms3, gpv._lib.ptr(ids), ids.size), ctx.h)
+P.check(L.gpvp_mfma_probe_overlap(DEV, 2000, ms3, gpv._lib.ptr(ids), ids.size))
 slot = ids & 0xF
 simd = (ids >> 4) & 0x3
 print("2 waves per SIMD, one round: all MFMA %.3f ms, all VALU %.3f ms, one of each per SIMD %.3f ms  (wave slots seen: %s)"

@@ -1,0 +1,55 @@
+"""ctypes binding of tools/probe/libgpvprobe.so (gpv_probe.h): instruction-rate microbenchmarks, the shader-clock sampler and the
+MFMA feasibility probe. Measurement only -- not part of the product package; bench.py and tools/mfma_probe.py import it by path."""
+import ctypes
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "libgpvprobe.so"
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError("%s not built -- make -C tools/probe" % LIB_PATH)
+        try:
+            import torch  # noqa: F401  (one HIP runtime per process, see gnark-plonky2-verifier_amd/_lib.py)
+        except Exception:
+            pass
+        L = ctypes.CDLL(str(LIB_PATH))
+        vp, sz, i32, dp = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double)
+        L.gpvp_microbench.argtypes = [i32, i32, dp]
+        L.gpvp_clock_sample_begin.argtypes = [i32, ctypes.c_uint]
+        L.gpvp_clock_sample_end.argtypes = [dp]
+        L.gpvp_mfma_probe.argtypes = [i32, i32, vp, vp, vp, vp, sz, i32, dp]
+        L.gpvp_mfma_probe_permute.argtypes = [i32, i32, vp, vp, sz, vp, sz, i32, dp]
+        L.gpvp_mfma_probe_overlap.argtypes = [i32, i32, dp, vp, sz]
+        L.gpvp_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libgpvprobe error %d: %s" % (rc, lib().gpvp_last_error().decode("utf-8", "replace")))
+
+
+MICROBENCH_NAMES = ["v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_fma_f64", "v_add_co_u32", "v_mad_u32_u24", "v_add_u32",
+                    "v_lshl_add_u64", "fr_row_mix(v_mad_u64_u32)"]
+
+
+def microbench(which, device=0):
+    v = ctypes.c_double()
+    check(lib().gpvp_microbench(device, which, ctypes.byref(v)))
+    return v.value
+
+
+def clock_sample_begin(microseconds, device=0):
+    check(lib().gpvp_clock_sample_begin(device, int(microseconds)))
+
+
+def clock_sample_end():
+    v = ctypes.c_double()
+    check(lib().gpvp_clock_sample_end(ctypes.byref(v)))
+    return v.value

@@ -1,4 +1,4 @@
-// MFMA feasibility probe (evidence only, NOT on the product path).
+// MFMA feasibility probe (evidence only; built into tools/probe/libgpvprobe.so, never into libgpv.so -- the product has no MFMA code).
 //
 // Question: 70 % of the multiply-adds of a Poseidon-BN254 permutation have a wave-uniform constant operand (mix rows, the
 // sparse partial-round rows, the modulus in the reduction). The Merkle kernels issue a VALU instruction in 99.5-99.8 % of
@@ -16,8 +16,7 @@
 // Both kernels write the same 18 normalised limbs (checked against exact integers by tools/mfma_probe.py), and run `iters`
 // rows per lane so that launch overhead vanishes. Operands A are re-loaded every row, as the product would have to (the
 // constants change from row to row).
-#include "../../include/gpv.h"
-#include "gpv_launch.h"
+#include "gpvp_launch.h"
 #include "gpv_poseidon.cuh"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -449,4 +448,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 void gpvk_probe_overlap(hipStream_t st, int mode, int iters, u64* out, u32* slots, int blocks) {
   GPVK_LAUNCH(k_probe_overlap, dim3(blocks), dim3(64), 0, st, mode, iters, out, slots);
+}
+
+// The product's Poseidon-BN254 permutation in its operand-scanning order (FrWide), instantiated from the shared device headers: the
+// baseline of gpvp_mfma_probe_permute (which = 0). The probe library does not link libgpv.so.
+__global__ __launch_bounds__(64) void k_probe_permute_product(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr s[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) s[k] = fr_from_canonical64(in + 16 * i + 4 * k);
+  poseidon_bn254_permute<false, FrWide>(s);
+#pragma unroll
+  for (int k = 0; k < 4; k++) fr_to_canonical64(s[k], out + 16 * i + 4 * k);
+}
+void gpvk_probe_permute_product(hipStream_t st, const u64* in, u64* out, size_t n) {
+  GPVK_LAUNCH(k_probe_permute_product, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, out, n);
 }

@@ -31,7 +31,7 @@ for name in ("decode_block", "step"):
     cases.append((name, gpv.variables.circuit_for(common, vo), common, ci, packed, None))
     ci2, packed2, (cj, voj, pj), ch2 = T.poseidon_gl_config_fixture(name)
     cc = gpv.types.CommonCircuitData(json.dumps(cj))
-    cases.append((name + "/poseidon-gl", gpv.variables.Circuit(cc, gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(voj))), cc, ci2, packed2, ch2))
+    cases.append((name + "/poseidon-gl", gpv.variables.Circuit(cc, gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(voj)), beyond_reference=True), cc, ci2, packed2, ch2))
 stop_at = time.time() + seconds
 counts, errors = {}, []
 lock = threading.Lock()
