@@ -69,12 +69,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 }
 __global__ __launch_bounds__(64) void k_clock_sample(u64* out, u32 spin_ticks) {
   if (threadIdx.x != 0) return;
-  __builtin_amdgcn_s_setprio(3);
   const u64 r0 = __builtin_amdgcn_s_memrealtime();
   const u64 c0 = __builtin_amdgcn_s_memtime();
   u64 r1 = r0;
   while (r1 - r0 < spin_ticks) {
-    __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_s_sleep(127);
     r1 = __builtin_amdgcn_s_memrealtime();
   }
   const u64 c1 = __builtin_amdgcn_s_memtime();
