@@ -467,9 +467,9 @@ static void launch_transcript(gpv_ctx* ctx, hipStream_t st, const DevCircuit* dc
   else
     gpvk_transcript(st, dcd, (const u64*)proofs, n, ctx->derived, verdict_of(ctx));
 }
-static void launch_plonk(gpv_ctx* ctx, hipStream_t st, const DevCircuit* dcd, const void* proofs, size_t n) {
+static void launch_plonk(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n) {
   Timed t(ctx, TK_PLONK, st);
-  gpvk_plonk(st, dcd, (const u64*)proofs, (const u64*)ctx->derived, n, verdict_of(ctx));
+  gpvk_plonk(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, verdict_of(ctx));
 }
 static void launch_merkle_leaves(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n) {
   Timed t(ctx, TK_LEAVES, st);
@@ -539,7 +539,7 @@ static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* p
   HIP_TRY(ctx, hipEventRecord(ctx->ev_cleared, main_st));
   launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_cleared, 0));  // plonk and the FRI queries OR into the fail masks
-  launch_plonk(ctx, side, dcd, proofs_dev, n);
+  launch_plonk(ctx, side, c, dcd, proofs_dev, n);
   launch_fri_query(ctx, side, c, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));
   HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_transcript, 0));
@@ -1010,7 +1010,7 @@ extern "C" int gpv_plonk_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* 
   StageSetup st;
   int rc = st.run(ctx, c, proofs, challenges, n);
   if (rc != GPV_OK) return rc;
-  launch_plonk(ctx, ctx->stream, st.dcd, st.hb.proofs.p, n);
+  launch_plonk(ctx, ctx->stream, c, st.dcd, st.hb.proofs.p, n);
   gpvk_finalize(ctx->stream, verdict_of(ctx), done_expect(ctx, c, n, DONE_BIT(GPV_DONE_DERIVED) | DONE_BIT(GPV_DONE_PLONK), false), nullptr, n);
   CHECK_LAUNCH(ctx);
   HIP_TRY(ctx, hipMemcpyAsync(fail_mask, ctx->fail, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1146,7 +1146,7 @@ static int verify_given_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const v
   if (rc != GPV_OK) return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_st));
   HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
-  launch_plonk(ctx, side, dcd, proofs_dev, n);
+  launch_plonk(ctx, side, c, dcd, proofs_dev, n);
   launch_fri_query(ctx, side, c, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));
   launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n);

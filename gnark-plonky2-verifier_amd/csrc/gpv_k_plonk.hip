@@ -5,6 +5,17 @@
 
 #define GPV_PLONK_BLOCK 64
 #define GPV_PLONK_LDS_PER_LANE (2 << (GPV_MAX_RA_BITS - 1))  // u64 words: 2^(bits-1) extension elements
+// LDS of the verification kernel: this lane's scratch of the RandomAccessGate fold, 2^(bits-1) extension elements for the widest
+// gate OF THE CIRCUIT (dynamic shared memory, sized by the launch wrapper). Sizing it for the 6 bits the ABI admits cost 32 KB per
+// 64-lane block, which capped the kernel at one wave per SIMD by LDS alone, let the compiler take 256 VGPRs -- and a 256-VGPR wave can
+// only land where TWO Merkle waves retire together: the kernel waited ~18 of its 19 ms for a slot. The fixtures'
+// widest gate has 4 bits: 8 KB per block, four waves per SIMD by LDS, and the kernel is compiled for 128 VGPRs like its neighbours.
+static u32 plonk_lds_words_per_lane(const DevCircuit& hc) {
+  u32 bits = 1;
+  for (u32 g = 0; g < hc.n_gates; g++)
+    if (hc.gates[g].kind == GPV_GATE_RANDOM_ACCESS && hc.gates[g].p0 > bits) bits = hc.gates[g].p0;
+  return 2u << (bits - 1);
+}
 
 __global__ __launch_bounds__(GPV_PLONK_BLOCK) void k_gate_eval_unfiltered(DevGate g, const u64* __restrict__ weights,
                                                                           const u64* __restrict__ constants, u32 n_constants,
@@ -29,7 +40,7 @@ __global__ __launch_bounds__(GPV_PLONK_BLOCK) void k_gate_eval_unfiltered(DevGat
 
 __global__ __launch_bounds__(GPV_PLONK_BLOCK) GPVK_SIDE_STREAM_KERNEL void k_plonk(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                            const u64* __restrict__ derived, size_t n, Verdict v) {
-  __shared__ u64 lds[GPV_PLONK_BLOCK * GPV_PLONK_LDS_PER_LANE];
+  extern __shared__ u64 lds[];  // GPV_PLONK_BLOCK x plonk_lds_words_per_lane(circuit) words
   gpvk_side_stream_priority();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -73,8 +84,9 @@ void gpvk_gate_eval_unfiltered(hipStream_t st, DevGate g, const u64* weights, co
   GPVK_LAUNCH(k_gate_eval_unfiltered, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, g, weights, constants,
                      n_constants, wires, n_wires, pih, out, max_out, n);
 }
-void gpvk_plonk(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, Verdict v) {
-  GPVK_LAUNCH_STAGE(GPV_STAGE_PLONK, k_plonk, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, dcd, proofs, derived, n, v);
+void gpvk_plonk(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, Verdict v) {
+  const unsigned lds_bytes = GPV_PLONK_BLOCK * plonk_lds_words_per_lane(hc) * 8;
+  GPVK_LAUNCH_STAGE(GPV_STAGE_PLONK, k_plonk, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), lds_bytes, st, dcd, proofs, derived, n, v);
 }
 void gpvk_gate_constraints(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u64* out) {
   GPVK_LAUNCH(k_gate_constraints, dim3(gpvk_blocks_for(n, GPV_PLONK_BLOCK)), dim3(GPV_PLONK_BLOCK), 0, st, dcd, proofs, derived, n,

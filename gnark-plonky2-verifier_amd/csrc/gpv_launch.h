@@ -145,7 +145,7 @@ void gpvk_gather_pih(hipStream_t st, const u64* derived, u64* out, u32 ncw, size
 // gpv_k_plonk.hip
 void gpvk_gate_eval_unfiltered(hipStream_t st, DevGate g, const u64* weights, const u64* constants, u32 n_constants, const u64* wires,
                                u32 n_wires, const u64* pih, u64* out, u32 max_out, size_t n);
-void gpvk_plonk(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, Verdict v);
+void gpvk_plonk(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, Verdict v);
 void gpvk_gate_constraints(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* derived, size_t n, u64* out);
 // gpv_k_fri.hip
 void gpvk_fri_query(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
