@@ -413,3 +413,108 @@ func (g *Group) Verify(c *Circuit, proofs []byte, nTotal int) []bool {
 	}
 	return out
 }
+
+// ---------------------------------------------------------------- the rest of include/gpv.h (round 3)
+
+// Option ids of gpv_ctx_set_option / gpv_group_set_option.
+const (
+	OptTranscriptVariant  = int(C.GPV_OPT_TRANSCRIPT_VARIANT)
+	OptMerkleSharedLevels = int(C.GPV_OPT_MERKLE_SHARED_LEVELS)
+	OptFrEvaluation       = int(C.GPV_OPT_FR_EVALUATION)
+	OptHostChunkFirst     = int(C.GPV_OPT_HOST_CHUNK_FIRST)
+	OptHostChunkMax       = int(C.GPV_OPT_HOST_CHUNK_MAX)
+	GroupOptCollective    = int(C.GPV_GROUP_OPT_COLLECTIVE)
+	FailIncomplete        = uint32(C.GPV_FAIL_INCOMPLETE) // a stage did not visit the proof: rejected (fail-closed verdict)
+	FailRange             = uint32(C.GPV_FAIL_RANGE)
+)
+
+// NewCircuitBeyondReference admits the shapes the reference panics on (gpv_circuit_from_json_ex, GPV_CIRCUIT_BEYOND_REFERENCE):
+// other FRI arities / cap heights, hiding, Poseidon-Goldilocks hashes, lookup gates. Parity unpinned (DESIGN.md).
+func NewCircuitBeyondReference(commonJSON, verifierOnlyJSON []byte) *Circuit {
+	var h *C.gpv_circuit
+	check(C.gpv_circuit_from_json_ex((*C.char)(unsafe.Pointer(&commonJSON[0])), C.size_t(len(commonJSON)),
+		(*C.char)(unsafe.Pointer(&verifierOnlyJSON[0])), C.size_t(len(verifierOnlyJSON)), C.GPV_CIRCUIT_BEYOND_REFERENCE, &h), nil)
+	return &Circuit{h}
+}
+
+func (c *Circuit) NumGateConstraints() int { return int(C.gpv_num_gate_constraints(c.h)) }
+
+// Describe returns the flat circuit description (gpv_circuit_describe; layout in DESIGN.md).
+func (c *Circuit) Describe() []uint64 {
+	n := int(C.gpv_circuit_describe(c.h, nil, 0))
+	blob := make([]uint64, n)
+	C.gpv_circuit_describe(c.h, u64p(blob), C.size_t(n))
+	return blob
+}
+
+func (ctx *Context) SetStream(hipStream unsafe.Pointer) { check(C.gpv_ctx_set_stream(ctx.h, hipStream), ctx.h) }
+
+// RangeCheck (goldilocks/base.go:362-400): true where a[i] < p.
+func (ctx *Context) RangeCheck(a []uint64) []bool {
+	out := make([]uint64, len(a))
+	check(C.gpv_gl_op(ctx.h, C.GPV_OP_RANGECHECK, u64p(a), nil, nil, u64p(out), C.size_t(len(a))), ctx.h)
+	ok := make([]bool, len(a))
+	for i := range out {
+		ok[i] = out[i] == 1
+	}
+	return ok
+}
+
+func (ctx *Context) PoseidonGLCoop(states []uint64) []uint64 {
+	out := make([]uint64, len(states))
+	check(C.gpv_poseidon_gl_permute_coop(ctx.h, u64p(states), u64p(out), C.size_t(len(states)/12)), ctx.h)
+	return out
+}
+
+// FriVerifyDev = fri.Chip.VerifyFriProof on device-resident proofs, challenges and masks (BASELINE config 3's timed form).
+func (ctx *Context) FriVerifyDev(c *Circuit, proofsDev, challengesDev unsafe.Pointer, n int, failMaskDev unsafe.Pointer) {
+	check(C.gpv_fri_verify_dev(ctx.h, c.h, proofsDev, (*C.uint64_t)(challengesDev), C.size_t(n), (*C.uint32_t)(failMaskDev)), ctx.h)
+}
+func (ctx *Context) PoseidonGLDev(statesDev, outDev unsafe.Pointer, n int) {
+	check(C.gpv_poseidon_gl_permute_dev(ctx.h, (*C.uint64_t)(statesDev), (*C.uint64_t)(outDev), C.size_t(n)), ctx.h)
+}
+func (ctx *Context) PoseidonBN254Dev(statesDev, outDev unsafe.Pointer, n int) {
+	check(C.gpv_poseidon_bn254_permute_dev(ctx.h, (*C.uint64_t)(statesDev), (*C.uint64_t)(outDev), C.size_t(n)), ctx.h)
+}
+
+// Timing of the kernel classes (gpv_timing_*): kind as listed in include/gpv.h.
+func (ctx *Context) TimingEnable(on bool) {
+	v := 0
+	if on {
+		v = 1
+	}
+	check(C.gpv_timing_enable(ctx.h, C.int(v)), ctx.h)
+}
+func (ctx *Context) TimingReset() { check(C.gpv_timing_reset(ctx.h), ctx.h) }
+func (ctx *Context) TimingGet(kind int) (float64, uint64) {
+	var ms C.double
+	var n C.uint64_t
+	check(C.gpv_timing_get(ctx.h, C.int(kind), &ms, &n), ctx.h)
+	return float64(ms), uint64(n)
+}
+
+func AcceptSlotBytes(n, world int) int { return int(C.gpv_accept_slot_bytes(C.size_t(n), C.int(world))) }
+func (g *Group) Rank(local int) int    { return int(C.gpv_group_rank(g.h, C.int(local))) }
+func (g *Group) Context(local int) *Context {
+	return &Context{C.gpv_group_ctx(g.h, C.int(local))} // owned by the group: do not Close
+}
+
+// VerifyDev: shardDev[i] = the block of local rank i on its device, acceptAllDev[i] = nTotal bytes there (the whole verdict).
+func (g *Group) VerifyDev(c *Circuit, shardDev []unsafe.Pointer, nTotal int, acceptAllDev []unsafe.Pointer) {
+	acc := make([]*C.uint8_t, len(acceptAllDev))
+	for i, p := range acceptAllDev {
+		acc[i] = (*C.uint8_t)(p)
+	}
+	groupCheck(C.gpv_group_verify_dev(g.h, c.h, (*unsafe.Pointer)(unsafe.Pointer(&shardDev[0])), C.size_t(nTotal), &acc[0]), g.h)
+}
+
+// ReadRankAccept: the gathered verdict as local rank `local` holds it on its own device after Verify.
+func (g *Group) ReadRankAccept(local, nTotal int) []bool {
+	acc := make([]byte, nTotal)
+	groupCheck(C.gpv_group_read_rank_accept(g.h, C.int(local), (*C.uint8_t)(unsafe.Pointer(&acc[0])), C.size_t(nTotal)), g.h)
+	out := make([]bool, nTotal)
+	for i := range acc {
+		out[i] = acc[i] == 1
+	}
+	return out
+}

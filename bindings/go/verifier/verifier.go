@@ -1,27 +1,91 @@
-// Package verifier keeps the reference's surface (verifier/verifier.go:14-39, :143-170) over libgpv.
-// UNCOMPILED in this repository (no Go toolchain in the build image).
+// Package verifier keeps the reference's verifier.VerifierChip surface (verifier/verifier.go:14-39, :41-82, :143-170) over libgpv.
+// UNCOMPILED in this repository (no Go toolchain in the build image); same method list as the tested Python mirror
+// (gnark-plonky2-verifier_amd/verifier.py) and the C++ one (host/gpv.hpp).
+//
+// What changes against the reference: the first argument is a *gpv.Context (one GPU) instead of a gnark frontend.API, values are
+// batches (a variables.Proof holds N packed proofs), and Verify RETURNS the per-proof accept bits instead of leaving an
+// unsatisfiable constraint system behind. Malformed shapes / unsupported circuits panic exactly where the reference panics.
 package verifier
 
-import "github.com/succinctlabs/gnark-plonky2-verifier/bindings/go/gpv"
+import (
+	"unsafe"
+
+	"github.com/succinctlabs/gnark-plonky2-verifier/bindings/go/gpv"
+	"github.com/succinctlabs/gnark-plonky2-verifier/bindings/go/types"
+	"github.com/succinctlabs/gnark-plonky2-verifier/bindings/go/variables"
+)
 
 type VerifierChip struct {
-	ctx     *gpv.Context
-	circuit *gpv.Circuit
+	ctx        *gpv.Context
+	commonData types.CommonCircuitData
 }
 
-// NewVerifierChip(api, commonCircuitData) in the reference; the verifier-only data joins here because the packed
-// layout and the device tables need both.
-func NewVerifierChip(ctx *gpv.Context, commonJSON, verifierOnlyJSON []byte) *VerifierChip {
-	return &VerifierChip{ctx: ctx, circuit: gpv.NewCircuit(commonJSON, verifierOnlyJSON)}
+// NewVerifierChip(api, commonCircuitData) -- verifier/verifier.go:24.
+func NewVerifierChip(ctx *gpv.Context, commonCircuitData types.CommonCircuitData) *VerifierChip {
+	return &VerifierChip{ctx, commonCircuitData}
 }
 
-// Verify panics on malformed input like the reference; returns accept per proof instead of failing a gnark solver.
-func (c *VerifierChip) Verify(proofJSONs [][]byte) []bool {
-	batch := make([]byte, 0, len(proofJSONs)*c.circuit.ProofNBytes())
-	for _, pj := range proofJSONs {
-		batch = append(batch, c.circuit.PackProof(pj)...)
+func (c *VerifierChip) circuit(verifierData variables.VerifierOnlyCircuitData) *gpv.Circuit {
+	return variables.CircuitFor(c.commonData, verifierData)
+}
+
+// GetPublicInputsHash (verifier.go:41): [N][4]. The reference takes the public inputs; they travel inside the packed record.
+func (c *VerifierChip) GetPublicInputsHash(proof variables.Proof) []uint64 {
+	return c.ctx.PublicInputsHash(proof.Circuit, proof.Packed)
+}
+
+// GetChallenges (verifier.go:45-82): [N][NumChallengeWords] = betas | gammas | alphas | zeta | fri_alpha | fri_betas | pow | query indices.
+func (c *VerifierChip) GetChallenges(proof variables.Proof) []uint64 {
+	return c.ctx.Challenges(proof.Circuit, proof.Packed)
+}
+
+// Verify(proof, publicInputs, verifierData) -- verifier.go:143-170. accept[i] is true iff the reference's circuit would be
+// satisfiable for proof i. publicInputs must be the ones the record carries (they are part of it; a different slice is a caller
+// error and panics -- the reference would hash whatever it is handed, which is how a caller binds a proof to ITS inputs).
+func (c *VerifierChip) Verify(proof variables.Proof, publicInputs []uint64, verifierData variables.VerifierOnlyCircuitData) []bool {
+	circuit := c.circuit(verifierData)
+	if circuit != proof.Circuit {
+		panic(&gpv.Error{Code: -4, Msg: "the proof was deserialised for another circuit"})
 	}
-	return c.ctx.Verify(c.circuit, batch)
+	if publicInputs != nil {
+		d := circuit.Dims()
+		rec := circuit.ProofNBytes() / 8
+		if len(publicInputs) != proof.N*d.NumPublicInputs {
+			panic(&gpv.Error{Code: -1, Msg: "public inputs of the wrong length"})
+		}
+		for i := 0; i < proof.N; i++ {
+			for k := 0; k < d.NumPublicInputs; k++ {
+				var v uint64
+				for b := 0; b < 8; b++ {
+					v |= uint64(proof.Packed[8*(i*rec+d.OffPublicInputs+k)+b]) << (8 * b)
+				}
+				if v != publicInputs[i*d.NumPublicInputs+k] {
+					panic(&gpv.Error{Code: -4, Msg: "publicInputs differ from the ones in the proof record"})
+				}
+			}
+		}
+	}
+	return c.ctx.Verify(circuit, proof.Packed)
 }
 
-func (c *VerifierChip) GetChallenges(packed []byte) []uint64 { return c.ctx.Challenges(c.circuit, packed) }
+// VerifyDetail: Verify plus the failure mask (gpv.Fail* bits) and the derived challenges.
+func (c *VerifierChip) VerifyDetail(proof variables.Proof, verifierData variables.VerifierOnlyCircuitData) ([]bool, []uint32, []uint64) {
+	return c.ctx.VerifyDetail(c.circuit(verifierData), proof.Packed)
+}
+
+// VerifyWithChallenges: Verify with step 2 (GetChallenges, verifier.go:150) replaced by the caller's ProofChallenges -- the shape of
+// the reference's own fri_test.go:106-133 / plonk_test.go:39-66.
+func (c *VerifierChip) VerifyWithChallenges(proof variables.Proof, challenges []uint64, verifierData variables.VerifierOnlyCircuitData) ([]bool, []uint32) {
+	return c.ctx.VerifyWithChallenges(c.circuit(verifierData), proof.Packed, challenges)
+}
+
+// Device-resident batches (raw device addresses; asynchronous on the context's stream).
+func (c *VerifierChip) VerifyDevice(circuit *gpv.Circuit, proofsDev unsafe.Pointer, n int, acceptDev unsafe.Pointer) {
+	c.ctx.VerifyDev(circuit, proofsDev, n, acceptDev)
+}
+func (c *VerifierChip) VerifyWithChallengesDevice(circuit *gpv.Circuit, proofsDev, challengesDev unsafe.Pointer, n int, acceptDev unsafe.Pointer) {
+	c.ctx.VerifyWithChallengesDev(circuit, proofsDev, challengesDev, n, acceptDev)
+}
+
+// VerifyGroup: the batch sharded over the GPUs of a gpv.Group (contiguous blocks, one RCCL all-gather of the packed accept bits).
+func VerifyGroup(g *gpv.Group, proof variables.Proof) []bool { return g.Verify(proof.Circuit, proof.Packed, proof.N) }
