@@ -13,6 +13,12 @@ extern "C" {
  * column-scanning Fr row as one serial chain per lane at 4 waves per SIMD (rate = multiply-adds only).
  * Returns lane-operations per second over the whole chip. */
 int gpvp_microbench(int device, int which, double* lane_ops_per_sec);
+/* The same with the shader clock (GHz) sampled during the timed launch: rate / (1024 SIMDs x clock x 64) = wave-instructions per SIMD cycle. */
+int gpvp_microbench_clocked(int device, int which, double* lane_ops_per_sec, double* ghz);
+/* One vs two interleaved Fr-row chains per lane (the instruction mix of which = 8) at `waves` in {1, 2, 3, 4} resident waves per SIMD:
+ * multiply-adds per second over the whole chip. Answers whether chain-level parallelism inside a lane can replace wave-level
+ * parallelism (two interleaved rows per lane cost ~22 more VGPRs in the real kernels, i.e. the fourth wave). */
+int gpvp_row_mix_rate(int device, int chains, int waves, double* lane_mads_per_sec);
 /* Shader clock under load: starts a one-wave sampler on its own high-priority stream that spins for `microseconds` and reports the
  * shader cycles that elapsed. Call gpvp_clock_sample_begin while the workload is being enqueued / running, _end after it: *ghz =
  * shader cycles / wall time of the sampling window. */

@@ -20,6 +20,8 @@ def lib():
         L = ctypes.CDLL(str(LIB_PATH))
         vp, sz, i32, dp = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double)
         L.gpvp_microbench.argtypes = [i32, i32, dp]
+        L.gpvp_microbench_clocked.argtypes = [i32, i32, dp, dp]
+        L.gpvp_row_mix_rate.argtypes = [i32, i32, i32, dp]
         L.gpvp_clock_sample_begin.argtypes = [i32, ctypes.c_uint]
         L.gpvp_clock_sample_end.argtypes = [dp]
         L.gpvp_mfma_probe.argtypes = [i32, i32, vp, vp, vp, vp, sz, i32, dp]
@@ -45,6 +47,19 @@ def microbench(which, device=0):
     return v.value
 
 
+def microbench_clocked(which, device=0):
+    """(lane-ops/s, shader clock in GHz during the timed launch)"""
+    v, g = ctypes.c_double(), ctypes.c_double()
+    check(lib().gpvp_microbench_clocked(device, which, ctypes.byref(v), ctypes.byref(g)))
+    return v.value, g.value
+
+
+def row_mix_rate(chains, waves, device=0):
+    v = ctypes.c_double()
+    check(lib().gpvp_row_mix_rate(device, chains, waves, ctypes.byref(v)))
+    return v.value
+
+
 def clock_sample_begin(microseconds, device=0):
     check(lib().gpvp_clock_sample_begin(device, int(microseconds)))
 
@@ -53,3 +68,15 @@ def clock_sample_end():
     v = ctypes.c_double()
     check(lib().gpvp_clock_sample_end(ctypes.byref(v)))
     return v.value
+
+
+if __name__ == "__main__":
+    print("# tools/probe/gpv_probe.py: instruction-rate microbenchmarks (lane-ops/s, whole chip)")
+    print("# instruction                lane-ops/s   clock GHz   SIMD cycles per wave64 instruction (1024 SIMDs)")
+    for i, nm in enumerate(MICROBENCH_NAMES):
+        r, g = microbench_clocked(i)
+        print("%-28s %.3e   %.3f       %.2f%s" % (nm, r, g, 1024 * g * 1e9 * 64 / r, "  (per multiply-add; the mix issues 41 instructions per 32 multiply-adds)" if i == 8 else ""))
+    print("# Fr-row instruction mix: chains per lane x resident waves per SIMD -> multiply-adds/s (whole chip)")
+    for waves in (1, 2, 3, 4):
+        for chains in (1, 2):
+            print("chains %d  waves/SIMD %d   %.3e" % (chains, waves, row_mix_rate(chains, waves)))

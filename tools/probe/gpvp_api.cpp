@@ -67,19 +67,60 @@ struct Streams {  // two streams + fork/join events, created per call (measureme
 };
 }  // namespace
 
-extern "C" int gpvp_microbench(int device, int which, double* lane_ops_per_sec) {
+extern "C" int gpvp_microbench_clocked(int device, int which, double* lane_ops_per_sec, double* ghz);
+extern "C" int gpvp_microbench(int device, int which, double* lane_ops_per_sec) { return gpvp_microbench_clocked(device, which, lane_ops_per_sec, nullptr); }
+// The same with the shader clock sampled DURING the timed launch (ghz != NULL): the sampler wave is started first, so it owns a
+// wave slot; the benchmark leaves two blocks out so that every one of its waves still fits the chip in one round. Rates divided by
+// (1024 SIMDs x clock) give cycles per wave-instruction -- the DVFS-free form of the measurement.
+extern "C" int gpvp_microbench_clocked(int device, int which, double* lane_ops_per_sec, double* ghz) {
   if (!lane_ops_per_sec || which < 0 || which > 8) return -(int)hipErrorInvalidValue;
   Streams s;
   int rc = s.open(device);
   if (rc) return rc;
-  // which = 8 (the row mix) runs one serial chain per lane at 4 waves per SIMD: 256 CUs x 4 SIMDs x 4 waves, four rounds of them
-  const int blocks = 256 * 8, threads = 256, iters = which == 8 ? 2048 : 4096;
+  // which = 8 (the row mix) runs one serial chain per lane at 4 waves per SIMD
+  const int blocks = 256 * 8 - (ghz ? 2 : 0), threads = 256, iters = which == 8 ? 4096 : 8192;
   DevBuf<u64> out;
   P_TRY(out.alloc((size_t)blocks * threads));
+  float best = 1e30f, last = 0;
+  double clk = 0;
+  for (int rep = 0; rep < 4; rep++) {
+    const bool sample = ghz && rep == 3;
+    if (sample) {
+      rc = gpvp_clock_sample_begin(device, (unsigned)(last * 1e3 * 0.7));  // 70 % of a launch, from just before it starts
+      if (rc) return rc;
+    }
+    hipEventRecord(s.e0, s.main);
+    gpvk_microbench(s.main, which, out.p, blocks, threads, iters);
+    hipEventRecord(s.e1, s.main);
+    P_TRY(hipEventSynchronize(s.e1));
+    float ms = 0;
+    hipEventElapsedTime(&ms, s.e0, s.e1);
+    last = ms;
+    if (rep > 0 && ms < best) best = ms;
+    if (sample) {
+      rc = gpvp_clock_sample_end(&clk);
+      if (rc) return rc;
+    }
+  }
+  P_LAUNCHED();
+  double ops = (double)blocks * threads * (double)iters * (double)gpvk_microbench_ops_per_iter();
+  *lane_ops_per_sec = ops / (best * 1e-3);
+  if (ghz) *ghz = clk;
+  return 0;
+}
+
+extern "C" int gpvp_row_mix_rate(int device, int chains, int waves, double* lane_mads_per_sec) {
+  if (!lane_mads_per_sec || (chains != 1 && chains != 2) || (waves != 1 && waves != 2 && waves != 3 && waves != 4)) return -(int)hipErrorInvalidValue;
+  Streams s;
+  int rc = s.open(device);
+  if (rc) return rc;
+  const int waves_total = 1024 * waves * 4, iters = 1024;  // four rounds of `waves` waves on every SIMD
+  DevBuf<u64> out;
+  P_TRY(out.alloc((size_t)waves_total * 64));
   float best = 1e30f;
   for (int rep = 0; rep < 4; rep++) {
     hipEventRecord(s.e0, s.main);
-    gpvk_microbench(s.main, which, out.p, blocks, threads, iters);
+    gpvk_microbench_row_mix_n(s.main, chains, waves, out.p, waves_total, iters);
     hipEventRecord(s.e1, s.main);
     P_TRY(hipEventSynchronize(s.e1));
     float ms = 0;
@@ -87,8 +128,7 @@ extern "C" int gpvp_microbench(int device, int which, double* lane_ops_per_sec) 
     if (rep > 0 && ms < best) best = ms;
   }
   P_LAUNCHED();
-  double ops = (double)blocks * threads * (double)iters * (double)gpvk_microbench_ops_per_iter();
-  *lane_ops_per_sec = ops / (best * 1e-3);
+  *lane_mads_per_sec = (double)waves_total * 64 * (double)iters * 32.0 * chains / (best * 1e-3);
   return 0;
 }
 

@@ -67,6 +67,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc ^ m;
 }
+// The same row mix with TWO independent chains per lane issued in lock step (what interleaving two Fr rows would look like to the
+// scheduler: a dependent v_mad_u64_u32 is always separated from its predecessor by an independent one). WAVES = waves per SIMD the
+// kernel is compiled for: compares chain-level against wave-level parallelism.
+template <int CHAINS, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_microbench_row_mix_n(u64* out, int iters) {
+  u32 a[9], m[CHAINS];
+  u64 acc[CHAINS];
+#pragma unroll
+  for (int k = 0; k < 9; k++) a[k] = (blockIdx.x * 40503u + 977u * k) & 0x1FFFFFFFu;
+#pragma unroll
+  for (int c = 0; c < CHAINS; c++) {
+    m[c] = threadIdx.x * 2654435761u + 12345u + c;
+    acc[c] = ((u64)m[c] << 3) + blockIdx.x;
+  }
+#pragma unroll 1
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int k = 0; k < 4 * MB_CHAINS; k++) {
+#pragma unroll
+      for (int c = 0; c < CHAINS; c++) {
+        acc[c] += (u64)a[k % 9] * m[c];
+        asm("" : "+v"(acc[c]));
+      }
+      if (k % 9 == 8) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; c++) {
+          m[c] = ((u32)acc[c] * 0x0FFFFFFFu) & 0x1FFFFFFFu;
+          acc[c] >>= 29;
+        }
+      }
+    }
+  }
+  u64 r = 0;
+#pragma unroll
+  for (int c = 0; c < CHAINS; c++) r ^= acc[c] ^ m[c];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
 __global__ __launch_bounds__(64) void k_clock_sample(u64* out, u32 spin_ticks) {
   if (threadIdx.x != 0) return;
   const u64 r0 = __builtin_amdgcn_s_memrealtime();
@@ -94,5 +131,18 @@ void gpvk_microbench(hipStream_t st, int which, u64* out, int blocks, int thread
     case 7: GPVK_LAUNCH(k_microbench<7>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
     case 8: GPVK_LAUNCH(k_microbench_row_mix, dim3(blocks * threads / 64), dim3(64), 0, st, out, iters); break;
   }
+}
+// chains in {1, 2}, waves per SIMD in {1, 2, 4}; `waves_total` one-wave blocks (a multiple of 1024 SIMDs x waves fills the chip evenly)
+void gpvk_microbench_row_mix_n(hipStream_t st, int chains, int waves, u64* out, int waves_total, int iters) {
+#define RM(C, W) GPVK_LAUNCH((k_microbench_row_mix_n<C, W>), dim3(waves_total), dim3(64), 0, st, out, iters)
+  if (chains == 1 && waves == 1) RM(1, 1);
+  else if (chains == 1 && waves == 2) RM(1, 2);
+  else if (chains == 1 && waves == 3) RM(1, 3);
+  else if (chains == 1) RM(1, 4);
+  else if (waves == 1) RM(2, 1);
+  else if (waves == 2) RM(2, 2);
+  else if (waves == 3) RM(2, 3);
+  else RM(2, 4);
+#undef RM
 }
 void gpvk_clock_sample(hipStream_t st, u64* out, u32 spin_ticks) { GPVK_LAUNCH(k_clock_sample, dim3(1), dim3(64), 0, st, out, spin_ticks); }

@@ -18,6 +18,7 @@ static inline unsigned gpvk_blocks_for(size_t n, unsigned bs) { return (unsigned
 // gpvp_k_microbench.hip
 void gpvk_microbench(hipStream_t st, int which, u64* out, int blocks, int threads, int iters);
 int gpvk_microbench_ops_per_iter();
+void gpvk_microbench_row_mix_n(hipStream_t st, int chains, int waves, u64* out, int waves_total, int iters);
 void gpvk_clock_sample(hipStream_t st, u64* out, u32 spin_ticks);
 // gpvp_k_mfma.hip
 void gpvk_probe_row_valu(hipStream_t st, const u32* x, const u32* c_limbs, u64* out, int iters, size_t n);
