@@ -986,6 +986,38 @@ extern "C" int gpv_public_inputs_hash(gpv_ctx* ctx, const gpv_circuit* c, const 
   return GPV_OK;
 }
 
+// Witness slice 1 (csrc/gpv_witness.cuh): the hint outputs of GetPublicInputsHash + GetChallenges in the reference's call order.
+extern "C" int gpv_witness_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint64_t* challenges) {
+  REQUIRE(ctx, ctx && c && proofs && trace);
+  ENTER(ctx);
+  if (n == 0) return GPV_OK;
+  const size_t words = gpv_witness_challenges_words(c), ncw = c->dc.n_challenge_words;
+  HostBatch hb;
+  int rc = hb.upload(ctx, c, proofs, n);
+  if (rc != GPV_OK) return rc;
+  const DevCircuit* dcd;
+  rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  DevBuf<u64> dtrace, dch, dwritten;
+  HIP_TRY(ctx, dtrace.alloc(words * n));
+  HIP_TRY(ctx, dch.alloc(ncw * n));
+  HIP_TRY(ctx, dwritten.alloc(n));
+  HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * n, ctx->stream));
+  gpvk_witness_challenges(ctx->stream, dcd, (const u64*)hb.proofs.p, n, dtrace.p, words, challenges ? dch.p : nullptr, dwritten.p);
+  CHECK_LAUNCH(ctx);
+  std::vector<u64> written(n);
+  HIP_TRY(ctx, hipMemcpyAsync(written.data(), dwritten.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(trace, dtrace.p, 8 * words * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (challenges) HIP_TRY(ctx, hipMemcpyAsync(challenges, dch.p, 8 * ncw * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; i++)
+    if (written[i] != words) {  // the kernel's walk and the host's layout are written separately: they must agree word for word
+      ctx_error(ctx, "witness trace of proof %zu has %llu words, the layout says %zu", i, (unsigned long long)written[i], words);
+      return GPV_EDEVICE;
+    }
+  return GPV_OK;
+}
+
 // shared prologue of the "stage with caller-supplied challenges" entry points
 struct StageSetup {
   HostBatch hb;

@@ -756,6 +756,94 @@ extern "C" size_t gpv_num_challenge_words(const gpv_circuit* c) { return c ? c->
 extern "C" size_t gpv_num_gate_constraints(const gpv_circuit* c) { return c ? c->dc.num_gate_constraints : 0; }
 extern "C" size_t gpv_num_query_rounds(const gpv_circuit* c) { return c ? c->dc.num_queries : 0; }
 extern "C" size_t gpv_num_merkle_trees(const gpv_circuit* c) { return c ? c->dc.n_trees : 0; }
+// ---- witness slice 1: which hint is called when, while the reference runs GetPublicInputsHash + GetChallenges. A function of
+// the circuit alone (the schedule is data-independent): the same walk as csrc/gpv_witness.cuh with the arithmetic left out.
+namespace {
+struct WitLayout {
+  std::vector<uint8_t>* kinds;
+  size_t hints = 0, words = 0;
+  void push(uint8_t kind, size_t w) {
+    if (kinds) kinds->push_back(kind);
+    hints++;
+    words += w;
+  }
+  void split() { push(GPV_HINT_SPLIT_LIMBS, 2); }
+  void mul_add() { push(GPV_HINT_MULADD, 2); split(); split(); }  // base.go:196-213
+  void reduce() { push(GPV_HINT_REDUCE, 5); split(); }            // base.go:246-281
+  void full_rounds() {                                            // goldilocks.go:92-100
+    for (int rd = 0; rd < 4; rd++) {
+      for (int i = 0; i < 12; i++) mul_add();
+      for (int i = 0; i < 12; i++) { reduce(); reduce(); }
+      for (int i = 0; i < 12; i++) reduce();
+    }
+  }
+  void poseidon() {  // goldilocks.go:30-37
+    full_rounds();
+    for (int i = 0; i < 12; i++) mul_add();  // :231-238
+    for (int i = 0; i < 12; i++) reduce();   // :251-275
+    for (int rd = 0; rd < 22; rd++) {        // :102-115, :300-331
+      reduce(); reduce();
+      mul_add();
+      reduce();
+      for (int i = 0; i < 12; i++) reduce();
+    }
+    full_rounds();
+  }
+  // challenger.go:42-49, :89-98, :146-166
+  uint32_t n_in = 0, n_out = 0;
+  void duplexing() {
+    for (uint32_t i = 0; i < n_in; i++) reduce();
+    n_in = 0;
+    poseidon();
+    n_out = 8;
+  }
+  void observe(size_t cnt) {
+    for (size_t i = 0; i < cnt; i++) {
+      n_out = 0;
+      if (++n_in == 8) duplexing();
+    }
+  }
+  void challenge(size_t cnt) {
+    for (size_t i = 0; i < cnt; i++) {
+      if (n_in != 0 || n_out == 0) duplexing();
+      n_out--;
+    }
+  }
+};
+WitLayout witness_challenges_layout(const DevCircuit& c, std::vector<uint8_t>* kinds) {
+  WitLayout L;
+  L.kinds = kinds;
+  for (uint32_t i = 0; i < c.num_pi; i++) L.reduce();  // HashNoPad goldilocks.go:72-86
+  for (uint32_t i = 0; i < c.num_pi; i += 8) L.poseidon();
+  const size_t hash_words = c.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS ? 4 : 5, cap = (size_t)1 << c.cap_height;
+  L.observe(hash_words);  // circuit digest, verifier.go:56
+  L.observe(4);           // public-inputs hash
+  L.observe(cap * hash_words);
+  L.challenge(2 * c.num_challenges);
+  L.observe(cap * hash_words);
+  L.challenge(c.num_challenges);
+  L.observe(cap * hash_words);
+  L.challenge(2);
+  L.observe(c.off_queries - c.off_constants);  // all openings: the zeta batch and the zeta*g batch (fri.go:63-73)
+  L.challenge(2);
+  for (uint32_t s = 0; s < c.num_steps; s++) {
+    L.observe(cap * hash_words);
+    L.challenge(2);
+  }
+  L.observe(2 * (size_t)c.final_len + 1);
+  L.challenge(1 + c.num_queries);
+  return L;
+}
+}  // namespace
+extern "C" size_t gpv_witness_challenges_words(const gpv_circuit* c) { return c ? witness_challenges_layout(c->dc, nullptr).words : 0; }
+extern "C" size_t gpv_witness_challenges_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap) {
+  if (!c) return 0;
+  std::vector<uint8_t> k;
+  WitLayout L = witness_challenges_layout(c->dc, kinds ? &k : nullptr);
+  if (kinds) memcpy(kinds, k.data(), k.size() < cap ? k.size() : cap);
+  return L.hints;
+}
+
 extern "C" size_t gpv_circuit_hash_kind(const gpv_circuit* c) { return c ? c->dc.hash_kind : 0; }
 
 // circuit blob: 32-word header + sections (same format the tests build independently, tests/gpv_testlib.py)

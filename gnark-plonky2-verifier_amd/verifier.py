@@ -26,6 +26,22 @@ class VerifierChip:
         _lib.check(_lib.lib().gpv_challenges(self.ctx.h, c.h, _lib.ptr(proofs.data), proofs.n, _lib.ptr(out)), self.ctx.h)
         return ProofChallenges(c, out)
 
+    def WitnessChallenges(self, proofs, with_challenges=True):
+        """Witness of the wrapping circuit, protocol slice 1 (gpv_witness_challenges): the outputs of every hint the
+        reference calls while Verify runs GetPublicInputsHash and GetChallenges (verifier.go:148-150), in call order. Returns
+        (trace [n][words] uint64, kinds [n_hints] uint8 = GPV_HINT_* per hint call, ProofChallenges or None)."""
+        import ctypes
+        c = proofs.circuit
+        L = _lib.lib()
+        words = L.gpv_witness_challenges_words(ctypes.c_void_p(c.h))
+        n_hints = L.gpv_witness_challenges_layout(ctypes.c_void_p(c.h), None, 0)
+        kinds = np.empty(n_hints, dtype=np.uint8)
+        L.gpv_witness_challenges_layout(ctypes.c_void_p(c.h), _lib.ptr(kinds), n_hints)
+        trace = np.empty((proofs.n, words), dtype=np.uint64)
+        ch = np.empty((proofs.n, c.num_challenge_words), dtype=np.uint64) if with_challenges else None
+        _lib.check(L.gpv_witness_challenges(self.ctx.h, c.h, _lib.ptr(proofs.data), proofs.n, _lib.ptr(trace), _lib.ptr(ch)), self.ctx.h)
+        return trace, kinds, (ProofChallenges(c, ch) if with_challenges else None)
+
     def Verify(self, proofs, verifierData=None, detail=False):
         """verifier.go:143. The reference's Verify returns nothing -- "accepted" means its gnark circuit is satisfiable.
         Here: accept[n] (uint8). With detail=True also the failure mask [n] and the ProofChallenges."""

@@ -187,6 +187,19 @@ int gpv_gl_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, const 
  * (SURVEY 8f.3). in [n][words_in], out [n][words_out] as listed at GPV_HINT_*; ok[i] = 0 (outputs zero) where the reference
  * hint panics or errors because an operand is not in the field (>= p). ok may be NULL. */
 int gpv_gl_hints(gpv_ctx* ctx, int hint, const uint64_t* in, uint64_t* out, uint8_t* ok, size_t n);
+/* The protocol layer of the same witness, slice 1: the outputs of every hint the reference calls while
+ * VerifierChip.Verify runs GetPublicInputsHash and GetChallenges (verifier/verifier.go:41-82, :148-150), in call order, per proof --
+ * evaluated literally (lazy values reduced exactly where poseidon/goldilocks.go:92-331 and challenger/challenger.go:146-166 reduce
+ * them; the verification kernels use an algebraically equal form that never sees these values). Concatenated hint outputs:
+ *   GPV_HINT_MULADD 2 words (quotient, remainder); GPV_HINT_REDUCE 5 words (quotient as 4 little-endian words, remainder);
+ *   GPV_HINT_SPLIT_LIMBS 2 words (hi, lo). gl.MulAdd (base.go:196-213) = MulAdd, SplitLimbs(quotient), SplitLimbs(remainder);
+ *   gl.Reduce (:246-281) = Reduce, SplitLimbs(remainder). gnark's own ToBinary hint inside BN254Chip.ToVec is not part of it.
+ * The sequence of hint kinds depends on the circuit only: gpv_witness_challenges_layout writes one GPV_HINT_* id per hint call (at
+ * most cap; kinds may be NULL) and returns the number of calls; gpv_witness_challenges_words is the trace length per proof
+ * (702 670 words for testdata/step, 655 470 for decode_block). trace [n][words]; challenges [n][gpv_num_challenge_words] or NULL. */
+size_t gpv_witness_challenges_words(const gpv_circuit* c);
+size_t gpv_witness_challenges_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap);
+int gpv_witness_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint64_t* challenges);
 /* Add/Sub/Mul/Inverse/DivExtension (goldilocks/quadratic_extension.go:31-140), [n][2]; ok[i] = 0 where the
  * reference's "operand != 0" assertion (:124-125) fails. ok may be NULL. */
 int gpv_gl2_op(gpv_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* ok, size_t n);

@@ -10,6 +10,7 @@
 #include <thread>
 
 #include "orc_protocol.h"
+#include "orc_witness.h"
 
 using namespace orc;
 
@@ -275,6 +276,29 @@ int orc_challenges(const void* cv, const void* proofs, size_t n, u64* out) {
     get_challenges(pv, h).flatten(out + i * c.n_challenge_words());
   }
   return 0;
+}
+// Witness slice 1 (orc_witness.h): the hint outputs of GetPublicInputsHash + GetChallenges in call order. First call with
+// trace == NULL to learn the trace length (words per proof, identical for every proof of a circuit) and the number of hint calls;
+// kinds (may be NULL) receives one GPV_HINT_* id per hint call. challenges (may be NULL): [n][n_challenge_words].
+size_t orc_witness_challenges(const void* cv, const void* proofs, size_t n, u64* trace, size_t words_per_proof, unsigned char* kinds,
+                              size_t* n_hints, u64* challenges) {
+  const Circuit& c = *(const Circuit*)cv;
+  size_t words = 0;
+  for (size_t i = 0; i < n; i++) {
+    ProofView pv(&c, (const char*)proofs + i * c.proof_nbytes());
+    std::vector<u64> w;
+    std::vector<unsigned char> k;
+    wit::Sink sink = {&w, &k};
+    wit::witness_challenges(pv, sink, challenges ? challenges + i * c.n_challenge_words() : nullptr);
+    words = w.size();
+    if (n_hints) *n_hints = k.size();
+    if (kinds && i == 0) memcpy(kinds, k.data(), k.size());
+    if (trace) {
+      if (w.size() != words_per_proof) return 0;
+      memcpy(trace + i * words_per_proof, w.data(), 8 * w.size());
+    }
+  }
+  return words;
 }
 int orc_plonk_verify(const void* cv, const void* proofs, const u64* challenges, size_t n, int32_t* fail) {
   const Circuit& c = *(const Circuit*)cv;

@@ -1,0 +1,245 @@
+// TEST INFRASTRUCTURE -- CPU oracle, not product code.
+//
+// Witness values of the wrapping circuit, protocol slice 1: the ordered outputs of the reference's gnark hints while
+// VerifierChip.Verify runs GetPublicInputsHash and GetChallenges (verifier/verifier.go:41-82, :148-150). The reference's purpose is to
+// prove this verification inside a gnark circuit; the values its solver obtains from hints ARE the non-deterministic part of that
+// circuit's witness. A literal restatement: unlike orc_poseidon.h (observationally "mod p") this file keeps the reference's LAZY values
+// -- MulNoReduce / MulAddNoReduce results live unreduced in the native field (< 2^196 here) until a Reduce -- because the hint inputs,
+// hence their quotients, depend on exactly where the reference reduces.
+//
+//   goldilocks.Chip.MulAdd      base.go:196-213  -> MulAddHint :223-243, then RangeCheck(quotient), RangeCheck(remainder)
+//   goldilocks.Chip.Add         base.go:162-164  = MulAdd(a, 1, b)
+//   goldilocks.Chip.Reduce*     base.go:246-281  -> ReduceHint :284-294, then RangeCheck(remainder)   (rangeCheckerCheck(quotient) has no hint)
+//   goldilocks.Chip.RangeCheck  base.go:362-400  -> SplitLimbsHint :339-359
+//   poseidon.GoldilocksChip     poseidon/goldilocks.go:30-37, :72-86, :92-125, :138-145, :154-161, :172-183, :203-216, :231-238, :251-275, :300-331
+//   challenger.Chip             challenger/challenger.go:42-166
+//
+// Trace format (shared with libgpv's gpv_witness_challenges, include/gpv.h): the hint outputs in call order, concatenated --
+//   MulAddHint     2 words  (quotient, remainder)
+//   ReduceHint     5 words  (quotient as 4 little-endian words, remainder)
+//   SplitLimbsHint 2 words  (most significant 32 bits, least significant 32 bits)
+// gnark's own ToBinary hint inside BN254Chip.ToVec (bn254.go:106-120) is not one of the reference's hint functions and is not part of it.
+#pragma once
+#include <vector>
+
+#include "orc_circuit.h"
+#include "orc_poseidon.h"
+
+namespace orc {
+namespace wit {
+
+enum { HINT_MULADD = 0, HINT_REDUCE = 1, HINT_SPLIT_LIMBS = 3 };  // GPV_HINT_* of include/gpv.h
+
+// a lazy native-field value: < 2^256 always suffices here (largest: a 13-term row of 64 x 64-bit products, < 2^132; x * x^6 < 2^192)
+struct Big {
+  u64 w[4];
+};
+static inline Big big(u64 x) { Big b = {{x, 0, 0, 0}}; return b; }
+static inline Big big_add(Big a, Big b) {
+  Big r;
+  u128 c = 0;
+  for (int i = 0; i < 4; i++) {
+    c += (u128)a.w[i] + b.w[i];
+    r.w[i] = (u64)c;
+    c >>= 64;
+  }
+  return r;
+}
+static inline Big big_mul64(Big a, u64 m) {
+  Big r;
+  u128 c = 0;
+  for (int i = 0; i < 4; i++) {
+    c += (u128)a.w[i] * m;
+    r.w[i] = (u64)c;
+    c >>= 64;
+  }
+  return r;
+}
+
+struct Sink {
+  std::vector<u64>* words;          // the trace
+  std::vector<unsigned char>* kinds;  // one entry per hint call (may be null)
+  void emit(int kind, const u64* v, int n) {
+    if (words) words->insert(words->end(), v, v + n);
+    if (kinds) kinds->push_back((unsigned char)kind);
+  }
+};
+
+// base.go:362-400 -> SplitLimbsHint :339-359
+static inline void range_check(Sink& t, u64 x) {
+  u64 v[2] = {x >> 32, x & 0xFFFFFFFFu};
+  t.emit(HINT_SPLIT_LIMBS, v, 2);
+}
+// base.go:196-213
+static inline u64 mul_add(Sink& t, u64 a, u64 b, u64 c) {
+  u128 s = (u128)a * b + c;  // MulAddHint :234-239
+  u64 v[2] = {(u64)(s / GL_P), (u64)(s % GL_P)};
+  t.emit(HINT_MULADD, v, 2);
+  range_check(t, v[0]);
+  range_check(t, v[1]);
+  return v[1];
+}
+static inline u64 add(Sink& t, u64 a, u64 b) { return mul_add(t, a, 1, b); }  // base.go:162-164
+// base.go:246-281 (Reduce and ReduceWithMaxBits issue the same hints)
+static inline u64 reduce(Sink& t, Big x) {
+  u64 v[5];
+  u128 rem = 0;  // schoolbook division by p, most significant word first (ReduceHint :284-294 does big.Int Div / Rem)
+  for (int k = 3; k >= 0; k--) {
+    u128 cur = (rem << 64) | x.w[k];
+    v[k] = (u64)(cur / GL_P);
+    rem = cur % GL_P;
+  }
+  v[4] = (u64)rem;
+  t.emit(HINT_REDUCE, v, 5);
+  range_check(t, v[4]);
+  return v[4];
+}
+
+// ---------------------------------------------------------------- poseidon/goldilocks.go, base-field layers
+static inline u64 sbox_monomial(Sink& t, u64 x) {  // :138-145
+  Big x2 = big_mul64(big(x), x);
+  Big x3b = big_mul64(x2, x);
+  u64 x3 = reduce(t, x3b);
+  Big x6 = big_mul64(big(x3), x3);
+  Big x7 = big_mul64(x6, x);
+  return reduce(t, x7);
+}
+static inline void constant_layer(Sink& t, u64 s[12], int round) {  // :117-125
+  for (int i = 0; i < 12; i++) s[i] = add(t, s[i], orc_const::GL_ALL_ROUND_CONSTANTS[i + 12 * round]);
+}
+static inline u64 mds_row_shf(Sink& t, int r, const u64 v[12]) {  // :172-183
+  Big res = big(0);
+  for (int i = 0; i < 12; i++) res = big_add(res, big_mul64(big(v[(i + r) % 12]), orc_const::GL_MDS_CIRC[i]));
+  res = big_add(res, big_mul64(big(v[r]), orc_const::GL_MDS_DIAG[r]));
+  return reduce(t, res);
+}
+static inline void mds_layer(Sink& t, u64 s[12]) {  // :203-216
+  u64 r[12];
+  for (int i = 0; i < 12; i++) r[i] = mds_row_shf(t, i, s);
+  memcpy(s, r, sizeof r);
+}
+static inline void full_rounds(Sink& t, u64 s[12], int* round) {  // :92-100
+  for (int i = 0; i < PGL_HALF_N_FULL_ROUNDS; i++) {
+    constant_layer(t, s, *round);
+    for (int j = 0; j < 12; j++) s[j] = sbox_monomial(t, s[j]);  // sBoxLayer :154-161
+    mds_layer(t, s);
+    *round += 1;
+  }
+}
+static inline void mds_partial_layer_init(Sink& t, u64 s[12]) {  // :251-275
+  Big res[12];
+  for (int i = 0; i < 12; i++) res[i] = big(0);
+  res[0] = big(s[0]);
+  for (int r = 1; r < 12; r++)
+    for (int d = 1; d < 12; d++)
+      res[d] = big_add(res[d], big_mul64(big(s[r]), orc_const::GL_FAST_PARTIAL_ROUND_INITIAL_MATRIX[(r - 1) * 11 + (d - 1)]));
+  for (int i = 0; i < 12; i++) s[i] = reduce(t, res[i]);
+}
+static inline void mds_partial_layer_fast(Sink& t, u64 s[12], int r) {  // :300-331
+  Big d_sum = big(0);
+  for (int i = 1; i < 12; i++) d_sum = big_add(d_sum, big_mul64(big(s[i]), orc_const::GL_FAST_PARTIAL_ROUND_W_HATS[r * 11 + i - 1]));
+  Big d = big_add(big_mul64(big(s[0]), orc_const::GL_MDS0TO0), d_sum);
+  Big res[12];
+  res[0] = big(reduce(t, d));
+  for (int i = 1; i < 12; i++) res[i] = big_add(big_mul64(big(s[0]), orc_const::GL_FAST_PARTIAL_ROUND_VS[r * 11 + i - 1]), big(s[i]));
+  for (int i = 0; i < 12; i++) s[i] = reduce(t, res[i]);
+}
+static inline void partial_rounds(Sink& t, u64 s[12], int* round) {  // :102-115
+  for (int i = 0; i < 12; i++) s[i] = add(t, s[i], orc_const::GL_FAST_PARTIAL_FIRST_ROUND_CONSTANT[i]);  // :231-238
+  mds_partial_layer_init(t, s);
+  for (int i = 0; i < PGL_N_PARTIAL_ROUNDS; i++) {
+    s[0] = sbox_monomial(t, s[0]);
+    s[0] = add(t, s[0], orc_const::GL_FAST_PARTIAL_ROUND_CONSTANTS[i]);
+    mds_partial_layer_fast(t, s, i);
+  }
+  *round += PGL_N_PARTIAL_ROUNDS;
+}
+static inline void poseidon(Sink& t, u64 s[12]) {  // :30-37
+  int round = 0;
+  full_rounds(t, s, &round);
+  partial_rounds(t, s, &round);
+  full_rounds(t, s, &round);
+}
+// HashNoPad :72-86 over HashNToMNoPad :41-68 with 4 outputs
+static inline void hash_no_pad(Sink& t, const u64* in, size_t n, u64 out[4]) {
+  std::vector<u64> red(n);
+  for (size_t i = 0; i < n; i++) red[i] = reduce(t, big(in[i]));
+  u64 s[12] = {0};
+  for (size_t i = 0; i < n; i += PGL_RATE) {
+    for (size_t j = 0; j < (size_t)PGL_RATE; j++)
+      if (i + j < n) s[j] = red[i + j];
+    poseidon(t, s);
+  }
+  for (int i = 0; i < 4; i++) out[i] = s[i];  // four outputs never need a second squeeze permutation
+}
+
+// ---------------------------------------------------------------- challenger/challenger.go
+struct Challenger {
+  Sink* t;
+  u64 sponge[12];
+  std::vector<u64> in_buf, out_buf;
+  explicit Challenger(Sink* t_) : t(t_) { memset(sponge, 0, sizeof sponge); }
+  void duplexing() {  // :146-166
+    for (size_t i = 0; i < in_buf.size(); i++) sponge[i] = reduce(*t, big(in_buf[i]));
+    in_buf.clear();
+    poseidon(*t, sponge);
+    out_buf.assign(sponge, sponge + PGL_RATE);
+  }
+  void observe_element(u64 e) {  // :42-49
+    out_buf.clear();
+    in_buf.push_back(e);
+    if ((int)in_buf.size() == PGL_RATE) duplexing();
+  }
+  void observe_elements(const u64* e, size_t n) { for (size_t i = 0; i < n; i++) observe_element(e[i]); }
+  void observe_merkle_hash(const u64 h[4], int hash_kind) {  // :57-65
+    if (hash_kind == HASH_POSEIDON_GOLDILOCKS) { observe_elements(h, 4); return; }
+    u64 v[5];
+    poseidon_bn254_to_vec(fr_from_canonical(h), v);  // bn254.go:106-120 (gnark ToBinary: not a reference hint)
+    observe_elements(v, 5);
+  }
+  void observe_cap(const u64* cap, size_t n, int hash_kind) { for (size_t i = 0; i < n; i++) observe_merkle_hash(cap + 4 * i, hash_kind); }
+  u64 get_challenge() {  // :89-98
+    if (!in_buf.empty() || out_buf.empty()) duplexing();
+    u64 c = out_buf.back();
+    out_buf.pop_back();
+    return c;
+  }
+};
+
+// GetPublicInputsHash (verifier.go:41-43) then GetChallenges (:45-82, challenger.go:117-144), in Verify's order (:148-150).
+// Fills the challenge vector in the layout of Challenges::flatten.
+static inline void witness_challenges(const ProofView& pv, Sink& t, u64* challenges_out) {
+  const Circuit& c = *pv.c;
+  u64 pih[4];
+  hash_no_pad(t, pv.public_inputs(), c.num_public_inputs, pih);
+  Challenger ch(&t);
+  std::vector<u64> out;
+  ch.observe_merkle_hash(c.circuit_digest, c.hash_kind);
+  ch.observe_elements(pih, 4);
+  ch.observe_cap(pv.fr_at(c.fr_off_wires_cap()), c.cap_len(), c.hash_kind);
+  for (u64 i = 0; i < 2 * c.num_challenges; i++) out.push_back(ch.get_challenge());  // betas, gammas
+  ch.observe_cap(pv.fr_at(c.fr_off_zs_pp_cap()), c.cap_len(), c.hash_kind);
+  for (u64 i = 0; i < c.num_challenges; i++) out.push_back(ch.get_challenge());  // alphas
+  ch.observe_cap(pv.fr_at(c.fr_off_quotient_cap()), c.cap_len(), c.hash_kind);
+  out.push_back(ch.get_challenge());  // zeta
+  out.push_back(ch.get_challenge());
+  // ObserveOpenings(ToOpenings(...)) fri.go:63-73: constants | sigmas | wires | Zs | partial products | quotient polys, then Zs_next
+  ch.observe_elements(pv.gl + c.off_constants(), c.off_zs_next() - c.off_constants());
+  ch.observe_elements(pv.gl + c.off_partial_products(), c.off_queries() - c.off_partial_products());
+  ch.observe_elements(pv.gl + c.off_zs_next(), c.off_partial_products() - c.off_zs_next());
+  out.push_back(ch.get_challenge());  // fri alpha
+  out.push_back(ch.get_challenge());
+  for (u64 s = 0; s < c.num_steps(); s++) {
+    ch.observe_cap(pv.fr_at(c.fr_off_commit_cap(s)), c.cap_len(), c.hash_kind);
+    out.push_back(ch.get_challenge());
+    out.push_back(ch.get_challenge());
+  }
+  ch.observe_elements(pv.gl + c.off_final_poly(), 2 * c.final_poly_len());
+  ch.observe_element(pv.pow_witness());
+  out.push_back(ch.get_challenge());  // pow response
+  for (u64 i = 0; i < c.num_query_rounds; i++) out.push_back(ch.get_challenge());
+  if (challenges_out) memcpy(challenges_out, out.data(), 8 * out.size());
+}
+
+}  // namespace wit
+}  // namespace orc

@@ -477,6 +477,21 @@ class Oracle:
         self.lib.orc_challenges(ctypes.c_void_p(oc.h), _p(buf), ctypes.c_size_t(n), _p(out))
         return out
 
+    def witness_challenges(self, oc, proofs):
+        """oracle/orc_witness.h: (trace [n][words], hint kinds [n_hints], challenges [n][ncw]) -- the hint outputs of
+        GetPublicInputsHash + GetChallenges in the reference's call order."""
+        buf, n = self._proofs(oc, proofs)
+        f = self.lib.orc_witness_challenges
+        f.restype = ctypes.c_size_t
+        nh = ctypes.c_size_t()
+        words = f(ctypes.c_void_p(oc.h), _p(buf), ctypes.c_size_t(1), None, ctypes.c_size_t(0), None, ctypes.byref(nh), None)
+        trace = np.empty((n, words), dtype=np.uint64)
+        kinds = np.empty(nh.value, dtype=np.uint8)
+        ch = np.empty((n, oc.ncw), dtype=np.uint64)
+        got = f(ctypes.c_void_p(oc.h), _p(buf), ctypes.c_size_t(n), _p(trace), ctypes.c_size_t(words), _p(kinds), ctypes.byref(nh), _p(ch))
+        assert got == words
+        return trace, kinds, ch
+
     def plonk_verify(self, oc, proofs, challenges):
         buf, n = self._proofs(oc, proofs)
         ch = u64arr(challenges).reshape(n, oc.ncw)
@@ -904,3 +919,177 @@ def synthetic_shape_fixture(name, arity_bits, cap_height, hiding, hash_kind=HASH
     fp["commit_phase_merkle_caps"] = caps[4:]
     ci = CircuitInfo(common, vo)
     return ci, pack_proof(ci, pj), (common, vo, pj), np.array(ch, dtype=np.uint64)
+
+
+# ---------------------------------------------------------------- witness slice 1: hint outputs of GetPublicInputsHash + GetChallenges
+# A third derivation of the trace of include/gpv.h's gpv_witness_challenges, in exact Python integers, written from the reference's Go
+# (goldilocks/base.go:162-164,196-213,246-281,362-400; poseidon/goldilocks.go:30-37,72-86,92-331; challenger/challenger.go:42-166;
+# verifier/verifier.go:41-82) and independent of both the GPU kernel and oracle/orc_witness.h. Every hint output is checked against its
+# defining equation as it is produced: quotient * p + remainder == the hinted value with 0 <= remainder < p (MulAddHint, ReduceHint),
+# hi * 2^32 + lo == x with both below 2^32 (SplitLimbsHint).
+HINT_MULADD, HINT_REDUCE, HINT_SPLIT_LIMBS = 0, 1, 3
+
+
+def _poseidon_gl_constants():
+    import re
+    text = (ROOT / "oracle" / "poseidon_constants.h").read_text()
+    out = {}
+    for m in re.finditer(r"static const uint64_t (GL_\w+)(?:\[\d+\])? = \{?([^;]*?)\}?;", text, re.S):
+        out[m.group(1)] = [int(x.rstrip("UL"), 16) if x.startswith("0x") else int(x.rstrip("UL")) for x in re.findall(r"0x[0-9a-fA-F]+(?:ULL)?|\b\d+\b", m.group(2))]
+    return out
+
+
+class ExactWitness:
+    def __init__(self):
+        self.K = _poseidon_gl_constants()
+        assert len(self.K["GL_ALL_ROUND_CONSTANTS"]) == 360 and self.K["GL_MDS0TO0"] == [25]
+        self.words, self.kinds = [], []
+
+    # ---- goldilocks.Chip
+    def range_check(self, x):  # base.go:362-400 -> SplitLimbsHint :339-359
+        assert 0 <= x < GL_P, "SplitLimbsHint: input is not in the field"
+        hi, lo = x >> 32, x & 0xFFFFFFFF
+        assert hi * 2**32 + lo == x and hi < 2**32 and lo < 2**32 and (hi != 2**32 - 1 or lo == 0)
+        self.kinds.append(HINT_SPLIT_LIMBS)
+        self.words += [hi, lo]
+
+    def mul_add(self, a, b, c):  # base.go:196-213 -> MulAddHint :223-243
+        assert a < GL_P and b < GL_P and c < GL_P
+        q, r = divmod(a * b + c, GL_P)
+        assert c + a * b == r + GL_P * q
+        self.kinds.append(HINT_MULADD)
+        self.words += [q, r]
+        self.range_check(q)
+        self.range_check(r)
+        return r
+
+    def add(self, a, b):  # base.go:162-164
+        return self.mul_add(a, 1, b)
+
+    def reduce(self, x, max_bits=144):  # base.go:246-281 -> ReduceHint :284-294
+        q, r = divmod(x, GL_P)
+        assert q < 2**max_bits and x == q * GL_P + r and q < 2**256
+        self.kinds.append(HINT_REDUCE)
+        self.words += [(q >> (64 * k)) & (2**64 - 1) for k in range(4)] + [r]
+        self.range_check(r)
+        return r
+
+    # ---- poseidon.GoldilocksChip
+    def sbox_monomial(self, x):  # goldilocks.go:138-145
+        x3 = self.reduce(x * (x * x), 192)
+        return self.reduce(x * (x3 * x3), 192)
+
+    def full_rounds(self, s, rnd):  # :92-100
+        K = self.K
+        for _ in range(4):
+            s = [self.add(s[i], K["GL_ALL_ROUND_CONSTANTS"][i + 12 * rnd]) for i in range(12)]           # constantLayer :117-125
+            s = [self.sbox_monomial(x) for x in s]                                                          # sBoxLayer :154-161
+            s = [self.reduce(sum(s[(i + r) % 12] * K["GL_MDS_CIRC"][i] for i in range(12)) + s[r] * K["GL_MDS_DIAG"][r])
+                 for r in range(12)]                                                                        # mdsLayer :203-216 / mdsRowShf :172-183
+            rnd += 1
+        return s, rnd
+
+    def partial_rounds(self, s, rnd):  # :102-115
+        K = self.K
+        s = [self.add(s[i], K["GL_FAST_PARTIAL_FIRST_ROUND_CONSTANT"][i]) for i in range(12)]               # :231-238
+        M = K["GL_FAST_PARTIAL_ROUND_INITIAL_MATRIX"]
+        res = [s[0]] + [sum(s[r] * M[(r - 1) * 11 + (d - 1)] for r in range(1, 12)) for d in range(1, 12)]  # mdsPartialLayerInit :251-275
+        s = [self.reduce(x) for x in res]
+        for i in range(22):
+            s[0] = self.sbox_monomial(s[0])
+            s[0] = self.add(s[0], K["GL_FAST_PARTIAL_ROUND_CONSTANTS"][i])
+            W, V = K["GL_FAST_PARTIAL_ROUND_W_HATS"], K["GL_FAST_PARTIAL_ROUND_VS"]                       # mdsPartialLayerFast :300-331
+            d = self.reduce(s[0] * 25 + sum(s[k] * W[i * 11 + k - 1] for k in range(1, 12)))
+            res = [d] + [s[0] * V[i * 11 + k - 1] + s[k] for k in range(1, 12)]
+            s = [self.reduce(x) for x in res]
+        return s, rnd + 22
+
+    def poseidon(self, s):  # :30-37
+        s, rnd = self.full_rounds(list(s), 0)
+        s, rnd = self.partial_rounds(s, rnd)
+        s, rnd = self.full_rounds(s, rnd)
+        return s
+
+    def hash_no_pad(self, inputs):  # :72-86 over :41-68, four outputs
+        red = [self.reduce(x) for x in inputs]
+        s = [0] * 12
+        for i in range(0, len(red), 8):
+            for j in range(8):
+                if i + j < len(red):
+                    s[j] = red[i + j]
+            s = self.poseidon(s)
+        return s[:4]
+
+
+class ExactChallenger:  # challenger/challenger.go:14-166
+    def __init__(self, w):
+        self.w, self.sponge, self.inb, self.outb = w, [0] * 12, [], []
+
+    def duplexing(self):  # :146-166
+        assert len(self.inb) <= 8
+        for i, x in enumerate(self.inb):
+            self.sponge[i] = self.w.reduce(x)
+        self.inb = []
+        self.sponge = self.w.poseidon(self.sponge)
+        self.outb = self.sponge[:8]
+
+    def observe(self, x):  # :42-49
+        self.outb = []
+        self.inb.append(x)
+        if len(self.inb) == 8:
+            self.duplexing()
+
+    def observe_all(self, xs):
+        for x in xs:
+            self.observe(int(x))
+
+    def observe_merkle_hash(self, words, hash_kind):  # :57-65; bn254.go:106-120 (56-bit chunks of the canonical value)
+        if hash_kind == HASH_POSEIDON_GOLDILOCKS:
+            return self.observe_all(words)
+        v = fr_from_limbs([int(x) for x in words]) % BN_R
+        self.observe_all([(v >> (56 * k)) & (2**56 - 1) for k in range(5)])
+
+    def challenge(self):  # :89-98
+        if self.inb or not self.outb:
+            self.duplexing()
+        return self.outb.pop()
+
+
+def witness_challenges_exact(ci, packed):
+    """(trace words, hint kinds, challenges) of one packed proof -- the reference's call order, exact integers."""
+    w = ExactWitness()
+    rec = np.frombuffer(packed, dtype=np.uint64)
+    n_open, qwords, fr_queries, qfr, n_gl = query_section_layout(ci)
+    frs = rec[n_gl:].reshape(-1, 4)
+    off_final = n_open + ci.num_query_rounds * qwords
+    off_pow = off_final + 2 * ci.final_poly_len
+    pis = [int(x) for x in rec[off_pow + 1:off_pow + 1 + ci.num_public_inputs]]
+    pih = w.hash_no_pad(pis)                                                   # verifier.go:41-43
+    ch, out = ExactChallenger(w), []
+    cl = ci.cap_len
+    ch.observe_merkle_hash(ci.circuit_digest, ci.hash_kind)                     # verifier.go:56
+    ch.observe_all(pih)                                                        # :57
+    for h in frs[0:cl]:                                                        # :58 wires cap
+        ch.observe_merkle_hash(h, ci.hash_kind)
+    out += [ch.challenge() for _ in range(2 * ci.num_challenges)]              # :59-60
+    for h in frs[cl:2 * cl]:                                                   # :62
+        ch.observe_merkle_hash(h, ci.hash_kind)
+    out += [ch.challenge() for _ in range(ci.num_challenges)]                  # :63
+    for h in frs[2 * cl:3 * cl]:                                               # :65
+        ch.observe_merkle_hash(h, ci.hash_kind)
+    out += [ch.challenge(), ch.challenge()]                                    # :66
+    nc = ci.num_challenges
+    n_a = 2 * (ci.num_constants + ci.num_routed_wires + ci.num_wires + nc)     # constants .. Zs
+    ch.observe_all(rec[:n_a])                                                  # :68 ObserveOpenings, fri.go:63-73
+    ch.observe_all(rec[n_a + 2 * nc:n_open])
+    ch.observe_all(rec[n_a:n_a + 2 * nc])
+    out += [ch.challenge(), ch.challenge()]                                    # challenger.go:123
+    for s in range(len(ci.arity_bits)):                                        # :125-129
+        for h in frs[(3 + s) * cl:(4 + s) * cl]:
+            ch.observe_merkle_hash(h, ci.hash_kind)
+        out += [ch.challenge(), ch.challenge()]
+    ch.observe_all(rec[off_final:off_pow])                                     # :131
+    ch.observe(int(rec[off_pow]))                                              # :132
+    out.append(ch.challenge())                                                 # :134
+    out += [ch.challenge() for _ in range(ci.num_query_rounds)]                # :135
+    return w.words, w.kinds, out

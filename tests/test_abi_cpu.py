@@ -336,3 +336,30 @@ def test_pack_unpack_bits_roundtrip(gpv):
         assert torch.equal(D.unpack_accept_bits(D.pack_accept_bits(a), m), a)
     assert [D.shard_bounds(65536, r, 8) for r in (0, 7)] == [(0, 8192), (57344, 65536)]
     assert [D.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_witness_challenges_layout_and_oracle_trace(gpv, name):
+    """Witness slice 1, the parts that need no GPU: (a) the oracle's literal restatement (oracle/orc_witness.h) and the
+    exact-integer Python derivation (tests/gpv_testlib.witness_challenges_exact, which checks every hint output against its defining
+    equation) produce the same trace, the same sequence of hint kinds and the reference's challenges; (b) libgpv's layout
+    (gpv_witness_challenges_words / _layout, host arithmetic) agrees with both."""
+    import ctypes
+    ci, packed, (common, vo, _) = T.load_fixture(name)
+    words, kinds, ch = T.witness_challenges_exact(ci, packed)
+    orc = T.oracle()
+    oc = orc.circuit(ci)
+    tr, ok, och = orc.witness_challenges(oc, packed)
+    assert tr.shape == (1, len(words)) and (tr[0] == np.array(words, dtype=np.uint64)).all()
+    assert (ok == np.array(kinds, dtype=np.uint8)).all()
+    assert (och[0] == np.array(ch, dtype=np.uint64)).all() and (och == orc.challenges(oc, packed)).all()
+    circuit = _circuit(gpv, common, vo)
+    L = gpv._lib.lib()
+    assert L.gpv_witness_challenges_words(ctypes.c_void_p(circuit.h)) == len(words) == {"decode_block": 655470, "step": 702670}[name]
+    n_hints = L.gpv_witness_challenges_layout(ctypes.c_void_p(circuit.h), None, 0)
+    assert n_hints == len(kinds)
+    got = np.empty(n_hints, dtype=np.uint8)
+    L.gpv_witness_challenges_layout(ctypes.c_void_p(circuit.h), gpv._lib.ptr(got), n_hints)
+    assert (got == ok).all()
+    # per permutation: 130 MulAdd + 630 Reduce + 890 SplitLimbs = 5190 words (DESIGN.md)
+    assert int((ok == 0).sum()) * 2 + int((ok == 1).sum()) * 5 + int((ok == 3).sum()) * 2 == len(words)

@@ -1603,3 +1603,43 @@ def test_group_rank_failure_does_not_strand_the_others(gpv, api):
         assert grp.verify(circuit, batch, n).tolist() == (~tampered).astype(np.uint8).tolist()
     finally:
         grp.close()
+
+
+# ---------------------------------------------------------------- witness generator, protocol slice 1
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_witness_challenges_trace(gpv, api, orc, name):
+    """gpv_witness_challenges: the ordered outputs of the reference's hints (MulAddHint / ReduceHint / SplitLimbsHint, base.go:223-359)
+    while Verify runs GetPublicInputsHash + GetChallenges -- GPU (literal lazy evaluation, csrc/gpv_witness.cuh) == oracle
+    (oracle/orc_witness.h) word for word on the fixture and on records with random openings / caps / public inputs / non-canonical
+    public inputs, == the exact-integer Python derivation on the fixture (which checks every entry against its defining equation); the
+    challenges that fall out are the reference's (fri_test.go:37-67 KATs via the oracle)."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    n = 12
+    batch, _ = T.synthetic_batch(ci, packed, n, seed=21, tamper_every=0)
+    w = batch.view(np.uint64).reshape(n, -1)
+    rng = np.random.default_rng(31)
+    n_open, qwords, fr_queries, qfr, n_gl = T.query_section_layout(ci)
+    for i in range(1, n):  # fresh transcripts: random canonical openings, final polynomial, pow witness, caps; public inputs incl. >= p
+        w[i, :n_open] = rand_gl(rng, n_open)
+        fin = n_open + ci.num_query_rounds * qwords
+        w[i, fin:fin + 2 * ci.final_poly_len + 1] = rand_gl(rng, 2 * ci.final_poly_len + 1)
+        if ci.num_public_inputs:
+            pis = rand_gl(rng, ci.num_public_inputs)
+            pis[::5] = np.uint64(2**64 - 1 - i)   # HashNoPad reduces its inputs (goldilocks.go:76-78): ReduceHint quotient 1
+            w[i, n_gl - ci.num_public_inputs:n_gl] = pis
+        ncap = (3 + len(ci.arity_bits)) * ci.cap_len
+        w[i, n_gl:n_gl + 4 * ncap] = np.array([T.fr_limbs(int.from_bytes(rng.bytes(32), "little") % T.BN_R) for _ in range(ncap)], dtype=np.uint64).reshape(-1)
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    chip = gpv.verifier.NewVerifierChip(api, common)
+    trace, kinds, ch = chip.WitnessChallenges(pb)
+    otr, okinds, och = orc.witness_challenges(oc, batch)
+    assert trace.shape == otr.shape and (kinds == okinds).all()
+    bad = np.nonzero((trace != otr).any(axis=1))[0]
+    assert bad.size == 0, (bad, np.nonzero(trace[bad[0]] != otr[bad[0]])[0][:4])
+    assert (ch.flat == och).all() and (ch.flat == chip.GetChallenges(pb).flat).all()
+    words, ekinds, ech = T.witness_challenges_exact(ci, batch[0].tobytes())
+    assert (trace[0] == np.array(words, dtype=np.uint64)).all() and (kinds == np.array(ekinds, dtype=np.uint8)).all()
+    words, _, _ = T.witness_challenges_exact(ci, batch[n - 1].tobytes())
+    assert (trace[n - 1] == np.array(words, dtype=np.uint64)).all()
