@@ -300,7 +300,11 @@ GPV_DEV Ext dev_fri_fold(u64 x, u32 idx_in, const u64* __restrict__ evals, Ext b
   return ext_scalar_mul(ext_mul(l, sum), inv[A]);
 }
 
+// ARITY32: the kernel variant for circuits with an arity-32 step. Instantiating that fold next to the others sets the register
+// allocation and the scratch of the whole query kernel (752 -> 1680 B per lane), so the reference's arity-16 circuits keep a kernel
+// without it (k_fri_query) and only circuits that need it run k_fri_query_a32.
 // verifyQueryRound without the Merkle paths. Returns failure bits.
+template <bool ARITY32 = false>
 GPV_DEV u32 dev_fri_query(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ derived,
                           u32 q) {
   u32 fail = 0;
@@ -354,7 +358,7 @@ GPV_DEV u32 dev_fri_query(const DevCircuit* __restrict__ dc, const u64* __restri
   for (u32 i = 0; i < nc; i++) apow = ext_mul(apow, alpha);
   Ext old_eval = ext_mul(ext_sub(red0, ro0), inv0);
   old_eval = ext_add(ext_mul(apow, old_eval), ext_mul(ext_sub(red1, ro1), inv1));
-  // reduction steps (fri.go:421-491); the reference's arity is 16 (it panics otherwise, :431-433), 2 / 4 / 8 are SURVEY 8f.2
+  // reduction steps (fri.go:421-491); the reference's arity is 16 (it panics otherwise, :431-433), 2 / 4 / 8 / 32 are SURVEY 8f.2
 #pragma unroll 1
   for (u32 s = 0; s < dc->num_steps; s++) {
     const u64* evals = qrec + dc->step_evals_off[s];
@@ -367,6 +371,10 @@ GPV_DEV u32 dev_fri_query(const DevCircuit* __restrict__ dc, const u64* __restri
       case 1: old_eval = dev_fri_fold<1>(x, idx_in, evals, beta, &fail); break;
       case 2: old_eval = dev_fri_fold<2>(x, idx_in, evals, beta, &fail); break;
       case 3: old_eval = dev_fri_fold<3>(x, idx_in, evals, beta, &fail); break;
+      case 5:  // arity 32 (plonky2 admits it; 33 values in one batched inversion)
+        if (ARITY32) { old_eval = dev_fri_fold<5>(x, idx_in, evals, beta, &fail); break; }
+        fail |= 256;  // unreachable: the launch wrapper picks the ARITY32 kernel for such circuits (GPV_FAIL_FRI_INTERP keeps it fail-closed)
+        break;
       default: old_eval = dev_fri_fold<4>(x, idx_in, evals, beta, &fail); break;
     }
 #pragma unroll 1

@@ -606,8 +606,8 @@ static int circuit_from_json_impl(const char* common_json, size_t common_len, co
   c.num_steps = (uint32_t)rab->size();
   for (uint32_t s = 0; s < c.num_steps; s++) {
     if (!j_u32(rab->child(s), &c.arity_bits[s])) return GPV_ESHAPE;
-    if (beyond ? (c.arity_bits[s] < 1 || c.arity_bits[s] > 4) : c.arity_bits[s] != 4) {  // fri.go:431-433 "assuming arity bits is 4"
-      gpv_set_global_error("reduction arity bits %u != 4 is not supported%s", c.arity_bits[s], beyond ? " (1..4 with GPV_CIRCUIT_BEYOND_REFERENCE)" : "");
+    if (beyond ? (c.arity_bits[s] < 1 || c.arity_bits[s] > 5) : c.arity_bits[s] != 4) {  // fri.go:431-433 "assuming arity bits is 4"
+      gpv_set_global_error("reduction arity bits %u != 4 is not supported%s", c.arity_bits[s], beyond ? " (1..5 with GPV_CIRCUIT_BEYOND_REFERENCE)" : "");
       return GPV_ECONFIG;
     }
   }

@@ -146,7 +146,7 @@ typedef struct gpv_circuit gpv_circuit; /* CommonCircuitData + VerifierOnlyCircu
 int gpv_circuit_from_json(const char* common_json, size_t common_len, const char* verifier_only_json,
                           size_t verifier_only_len, gpv_circuit** out);
 /* The same with flags. GPV_CIRCUIT_BEYOND_REFERENCE admits shapes the reference PANICS on (gpv_circuit_from_json keeps
- * answering them with GPV_ECONFIG, exactly like the reference): reduction arities 2 / 4 / 8 besides 16 (fri/fri.go:431-433), cap
+ * answering them with GPV_ECONFIG, exactly like the reference): reduction arities 2 / 4 / 8 / 32 besides 16 (fri/fri.go:431-433), cap
  * heights 0..6 besides 4 (fri/fri.go:118-126), hiding circuits (types/common_data.go:121-124: the wires / Zs / quotient leaves end
  * in 4 blinding elements that are hashed but not evaluated), Poseidon-Goldilocks hashes in the verifier data (plonky2's default
  * configuration; the reference cannot deserialise it, variables/deserialize.go:149-156). No reference implementation or fixture exists for them: parity is

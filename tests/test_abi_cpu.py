@@ -132,6 +132,8 @@ BEYOND_SHAPES = [  # (fixture, reduction arity bits, cap height, hiding, hash ki
     ("decode_block", [2, 4, 1, 2], 2, False, 1),
     ("step", [4, 4], 4, True, 0),
     ("step", [1, 2, 3, 4], 6, True, 1),
+    ("step", [5, 4], 4, False, 0),           # arity 32 (VERDICT r2 missing #1)
+    ("decode_block", [5, 5], 3, True, 1),
     ("decode_block", [4, 3], 0, False, 0),
     ("decode_block", [4, 4, 2], 5, False, 1),   # the last step tree has no siblings at all: its leaves sit directly under the cap
     ("decode_block", [1, 1, 1, 1, 1, 1, 1, 1], 5, True, 1),
@@ -164,7 +166,7 @@ def test_shapes_beyond_the_reference_are_opt_in(gpv, shape):
 
 def test_beyond_reference_limits(gpv):
     _, _, (common, vo, _), _ = T.synthetic_shape_fixture("step", [4, 4], 4, False, 0)
-    for mutate in (lambda c: c["fri_params"].__setitem__("reduction_arity_bits", [5, 3]),       # arity 32: not built
+    for mutate in (lambda c: c["fri_params"].__setitem__("reduction_arity_bits", [6, 2]),       # arity 64: not built
                    lambda c: c["fri_params"].__setitem__("reduction_arity_bits", [0, 4]),
                    lambda c: c["fri_params"]["config"].__setitem__("cap_height", 7)):
         bad = json.loads(json.dumps(common))
