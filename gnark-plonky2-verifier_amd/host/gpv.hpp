@@ -257,6 +257,20 @@ class Chip {
     gpv::check(gpv_fri_verify(api_.h(), c_.h(), proofs.data(), challenges.data(), n, mask.data()), api_.h());
     return mask;
   }
+  // verifyMerkleProofToCapWithCapIndex (fri.go:97-144) for every (proof, query, tree): ok [n][queries][trees]
+  std::vector<uint8_t> VerifyMerkleProofsToCap(const std::vector<uint8_t>& proofs, const std::vector<uint64_t>& challenges) {
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint8_t> ok(n * gpv_num_query_rounds(c_.h()) * gpv_num_merkle_trees(c_.h()));
+    gpv::check(gpv_merkle_verify(api_.h(), c_.h(), proofs.data(), challenges.data(), n, ok.data()), api_.h());
+    return ok;
+  }
+  // device-resident forms (BASELINE configs 3 and 5): raw device pointers, enqueued on the context's stream
+  void VerifyFriProofDevice(const void* proofs_dev, const uint64_t* challenges_dev, size_t n, uint32_t* fail_mask_dev) {
+    gpv::check(gpv_fri_verify_dev(api_.h(), c_.h(), proofs_dev, challenges_dev, n, fail_mask_dev), api_.h());
+  }
+  void VerifyMerkleProofsToCapDevice(const void* proofs_dev, const uint64_t* challenges_dev, size_t n, uint8_t* ok_dev) {
+    gpv::check(gpv_merkle_verify_dev(api_.h(), c_.h(), proofs_dev, challenges_dev, n, ok_dev), api_.h());
+  }
  private:
   gpv::Api& api_;
   const gpv::Circuit& c_;
@@ -305,6 +319,32 @@ class VerifierChip {
     gpv::check(gpv_verify_given_challenges(api_.h(), c_.h(), proofs.data(), challenges.data(), n, accept.data(),
                                            fail_mask ? fail_mask->data() : nullptr), api_.h());
     return accept;
+  }
+  // Verify plus the failure masks (GPV_FAIL_*; GPV_FAIL_INCOMPLETE = a stage did not visit the proof) and the derived challenges
+  std::vector<uint8_t> VerifyDetail(const std::vector<uint8_t>& proofs, std::vector<uint32_t>* fail_mask, std::vector<uint64_t>* challenges) {
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint8_t> accept(n);
+    if (fail_mask) fail_mask->resize(n);
+    if (challenges) challenges->resize(n * c_.num_challenge_words());
+    gpv::check(gpv_verify_detail(api_.h(), c_.h(), proofs.data(), n, accept.data(), fail_mask ? fail_mask->data() : nullptr,
+                                 challenges ? challenges->data() : nullptr), api_.h());
+    return accept;
+  }
+  // Witness of the wrapping circuit, protocol slice 1: the outputs of every hint the reference calls while Verify runs
+  // GetPublicInputsHash + GetChallenges (verifier.go:148-150), in call order: trace [n][WitnessChallengesWords()]; kinds (optional)
+  // receives one GPV_HINT_* id per hint call; challenges (optional) [n][num_challenge_words]
+  size_t WitnessChallengesWords() const { return gpv_witness_challenges_words(c_.h()); }
+  std::vector<uint64_t> WitnessChallenges(const std::vector<uint8_t>& proofs, std::vector<uint8_t>* kinds = nullptr,
+                                          std::vector<uint64_t>* challenges = nullptr) {
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint64_t> trace(n * WitnessChallengesWords());
+    if (kinds) {
+      kinds->resize(gpv_witness_challenges_layout(c_.h(), nullptr, 0));
+      gpv_witness_challenges_layout(c_.h(), kinds->data(), kinds->size());
+    }
+    if (challenges) challenges->resize(n * c_.num_challenge_words());
+    gpv::check(gpv_witness_challenges(api_.h(), c_.h(), proofs.data(), n, trace.data(), challenges ? challenges->data() : nullptr), api_.h());
+    return trace;
   }
   // Verify (verifier.go:143): accept[i] == 1 iff the reference's circuit is satisfiable for proof i
   std::vector<uint8_t> Verify(const std::vector<uint8_t>& proofs) {

@@ -87,6 +87,28 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> acc2 = chip.VerifyWithChallenges(batch, ch2, &mask);
     EXPECT(acc2[0] == 1 && acc2[1] == 0 && mask[0] == 0 && mask[1] != 0);
   }
+  // fail-closed verdict + defined masks: VerifyDetail reports mask 0 for the valid proof, no GPV_FAIL_INCOMPLETE anywhere
+  {
+    std::vector<uint32_t> mask;
+    std::vector<uint64_t> ch3;
+    std::vector<uint8_t> acc3 = chip.VerifyDetail(batch, &mask, &ch3);
+    EXPECT(acc3[0] == 1 && acc3[1] == 0 && mask[0] == 0 && mask[1] != 0 && !(mask[1] & GPV_FAIL_INCOMPLETE));
+    EXPECT(std::vector<uint64_t>(ch3.begin(), ch3.begin() + ch.size()) == ch);
+    std::vector<uint8_t> ok = fri::Chip(api, circuit).VerifyMerkleProofsToCap(proof, ch);
+    EXPECT(ok.size() == gpv_num_query_rounds(circuit.h()) * gpv_num_merkle_trees(circuit.h()));
+    for (uint8_t b : ok) EXPECT(b == 1);
+  }
+  // witness slice 1: the hint trace of GetPublicInputsHash + GetChallenges; its first MulAdd record is
+  // quotient * p + remainder = a * 1 + b, and the challenges that fall out are GetChallenges'
+  {
+    std::vector<uint8_t> kinds;
+    std::vector<uint64_t> wch;
+    std::vector<uint64_t> trace = chip.WitnessChallenges(proof, &kinds, &wch);
+    EXPECT(trace.size() == chip.WitnessChallengesWords() && wch == ch && !kinds.empty());
+    size_t words = 0;
+    for (uint8_t k : kinds) words += k == GPV_HINT_REDUCE ? 5 : 2;
+    EXPECT(words == trace.size());
+  }
   // hint functions (base.go:223-243 and base_test.go:97-116): 2^63 * 2^63 + 3 = quotient * p + 18446744068340842500
   {
     auto h = gl.MulAddHint({1ULL << 63, 1ULL << 63, 3, /* not in the field: */ 0xFFFFFFFF00000001ULL, 1, 1});
