@@ -86,6 +86,12 @@ int main(int argc, char** argv) {
     int rc = gpv_circuit_from_json(m.data(), m.size(), v.data(), v.size(), &c2);
     if (rc != 0) { serr++; continue; }
     sok++;
+    {  // the witness layout walks the circuit's dimensions on the host (csrc/gpv_ingest.cpp): its two entry points must agree
+      std::vector<uint8_t> kinds(gpv_witness_challenges_layout(c2, nullptr, 0));
+      size_t calls = gpv_witness_challenges_layout(c2, kinds.data(), kinds.size()), words = 0;
+      for (uint8_t k : kinds) words += k == GPV_HINT_REDUCE ? 5 : 2;
+      if (calls != kinds.size() || words != gpv_witness_challenges_words(c2)) other++;
+    }
     size_t nb = gpv_proof_nbytes(c2);
     if (nb <= (64u << 20)) {
       std::vector<uint8_t> buf(nb);  // exactly the promised size: one byte past it is an ASan report
