@@ -134,6 +134,27 @@ struct HashGL {
   }
 };
 
+// ---------------------------------------------------------------- visit counters of the fail-closed verdict (gpv_launch.h)
+// Consecutive lanes of a wave work for the same proof in runs (28 queries per proof): the first lane of every run adds the run's
+// length with ONE atomic instead of one atomic per lane (a fire-and-forget atomic is a 32-byte write at the memory side: per lane it
+// doubled the write traffic of the Merkle kernels, profiles/r03p_pmc_write.txt). Call it with every lane that passed the bounds
+// check (the exited lanes of a partial last wave are simply absent from the ballot).
+GPV_DEV void visit_count_runs(u32* __restrict__ done, size_t p, u32 stage) {
+  const u32 lane = threadIdx.x & 63;
+  const u64 active = __ballot(true);
+  const u32 p_lo = (u32)p;
+  const u32 prev = (u32)__shfl_up((int)p_lo, 1);
+  const bool has_prev = lane != 0 && ((active >> (lane - 1)) & 1);
+  const bool leader = !has_prev || prev != p_lo;
+  const u64 leaders = __ballot(leader);
+  if (leader) {
+    const u64 later = lane == 63 ? 0 : (leaders >> (lane + 1)) << (lane + 1);  // leaders above this lane
+    const u64 upto = later ? (later & (0 - later)) - 1 : ~(u64)0;               // lanes below the next leader
+    const u32 count = (u32)__popcll(active & upto & ~(((u64)1 << lane) - 1));
+    atomicAdd(&done[p * GPV_DONE_STRIDE + stage], count);
+  }
+}
+
 // ---------------------------------------------------------------- Merkle path (one lane), in two phases
 // Phase 1 (leaf digest) needs only the proof bytes; phase 2 (climb + cap comparison) needs the query index from the
 // Fiat-Shamir transcript. Splitting them lets the latency-bound transcript kernel run concurrently with phase 1.

@@ -82,7 +82,7 @@ GPV_DEV void merkle_leaves_body(const DevCircuit* __restrict__ dc, const u64* __
   size_t p = item / nq;
   u32 q = (u32)(item - p * nq);
   u32 tree = order.cls[blockIdx.y];
-  atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_LEAVES], 1u);
+  visit_count_runs(v.done, p, GPV_DONE_LEAVES);
   const u64* rec = proofs + p * (dc->proof_nbytes / 8);
   const u64* qrec = rec + dc->off_queries + (size_t)q * dc->query_words;
   const u64* leaf;
@@ -133,7 +133,7 @@ GPV_DEV void merkle_climb_lower_body(const DevCircuit* __restrict__ dc, const u6
   u32 tree = order.cls[blockIdx.y];
   const u64* rec = proofs + p * (dc->proof_nbytes / 8);
   const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
-  atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_CLIMB], 1u);
+  visit_count_runs(v.done, p, GPV_DONE_CLIMB);
   MerklePath m = dev_merkle_path(dc, rec, d, q, tree);
   typename H::Node cur = H::load_digest(digests + ((size_t)tree * items + item) * FR_LIMBS);
   u32 top = m.n_sib < crown_levels ? m.n_sib : crown_levels;

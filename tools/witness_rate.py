@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Throughput of the witness slice (gpv_witness_challenges, host buffers in and out): python tools/witness_rate.py [n]"""
+import importlib
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import gpv_testlib as T  # noqa: E402
+
+gpv = importlib.import_module("gnark-plonky2-verifier_amd")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ctx = gpv.default_context()
+print("# gpv_witness_challenges: hint trace of GetPublicInputsHash + GetChallenges, %d proofs per call, host buffers in and out (one lane per proof)" % n)
+for name in ("step", "decode_block"):
+    d = T.GOLDEN / name
+    common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
+    vo = gpv.variables.DeserializeVerifierOnlyCircuitData(gpv.types.ReadVerifierOnlyCircuitData(d / "verifier_only_circuit_data.json"))
+    circuit = gpv.variables.circuit_for(common, vo)
+    ci, packed, _ = T.load_fixture(name)
+    batch, _ = T.synthetic_batch(ci, packed, n, seed=3, tamper_every=0)
+    chip = gpv.verifier.NewVerifierChip(ctx, common)
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    chip.WitnessChallenges(pb)
+    t = time.perf_counter()
+    trace, kinds, ch = chip.WitnessChallenges(pb)
+    dt = time.perf_counter() - t
+    orc = T.oracle()
+    t = time.perf_counter()
+    otr, _, _ = orc.witness_challenges(orc.circuit(ci), batch[:16])
+    dto = (time.perf_counter() - t) / 16
+    assert (trace[:16] == otr).all()
+    print("%-13s %d words / %d hint calls per proof: %.1f ms per call = %.0f proofs/s = %.2f G trace words/s (%.2f GB/s incl. the copy back); oracle, one thread: %.1f ms per proof"
+          % (name, trace.shape[1], len(kinds), dt * 1e3, n / dt, n * trace.shape[1] / dt / 1e9, 8 * n * trace.shape[1] / dt / 1e9, dto * 1e3))
