@@ -518,3 +518,31 @@ func (g *Group) ReadRankAccept(local, nTotal int) []bool {
 	}
 	return out
 }
+
+// WitnessRangeCheck / WitnessChallenges: the hint outputs of Verify's first three statements (verifier/verifier.go:148-150) in call order
+// (SURVEY 8f.3): rangeCheckProof = one SplitLimbs (hi, lo) per proof element; GetPublicInputsHash + GetChallenges = MulAdd (2 words),
+// Reduce (5), SplitLimbs (2) records as listed by WitnessChallengesLayout (one GPV_HINT_* id per hint call).
+func (ctx *Context) WitnessRangeCheck(c *Circuit, proofs []byte) ([]uint64, []bool) {
+	n := len(proofs) / c.ProofNBytes()
+	trace := make([]uint64, n*int(C.gpv_witness_range_check_words(c.h)))
+	okb := make([]byte, n)
+	check(C.gpv_witness_range_check(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(trace), (*C.uint8_t)(unsafe.Pointer(&okb[0]))), ctx.h)
+	ok := make([]bool, n)
+	for i := range okb {
+		ok[i] = okb[i] == 1
+	}
+	return trace, ok
+}
+func (c *Circuit) WitnessChallengesLayout() []uint8 {
+	n := int(C.gpv_witness_challenges_layout(c.h, nil, 0))
+	kinds := make([]uint8, n)
+	C.gpv_witness_challenges_layout(c.h, (*C.uint8_t)(unsafe.Pointer(&kinds[0])), C.size_t(n))
+	return kinds
+}
+func (ctx *Context) WitnessChallenges(c *Circuit, proofs []byte) (trace []uint64, challenges []uint64) {
+	n := len(proofs) / c.ProofNBytes()
+	trace = make([]uint64, n*int(C.gpv_witness_challenges_words(c.h)))
+	challenges = make([]uint64, n*c.NumChallengeWords())
+	check(C.gpv_witness_challenges(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(trace), u64p(challenges)), ctx.h)
+	return trace, challenges
+}

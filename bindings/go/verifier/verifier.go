@@ -79,6 +79,15 @@ func (c *VerifierChip) VerifyWithChallenges(proof variables.Proof, challenges []
 	return c.ctx.VerifyWithChallenges(c.circuit(verifierData), proof.Packed, challenges)
 }
 
+// WitnessRangeCheck / WitnessChallenges: the hint outputs the wrapping gnark circuit's solver asks for while Verify executes
+// rangeCheckProof, GetPublicInputsHash and GetChallenges (verifier.go:148-150), in call order (SURVEY 8f.3).
+func (c *VerifierChip) WitnessRangeCheck(proof variables.Proof) ([]uint64, []bool) {
+	return c.ctx.WitnessRangeCheck(proof.Circuit, proof.Packed)
+}
+func (c *VerifierChip) WitnessChallenges(proof variables.Proof) (trace []uint64, challenges []uint64) {
+	return c.ctx.WitnessChallenges(proof.Circuit, proof.Packed)
+}
+
 // Device-resident batches (raw device addresses; asynchronous on the context's stream).
 func (c *VerifierChip) VerifyDevice(circuit *gpv.Circuit, proofsDev unsafe.Pointer, n int, acceptDev unsafe.Pointer) {
 	c.ctx.VerifyDev(circuit, proofsDev, n, acceptDev)

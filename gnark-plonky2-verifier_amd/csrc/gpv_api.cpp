@@ -1018,6 +1018,31 @@ extern "C" int gpv_witness_challenges(gpv_ctx* ctx, const gpv_circuit* c, const 
   return GPV_OK;
 }
 
+// Witness slice 0: rangeCheckProof (verifier.go:84-141), the first statement of Verify -- one SplitLimbsHint per proof element.
+extern "C" int gpv_witness_range_check(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint8_t* ok) {
+  REQUIRE(ctx, ctx && c && proofs && trace);
+  ENTER(ctx);
+  if (n == 0) return GPV_OK;
+  const size_t words = gpv_witness_range_check_words(c);
+  HostBatch hb;
+  int rc = hb.upload(ctx, c, proofs, n);
+  if (rc != GPV_OK) return rc;
+  const DevCircuit* dcd;
+  rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  DevBuf<u64> dtrace;
+  DevBuf<uint8_t> dok;
+  HIP_TRY(ctx, dtrace.alloc(words * n));
+  HIP_TRY(ctx, dok.alloc(n));
+  HIP_TRY(ctx, hipMemsetAsync(dok.p, 1, n, ctx->stream));
+  gpvk_witness_range_check(ctx->stream, dcd, (const u64*)hb.proofs.p, n, dtrace.p, dok.p);
+  CHECK_LAUNCH(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(trace, dtrace.p, 8 * words * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (ok) HIP_TRY(ctx, hipMemcpyAsync(ok, dok.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+
 // shared prologue of the "stage with caller-supplied challenges" entry points
 struct StageSetup {
   HostBatch hb;

@@ -835,6 +835,7 @@ WitLayout witness_challenges_layout(const DevCircuit& c, std::vector<uint8_t>* k
   return L;
 }
 }  // namespace
+extern "C" size_t gpv_witness_range_check_words(const gpv_circuit* c) { return c ? 2 * (size_t)c->dc.off_pi : 0; }
 extern "C" size_t gpv_witness_challenges_words(const gpv_circuit* c) { return c ? witness_challenges_layout(c->dc, nullptr).words : 0; }
 extern "C" size_t gpv_witness_challenges_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap) {
   if (!c) return 0;

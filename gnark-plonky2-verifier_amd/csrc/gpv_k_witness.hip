@@ -16,3 +16,25 @@ void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* p
                              u64* challenges, u64* written) {
   GPVK_LAUNCH(k_witness_challenges, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, trace, words_per_proof, challenges, written);
 }
+
+// rangeCheckProof (verifier/verifier.go:84-141): RangeCheck / RangeCheckQE of every proof element except the public inputs, in the order
+// of the proof struct -- which is the order of the packed record's Goldilocks section -- i.e. one SplitLimbsHint (base.go:339-359) per
+// word: trace[i][2 w] = x >> 32, trace[i][2 w + 1] = x mod 2^32. The reference's hint returns an error for x >= p: ok[i] = 0 then (the
+// limbs are written anyway). One lane per word, coalesced.
+__global__ __launch_bounds__(256) void k_witness_range_check(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+                                                             u64* __restrict__ trace, uint8_t* __restrict__ ok) {
+  const u32 words = dc->off_pi;
+  const size_t total = (size_t)words * n, stride = dc->proof_nbytes / 8;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = t / words;
+    const u32 w = (u32)(t - p * words);
+    const u64 x = proofs[p * stride + w];
+    u64* o = trace + 2 * t;
+    o[0] = x >> 32;
+    o[1] = x & 0xFFFFFFFFu;
+    if (x >= GLP) ok[p] = 0;
+  }
+}
+void gpvk_witness_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, uint8_t* ok) {
+  GPVK_LAUNCH(k_witness_range_check, dim3(4096), dim3(256), 0, st, dcd, proofs, n, trace, ok);
+}

@@ -333,6 +333,14 @@ class VerifierChip {
   // Witness of the wrapping circuit, protocol slice 1: the outputs of every hint the reference calls while Verify runs
   // GetPublicInputsHash + GetChallenges (verifier.go:148-150), in call order: trace [n][WitnessChallengesWords()]; kinds (optional)
   // receives one GPV_HINT_* id per hint call; challenges (optional) [n][num_challenge_words]
+  // slice 0: rangeCheckProof (verifier.go:84-141), one SplitLimbsHint (hi, lo) per proof element
+  std::vector<uint64_t> WitnessRangeCheck(const std::vector<uint8_t>& proofs, std::vector<uint8_t>* ok = nullptr) {
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint64_t> trace(n * gpv_witness_range_check_words(c_.h()));
+    if (ok) ok->resize(n);
+    gpv::check(gpv_witness_range_check(api_.h(), c_.h(), proofs.data(), n, trace.data(), ok ? ok->data() : nullptr), api_.h());
+    return trace;
+  }
   size_t WitnessChallengesWords() const { return gpv_witness_challenges_words(c_.h()); }
   std::vector<uint64_t> WitnessChallenges(const std::vector<uint8_t>& proofs, std::vector<uint8_t>* kinds = nullptr,
                                           std::vector<uint64_t>* challenges = nullptr) {

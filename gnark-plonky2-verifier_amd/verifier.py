@@ -26,6 +26,18 @@ class VerifierChip:
         _lib.check(_lib.lib().gpv_challenges(self.ctx.h, c.h, _lib.ptr(proofs.data), proofs.n, _lib.ptr(out)), self.ctx.h)
         return ProofChallenges(c, out)
 
+    def WitnessRangeCheck(self, proofs):
+        """Witness slice 0 (gpv_witness_range_check): the SplitLimbsHint outputs of rangeCheckProof (verifier.go:84-141), one (hi, lo) pair
+        per proof element in the order of the proof struct. Returns (trace [n][words], ok [n])."""
+        import ctypes
+        c = proofs.circuit
+        L = _lib.lib()
+        words = L.gpv_witness_range_check_words(ctypes.c_void_p(c.h))
+        trace = np.empty((proofs.n, words), dtype=np.uint64)
+        ok = np.empty(proofs.n, dtype=np.uint8)
+        _lib.check(L.gpv_witness_range_check(self.ctx.h, c.h, _lib.ptr(proofs.data), proofs.n, _lib.ptr(trace), _lib.ptr(ok)), self.ctx.h)
+        return trace, ok
+
     def WitnessChallenges(self, proofs, with_challenges=True):
         """Witness of the wrapping circuit, protocol slice 1 (gpv_witness_challenges): the outputs of every hint the
         reference calls while Verify runs GetPublicInputsHash and GetChallenges (verifier.go:148-150), in call order. Returns

@@ -198,6 +198,13 @@ int gpv_gl_hints(gpv_ctx* ctx, int hint, const uint64_t* in, uint64_t* out, uint
  * most cap; kinds may be NULL) and returns the number of calls; gpv_witness_challenges_words is the trace length per proof
  * (702 670 words for testdata/step, 655 470 for decode_block). trace [n][words]; challenges [n][gpv_num_challenge_words] or NULL. */
 size_t gpv_witness_challenges_words(const gpv_circuit* c);
+/* Slice 0, the first statement of Verify: rangeCheckProof (verifier/verifier.go:84-141) = one GPV_HINT_SPLIT_LIMBS record (hi, lo) per
+ * proof element except the public inputs, in the order of the proof struct (= the order of the packed record's Goldilocks section).
+ * trace [n][gpv_witness_range_check_words] (19 078 words for decode_block, 19 202 for step); ok[i] = 0 (may be NULL) where an element is
+ * not in the field -- the reference's hint returns an error there. The hint trace of Verify up to verifier.go:150 is this trace followed
+ * by gpv_witness_challenges'. */
+size_t gpv_witness_range_check_words(const gpv_circuit* c);
+int gpv_witness_range_check(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint8_t* ok);
 size_t gpv_witness_challenges_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap);
 int gpv_witness_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint64_t* challenges);
 /* Add/Sub/Mul/Inverse/DivExtension (goldilocks/quadratic_extension.go:31-140), [n][2]; ok[i] = 0 where the

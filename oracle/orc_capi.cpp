@@ -300,6 +300,16 @@ size_t orc_witness_challenges(const void* cv, const void* proofs, size_t n, u64*
   }
   return words;
 }
+// Witness slice 0: the SplitLimbsHint outputs of rangeCheckProof, one proof. Returns the number of words (trace may be NULL).
+size_t orc_witness_range_check(const void* cv, const void* proof, u64* trace) {
+  const Circuit& c = *(const Circuit*)cv;
+  ProofView pv(&c, proof);
+  std::vector<u64> w;
+  wit::Sink sink = {&w, nullptr};
+  wit::witness_range_check(pv, sink);
+  if (trace) memcpy(trace, w.data(), 8 * w.size());
+  return w.size();
+}
 int orc_plonk_verify(const void* cv, const void* proofs, const u64* challenges, size_t n, int32_t* fail) {
   const Circuit& c = *(const Circuit*)cv;
   for (size_t i = 0; i < n; i++) {

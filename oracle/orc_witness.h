@@ -206,6 +206,28 @@ struct Challenger {
   }
 };
 
+// rangeCheckProof (verifier.go:84-141): RangeCheckQE / RangeCheck of the openings (constants, sigmas, wires, Zs, Zs_next, partial products,
+// quotient polys), then per query round the four initial leaves and the evaluations of every step, the final polynomial, the pow witness --
+// the order of the proof struct. Public inputs are not checked (:87-88).
+static inline void witness_range_check(const ProofView& pv, Sink& t) {
+  const Circuit& c = *pv.c;
+  for (u64 i = 0; i < c.num_constants; i++) { range_check(t, pv.constant(i).c[0]); range_check(t, pv.constant(i).c[1]); }
+  for (u64 i = 0; i < c.num_routed_wires; i++) { range_check(t, pv.sigma(i).c[0]); range_check(t, pv.sigma(i).c[1]); }
+  for (u64 i = 0; i < c.num_wires; i++) { range_check(t, pv.wire(i).c[0]); range_check(t, pv.wire(i).c[1]); }
+  for (u64 i = 0; i < c.num_challenges; i++) { range_check(t, pv.z(i).c[0]); range_check(t, pv.z(i).c[1]); }
+  for (u64 i = 0; i < c.num_challenges; i++) { range_check(t, pv.z_next(i).c[0]); range_check(t, pv.z_next(i).c[1]); }
+  for (u64 i = 0; i < c.num_challenges * c.num_partial_products; i++) { range_check(t, pv.partial_product(i).c[0]); range_check(t, pv.partial_product(i).c[1]); }
+  for (u64 i = 0; i < c.num_challenges * c.quotient_degree_factor; i++) { range_check(t, pv.quotient_poly(i).c[0]); range_check(t, pv.quotient_poly(i).c[1]); }
+  for (u64 q = 0; q < c.num_query_rounds; q++) {
+    for (int o = 0; o < 4; o++)
+      for (u64 k = 0; k < c.leaf_len(o); k++) range_check(t, pv.leaf(q, o)[k]);
+    for (u64 s = 0; s < c.num_steps(); s++)
+      for (u64 k = 0; k < ((u64)1 << c.arity_bits[s]); k++) { range_check(t, pv.step_eval(q, s, k).c[0]); range_check(t, pv.step_eval(q, s, k).c[1]); }
+  }
+  for (u64 i = 0; i < c.final_poly_len(); i++) { range_check(t, pv.final_coeff(i).c[0]); range_check(t, pv.final_coeff(i).c[1]); }
+  range_check(t, pv.pow_witness());
+}
+
 // GetPublicInputsHash (verifier.go:41-43) then GetChallenges (:45-82, challenger.go:117-144), in Verify's order (:148-150).
 // Fills the challenge vector in the layout of Challenges::flatten.
 static inline void witness_challenges(const ProofView& pv, Sink& t, u64* challenges_out) {

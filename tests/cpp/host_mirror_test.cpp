@@ -2,6 +2,7 @@
 // gnark-plonky2-verifier_amd/host/gpv.hpp -> include/gpv.h -> libgpv.so. Built and run by tests/test_host_mirror_cpp.py.
 //   usage: host_mirror_test <fixture dir> [--no-gpu]
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 
@@ -108,6 +109,12 @@ int main(int argc, char** argv) {
     size_t words = 0;
     for (uint8_t k : kinds) words += k == GPV_HINT_REDUCE ? 5 : 2;
     EXPECT(words == trace.size());
+    std::vector<uint8_t> rok;
+    std::vector<uint64_t> rtrace = chip.WitnessRangeCheck(proof, &rok);  // slice 0: (hi, lo) of every proof element
+    EXPECT(rtrace.size() == gpv_witness_range_check_words(circuit.h()) && rok[0] == 1);
+    uint64_t first;
+    memcpy(&first, proof.data(), 8);
+    EXPECT(rtrace[0] == first >> 32 && rtrace[1] == (first & 0xFFFFFFFFu));
   }
   // hint functions (base.go:223-243 and base_test.go:97-116): 2^63 * 2^63 + 3 = quotient * p + 18446744068340842500
   {

@@ -492,6 +492,18 @@ class Oracle:
         assert got == words
         return trace, kinds, ch
 
+    def witness_range_check(self, oc, proofs):
+        """oracle/orc_witness.h witness_range_check: [n][words] SplitLimbsHint outputs of rangeCheckProof (verifier.go:84-141)."""
+        buf, n = self._proofs(oc, proofs)
+        f = self.lib.orc_witness_range_check
+        f.restype = ctypes.c_size_t
+        rows = buf.reshape(n, -1)
+        words = f(ctypes.c_void_p(oc.h), _p(rows[0]), None)
+        out = np.empty((n, words), dtype=np.uint64)
+        for i in range(n):
+            assert f(ctypes.c_void_p(oc.h), _p(np.ascontiguousarray(rows[i])), _p(out[i])) == words
+        return out
+
     def plonk_verify(self, oc, proofs, challenges):
         buf, n = self._proofs(oc, proofs)
         ch = u64arr(challenges).reshape(n, oc.ncw)

@@ -363,5 +363,13 @@ def test_witness_challenges_layout_and_oracle_trace(gpv, name):
     got = np.empty(n_hints, dtype=np.uint8)
     L.gpv_witness_challenges_layout(ctypes.c_void_p(circuit.h), gpv._lib.ptr(got), n_hints)
     assert (got == ok).all()
+    # slice 0, rangeCheckProof (verifier.go:84-141): the oracle walks the proof struct field by field; the result is one (hi, lo) pair per
+    # word of the record's Goldilocks section up to the public inputs, in record order -- which is what the GPU kernel emits
+    rc = orc.witness_range_check(oc, packed)
+    rec = np.frombuffer(packed, dtype=np.uint64)
+    n_gl = T.query_section_layout(ci)[4]
+    body = rec[:n_gl - ci.num_public_inputs]
+    assert rc.shape == (1, 2 * body.size) and (rc[0, 0::2] == body >> np.uint64(32)).all() and (rc[0, 1::2] == (body & np.uint64(0xFFFFFFFF))).all()
+    assert L.gpv_witness_range_check_words(ctypes.c_void_p(circuit.h)) == rc.shape[1] == {"decode_block": 19078, "step": 19202}[name]
     # per permutation: 130 MulAdd + 630 Reduce + 890 SplitLimbs = 5190 words
     assert int((ok == 0).sum()) * 2 + int((ok == 1).sum()) * 5 + int((ok == 3).sum()) * 2 == len(words)

@@ -1643,3 +1643,11 @@ def test_witness_challenges_trace(gpv, api, orc, name):
     assert (trace[0] == np.array(words, dtype=np.uint64)).all() and (kinds == np.array(ekinds, dtype=np.uint8)).all()
     words, _, _ = T.witness_challenges_exact(ci, batch[n - 1].tobytes())
     assert (trace[n - 1] == np.array(words, dtype=np.uint64)).all()
+    # slice 0: rangeCheckProof (verifier.go:84-141) -- one SplitLimbs (hi, lo) per proof element in the order of the proof struct;
+    # a non-canonical element is where the reference's hint returns an error (ok = 0)
+    w[3, 11] = np.uint64(P)
+    w[5, n_open + 7] = np.uint64(2**64 - 1)
+    pb2 = gpv.variables.ProofBatch(circuit, batch)
+    rtrace, ok = chip.WitnessRangeCheck(pb2)
+    assert (rtrace == orc.witness_range_check(oc, batch)).all()
+    assert ok.tolist() == [0 if i in (3, 5) else 1 for i in range(n)]
