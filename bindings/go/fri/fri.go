@@ -151,6 +151,11 @@ func (f *Chip) VerifyMerkleProofsToCap(p variables.Proof, challenges []uint64) [
 	return f.ctx.MerkleVerify(f.circuit, p.Packed, challenges)
 }
 
+// WitnessFriProof: the hint outputs the wrapping circuit's solver asks for in GetInstance + VerifyFriProof, in call order (SURVEY 8f.3).
+func (f *Chip) WitnessFriProof(p variables.Proof, challenges []uint64) (trace []uint64, consistent []bool) {
+	return f.ctx.WitnessFri(f.circuit, p.Packed, challenges)
+}
+
 // Device-resident forms (BASELINE configs 3 and 5): raw device addresses, enqueued on the context's stream.
 func (f *Chip) VerifyFriProofDevice(proofsDev, challengesDev unsafe.Pointer, n int, failMaskDev unsafe.Pointer) {
 	f.ctx.FriVerifyDev(f.circuit, proofsDev, challengesDev, n, failMaskDev)

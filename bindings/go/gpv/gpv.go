@@ -546,3 +546,23 @@ func (ctx *Context) WitnessChallenges(c *Circuit, proofs []byte) (trace []uint64
 	check(C.gpv_witness_challenges(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(trace), u64p(challenges)), ctx.h)
 	return trace, challenges
 }
+
+// WitnessFri: slice 2, the hint outputs of fri.Chip.GetInstance + VerifyFriProof (fri/fri.go:40-61, :500-548) for the given challenges;
+// consistent[i] is false where one of the reference's FRI consistency assertions fails.
+func (c *Circuit) WitnessFriLayout() []uint8 {
+	n := int(C.gpv_witness_fri_layout(c.h, nil, 0))
+	kinds := make([]uint8, n)
+	C.gpv_witness_fri_layout(c.h, (*C.uint8_t)(unsafe.Pointer(&kinds[0])), C.size_t(n))
+	return kinds
+}
+func (ctx *Context) WitnessFri(c *Circuit, proofs []byte, challenges []uint64) ([]uint64, []bool) {
+	n := len(proofs) / c.ProofNBytes()
+	trace := make([]uint64, n*int(C.gpv_witness_fri_words(c.h)))
+	cb := make([]byte, n)
+	check(C.gpv_witness_fri(ctx.h, c.h, unsafe.Pointer(&proofs[0]), u64p(challenges), C.size_t(n), u64p(trace), (*C.uint8_t)(unsafe.Pointer(&cb[0]))), ctx.h)
+	cons := make([]bool, n)
+	for i := range cb {
+		cons[i] = cb[i] == 1
+	}
+	return trace, cons
+}

@@ -1018,6 +1018,47 @@ extern "C" int gpv_witness_challenges(gpv_ctx* ctx, const gpv_circuit* c, const 
   return GPV_OK;
 }
 
+// Witness slice 2 (csrc/gpv_witness.cuh): the hint outputs of fri.Chip.GetInstance + VerifyFriProof for caller-supplied challenges.
+extern "C" int gpv_witness_fri(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n, uint64_t* trace,
+                               uint8_t* consistent) {
+  REQUIRE(ctx, ctx && c && proofs && challenges && trace);
+  ENTER(ctx);
+  if (n == 0) return GPV_OK;
+  for (u32 s = 0; s < c->dc.num_steps; s++) REQUIRE(ctx, c->dc.arity_bits[s] <= 5);
+  size_t prefix = 0, round = 0;
+  gpvi_witness_fri_sizes(c, &prefix, &round);
+  const size_t nq = c->dc.num_queries, words = prefix + nq * round, ncw = c->dc.n_challenge_words;
+  HostBatch hb;
+  int rc = hb.upload(ctx, c, proofs, n);
+  if (rc != GPV_OK) return rc;
+  const DevCircuit* dcd;
+  rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  DevBuf<u64> dtrace, dch, dwritten;
+  DevBuf<uint8_t> dcons;
+  HIP_TRY(ctx, dtrace.alloc(words * n));
+  HIP_TRY(ctx, dch.alloc(ncw * n));
+  HIP_TRY(ctx, dwritten.alloc(nq * n));
+  HIP_TRY(ctx, dcons.alloc(n));
+  HIP_TRY(ctx, hipMemcpyAsync(dch.p, challenges, 8 * ncw * n, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * nq * n, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(dcons.p, 1, n, ctx->stream));
+  gpvk_witness_fri(ctx->stream, dcd, c->dc, (const u64*)hb.proofs.p, dch.p, n, dtrace.p, words, prefix, round, dcons.p, dwritten.p);
+  CHECK_LAUNCH(ctx);
+  std::vector<u64> written(nq * n);
+  HIP_TRY(ctx, hipMemcpyAsync(written.data(), dwritten.p, 8 * nq * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(trace, dtrace.p, 8 * words * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (consistent) HIP_TRY(ctx, hipMemcpyAsync(consistent, dcons.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < nq * n; i++)
+    if (written[i] != round + (i % nq == 0 ? prefix : 0)) {  // the kernel's walk and the host's layout are written separately
+      ctx_error(ctx, "witness trace of proof %zu, query round %zu has %llu words, the layout says %zu", i / nq, i % nq,
+                (unsigned long long)written[i], round + (i % nq == 0 ? prefix : 0));
+      return GPV_EDEVICE;
+    }
+  return GPV_OK;
+}
+
 // Witness slice 0: rangeCheckProof (verifier.go:84-141), the first statement of Verify -- one SplitLimbsHint per proof element.
 extern "C" int gpv_witness_range_check(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint8_t* ok) {
   REQUIRE(ctx, ctx && c && proofs && trace);

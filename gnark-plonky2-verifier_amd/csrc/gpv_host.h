@@ -22,3 +22,4 @@ struct gpv_circuit {
 void gpv_set_global_error(const char* fmt, ...);
 const char* gpv_get_global_error();
 void gpv_circuit_release_device(gpv_circuit* c);
+void gpvi_witness_fri_sizes(const gpv_circuit* c, size_t* prefix_words, size_t* round_words);  // gpv_ingest.cpp

@@ -810,6 +810,74 @@ struct WitLayout {
     }
   }
 };
+// ---- slice 2: fri.Chip.GetInstance + VerifyFriProof (csrc/gpv_witness.cuh, second half), the same walk without the arithmetic
+struct FriWitLayout : WitLayout {
+  void inverse() { push(GPV_HINT_INVERSE, 1); split(); mul_add(); }  // base.go:297-313
+  void ext2_mul_add() { mul_add(); mul_add(); }                      // AddExtension / SubExtension / ScalarMulExtension
+  void reduce_ext() { reduce(); reduce(); }                          // Mul / MulAdd / SubMul Extension
+  void inverse_ext() { mul_add(); reduce_ext(); inverse(); ext2_mul_add(); }  // quadratic_extension.go:123-134
+  void div_ext() { inverse_ext(); reduce_ext(); }
+  void exp_ext(uint64_t e) {  // :143-171
+    if (e < 2) return;
+    if (e == 2) { reduce_ext(); return; }
+    int len = 64 - __builtin_clzll(e);
+    for (int i = 0; i < len; i++) {
+      if (i != 0) reduce_ext();
+      if ((e >> i) & 1) reduce_ext();
+    }
+  }
+  void exp_from_bits(uint32_t n_bits) { for (uint32_t i = 0; i < 3 * n_bits; i++) mul_add(); }  // fri.go:159-185
+  void compute_evaluation(uint32_t ab) {  // fri.go:314-384 + :261-312
+    const uint32_t A = 1u << ab;
+    exp_from_bits(ab);
+    mul_add();
+    for (uint32_t i = 1; i < A; i++) reduce_ext();
+    for (uint32_t i = 0; i < A; i++) {
+      for (uint32_t j = 0; j + 1 < A; j++) reduce_ext();
+      inverse_ext();
+    }
+    for (uint32_t i = 0; i < A; i++) reduce_ext();
+    for (uint32_t i = 0; i < A; i++) { ext2_mul_add(); div_ext(); reduce_ext(); ext2_mul_add(); }
+    reduce_ext();
+    for (uint32_t i = 0; i < A; i++) ext2_mul_add();
+  }
+};
+struct FriWitSizes {
+  size_t prefix_words, round_words, hints;
+};
+FriWitSizes witness_fri_layout(const DevCircuit& c, std::vector<uint8_t>* kinds) {
+  FriWitLayout L;
+  L.kinds = kinds;
+  const size_t n_all = (c.off_zs_next - c.off_constants) / 2 + (c.off_queries - c.off_pp) / 2;  // polynomials opened at zeta
+  L.reduce_ext();                                        // GetInstance fri.go:46-50
+  for (size_t i = 0; i < n_all; i++) L.reduce_ext();     // fromOpeningsAndAlpha :82-95
+  for (uint32_t i = 0; i < c.num_challenges; i++) L.reduce_ext();
+  FriWitSizes z;
+  z.prefix_words = L.words;
+  for (uint32_t q = 0; q < c.num_queries; q++) {         // verifyQueryRound :386-498
+    const size_t before = L.words;
+    L.reduce();
+    L.exp_from_bits(c.lde_bits);
+    L.mul_add();
+    const size_t lens[2] = {n_all, c.num_challenges};
+    for (int b = 0; b < 2; b++) {                        // friCombineInitial :208-251
+      for (size_t i = 0; i < lens[b]; i++) L.reduce_ext();
+      L.ext2_mul_add();
+      L.exp_ext(lens[b]);
+      L.reduce_ext();
+      L.inverse_ext();
+      L.reduce_ext();
+    }
+    for (uint32_t s = 0; s < c.num_steps; s++) {
+      L.compute_evaluation(c.arity_bits[s]);
+      for (uint32_t j = 0; j < c.arity_bits[s]; j++) L.mul_add();
+    }
+    for (uint32_t i = 0; i < c.final_len; i++) L.reduce_ext();
+    z.round_words = L.words - before;  // the same for every round: the schedule is data-independent
+  }
+  z.hints = L.hints;
+  return z;
+}
 WitLayout witness_challenges_layout(const DevCircuit& c, std::vector<uint8_t>* kinds) {
   WitLayout L;
   L.kinds = kinds;
@@ -835,6 +903,24 @@ WitLayout witness_challenges_layout(const DevCircuit& c, std::vector<uint8_t>* k
   return L;
 }
 }  // namespace
+extern "C" size_t gpv_witness_fri_words(const gpv_circuit* c) {
+  if (!c) return 0;
+  FriWitSizes z = witness_fri_layout(c->dc, nullptr);
+  return z.prefix_words + (size_t)c->dc.num_queries * z.round_words;
+}
+extern "C" size_t gpv_witness_fri_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap) {
+  if (!c) return 0;
+  std::vector<uint8_t> k;
+  FriWitSizes z = witness_fri_layout(c->dc, kinds ? &k : nullptr);
+  if (kinds) memcpy(kinds, k.data(), k.size() < cap ? k.size() : cap);
+  return z.hints;
+}
+// sizes the kernel launch needs (gpv_api.cpp)
+void gpvi_witness_fri_sizes(const gpv_circuit* c, size_t* prefix_words, size_t* round_words) {
+  FriWitSizes z = witness_fri_layout(c->dc, nullptr);
+  *prefix_words = z.prefix_words;
+  *round_words = z.round_words;
+}
 extern "C" size_t gpv_witness_range_check_words(const gpv_circuit* c) { return c ? 2 * (size_t)c->dc.off_pi : 0; }
 extern "C" size_t gpv_witness_challenges_words(const gpv_circuit* c) { return c ? witness_challenges_layout(c->dc, nullptr).words : 0; }
 extern "C" size_t gpv_witness_challenges_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap) {

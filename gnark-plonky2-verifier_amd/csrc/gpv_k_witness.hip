@@ -38,3 +38,25 @@ __global__ __launch_bounds__(256) void k_witness_range_check(const DevCircuit* _
 void gpvk_witness_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, uint8_t* ok) {
   GPVK_LAUNCH(k_witness_range_check, dim3(4096), dim3(256), 0, st, dcd, proofs, n, trace, ok);
 }
+
+// Witness slice 2: one lane per (proof, query round); the lane of query 0 also emits what precedes the rounds. written[p * nq + q] =
+// words the lane wrote (checked on the host against the layout).
+__global__ __launch_bounds__(64) void k_witness_fri(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ challenges,
+                                                    size_t n, u64* __restrict__ trace, size_t words_per_proof, size_t prefix_words, size_t round_words,
+                                                    uint8_t* __restrict__ consistent, u64* __restrict__ written) {
+  size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nq = dc->num_queries;
+  if (item >= n * nq) return;
+  const size_t p = item / nq;
+  const u32 q = (u32)(item - p * nq);
+  size_t wrote = 0;
+  const bool ok = dev_witness_fri(dc, proofs + p * (dc->proof_nbytes / 8), challenges + p * dc->n_challenge_words, q, trace + p * words_per_proof,
+                                  prefix_words, round_words, &wrote);
+  written[item] = wrote;
+  if (!ok) consistent[p] = 0;
+}
+void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
+                      size_t words_per_proof, size_t prefix_words, size_t round_words, uint8_t* consistent, u64* written) {
+  GPVK_LAUNCH(k_witness_fri, dim3(gpvk_blocks_for(n * hc.num_queries, 64)), dim3(64), 0, st, dcd, proofs, challenges, n, trace, words_per_proof,
+              prefix_words, round_words, consistent, written);
+}

@@ -145,6 +145,8 @@ void gpvk_gather_pih(hipStream_t st, const u64* derived, u64* out, u32 ncw, size
 // gpv_k_witness.hip
 void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof,
                              u64* challenges, u64* written);
+void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
+                      size_t words_per_proof, size_t prefix_words, size_t round_words, uint8_t* consistent, u64* written);
 void gpvk_witness_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, uint8_t* ok);
 // gpv_k_plonk.hip
 void gpvk_gate_eval_unfiltered(hipStream_t st, DevGate g, const u64* weights, const u64* constants, u32 n_constants, const u64* wires,

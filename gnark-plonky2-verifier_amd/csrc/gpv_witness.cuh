@@ -258,3 +258,227 @@ GPV_DEV size_t dev_witness_challenges(const DevCircuit* __restrict__ dc, const u
   for (u32 q = 0; q < dc->num_queries; q++, k += step) out[k] = ch.challenge();
   return (size_t)(t.p - trace);
 }
+
+// ================================================================ slice 2: fri.Chip.GetInstance + VerifyFriProof (fri/fri.go:40-61, :500-548)
+// The field part of FRI, literally -- every gl.Chip call of verifyQueryRound (:386-498), calculateSubgroupX (:187-206),
+// expFromBitsConstBase (:159-185), friCombineInitial (:208-251), computeEvaluation (:314-384), interpolate (:261-312) and finalPolyEval
+// (:253-259), with the lazy values of quadratic_extension.go:31-193: n^2 barycentric weights, 32 extension inversions per reduction step,
+// one Reduce pair per extension product. (The verification kernel, dev_fri_query, folds in closed form with two base-field inversions per
+// step and never sees these values.) The Merkle verification of a query round runs in the native BN254 field and calls none of the
+// reference's hint functions; api.ToBinary / Lookup / IsZero are gnark's. InverseHint (base.go:316-336) contributes ONE word.
+// The number of hint calls of a query round depends on the circuit only, so every (proof, query) lane writes at a fixed offset.
+struct WBigExt {
+  WBig c[2];
+};
+GPV_DEV WBigExt wbe_from(Ext a) {
+  WBigExt e;
+  e.c[0] = wb_from(a.a);
+  e.c[1] = wb_from(a.b);
+  return e;
+}
+GPV_DEV u64 wt_mul(WTrace& t, u64 a, u64 b) { return wt_mul_add(t, a, b, 0); }           // base.go:184
+GPV_DEV u64 wt_sub(WTrace& t, u64 a, u64 b) { return wt_mul_add(t, b, GLP - 1, a); }      // base.go:174
+GPV_DEV u64 wt_inverse(WTrace& t, u64 x) {                                               // base.go:297-313 -> InverseHint :316-336
+  u64 inv = gl_inv(x);
+  t.p[0] = inv;
+  t.p += 1;
+  wt_range_check(t, inv);
+  wt_mul(t, inv, x);
+  return inv;
+}
+GPV_DEV Ext wt_add_ext(WTrace& t, Ext a, Ext b) { u64 c0 = wt_add(t, a.a, b.a); u64 c1 = wt_add(t, a.b, b.b); return ext_make(c0, c1); }  // :31
+GPV_DEV Ext wt_sub_ext(WTrace& t, Ext a, Ext b) { u64 c0 = wt_sub(t, a.a, b.a); u64 c1 = wt_sub(t, a.b, b.b); return ext_make(c0, c1); }  // :45
+// a + b (p - 1), unreduced (:53-57 via base.go:179-181); a may be lazy already
+GPV_DEV WBigExt wt_sub_ext_nr(const WBigExt& a, Ext b) {
+  WBigExt r = a;
+  wb_mac(r.c[0], wb_from(b.a), GLP - 1);
+  wb_mac(r.c[1], wb_from(b.b), GLP - 1);
+  return r;
+}
+// (a0 b0 + (7 a1) b1, a0 b1 + a1 b0) + c, unreduced (:65-71, :75-79); a lazy, b and c canonical
+GPV_DEV WBigExt wt_mul_ext_nr_add(const WBigExt& a, Ext b, Ext c) {
+  WBigExt r;
+  r.c[0] = wb_from(c.a);
+  r.c[1] = wb_from(c.b);
+  wb_mac(r.c[0], a.c[0], b.a);
+  wb_mac(r.c[0], wb_mul(a.c[1], 7), b.b);
+  wb_mac(r.c[1], a.c[0], b.b);
+  wb_mac(r.c[1], a.c[1], b.a);
+  return r;
+}
+GPV_DEV Ext wt_reduce_ext(WTrace& t, const WBigExt& x) { u64 c0 = wt_reduce(t, x.c[0]); u64 c1 = wt_reduce(t, x.c[1]); return ext_make(c0, c1); }  // :173-175
+GPV_DEV Ext wt_mul_ext(WTrace& t, Ext a, Ext b) { return wt_reduce_ext(t, wt_mul_ext_nr_add(wbe_from(a), b, ext_make(0, 0))); }                  // :59
+GPV_DEV Ext wt_mul_add_ext(WTrace& t, const WBigExt& a, Ext b, Ext c) { return wt_reduce_ext(t, wt_mul_ext_nr_add(a, b, c)); }                     // :75-79
+GPV_DEV Ext wt_sub_mul_ext(WTrace& t, Ext a, Ext b, Ext c) {                                                                                      // :89-93
+  return wt_reduce_ext(t, wt_mul_ext_nr_add(wt_sub_ext_nr(wbe_from(a), b), c, ext_make(0, 0)));
+}
+GPV_DEV Ext wt_scalar_mul_ext(WTrace& t, Ext a, u64 b) { u64 c0 = wt_mul(t, a.a, b); u64 c1 = wt_mul(t, a.b, b); return ext_make(c0, c1); }      // :96-104
+__device__ __noinline__ Ext wt_inverse_ext(WTrace& t, Ext a) {  // :123-134
+  Ext f = ext_make(a.a, wt_mul(t, a.b, GLP - 1));               // DTH_ROOT = p - 1
+  Ext n = wt_mul_ext(t, f, a);
+  return wt_scalar_mul_ext(t, f, wt_inverse(t, n.a));
+}
+GPV_DEV Ext wt_div_ext(WTrace& t, Ext a, Ext b) { Ext bi = wt_inverse_ext(t, b); return wt_mul_ext(t, a, bi); }  // :137-140
+GPV_DEV Ext wt_exp_ext(WTrace& t, Ext a, u64 e) {  // :143-171
+  if (e == 0) return ext_make(1, 0);
+  if (e == 1) return a;
+  if (e == 2) return wt_mul_ext(t, a, a);
+  Ext cur = a, prod = ext_make(1, 0);
+  const int len = 64 - __clzll((long long)e);
+#pragma unroll 1
+  for (int i = 0; i < len; i++) {
+    if (i != 0) cur = wt_mul_ext(t, cur, cur);
+    if ((e >> i) & 1) prod = wt_mul_ext(t, prod, cur);
+  }
+  return prod;
+}
+// fri.go:159-185; bits: bit i of `bits` pairs with base^(2^i)
+GPV_DEV u64 wt_exp_from_bits_const_base(WTrace& t, u64 base, u32 bits, u32 n_bits) {
+  u64 product = 1, base_pow = base;
+#pragma unroll 1
+  for (u32 i = 0; i < n_bits; i++) {
+    u64 m1 = wt_mul(t, gl_sub(base_pow, 1), product);
+    u64 m2 = wt_mul(t, m1, (bits >> i) & 1);
+    product = wt_add(t, m2, product);
+    base_pow = gl_sqr(base_pow);
+  }
+  return product;
+}
+#define GPV_WIT_MAX_ARITY 32
+// computeEvaluation :314-384 + interpolate :261-312
+__device__ __noinline__ Ext wt_compute_evaluation(WTrace& t, u64 x, u32 idx_in, u32 ab, const u64* __restrict__ evals, Ext beta) {
+  const u32 A = 1u << ab;
+  u64 g = 1753635133440165772ULL;
+#pragma unroll 1
+  for (u32 i = 0; i < 32 - ab; i++) g = gl_sqr(g);
+  u64 g_inv = 1;
+  {
+    u64 gp = g;
+#pragma unroll 1
+    for (u32 b = 0; b < ab; b++) {  // g^(A-1) = product of g^(2^b)
+      g_inv = gl_mul(g_inv, gp);
+      gp = gl_sqr(gp);
+    }
+  }
+  const u32 rev = __brev(idx_in) >> (32 - ab);  // bit i of the reversed list = bit (ab - 1 - i) of idx_in
+  const u64 start = wt_exp_from_bits_const_base(t, g_inv, rev, ab);
+  const u64 coset_start = wt_mul(t, start, x);
+  Ext xs[GPV_WIT_MAX_ARITY], ws[GPV_WIT_MAX_ARITY];
+  xs[0] = ext_make(coset_start, 0);
+#pragma unroll 1
+  for (u32 i = 1; i < A; i++) xs[i] = wt_mul_ext(t, xs[i - 1], ext_make(g, 0));
+#pragma unroll 1
+  for (u32 i = 0; i < A; i++) {
+    Ext w = ext_make(1, 0);
+#pragma unroll 1
+    for (u32 j = 0; j < A; j++)
+      if (i != j) w = wt_sub_mul_ext(t, xs[i], xs[j], w);
+    ws[i] = wt_inverse_ext(t, w);
+  }
+  Ext lx = ext_make(1, 0);
+#pragma unroll 1
+  for (u32 i = 0; i < A; i++) lx = wt_sub_mul_ext(t, beta, xs[i], lx);
+  Ext total = ext_make(0, 0);
+#pragma unroll 1
+  for (u32 i = 0; i < A; i++) {
+    const u32 src = __brev(i) >> (32 - ab);  // permutedEvals[i] = evals[bitrev(i)] (the permutation is an involution)
+    Ext d = wt_sub_ext(t, beta, xs[i]);
+    Ext q = wt_div_ext(t, ws[i], d);
+    Ext m = wt_mul_ext(t, ext_make(evals[2 * src], evals[2 * src + 1]), q);
+    total = wt_add_ext(t, m, total);
+  }
+  Ext interpolation = wt_mul_ext(t, lx, total);
+#pragma unroll 1
+  for (u32 i = 0; i < A; i++) wt_sub_ext(t, beta, xs[i]);  // the lookup loop :301-309 (IsZero / Lookup have no hints)
+  return interpolation;
+}
+// ReduceWithPowers (:177-193) over extension elements stored as consecutive words, from the last one down
+GPV_DEV Ext wt_reduce_with_powers_words(WTrace& t, const u64* __restrict__ lo, const u64* __restrict__ hi, Ext acc, Ext s) {
+#pragma unroll 1
+  for (const u64* w = hi; w > lo; w -= 2) acc = wt_mul_add_ext(t, wbe_from(acc), s, ext_make(w[-2], w[-1]));
+  return acc;
+}
+// One (proof, query) lane. prefix_words: length of the part that precedes the query rounds (GetInstance + fromOpeningsAndAlpha), emitted
+// by the lane of query 0; round_words: length of one query round. Returns false when one of the reference's FRI consistency assertions
+// (:460-461, :496-497) fails -- the trace is what the solver would be handed either way.
+GPV_DEV bool dev_witness_fri(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch, u32 q,
+                             u64* __restrict__ trace, size_t prefix_words, size_t round_words, size_t* written) {
+  const Ext zeta = ext_make(ch[dc->ch_zeta], ch[dc->ch_zeta + 1]), alpha = ext_make(ch[dc->ch_fri_alpha], ch[dc->ch_fri_alpha + 1]);
+  const OpeningRanges orr = opening_ranges(dc);
+  Ext points[2], precomputed[2];
+  size_t wrote = 0;
+  if (q == 0) {  // GetInstance fri.go:46-50, then fromOpeningsAndAlpha :82-95: the zeta batch, then the zeta*g batch
+    WTrace t;
+    t.p = trace;
+    points[1] = wt_mul_ext(t, ext_make(dc->root_degree, 0), zeta);
+    Ext acc = wt_reduce_with_powers_words(t, rec + orr.b0, rec + orr.b1, ext_make(0, 0), alpha);
+    precomputed[0] = wt_reduce_with_powers_words(t, rec + orr.a0, rec + orr.a1, acc, alpha);
+    precomputed[1] = wt_reduce_with_powers_words(t, rec + orr.c0, rec + orr.c1, ext_make(0, 0), alpha);
+    wrote = (size_t)(t.p - trace);
+  } else {  // the same values without a trace
+    points[1] = ext_scalar_mul(zeta, dc->root_degree);
+    Ext acc = ext_make(0, 0);
+    for (u32 w = orr.b1; w > orr.b0; w -= 2) acc = ext_muladd(acc, alpha, ext_make(rec[w - 2], rec[w - 1]));
+    for (u32 w = orr.a1; w > orr.a0; w -= 2) acc = ext_muladd(acc, alpha, ext_make(rec[w - 2], rec[w - 1]));
+    precomputed[0] = acc;
+    acc = ext_make(0, 0);
+    for (u32 w = orr.c1; w > orr.c0; w -= 2) acc = ext_muladd(acc, alpha, ext_make(rec[w - 2], rec[w - 1]));
+    precomputed[1] = acc;
+  }
+  points[0] = zeta;
+  WTrace t;
+  t.p = trace + prefix_words + (size_t)q * round_words;
+  u64* const round_start = t.p;
+  bool ok = true;
+  const u64* qrec = rec + dc->off_queries + (size_t)q * dc->query_words;
+  const u32 nlog = dc->lde_bits;
+  WBig xi = wb_from(ch[dc->ch_queries + q]);
+  const u64 x_index = wt_reduce(t, xi);  // :400
+  u32 idx = (u32)(x_index & (((u64)1 << nlog) - 1));
+  // calculateSubgroupX :187-206: the reversed bit list pairs bit (nlog - 1 - i) with base^(2^i)
+  u64 x = wt_mul(t, 7, wt_exp_from_bits_const_base(t, dc->root_lde, __brev(idx) >> (32 - nlog), nlog));
+  // friCombineInitial :208-251
+  Ext total = ext_make(0, 0);
+#pragma unroll 1
+  for (int b = 0; b < 2; b++) {
+    Ext reduced = ext_make(0, 0);
+    u32 n_evals = 0;
+    if (b == 0) {
+#pragma unroll 1
+      for (int o = 3; o >= 0; o--) {  // ReduceWithPowers runs from the last polynomial down: oracle 3 first
+        const u32 len = dc->leaf_len[o] - dc->leaf_salt[o];
+        n_evals += len;
+#pragma unroll 1
+        for (u32 i = len; i-- > 0;) reduced = wt_mul_add_ext(t, wbe_from(reduced), alpha, ext_make(qrec[dc->leaf_off[o] + i], 0));
+      }
+    } else {
+      n_evals = dc->num_challenges;
+#pragma unroll 1
+      for (u32 i = n_evals; i-- > 0;) reduced = wt_mul_add_ext(t, wbe_from(reduced), alpha, ext_make(qrec[dc->leaf_off[2] + i], 0));
+    }
+    WBigExt numerator = wt_sub_ext_nr(wbe_from(reduced), precomputed[b]);
+    Ext denominator = wt_sub_ext(t, ext_make(x, 0), points[b]);
+    Ext e = wt_exp_ext(t, alpha, n_evals);
+    total = wt_mul_ext(t, e, total);
+    Ext inv = wt_inverse_ext(t, denominator);
+    total = wt_mul_add_ext(t, numerator, inv, total);
+  }
+  Ext old_eval = total;
+#pragma unroll 1
+  for (u32 s = 0; s < dc->num_steps; s++) {
+    const u64* evals = qrec + dc->step_evals_off[s];
+    const u32 ab = dc->arity_bits[s];
+    const u32 idx_in = idx & ((1u << ab) - 1);
+    ok &= evals[2 * idx_in] == old_eval.a && evals[2 * idx_in + 1] == old_eval.b;  // :460-461
+    old_eval = wt_compute_evaluation(t, x, idx_in, ab, evals, ext_make(ch[dc->ch_fri_betas + 2 * s], ch[dc->ch_fri_betas + 2 * s + 1]));
+#pragma unroll 1
+    for (u32 j = 0; j < ab; j++) x = wt_mul(t, x, x);  // :486-488
+    idx >>= ab;
+  }
+  Ext fin = ext_make(0, 0);  // finalPolyEval :253-259
+#pragma unroll 1
+  for (u32 i = dc->final_len; i-- > 0;) fin = wt_mul_add_ext(t, wbe_from(fin), ext_make(x, 0), ext_make(rec[dc->off_final + 2 * i], rec[dc->off_final + 2 * i + 1]));
+  ok &= fin.a == old_eval.a && fin.b == old_eval.b;  // :496-497
+  *written = wrote + (size_t)(t.p - round_start);
+  return ok;
+}

@@ -129,6 +129,24 @@ class Chip:
         _lib.check(_lib.lib().gpv_fri_verify(self.ctx.h, c.h, _lib.ptr(proofs.data), _lib.ptr(flat), proofs.n, _lib.ptr(mask)), self.ctx.h)
         return mask
 
+    def WitnessFriProof(self, proofs, challenges):
+        """Witness slice 2 (gpv_witness_fri): the outputs of every hint the reference calls in GetInstance + VerifyFriProof
+        (fri.go:40-61, :500-548), in call order, for the given challenges. Returns (trace [n][words], kinds [n_hints] = GPV_HINT_* per
+        hint call, consistent [n] = the reference's FRI consistency assertions hold)."""
+        import ctypes
+        c = proofs.circuit
+        L = _lib.lib()
+        flat = challenges.flat if hasattr(challenges, "flat") else challenges
+        flat = _lib.u64c(flat).reshape(proofs.n, c.num_challenge_words)
+        words = L.gpv_witness_fri_words(ctypes.c_void_p(c.h))
+        n_hints = L.gpv_witness_fri_layout(ctypes.c_void_p(c.h), None, 0)
+        kinds = np.empty(n_hints, dtype=np.uint8)
+        L.gpv_witness_fri_layout(ctypes.c_void_p(c.h), _lib.ptr(kinds), n_hints)
+        trace = np.empty((proofs.n, words), dtype=np.uint64)
+        cons = np.empty(proofs.n, dtype=np.uint8)
+        _lib.check(L.gpv_witness_fri(self.ctx.h, c.h, _lib.ptr(proofs.data), _lib.ptr(flat), proofs.n, _lib.ptr(trace), _lib.ptr(cons)), self.ctx.h)
+        return trace, kinds, cons
+
     def VerifyFriProofDevice(self, circuit, proofs_dev_ptr, challenges_dev_ptr, n, fail_mask_dev_ptr):
         """VerifyFriProof on device-resident proofs / challenges / masks (gpv_fri_verify_dev): enqueued on the context's stream."""
         _lib.check(_lib.lib().gpv_fri_verify_dev(self.ctx.h, circuit.h, _lib.ptr(proofs_dev_ptr), _lib.ptr(challenges_dev_ptr), n,

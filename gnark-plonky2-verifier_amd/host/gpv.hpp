@@ -264,6 +264,20 @@ class Chip {
     gpv::check(gpv_merkle_verify(api_.h(), c_.h(), proofs.data(), challenges.data(), n, ok.data()), api_.h());
     return ok;
   }
+  // Witness slice 2: the hint outputs of GetInstance + VerifyFriProof in call order for the given challenges; consistent
+  // (optional) = the reference's FRI consistency assertions hold; kinds (optional) = one GPV_HINT_* id per hint call
+  std::vector<uint64_t> WitnessFriProof(const std::vector<uint8_t>& proofs, const std::vector<uint64_t>& challenges,
+                                        std::vector<uint8_t>* consistent = nullptr, std::vector<uint8_t>* kinds = nullptr) {
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint64_t> trace(n * gpv_witness_fri_words(c_.h()));
+    if (consistent) consistent->resize(n);
+    if (kinds) {
+      kinds->resize(gpv_witness_fri_layout(c_.h(), nullptr, 0));
+      gpv_witness_fri_layout(c_.h(), kinds->data(), kinds->size());
+    }
+    gpv::check(gpv_witness_fri(api_.h(), c_.h(), proofs.data(), challenges.data(), n, trace.data(), consistent ? consistent->data() : nullptr), api_.h());
+    return trace;
+  }
   // device-resident forms (BASELINE configs 3 and 5): raw device pointers, enqueued on the context's stream
   void VerifyFriProofDevice(const void* proofs_dev, const uint64_t* challenges_dev, size_t n, uint32_t* fail_mask_dev) {
     gpv::check(gpv_fri_verify_dev(api_.h(), c_.h(), proofs_dev, challenges_dev, n, fail_mask_dev), api_.h());

@@ -204,6 +204,19 @@ size_t gpv_witness_challenges_words(const gpv_circuit* c);
  * not in the field -- the reference's hint returns an error there. The hint trace of Verify up to verifier.go:150 is this trace followed
  * by gpv_witness_challenges'. */
 size_t gpv_witness_range_check_words(const gpv_circuit* c);
+/* Slice 2: fri.Chip.GetInstance + VerifyFriProof (fri/fri.go:40-61, :500-548) for the given challenges -- the field part of FRI evaluated
+ * literally (n^2 barycentric weights, 32 extension inversions per reduction step, one Reduce pair per extension product: the reference's
+ * verifyQueryRound / friCombineInitial / computeEvaluation / interpolate / finalPolyEval op by op; the verification kernel folds in closed
+ * form and never sees these values). Adds GPV_HINT_INVERSE records of 1 word (InverseHint, base.go:316-336; gl.Inverse = Inverse,
+ * SplitLimbs(inverse), then the MulAdd of inverse * x). The Merkle paths of a query round run in the native BN254 field and call none of
+ * the reference's hint functions. 485 170 words / 160 280 hint calls per testdata/step proof (477 988 / 158 120 for decode_block).
+ * challenges [n][gpv_num_challenge_words] (e.g. from gpv_witness_challenges); trace [n][gpv_witness_fri_words]; consistent[i] (may be
+ * NULL) = 0 where one of the reference's FRI consistency assertions (fri.go:460-461, :496-497) fails -- the trace is what the solver
+ * would be handed either way. Every proof element must be in the field (gpv_witness_range_check's ok), or the reference's hints panic. */
+size_t gpv_witness_fri_words(const gpv_circuit* c);
+size_t gpv_witness_fri_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap);
+int gpv_witness_fri(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n, uint64_t* trace,
+                    uint8_t* consistent);
 int gpv_witness_range_check(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint8_t* ok);
 size_t gpv_witness_challenges_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap);
 int gpv_witness_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint64_t* challenges);

@@ -300,6 +300,23 @@ size_t orc_witness_challenges(const void* cv, const void* proofs, size_t n, u64*
   }
   return words;
 }
+// Witness slice 2 (orc_witness.h): the hint outputs of fri.Chip.GetInstance + VerifyFriProof for supplied challenges, one proof. Returns the
+// number of words; trace / kinds may be NULL (kinds: one GPV_HINT_* id per hint call, *n_hints their number); *consistent = 1 iff every FRI
+// consistency assertion of the reference holds.
+size_t orc_witness_fri(const void* cv, const void* proof, const u64* challenges, u64* trace, unsigned char* kinds, size_t* n_hints, int* consistent) {
+  const Circuit& c = *(const Circuit*)cv;
+  ProofView pv(&c, proof);
+  std::vector<u64> w;
+  std::vector<unsigned char> k;
+  wit::Sink sink = {&w, &k};
+  bool ok = true;
+  wit::witness_fri(pv, Challenges::unflatten(c, challenges), sink, &ok);
+  if (trace) memcpy(trace, w.data(), 8 * w.size());
+  if (kinds) memcpy(kinds, k.data(), k.size());
+  if (n_hints) *n_hints = k.size();
+  if (consistent) *consistent = ok ? 1 : 0;
+  return w.size();
+}
 // Witness slice 0: the SplitLimbsHint outputs of rangeCheckProof, one proof. Returns the number of words (trace may be NULL).
 size_t orc_witness_range_check(const void* cv, const void* proof, u64* trace) {
   const Circuit& c = *(const Circuit*)cv;

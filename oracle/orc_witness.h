@@ -28,7 +28,7 @@
 namespace orc {
 namespace wit {
 
-enum { HINT_MULADD = 0, HINT_REDUCE = 1, HINT_SPLIT_LIMBS = 3 };  // GPV_HINT_* of include/gpv.h
+enum { HINT_MULADD = 0, HINT_REDUCE = 1, HINT_INVERSE = 2, HINT_SPLIT_LIMBS = 3 };  // GPV_HINT_* of include/gpv.h
 
 // a lazy native-field value: < 2^256 always suffices here (largest: a 13-term row of 64 x 64-bit products, < 2^132; x * x^6 < 2^192)
 struct Big {
@@ -261,6 +261,183 @@ static inline void witness_challenges(const ProofView& pv, Sink& t, u64* challen
   out.push_back(ch.get_challenge());  // pow response
   for (u64 i = 0; i < c.num_query_rounds; i++) out.push_back(ch.get_challenge());
   if (challenges_out) memcpy(challenges_out, out.data(), 8 * out.size());
+}
+
+
+// ================================================================ slice 2: fri.Chip.GetInstance + VerifyFriProof (fri/fri.go:40-61, :500-548)
+// The field part of FRI, literally: every gl.Chip call of verifyQueryRound (:386-498), calculateSubgroupX (:187-206), expFromBitsConstBase
+// (:159-185), friCombineInitial (:208-251), computeEvaluation (:314-384), interpolate (:261-312) and finalPolyEval (:253-259) with the lazy
+// values of quadratic_extension.go:31-193. The Merkle verification of a query round runs in the native BN254 field and calls none of the
+// reference's hint functions; api.ToBinary / Lookup / IsZero are gnark's. InverseHint (base.go:316-336) contributes ONE word.
+struct BigExt {
+  Big c[2];
+};
+static inline BigExt bext(u64 a, u64 b) { BigExt e; e.c[0] = big(a); e.c[1] = big(b); return e; }
+static inline BigExt bext(Ext a) { return bext(a.c[0], a.c[1]); }
+// 256-bit product of two lazy values (the wider operand stays below 2^132 here, the other below 2^64 .. 2^128): schoolbook on 64-bit words
+static inline Big big_mul(Big a, Big b) {
+  Big r = big(0);
+  for (int i = 0; i < 4; i++) {
+    if (!b.w[i]) continue;
+    Big t = big_mul64(a, b.w[i]);
+    Big sh = big(0);
+    for (int k = 0; k + i < 4; k++) sh.w[k + i] = t.w[k];
+    r = big_add(r, sh);
+  }
+  return r;
+}
+static inline u64 mul(Sink& t, u64 a, u64 b) { return mul_add(t, a, b, 0); }                 // base.go:184
+static inline u64 sub(Sink& t, u64 a, u64 b) { return mul_add(t, b, GL_P - 1, a); }           // base.go:174
+static inline u64 inverse(Sink& t, u64 x) {                                                  // base.go:297-313, hint :316-336
+  u64 inv = gl_inverse(x);
+  t.emit(HINT_INVERSE, &inv, 1);
+  range_check(t, inv);
+  mul(t, inv, x);
+  return inv;
+}
+static inline Ext add_ext(Sink& t, Ext a, Ext b) { u64 c0 = add(t, a.c[0], b.c[0]); u64 c1 = add(t, a.c[1], b.c[1]); return ext(c0, c1); }  // :31
+static inline Ext sub_ext(Sink& t, Ext a, Ext b) { u64 c0 = sub(t, a.c[0], b.c[0]); u64 c1 = sub(t, a.c[1], b.c[1]); return ext(c0, c1); }  // :45
+static inline BigExt sub_ext_nr(BigExt a, Ext b) {  // :53-57 via base.go:179-181: a + b * (p - 1), unreduced
+  BigExt r;
+  for (int k = 0; k < 2; k++) r.c[k] = big_add(a.c[k], big_mul64(big(b.c[k]), GL_P - 1));
+  return r;
+}
+static inline BigExt mul_ext_nr(BigExt a, BigExt b) {  // :65-71
+  BigExt r;
+  r.c[0] = big_add(big_mul(a.c[0], b.c[0]), big_mul(big_mul64(a.c[1], GL_W), b.c[1]));
+  r.c[1] = big_add(big_mul(a.c[0], b.c[1]), big_mul(a.c[1], b.c[0]));
+  return r;
+}
+static inline Ext reduce_ext(Sink& t, BigExt x) { u64 c0 = reduce(t, x.c[0]); u64 c1 = reduce(t, x.c[1]); return ext(c0, c1); }  // :173-175
+static inline Ext mul_ext(Sink& t, Ext a, Ext b) { return reduce_ext(t, mul_ext_nr(bext(a), bext(b))); }                      // :59
+static inline Ext mul_add_ext(Sink& t, BigExt a, Ext b, Ext c) {                                                              // :75-79
+  BigExt p = mul_ext_nr(a, bext(b));
+  p.c[0] = big_add(p.c[0], big(c.c[0]));
+  p.c[1] = big_add(p.c[1], big(c.c[1]));
+  return reduce_ext(t, p);
+}
+static inline Ext sub_mul_ext(Sink& t, Ext a, Ext b, Ext c) { return reduce_ext(t, mul_ext_nr(sub_ext_nr(bext(a), b), bext(c))); }  // :89-93
+static inline Ext scalar_mul_ext(Sink& t, Ext a, u64 b) { u64 c0 = mul(t, a.c[0], b); u64 c1 = mul(t, a.c[1], b); return ext(c0, c1); }  // :96-104
+static inline Ext inverse_ext(Sink& t, Ext a) {  // :123-134
+  Ext f = ext(a.c[0], mul(t, a.c[1], GL_DTH_ROOT));
+  Ext n = mul_ext(t, f, a);
+  return scalar_mul_ext(t, f, inverse(t, n.c[0]));
+}
+static inline Ext div_ext(Sink& t, Ext a, Ext b) { Ext bi = inverse_ext(t, b); return mul_ext(t, a, bi); }  // :137-140
+static inline Ext exp_ext(Sink& t, Ext a, u64 e) {  // :143-171
+  if (e == 0) return ext_one();
+  if (e == 1) return a;
+  if (e == 2) return mul_ext(t, a, a);
+  Ext cur = a, prod = ext_one();
+  int len = 64 - __builtin_clzll(e);
+  for (int i = 0; i < len; i++) {
+    if (i != 0) cur = mul_ext(t, cur, cur);
+    if ((e >> i) & 1) prod = mul_ext(t, prod, cur);
+  }
+  return prod;
+}
+static inline Ext reduce_with_powers(Sink& t, const std::vector<Ext>& terms, Ext s) {  // :177-193
+  Ext acc = ext_zero();
+  for (size_t i = terms.size(); i-- > 0;) acc = mul_add_ext(t, bext(acc), s, terms[i]);
+  return acc;
+}
+static inline u64 exp_from_bits_const_base(Sink& t, u64 base, const std::vector<u64>& bits) {  // fri.go:159-185
+  u64 product = 1;
+  for (size_t i = 0; i < bits.size(); i++) {
+    u64 base_pow = gl_exp(base, (u64)1 << i);
+    u64 m1 = mul(t, gl_sub(base_pow, 1), product);
+    u64 m2 = mul(t, m1, bits[i]);
+    product = add(t, m2, product);
+  }
+  return product;
+}
+static inline Ext compute_evaluation(Sink& t, u64 x, const std::vector<u64>& idx_bits, u64 arity_bits, const std::vector<Ext>& evals, Ext beta) {  // :314-384
+  const size_t arity = (size_t)1 << arity_bits;
+  u64 g = gl_primitive_root_of_unity((unsigned)arity_bits);
+  u64 g_inv = gl_exp(g, arity - 1);
+  std::vector<Ext> permuted(arity);
+  for (size_t i = 0; i < arity; i++) {
+    size_t r = 0;
+    for (u64 b = 0; b < arity_bits; b++) r |= ((i >> b) & 1) << (arity_bits - 1 - b);
+    permuted[r] = evals[i];
+  }
+  std::vector<u64> rev(idx_bits.rbegin(), idx_bits.rend());
+  u64 start = exp_from_bits_const_base(t, g_inv, rev);
+  u64 coset_start = mul(t, start, x);
+  std::vector<Ext> xs(arity), ws(arity);
+  xs[0] = ext(coset_start, 0);
+  for (size_t i = 1; i < arity; i++) xs[i] = mul_ext(t, xs[i - 1], ext(g, 0));
+  for (size_t i = 0; i < arity; i++) {
+    Ext w = ext_one();
+    for (size_t j = 0; j < arity; j++)
+      if (i != j) w = sub_mul_ext(t, xs[i], xs[j], w);
+    ws[i] = inverse_ext(t, w);
+  }
+  Ext lx = ext_one();  // interpolate :261-312
+  for (size_t i = 0; i < arity; i++) lx = sub_mul_ext(t, beta, xs[i], lx);
+  Ext total = ext_zero();
+  for (size_t i = 0; i < arity; i++) {
+    Ext d = sub_ext(t, beta, xs[i]);
+    Ext q = div_ext(t, ws[i], d);
+    Ext m = mul_ext(t, permuted[i], q);
+    total = add_ext(t, m, total);
+  }
+  Ext interpolation = mul_ext(t, lx, total);
+  for (size_t i = 0; i < arity; i++) sub_ext(t, beta, xs[i]);  // the lookup loop :301-309 (IsZero / Lookup have no hints)
+  return interpolation;
+}
+// One proof: GetInstance, fromOpeningsAndAlpha, then every query round in order. `ok` is cleared when one of the reference's FRI
+// consistency assertions (:460-461, :496-497) fails -- the trace is the solver's either way.
+static inline void witness_fri(const ProofView& pv, const Challenges& ch, Sink& t, bool* ok) {
+  const Circuit& c = *pv.c;
+  Ext zeta_next = mul_ext(t, ext(gl_primitive_root_of_unity((unsigned)c.degree_bits), 0), ch.zeta);  // GetInstance fri.go:46-50
+  Ext points[2] = {ch.zeta, zeta_next};
+  std::vector<Ext> zb, znb;
+  fri_openings(pv, zb, znb);
+  Ext precomputed[2] = {reduce_with_powers(t, zb, ch.fri_alpha), reduce_with_powers(t, znb, ch.fri_alpha)};  // :82-95
+  const u64 nlog = c.lde_bits();
+  for (u64 q = 0; q < c.num_query_rounds; q++) {  // verifyQueryRound :386-498
+    u64 x_index = reduce(t, big(ch.fri_query_indices[q]));
+    std::vector<u64> bits(nlog);
+    for (u64 i = 0; i < nlog; i++) bits[i] = (x_index >> i) & 1;
+    std::vector<u64> rev(bits.rbegin(), bits.rend());
+    u64 subgroup_x = mul(t, GL_MULT_GEN, exp_from_bits_const_base(t, gl_primitive_root_of_unity((unsigned)nlog), rev));  // :187-206
+    Ext total = ext_zero();  // friCombineInitial :208-251
+    for (int b = 0; b < 2; b++) {
+      std::vector<Ext> evals;
+      if (b == 0) {
+        const u64 sizes[4] = {c.num_constants + c.num_routed_wires, c.num_wires, c.num_challenges * (1 + c.num_partial_products),
+                              c.num_challenges * c.quotient_degree_factor};
+        for (int o = 0; o < 4; o++)
+          for (u64 i = 0; i < sizes[o]; i++) evals.push_back(ext(pv.leaf(q, o)[i], 0));
+      } else {
+        for (u64 i = 0; i < c.num_challenges; i++) evals.push_back(ext(pv.leaf(q, 2)[i], 0));
+      }
+      Ext reduced = reduce_with_powers(t, evals, ch.fri_alpha);
+      BigExt numerator = sub_ext_nr(bext(reduced), precomputed[b]);
+      Ext denominator = sub_ext(t, ext(subgroup_x, 0), points[b]);
+      Ext e = exp_ext(t, ch.fri_alpha, evals.size());
+      total = mul_ext(t, e, total);
+      Ext inv = inverse_ext(t, denominator);
+      total = mul_add_ext(t, numerator, inv, total);
+    }
+    Ext old_eval = total;
+    for (u64 s = 0; s < c.num_steps(); s++) {
+      const u64 ab = c.arity_bits[s];
+      std::vector<Ext> evals;
+      for (u64 k = 0; k < ((u64)1 << ab); k++) evals.push_back(pv.step_eval(q, s, k));
+      std::vector<u64> within(bits.begin(), bits.begin() + ab);
+      u64 idx_in = 0;
+      for (u64 i = 0; i < ab; i++) idx_in |= within[i] << i;
+      if (!(evals[idx_in] == old_eval)) *ok = false;
+      old_eval = compute_evaluation(t, subgroup_x, within, ab, evals, ch.fri_betas[s]);
+      for (u64 j = 0; j < ab; j++) subgroup_x = mul(t, subgroup_x, subgroup_x);
+      bits.erase(bits.begin(), bits.begin() + ab);
+    }
+    Ext fin = ext_zero();  // finalPolyEval :253-259
+    for (u64 i = c.final_poly_len(); i-- > 0;) fin = mul_add_ext(t, bext(fin), ext(subgroup_x, 0), pv.final_coeff(i));
+    if (!(fin == old_eval)) *ok = false;
+  }
 }
 
 }  // namespace wit

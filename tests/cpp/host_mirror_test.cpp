@@ -112,6 +112,11 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> rok;
     std::vector<uint64_t> rtrace = chip.WitnessRangeCheck(proof, &rok);  // slice 0: (hi, lo) of every proof element
     EXPECT(rtrace.size() == gpv_witness_range_check_words(circuit.h()) && rok[0] == 1);
+    std::vector<uint8_t> fcons, fkinds;
+    std::vector<uint64_t> ftrace = fri::Chip(api, circuit).WitnessFriProof(proof, wch, &fcons, &fkinds);  // slice 2: the field part of FRI
+    size_t fwords = 0;
+    for (uint8_t k : fkinds) fwords += k == GPV_HINT_REDUCE ? 5 : k == GPV_HINT_INVERSE ? 1 : 2;
+    EXPECT(ftrace.size() == fwords && fcons[0] == 1);
     uint64_t first;
     memcpy(&first, proof.data(), 8);
     EXPECT(rtrace[0] == first >> 32 && rtrace[1] == (first & 0xFFFFFFFFu));

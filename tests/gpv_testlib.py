@@ -492,6 +492,26 @@ class Oracle:
         assert got == words
         return trace, kinds, ch
 
+    def witness_fri(self, oc, proofs, challenges):
+        """oracle/orc_witness.h witness_fri: (trace [n][words], kinds [n_hints], consistent [n]) -- the hint outputs of GetInstance +
+        VerifyFriProof (fri.go:40-61, :500-548) for the supplied challenges."""
+        buf, n = self._proofs(oc, proofs)
+        rows = buf.reshape(n, -1)
+        ch = u64arr(challenges).reshape(n, oc.ncw)
+        f = self.lib.orc_witness_fri
+        f.restype = ctypes.c_size_t
+        nh = ctypes.c_size_t()
+        words = f(ctypes.c_void_p(oc.h), _p(np.ascontiguousarray(rows[0])), _p(np.ascontiguousarray(ch[0])), None, None, ctypes.byref(nh), None)
+        trace = np.empty((n, words), dtype=np.uint64)
+        kinds = np.empty(nh.value, dtype=np.uint8)
+        cons = np.empty(n, dtype=np.uint8)
+        for i in range(n):
+            c = ctypes.c_int()
+            assert f(ctypes.c_void_p(oc.h), _p(np.ascontiguousarray(rows[i])), _p(np.ascontiguousarray(ch[i])), _p(trace[i]), _p(kinds), ctypes.byref(nh),
+                     ctypes.byref(c)) == words
+            cons[i] = c.value
+        return trace, kinds, cons
+
     def witness_range_check(self, oc, proofs):
         """oracle/orc_witness.h witness_range_check: [n][words] SplitLimbsHint outputs of rangeCheckProof (verifier.go:84-141)."""
         buf, n = self._proofs(oc, proofs)
@@ -1105,3 +1125,172 @@ def witness_challenges_exact(ci, packed):
     out.append(ch.challenge())                                                 # :134
     out += [ch.challenge() for _ in range(ci.num_query_rounds)]                # :135
     return w.words, w.kinds, out
+
+
+# ---------------------------------------------------------------- witness slice 2: the hint outputs of fri.Chip.GetInstance + VerifyFriProof
+# (fri/fri.go:40-61, :500-548 -> :386-498 verifyQueryRound, :159-206, :208-251, :253-259, :261-384; goldilocks/quadratic_extension.go:31-193;
+# base.go:162-213, :246-336), exact integers, in the reference's call order. The Merkle verification inside verifyQueryRound runs in the
+# native BN254 field and calls none of the reference's hint functions. InverseHint (base.go:316-336) contributes one word (the inverse).
+HINT_INVERSE = 2
+GL_W, GL_DTH_ROOT, GL_GENERATOR, GL_POW2_GENERATOR = 7, GL_P - 1, 7, 1753635133440165772
+
+
+class ExactFriWitness(ExactWitness):
+    def __init__(self):
+        self.words, self.kinds = [], []
+
+    # ---- base field (lazy values are plain Python integers: the native field is never wrapped here, every value stays below 2^200)
+    def mul(self, a, b):  # base.go:184
+        return self.mul_add(a, b, 0)
+
+    def sub(self, a, b):  # base.go:174: MulAdd(b, -1, a)
+        return self.mul_add(b, GL_P - 1, a)
+
+    def inverse(self, x):  # base.go:297-313 -> InverseHint :316-336
+        assert x < GL_P
+        inv = pow(x, GL_P - 2, GL_P)
+        self.kinds.append(HINT_INVERSE)
+        self.words.append(inv)
+        self.range_check(inv)
+        prod = self.mul(inv, x)
+        assert prod == (1 if x else 0)
+        return inv
+
+    # ---- quadratic extension (quadratic_extension.go)
+    def add_ext(self, a, b): return [self.add(a[0], b[0]), self.add(a[1], b[1])]                 # :31
+    def sub_ext(self, a, b): return [self.sub(a[0], b[0]), self.sub(a[1], b[1])]                 # :45
+    @staticmethod
+    def sub_ext_nr(a, b): return [a[0] + b[0] * (GL_P - 1), a[1] + b[1] * (GL_P - 1)]            # :53 / base.go:179-181
+    @staticmethod
+    def mul_ext_nr(a, b): return [a[0] * b[0] + (GL_W * a[1]) * b[1], a[0] * b[1] + a[1] * b[0]]  # :65-71
+    def reduce_ext(self, x): return [self.reduce(x[0]), self.reduce(x[1])]                       # :173-175
+    def mul_ext(self, a, b): return self.reduce_ext(self.mul_ext_nr(a, b))                       # :59
+    def mul_add_ext(self, a, b, c):                                                              # :75-79
+        p = self.mul_ext_nr(a, b)
+        return self.reduce_ext([p[0] + c[0], p[1] + c[1]])
+    def sub_mul_ext(self, a, b, c): return self.reduce_ext(self.mul_ext_nr(self.sub_ext_nr(a, b), c))  # :89-93
+    def scalar_mul_ext(self, a, b): return [self.mul(a[0], b), self.mul(a[1], b)]                # :96-104
+    def inverse_ext(self, a):                                                                    # :123-134
+        f = [a[0], self.mul(a[1], GL_DTH_ROOT)]
+        n = self.mul_ext(f, a)
+        return self.scalar_mul_ext(f, self.inverse(n[0]))
+    def div_ext(self, a, b):                                                                     # :137-140
+        return self.mul_ext(a, self.inverse_ext(b))
+    def exp_ext(self, a, e):                                                                     # :143-171
+        if e == 0: return [1, 0]
+        if e == 1: return a
+        if e == 2: return self.mul_ext(a, a)
+        cur, prod = a, [1, 0]
+        for i in range(e.bit_length()):
+            if i: cur = self.mul_ext(cur, cur)
+            if (e >> i) & 1: prod = self.mul_ext(prod, cur)
+        return prod
+    def reduce_with_powers(self, terms, s):                                                      # :177-193
+        acc = [0, 0]
+        for t in reversed(terms):
+            p = self.mul_ext_nr(acc, s)
+            acc = self.reduce_ext([p[0] + t[0], p[1] + t[1]])
+        return acc
+
+    # ---- fri.go
+    def exp_from_bits_const_base(self, base, bits):  # :159-185
+        product = 1
+        for i, bit in enumerate(bits):
+            base_pow = pow(base, 1 << i, GL_P)
+            product = self.add(self.mul(self.mul((base_pow - 1) % GL_P, product), bit), product)
+        return product
+
+    def compute_evaluation(self, x, idx_bits, arity_bits, evals, beta):  # :314-384
+        arity = 1 << arity_bits
+        g = pow(GL_POW2_GENERATOR, 1 << (32 - arity_bits), GL_P)
+        g_inv = pow(g, arity - 1, GL_P)
+        permuted = [None] * arity
+        for i in range(arity):
+            permuted[int(format(i, "0%db" % arity_bits)[::-1], 2)] = evals[i]
+        start = self.exp_from_bits_const_base(g_inv, idx_bits[::-1])
+        coset_start = self.mul(start, x)
+        xs = [[coset_start, 0]]
+        for _ in range(1, arity):
+            xs.append(self.mul_ext(xs[-1], [g, 0]))
+        ws = []
+        for i in range(arity):
+            w = [1, 0]
+            for j in range(arity):
+                if i != j:
+                    w = self.sub_mul_ext(xs[i], xs[j], w)
+            ws.append(self.inverse_ext(w))
+        # interpolate :261-312
+        lx = [1, 0]
+        for i in range(arity):
+            lx = self.sub_mul_ext(beta, xs[i], lx)
+        total = [0, 0]
+        for i in range(arity):
+            q = self.div_ext(ws[i], self.sub_ext(beta, xs[i]))
+            total = self.add_ext(self.mul_ext(permuted[i], q), total)
+        interpolation = self.mul_ext(lx, total)
+        for i in range(arity):
+            self.sub_ext(beta, xs[i])  # the lookup loop :301-309: SubExtension's hints, IsZero / Lookup have none
+        return interpolation
+
+    def query_round(self, ci, rec, ch, precomputed, points, q):  # :386-498
+        nlog = ci.lde_bits
+        n_open, qwords, fr_queries, qfr, n_gl = query_section_layout(ci)
+        qrec = rec[n_open + q * qwords:n_open + (q + 1) * qwords]
+        x_index = self.reduce(ch["query_indices"][q])
+        bits = [(x_index >> i) & 1 for i in range(nlog)]
+        subgroup_x = self.mul(GL_GENERATOR, self.exp_from_bits_const_base(pow(GL_POW2_GENERATOR, 1 << (32 - nlog), GL_P), bits[::-1]))  # :187-206
+        # friCombineInitial :208-251
+        leaf_off = [sum(ci.leaf_len(k) for k in range(o)) for o in range(4)]
+        sizes = [ci.num_constants + ci.num_routed_wires, ci.num_wires, ci.num_challenges * (1 + ci.num_partial_products),
+                 ci.num_challenges * ci.quotient_degree_factor]
+        batches = [[(o, i) for o in range(4) for i in range(sizes[o])], [(2, i) for i in range(ci.num_challenges)]]
+        total = [0, 0]
+        for b in range(2):
+            evals = [[int(qrec[leaf_off[o] + i]), 0] for o, i in batches[b]]
+            reduced = self.reduce_with_powers(evals, ch["fri_alpha"])
+            numerator = self.sub_ext_nr(reduced, precomputed[b])
+            denominator = self.sub_ext([subgroup_x, 0], points[b])
+            total = self.mul_ext(self.exp_ext(ch["fri_alpha"], len(evals)), total)
+            total = self.mul_add_ext(numerator, self.inverse_ext(denominator), total)
+        old_eval = total
+        off = sum(ci.leaf_len(o) for o in range(4))
+        for s, ab in enumerate(ci.arity_bits):
+            evals = [[int(qrec[off + 2 * k]), int(qrec[off + 2 * k + 1])] for k in range(1 << ab)]
+            off += 2 << ab
+            within = bits[:ab]
+            chosen = evals[sum(b << i for i, b in enumerate(within))]
+            self.consistent &= chosen == old_eval                                               # :460-461
+            old_eval = self.compute_evaluation(subgroup_x, within, ab, evals, ch["fri_betas"][s])
+            for _ in range(ab):
+                subgroup_x = self.mul(subgroup_x, subgroup_x)                                   # :486-488
+            bits = bits[ab:]
+        fin = [0, 0]
+        coeffs = rec[n_open + ci.num_query_rounds * qwords:]
+        for i in reversed(range(ci.final_poly_len)):                                            # finalPolyEval :253-259
+            fin = self.mul_add_ext(fin, [subgroup_x, 0], [int(coeffs[2 * i]), int(coeffs[2 * i + 1])])
+        self.consistent &= fin == old_eval                                                      # :496-497
+
+
+def witness_fri_exact(ci, packed, challenges):
+    """(trace words, hint kinds, all FRI consistency assertions hold) of one packed proof: GetInstance + VerifyFriProof, exact integers."""
+    w = ExactFriWitness()
+    w.consistent = True
+    rec = np.frombuffer(packed, dtype=np.uint64)
+    nc = ci.num_challenges
+    flat = [int(x) for x in challenges]
+    ch = {"zeta": flat[3 * nc:3 * nc + 2], "fri_alpha": flat[3 * nc + 2:3 * nc + 4]}
+    k = 3 * nc + 4
+    ch["fri_betas"] = [flat[k + 2 * s:k + 2 * s + 2] for s in range(len(ci.arity_bits))]
+    k += 2 * len(ci.arity_bits)
+    ch["pow"], ch["query_indices"] = flat[k], flat[k + 1:k + 1 + ci.num_query_rounds]
+    g = pow(GL_POW2_GENERATOR, 1 << (32 - ci.degree_bits), GL_P)
+    zeta_next = w.mul_ext([g, 0], ch["zeta"])                                                   # GetInstance fri.go:46-50
+    points = [ch["zeta"], zeta_next]
+    n_a = 2 * (ci.num_constants + ci.num_routed_wires + ci.num_wires + nc)
+    n_open = query_section_layout(ci)[0]
+    ext = lambda lo, hi: [[int(rec[i]), int(rec[i + 1])] for i in range(lo, hi, 2)]            # noqa: E731
+    openings = [ext(0, n_a) + ext(n_a + 2 * nc, n_open), ext(n_a, n_a + 2 * nc)]                # ToOpenings fri.go:63-73
+    precomputed = [w.reduce_with_powers(b, ch["fri_alpha"]) for b in openings]                  # fromOpeningsAndAlpha :82-95
+    for q in range(ci.num_query_rounds):
+        w.query_round(ci, rec, ch, precomputed, points, q)
+    return w.words, w.kinds, w.consistent

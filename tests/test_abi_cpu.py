@@ -373,3 +373,34 @@ def test_witness_challenges_layout_and_oracle_trace(gpv, name):
     assert L.gpv_witness_range_check_words(ctypes.c_void_p(circuit.h)) == rc.shape[1] == {"decode_block": 19078, "step": 19202}[name]
     # per permutation: 130 MulAdd + 630 Reduce + 890 SplitLimbs = 5190 words
     assert int((ok == 0).sum()) * 2 + int((ok == 1).sum()) * 5 + int((ok == 3).sum()) * 2 == len(words)
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_witness_fri_layout_and_oracle_trace(gpv, name):
+    """Witness slice 2 (fri.Chip.GetInstance + VerifyFriProof), the parts that need no GPU: the oracle's literal restatement
+    (oracle/orc_witness.h witness_fri) == the exact-integer Python derivation (gpv_testlib.witness_fri_exact, every hint output checked
+    against its defining equation, the reference's FRI consistency assertions evaluated on the way: they hold for the fixture and fail
+    for a tampered opening) word for word, and libgpv's host-side layout (gpv_witness_fri_words / _layout) agrees with both."""
+    import ctypes
+    ci, packed, (common, vo, _) = T.load_fixture(name)
+    orc = T.oracle()
+    oc = orc.circuit(ci)
+    ch = orc.challenges(oc, packed)
+    words, kinds, consistent = T.witness_fri_exact(ci, packed, ch[0])
+    assert consistent
+    tr, ok, cons = orc.witness_fri(oc, packed, ch)
+    assert cons.tolist() == [1] and tr.shape == (1, len(words)) and (tr[0] == np.array(words, dtype=np.uint64)).all()
+    assert (ok == np.array(kinds, dtype=np.uint8)).all()
+    assert int((ok == 2).sum()) == ci.num_query_rounds * (2 + 32 * len(ci.arity_bits))  # 66 InverseHints per query round: 2 + 2 x 32
+    rec = np.frombuffer(packed, dtype=np.uint64).copy()
+    rec[5] ^= np.uint64(1)
+    w2, _, c2 = T.witness_fri_exact(ci, rec.tobytes(), ch[0])
+    tr2, _, cons2 = orc.witness_fri(oc, rec.tobytes(), ch)
+    assert not c2 and cons2.tolist() == [0] and (tr2[0] == np.array(w2, dtype=np.uint64)).all()
+    circuit = _circuit(gpv, common, vo)
+    L = gpv._lib.lib()
+    assert L.gpv_witness_fri_words(ctypes.c_void_p(circuit.h)) == len(words) == {"decode_block": 477988, "step": 485170}[name]
+    n_hints = L.gpv_witness_fri_layout(ctypes.c_void_p(circuit.h), None, 0)
+    got = np.empty(n_hints, dtype=np.uint8)
+    L.gpv_witness_fri_layout(ctypes.c_void_p(circuit.h), gpv._lib.ptr(got), n_hints)
+    assert n_hints == len(kinds) and (got == ok).all()

@@ -1651,3 +1651,43 @@ def test_witness_challenges_trace(gpv, api, orc, name):
     rtrace, ok = chip.WitnessRangeCheck(pb2)
     assert (rtrace == orc.witness_range_check(oc, batch)).all()
     assert ok.tolist() == [0 if i in (3, 5) else 1 for i in range(n)]
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_witness_fri_trace(gpv, api, orc, name):
+    """gpv_witness_fri: the ordered hint outputs of fri.Chip.GetInstance + VerifyFriProof (fri.go:40-61, :500-548) -- the GPU's literal
+    evaluation (csrc/gpv_witness.cuh: n^2 barycentric weights, 66 extension inversions per query round) == the oracle's, word for word,
+    on the fixture, on records with corrupted openings / leaves / step evaluations / final polynomial (the consistency flag must follow
+    the reference's assertions) and under foreign challenges; == the exact-integer derivation on the fixture and on a corrupted record."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    n = 10
+    batch, _ = T.synthetic_batch(ci, packed, n, seed=41, tamper_every=0)
+    w = batch.view(np.uint64).reshape(n, -1)
+    rng = np.random.default_rng(43)
+    n_open, qwords, fr_queries, qfr, n_gl = T.query_section_layout(ci)
+    ch = np.tile(orc.challenges(oc, packed), (n, 1))
+    fin = n_open + ci.num_query_rounds * qwords
+    w[1, 9] ^= np.uint64(1)                                                   # an opening
+    w[2, n_open + 3] ^= np.uint64(1 << 17)                                    # a leaf element of query 0
+    w[3, n_open + 5 * qwords + sum(ci.leaf_len(o) for o in range(4)) + 6] ^= np.uint64(1)   # a step evaluation of query 5
+    w[4, fin + 3] ^= np.uint64(1 << 40)                                       # a final-polynomial coefficient
+    w[5, n_open:fin] = rand_gl(rng, fin - n_open)                             # random query data altogether
+    ch[6] = rand_gl(rng, ch.shape[1])                                         # foreign challenges (random query indices, betas, alpha, zeta)
+    ch[7, -ci.num_query_rounds:] = np.uint64(2**64 - 1)                       # non-canonical query indices: Reduce's quotient is 1
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    fchip = gpv.fri.NewChip(api, common)
+    trace, kinds, cons = fchip.WitnessFriProof(pb, ch)
+    otr, okinds, ocons = orc.witness_fri(oc, batch, ch)
+    assert trace.shape == otr.shape and (kinds == okinds).all()
+    bad = np.nonzero((trace != otr).any(axis=1))[0]
+    assert bad.size == 0, (bad, np.nonzero(trace[bad[0]] != otr[bad[0]])[0][:4])
+    assert cons.tolist() == ocons.tolist() and cons.tolist()[:6] == [1, 0, 0, 0, 0, 0] and cons[8] == 1 and cons[9] == 1
+    # the same verdict as the verification kernels (FRI consistency bits of gpv_fri_verify's mask)
+    mask = fchip.VerifyFriProof(pb, ch)
+    fri_bits = 0x80 | 0x200   # GPV_FAIL_FRI_EVAL | GPV_FAIL_FRI_FINAL
+    assert ((mask & fri_bits) != 0).tolist() == [c == 0 for c in cons.tolist()]
+    for i in (0, 3):
+        words, ekinds, econs = T.witness_fri_exact(ci, batch[i].tobytes(), ch[i])
+        assert (trace[i] == np.array(words, dtype=np.uint64)).all() and (kinds == np.array(ekinds, dtype=np.uint8)).all() and int(econs) == cons[i]
