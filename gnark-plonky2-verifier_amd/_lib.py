@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "gpv_circuit_from_json", "gpv_circuit_from_json_ex", "gpv_circuit_destroy", "gpv_proof_nbytes", "gpv_num_challenge_words",
     "gpv_num_gate_constraints", "gpv_num_query_rounds", "gpv_num_merkle_trees", "gpv_circuit_hash_kind", "gpv_circuit_describe",
     "gpv_proof_pack_json", "gpv_proof_pack_json_batch",
-    "gpv_gl_op", "gpv_gl_hints", "gpv_witness_fri_words", "gpv_witness_fri_layout", "gpv_witness_fri", "gpv_witness_range_check_words", "gpv_witness_range_check", "gpv_witness_challenges_words", "gpv_witness_challenges_layout", "gpv_witness_challenges", "gpv_gl2_op", "gpv_gl2_op3", "gpv_gl2_exp", "gpv_gl2_reduce_with_powers", "gpv_gl2alg_op",
+    "gpv_gl_op", "gpv_gl_hints", "gpv_witness_fri_words", "gpv_witness_fri_layout", "gpv_witness_fri", "gpv_witness_plonk_words", "gpv_witness_plonk_layout", "gpv_witness_plonk", "gpv_witness_verify_words", "gpv_witness_verify_layout", "gpv_witness_verify", "gpv_witness_verify_dev", "gpv_witness_range_check_words", "gpv_witness_range_check", "gpv_witness_challenges_words", "gpv_witness_challenges_layout", "gpv_witness_challenges", "gpv_gl2_op", "gpv_gl2_op3", "gpv_gl2_exp", "gpv_gl2_reduce_with_powers", "gpv_gl2alg_op",
     "gpv_poseidon_gl_hash_n_to_m_no_pad", "gpv_challenger_run", "gpv_poseidon_gl_permute", "gpv_poseidon_gl_permute_dev", "gpv_poseidon_gl_permute_coop",
     "gpv_poseidon_gl_permute_coop_dev", "gpv_poseidon_gl_hash_no_pad",
     "gpv_poseidon_bn254_permute", "gpv_poseidon_bn254_permute_dev", "gpv_poseidon_bn254_hash_or_noop",
@@ -99,6 +99,17 @@ def lib():
         L.gpv_witness_fri_layout.argtypes = [vp, vp, sz]
         L.gpv_witness_fri_layout.restype = sz
         L.gpv_witness_fri.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+        L.gpv_witness_plonk_words.argtypes = [vp]
+        L.gpv_witness_plonk_words.restype = sz
+        L.gpv_witness_plonk_layout.argtypes = [vp, vp, sz]
+        L.gpv_witness_plonk_layout.restype = sz
+        L.gpv_witness_plonk.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+        L.gpv_witness_verify_words.argtypes = [vp]
+        L.gpv_witness_verify_words.restype = sz
+        L.gpv_witness_verify_layout.argtypes = [vp, vp, sz]
+        L.gpv_witness_verify_layout.restype = sz
+        L.gpv_witness_verify.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+        L.gpv_witness_verify_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp]
         L.gpv_witness_range_check_words.argtypes = [vp]
         L.gpv_witness_range_check_words.restype = sz
         L.gpv_witness_range_check.argtypes = [vp, vp, vp, sz, vp, vp]

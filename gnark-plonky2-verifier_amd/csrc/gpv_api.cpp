@@ -1059,6 +1059,43 @@ extern "C" int gpv_witness_fri(gpv_ctx* ctx, const gpv_circuit* c, const void* p
   return GPV_OK;
 }
 
+// Witness slice 3 (csrc/gpv_witness.cuh): the hint outputs of plonk.PlonkChip.Verify for caller-supplied challenges.
+extern "C" int gpv_witness_plonk(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n, uint64_t* trace,
+                                 uint8_t* consistent) {
+  REQUIRE(ctx, ctx && c && proofs && challenges && trace);
+  ENTER(ctx);
+  if (n == 0) return GPV_OK;
+  const size_t words = gpv_witness_plonk_words(c), ncw = c->dc.n_challenge_words, wsw = gpv_wit_plonk_ws_words(c->dc);
+  HostBatch hb;
+  int rc = hb.upload(ctx, c, proofs, n);
+  if (rc != GPV_OK) return rc;
+  const DevCircuit* dcd;
+  rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  DevBuf<u64> dtrace, dch, dwritten, dws;
+  DevBuf<uint8_t> dcons;
+  HIP_TRY(ctx, dtrace.alloc(words * n));
+  HIP_TRY(ctx, dch.alloc(ncw * n));
+  HIP_TRY(ctx, dwritten.alloc(n));
+  HIP_TRY(ctx, dws.alloc(wsw * n));
+  HIP_TRY(ctx, dcons.alloc(n));
+  HIP_TRY(ctx, hipMemcpyAsync(dch.p, challenges, 8 * ncw * n, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * n, ctx->stream));
+  gpvk_witness_plonk(ctx->stream, dcd, (const u64*)hb.proofs.p, dch.p, n, dtrace.p, words, dws.p, wsw, dcons.p, dwritten.p);
+  CHECK_LAUNCH(ctx);
+  std::vector<u64> written(n);
+  HIP_TRY(ctx, hipMemcpyAsync(written.data(), dwritten.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(trace, dtrace.p, 8 * words * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (consistent) HIP_TRY(ctx, hipMemcpyAsync(consistent, dcons.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; i++)
+    if (written[i] != words) {  // the kernel's walk and the host's layout are written separately
+      ctx_error(ctx, "plonk witness trace of proof %zu has %llu words, the layout says %zu", i, (unsigned long long)written[i], words);
+      return GPV_EDEVICE;
+    }
+  return GPV_OK;
+}
+
 // Witness slice 0: rangeCheckProof (verifier.go:84-141), the first statement of Verify -- one SplitLimbsHint per proof element.
 extern "C" int gpv_witness_range_check(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint8_t* ok) {
   REQUIRE(ctx, ctx && c && proofs && trace);
@@ -1076,10 +1113,100 @@ extern "C" int gpv_witness_range_check(gpv_ctx* ctx, const gpv_circuit* c, const
   HIP_TRY(ctx, dtrace.alloc(words * n));
   HIP_TRY(ctx, dok.alloc(n));
   HIP_TRY(ctx, hipMemsetAsync(dok.p, 1, n, ctx->stream));
-  gpvk_witness_range_check(ctx->stream, dcd, (const u64*)hb.proofs.p, n, dtrace.p, dok.p);
+  gpvk_witness_range_check(ctx->stream, dcd, (const u64*)hb.proofs.p, n, dtrace.p, words, dok.p);
   CHECK_LAUNCH(ctx);
   HIP_TRY(ctx, hipMemcpyAsync(trace, dtrace.p, 8 * words * n, hipMemcpyDeviceToHost, ctx->stream));
   if (ok) HIP_TRY(ctx, hipMemcpyAsync(ok, dok.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GPV_OK;
+}
+
+// The whole hint trace of VerifierChip.Verify (verifier.go:143-178) per proof: range_check | challenges | plonk | fri, the challenges handed
+// from slice 1 to slices 3 and 2 in HBM. Main stream: range check, challenges, FRI; side stream: plonk (both consumers are a few waves of
+// long dependent chains -- they overlap). Synchronises: the lanes' word counts are checked against the host layout before returning.
+static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* dcd, const u64* dproofs, size_t n, u64* dtrace, u64* dch,
+                               uint8_t* dstatus) {
+  const size_t w_rc = gpv_witness_range_check_words(c), w_ch = gpv_witness_challenges_words(c), w_pl = gpv_witness_plonk_words(c);
+  size_t prefix = 0, round = 0;
+  gpvi_witness_fri_sizes(c, &prefix, &round);
+  const size_t nq = c->dc.num_queries, w_fri = prefix + nq * round, total = w_rc + w_ch + w_pl + w_fri, wsw = gpv_wit_plonk_ws_words(c->dc);
+  for (u32 s = 0; s < c->dc.num_steps; s++) REQUIRE(ctx, c->dc.arity_bits[s] <= 5);
+  DevBuf<u64> dwritten, dws, dch_own;
+  DevBuf<uint8_t> dflags;  // [3][n]: range ok, plonk consistent, fri consistent
+  HIP_TRY(ctx, dwritten.alloc((2 + nq) * n));
+  HIP_TRY(ctx, dws.alloc(wsw * n));
+  HIP_TRY(ctx, dflags.alloc(3 * n));
+  if (!dch) {
+    HIP_TRY(ctx, dch_own.alloc((size_t)c->dc.n_challenge_words * n));
+    dch = dch_own.p;
+  }
+  hipStream_t main_st = ctx->stream, side = ctx->side;
+  HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * (2 + nq) * n, main_st));
+  HIP_TRY(ctx, hipMemsetAsync(dflags.p, 1, 3 * n, main_st));
+  u64 *wr_ch = dwritten.p, *wr_pl = dwritten.p + n, *wr_fri = dwritten.p + 2 * n;
+  gpvk_witness_challenges(main_st, dcd, dproofs, n, dtrace + w_rc, total, dch, wr_ch);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_st));
+  HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
+  gpvk_witness_plonk(side, dcd, dproofs, dch, n, dtrace + w_rc + w_ch, total, dws.p, wsw, dflags.p + n, wr_pl);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));
+  gpvk_witness_fri(main_st, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch + w_pl, total, prefix, round, dflags.p + 2 * n, wr_fri);
+  gpvk_witness_range_check(main_st, dcd, dproofs, n, dtrace, total, dflags.p);
+  HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_side_done, 0));
+  CHECK_LAUNCH(ctx);
+  std::vector<u64> written((2 + nq) * n);
+  std::vector<uint8_t> flags(3 * n);
+  HIP_TRY(ctx, hipMemcpyAsync(written.data(), dwritten.p, 8 * written.size(), hipMemcpyDeviceToHost, main_st));
+  HIP_TRY(ctx, hipMemcpyAsync(flags.data(), dflags.p, flags.size(), hipMemcpyDeviceToHost, main_st));
+  HIP_TRY(ctx, hipStreamSynchronize(main_st));
+  for (size_t i = 0; i < n; i++) {
+    bool good = written[i] == w_ch && written[n + i] == w_pl;
+    for (size_t q = 0; q < nq; q++) good &= written[2 * n + i * nq + q] == round + (q == 0 ? prefix : 0);
+    if (!good) {
+      ctx_error(ctx, "witness trace of proof %zu: a lane's word count differs from the host layout", i);
+      return GPV_EDEVICE;
+    }
+  }
+  if (dstatus) {
+    std::vector<uint8_t> st(n);
+    for (size_t i = 0; i < n; i++)
+      st[i] = (uint8_t)((flags[i] ? 0 : GPV_WITNESS_RANGE) | (flags[n + i] ? 0 : GPV_WITNESS_PLONK) | (flags[2 * n + i] ? 0 : GPV_WITNESS_FRI));
+    HIP_TRY(ctx, hipMemcpyAsync(dstatus, st.data(), n, hipMemcpyHostToDevice, main_st));
+    HIP_TRY(ctx, hipStreamSynchronize(main_st));
+  }
+  return GPV_OK;
+}
+extern "C" int gpv_witness_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint64_t* trace_dev,
+                                      uint64_t* challenges_dev, uint8_t* status_dev) {
+  REQUIRE(ctx, ctx && c && proofs_dev && trace_dev);
+  ENTER(ctx);
+  if (n == 0) return GPV_OK;
+  const DevCircuit* dcd;
+  int rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  return witness_verify_core(ctx, c, dcd, (const u64*)proofs_dev, n, trace_dev, challenges_dev, status_dev);
+}
+extern "C" int gpv_witness_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint64_t* challenges,
+                                  uint8_t* status) {
+  REQUIRE(ctx, ctx && c && proofs && trace);
+  ENTER(ctx);
+  if (n == 0) return GPV_OK;
+  const size_t total = gpv_witness_verify_words(c), ncw = c->dc.n_challenge_words;
+  HostBatch hb;
+  int rc = hb.upload(ctx, c, proofs, n);
+  if (rc != GPV_OK) return rc;
+  const DevCircuit* dcd;
+  rc = circuit_on_device(ctx, c, &dcd);
+  if (rc != GPV_OK) return rc;
+  DevBuf<u64> dtrace, dch;
+  DevBuf<uint8_t> dst;
+  HIP_TRY(ctx, dtrace.alloc(total * n));
+  HIP_TRY(ctx, dch.alloc(ncw * n));
+  HIP_TRY(ctx, dst.alloc(n));
+  rc = witness_verify_core(ctx, c, dcd, (const u64*)hb.proofs.p, n, dtrace.p, dch.p, dst.p);
+  if (rc != GPV_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(trace, dtrace.p, 8 * total * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (challenges) HIP_TRY(ctx, hipMemcpyAsync(challenges, dch.p, 8 * ncw * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (status) HIP_TRY(ctx, hipMemcpyAsync(status, dst.p, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GPV_OK;
 }

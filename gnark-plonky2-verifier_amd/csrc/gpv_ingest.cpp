@@ -878,6 +878,149 @@ FriWitSizes witness_fri_layout(const DevCircuit& c, std::vector<uint8_t>* kinds)
   z.hints = L.hints;
   return z;
 }
+// ---- slice 3: plonk.PlonkChip.Verify (csrc/gpv_witness.cuh, third part), the same walk without the arithmetic
+struct PlonkWitLayout : FriWitLayout {
+  void add_ext() { ext2_mul_add(); }
+  void sub_ext() { ext2_mul_add(); }
+  void scalar_mul_ext() { ext2_mul_add(); }
+  void mul_ext() { reduce_ext(); }
+  void inner_product(int pairs) { for (int i = 0; i < pairs; i++) scalar_mul_ext(); reduce_ext(); }  // quadratic_extension.go:107-120
+  void add_alg() { add_ext(); add_ext(); }
+  void sub_alg() { sub_ext(); sub_ext(); }
+  void mul_alg() { inner_product(1); inner_product(1); inner_product(0); inner_product(2); }  // quadratic_extension_algebra.go:50-75
+  void scalar_mul_alg() { mul_ext(); mul_ext(); }
+  void partial_interpolate(uint32_t n) {  // :88-125
+    for (uint32_t i = 0; i < n; i++) { sub_alg(); scalar_mul_alg(); mul_alg(); mul_alg(); add_alg(); mul_alg(); }
+  }
+  void reduce_with_powers(uint32_t n) { for (uint32_t i = 0; i < n; i++) reduce_ext(); }
+  void sbox_ext() { for (int i = 0; i < 4; i++) mul_ext(); }
+  void constant_layer_ext() { for (int i = 0; i < 12; i++) add_ext(); }
+  void mds_layer_ext() { for (int i = 0; i < 12 * 13; i++) { mul_ext(); add_ext(); } }
+  void mds_partial_fast_ext() { mul_ext(); for (int i = 0; i < 22; i++) { mul_ext(); add_ext(); } }
+  uint32_t gate(const DevGate& g) {  // the gate's EvalUnfiltered; returns its number of constraints
+    uint32_t k = 0;
+    switch (g.kind) {
+      case GPV_GATE_NOOP: break;
+      case GPV_GATE_CONSTANT: for (uint32_t i = 0; i < g.p0; i++, k++) sub_ext(); break;
+      case GPV_GATE_PUBLIC_INPUT: for (int i = 0; i < 4; i++, k++) sub_ext(); break;
+      case GPV_GATE_BASE_SUM:
+        reduce_with_powers(g.p0);
+        sub_ext();
+        for (uint32_t l = 0; l < g.p0; l++)
+          for (uint32_t i = 0; i < g.p1; i++) { sub_ext(); mul_ext(); }
+        k = 1 + g.p0;
+        break;
+      case GPV_GATE_ARITHMETIC:
+        for (uint32_t i = 0; i < g.p0; i++, k++) { mul_ext(); mul_ext(); mul_ext(); add_ext(); sub_ext(); }
+        break;
+      case GPV_GATE_ARITHMETIC_EXT:
+        for (uint32_t i = 0; i < g.p0; i++, k += 2) { mul_alg(); scalar_mul_alg(); scalar_mul_alg(); add_alg(); sub_alg(); }
+        break;
+      case GPV_GATE_MUL_EXT:
+        for (uint32_t i = 0; i < g.p0; i++, k += 2) { mul_alg(); scalar_mul_alg(); sub_alg(); }
+        break;
+      case GPV_GATE_REDUCING:
+      case GPV_GATE_REDUCING_EXT:
+        for (uint32_t i = 0; i < g.p0; i++, k += 2) { mul_alg(); add_alg(); sub_alg(); }
+        break;
+      case GPV_GATE_EXPONENTIATION:
+        for (uint32_t i = 0; i < g.p0; i++, k++) {
+          if (i != 0) mul_ext();
+          mul_ext(); sub_ext(); mul_ext(); sub_ext(); mul_ext(); sub_ext();
+        }
+        sub_ext();
+        k++;
+        break;
+      case GPV_GATE_RANDOM_ACCESS:
+        for (uint32_t cp = 0; cp < g.p1; cp++) {
+          for (uint32_t i = 0; i < g.p0; i++, k++) { mul_ext(); sub_ext(); }
+          reduce_with_powers(g.p0);
+          sub_ext();
+          for (uint32_t cnt = (1u << g.p0) >> 1, lvl = 0; lvl < g.p0; lvl++, cnt >>= 1)
+            for (uint32_t i = 0; i < cnt; i++) { sub_ext(); mul_ext(); add_ext(); }
+          sub_ext();
+          k += 2;
+        }
+        for (uint32_t i = 0; i < g.p2; i++, k++) sub_ext();
+        break;
+      case GPV_GATE_COSET_INTERPOLATION: {
+        const uint32_t degree = g.p1, npts = 1u << g.p0, n_inter = (npts - 2) / (degree - 1);
+        scalar_mul_ext(); scalar_mul_alg(); add_alg();
+        partial_interpolate(degree);
+        for (uint32_t i = 0; i < n_inter; i++) {
+          sub_alg(); sub_alg();
+          const uint32_t lo = 1 + (degree - 1) * (i + 1), hi = lo + degree - 1 < npts ? lo + degree - 1 : npts;
+          partial_interpolate(hi - lo);
+        }
+        sub_alg();
+        k = 2 + 4 * n_inter + 2;
+        break;
+      }
+      case GPV_GATE_POSEIDON:
+        sub_ext(); mul_ext();
+        for (int i = 0; i < 4; i++) { sub_ext(); mul_ext(); sub_ext(); }
+        for (int i = 0; i < 4; i++) { add_ext(); sub_ext(); }
+        for (int r = 0; r < 4; r++) {
+          constant_layer_ext();
+          if (r != 0) for (int i = 0; i < 12; i++) sub_ext();
+          for (int i = 0; i < 12; i++) sbox_ext();
+          mds_layer_ext();
+        }
+        for (int i = 0; i < 12; i++) add_ext();
+        for (int i = 0; i < 11 * 11; i++) { mul_ext(); add_ext(); }
+        for (int r = 0; r < 22; r++) {
+          sub_ext(); sbox_ext();
+          if (r != 21) add_ext();
+          mds_partial_fast_ext();
+        }
+        for (int r = 0; r < 4; r++) {
+          constant_layer_ext();
+          for (int i = 0; i < 12; i++) sub_ext();
+          for (int i = 0; i < 12; i++) sbox_ext();
+          mds_layer_ext();
+        }
+        for (int i = 0; i < 12; i++) sub_ext();
+        k = 1 + 4 + 36 + 22 + 48 + 12;
+        break;
+      case GPV_GATE_POSEIDON_MDS:
+        for (int i = 0; i < 12 * 13; i++) { scalar_mul_alg(); add_alg(); }
+        for (int i = 0; i < 12; i++) sub_alg();
+        k = 24;
+        break;
+      default: break;
+    }
+    return k;
+  }
+};
+PlonkWitLayout witness_plonk_layout(const DevCircuit& c, std::vector<uint8_t>* kinds) {
+  PlonkWitLayout L;
+  L.kinds = kinds;
+  for (uint32_t i = 0; i < c.degree_bits; i++) L.mul_ext();  // expPowerOf2Extension plonk.go:55-61
+  for (uint32_t row = 0; row < c.n_gates; row++) {           // EvaluateGateConstraints evaluate_gates.go:77-105
+    const uint32_t sel = c.selector_index[row];
+    for (uint32_t i = c.group_start[sel]; i < c.group_end[sel]; i++)
+      if (i != row) { L.sub_ext(); L.mul_ext(); }
+    if (c.n_groups > 1) { L.sub_ext(); L.mul_ext(); }
+    const uint32_t n = L.gate(c.gates[row]);
+    for (uint32_t i = 0; i < n; i++) L.mul_ext();
+    for (uint32_t i = 0; i < n; i++) L.add_ext();
+  }
+  for (uint32_t i = 0; i < c.num_routed; i++) L.scalar_mul_ext();  // evalVanishingPoly :121-207
+  L.sub_ext(); L.scalar_mul_ext(); L.sub_ext(); L.div_ext();       // evalL0 :63-83
+  for (uint32_t i = 0; i < c.num_challenges; i++) {
+    L.sub_ext(); L.mul_ext();
+    for (uint32_t j = 0; j < c.num_routed; j++) { L.add_ext(); L.mul_ext(); L.add_ext(); L.mul_ext(); L.add_ext(); }
+    for (uint32_t k = 0; k <= c.num_pp; k++) {                     // checkPartialProducts :85-119
+      for (uint32_t j = 1; j < c.qdf; j++) { L.mul_ext(); L.mul_ext(); }
+      L.mul_ext(); L.mul_ext(); L.sub_ext();
+    }
+  }
+  const size_t n_terms = (size_t)c.num_challenges * (c.num_pp + 2) + c.num_gate_constraints;
+  for (size_t i = 0; i < n_terms * c.num_challenges; i++) { L.scalar_mul_ext(); L.add_ext(); }
+  L.sub_ext();                                                     // Verify :209-250
+  for (uint32_t i = 0; i < c.num_challenges; i++) { L.reduce_with_powers(c.qdf); L.mul_ext(); }
+  return L;
+}
 WitLayout witness_challenges_layout(const DevCircuit& c, std::vector<uint8_t>* kinds) {
   WitLayout L;
   L.kinds = kinds;
@@ -920,6 +1063,14 @@ void gpvi_witness_fri_sizes(const gpv_circuit* c, size_t* prefix_words, size_t* 
   FriWitSizes z = witness_fri_layout(c->dc, nullptr);
   *prefix_words = z.prefix_words;
   *round_words = z.round_words;
+}
+extern "C" size_t gpv_witness_plonk_words(const gpv_circuit* c) { return c ? witness_plonk_layout(c->dc, nullptr).words : 0; }
+extern "C" size_t gpv_witness_plonk_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap) {
+  if (!c) return 0;
+  std::vector<uint8_t> k;
+  PlonkWitLayout L = witness_plonk_layout(c->dc, kinds ? &k : nullptr);
+  if (kinds) memcpy(kinds, k.data(), k.size() < cap ? k.size() : cap);
+  return L.hints;
 }
 extern "C" size_t gpv_witness_range_check_words(const gpv_circuit* c) { return c ? 2 * (size_t)c->dc.off_pi : 0; }
 extern "C" size_t gpv_witness_challenges_words(const gpv_circuit* c) { return c ? witness_challenges_layout(c->dc, nullptr).words : 0; }
@@ -1118,4 +1269,25 @@ extern "C" int gpv_proof_pack_json_batch(const gpv_circuit* circ, const char* co
       return rc[i];
     }
   return GPV_OK;
+}
+// VerifierChip.Verify as a whole (verifier.go:143-178): range_check | challenges | plonk | fri
+extern "C" size_t gpv_witness_verify_words(const gpv_circuit* c) {
+  return c ? gpv_witness_range_check_words(c) + gpv_witness_challenges_words(c) + gpv_witness_plonk_words(c) + gpv_witness_fri_words(c) : 0;
+}
+extern "C" size_t gpv_witness_verify_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap) {
+  if (!c) return 0;
+  std::vector<uint8_t> k, part;
+  const size_t n_rc = c->dc.off_pi;
+  if (kinds) k.assign(n_rc, GPV_HINT_SPLIT_LIMBS);
+  size_t hints = n_rc;
+  hints += witness_challenges_layout(c->dc, kinds ? &part : nullptr).hints;
+  k.insert(k.end(), part.begin(), part.end());
+  part.clear();
+  hints += witness_plonk_layout(c->dc, kinds ? &part : nullptr).hints;
+  k.insert(k.end(), part.begin(), part.end());
+  part.clear();
+  hints += witness_fri_layout(c->dc, kinds ? &part : nullptr).hints;
+  k.insert(k.end(), part.begin(), part.end());
+  if (kinds) memcpy(kinds, k.data(), k.size() < cap ? k.size() : cap);
+  return hints;
 }

@@ -19,24 +19,24 @@ void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* p
 
 // rangeCheckProof (verifier/verifier.go:84-141): RangeCheck / RangeCheckQE of every proof element except the public inputs, in the order
 // of the proof struct -- which is the order of the packed record's Goldilocks section -- i.e. one SplitLimbsHint (base.go:339-359) per
-// word: trace[i][2 w] = x >> 32, trace[i][2 w + 1] = x mod 2^32. The reference's hint returns an error for x >= p: ok[i] = 0 then (the
+// word: trace[i][2 w] = x >> 32, trace[i][2 w + 1] = x mod 2^32 (rows words_per_proof apart). The reference's hint returns an error for x >= p: ok[i] = 0 then (the
 // limbs are written anyway). One lane per word, coalesced.
 __global__ __launch_bounds__(256) void k_witness_range_check(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
-                                                             u64* __restrict__ trace, uint8_t* __restrict__ ok) {
+                                                             u64* __restrict__ trace, size_t words_per_proof, uint8_t* __restrict__ ok) {
   const u32 words = dc->off_pi;
   const size_t total = (size_t)words * n, stride = dc->proof_nbytes / 8;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
     const size_t p = t / words;
     const u32 w = (u32)(t - p * words);
     const u64 x = proofs[p * stride + w];
-    u64* o = trace + 2 * t;
+    u64* o = trace + p * words_per_proof + 2 * w;
     o[0] = x >> 32;
     o[1] = x & 0xFFFFFFFFu;
     if (x >= GLP) ok[p] = 0;
   }
 }
-void gpvk_witness_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, uint8_t* ok) {
-  GPVK_LAUNCH(k_witness_range_check, dim3(4096), dim3(256), 0, st, dcd, proofs, n, trace, ok);
+void gpvk_witness_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, uint8_t* ok) {
+  GPVK_LAUNCH(k_witness_range_check, dim3(4096), dim3(256), 0, st, dcd, proofs, n, trace, words_per_proof, ok);
 }
 
 // Witness slice 2: one lane per (proof, query round); the lane of query 0 also emits what precedes the rounds. written[p * nq + q] =
@@ -59,4 +59,26 @@ void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& h
                       size_t words_per_proof, size_t prefix_words, size_t round_words, uint8_t* consistent, u64* written) {
   GPVK_LAUNCH(k_witness_fri, dim3(gpvk_blocks_for(n * hc.num_queries, 64)), dim3(64), 0, st, dcd, proofs, challenges, n, trace, words_per_proof,
               prefix_words, round_words, consistent, written);
+}
+
+// Witness slice 3: PlonkChip.Verify, one lane per proof (41 % of the trace is the Poseidon gate's extension-field permutation, a dependent
+// chain). ws: [n][ws_words] workspace for the values the reference holds in Go slices (gate_terms, the gate's constraints, sIDs, numerators,
+// denominators, the permutation terms); the public-inputs hash is recomputed natively (its hints are slice 1's).
+__global__ __launch_bounds__(64) void k_witness_plonk(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ challenges,
+                                                      size_t n, u64* __restrict__ trace, size_t words_per_proof, u64* __restrict__ ws, size_t ws_words,
+                                                      uint8_t* __restrict__ consistent, u64* __restrict__ written) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64* rec = proofs + i * (dc->proof_nbytes / 8);
+  u64 pih[4];
+  dev_public_inputs_hash(dc, rec, pih);
+  size_t wrote = 0;
+  const bool ok = dev_witness_plonk(dc, rec, challenges + i * dc->n_challenge_words, pih, trace + i * words_per_proof, ws + i * ws_words, &wrote);
+  written[i] = wrote;
+  consistent[i] = ok ? 1 : 0;
+}
+void gpvk_witness_plonk(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* challenges, size_t n, u64* trace, size_t words_per_proof,
+                        u64* ws, size_t ws_words, uint8_t* consistent, u64* written) {
+  GPVK_LAUNCH(k_witness_plonk, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, challenges, n, trace, words_per_proof, ws, ws_words,
+              consistent, written);
 }

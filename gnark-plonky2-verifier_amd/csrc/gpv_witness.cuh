@@ -482,3 +482,529 @@ GPV_DEV bool dev_witness_fri(const DevCircuit* __restrict__ dc, const u64* __res
   *written = wrote + (size_t)(t.p - round_start);
   return ok;
 }
+
+// ================================================================ slice 3: plonk.PlonkChip.Verify (plonk/plonk.go:55-250)
+// Every gl.Chip call of Verify, evalVanishingPoly, evalL0, checkPartialProducts, EvaluateGateConstraints / computeFilter / evalFiltered
+// (plonk/gates/evaluate_gates.go:33-105), the 14 gates' EvalUnfiltered, the extension-algebra helpers
+// (goldilocks/quadratic_extension_algebra.go:28-125) and the *Extension Poseidon layers (poseidon/goldilocks.go:127-357), op by op in call
+// order: every gate constraint is materialised, multiplied by its filter and added into the per-index sum (the verification kernel,
+// dev_plonk_verify, streams constraints into a running power-of-alpha sum and never holds them). One lane per proof; the values the
+// reference keeps in Go slices live in a per-proof workspace in HBM (WPlonkWs).
+struct WPlonkWs {  // extension elements as word pairs
+  u64 *gate_terms, *unf, *s_ids, *num, *den, *head, *tmp;
+};
+// (sized on the host by gpv_wit_plonk_ws_words, gpv_launch.h)
+GPV_DEV Ext ws_ld(const u64* a, u32 i) { return ext_make(a[2 * i], a[2 * i + 1]); }
+GPV_DEV void ws_st(u64* a, u32 i, Ext v) {
+  a[2 * i] = v.a;
+  a[2 * i + 1] = v.b;
+}
+struct WPairs {
+  Ext a[2], b[2];
+};
+// InnerProductExtension (quadratic_extension.go:107-120): per pair ScalarMulExtension(a, constant) then a lazy multiply-add; one ReduceExtension
+__device__ __noinline__ Ext wt_inner_product_ext(WTrace& t, u64 constant, Ext acc0, const WPairs& pr, int n) {
+  WBigExt acc = wbe_from(acc0);
+#pragma unroll 1
+  for (int i = 0; i < n; i++) {
+    Ext m = wt_scalar_mul_ext(t, pr.a[i], constant);
+    Ext b = pr.b[i];
+    wb_mac(acc.c[0], wb_from(m.a), b.a);
+    wb_mac(acc.c[0], wb_mul(wb_from(m.b), 7), b.b);
+    wb_mac(acc.c[1], wb_from(m.a), b.b);
+    wb_mac(acc.c[1], wb_from(m.b), b.a);
+  }
+  return wt_reduce_ext(t, acc);
+}
+GPV_DEV ExtAlg wt_add_alg(WTrace& t, ExtAlg a, ExtAlg b) { Ext c0 = wt_add_ext(t, a.a, b.a); Ext c1 = wt_add_ext(t, a.b, b.b); return alg_make(c0, c1); }  // :28
+GPV_DEV ExtAlg wt_sub_alg(WTrace& t, ExtAlg a, ExtAlg b) { Ext c0 = wt_sub_ext(t, a.a, b.a); Ext c1 = wt_sub_ext(t, a.b, b.b); return alg_make(c0, c1); }  // :39
+__device__ __noinline__ ExtAlg wt_mul_alg(WTrace& t, ExtAlg a, ExtAlg b) {  // :50-75 with D = 2
+  WPairs pr;
+  pr.a[0] = a.b;
+  pr.b[0] = b.b;
+  Ext acc = wt_inner_product_ext(t, 7, ext_make(0, 0), pr, 1);  // innerW[0] = {(a1, b1)}
+  pr.a[0] = a.a;
+  pr.b[0] = b.a;
+  Ext p0 = wt_inner_product_ext(t, 1, acc, pr, 1);              // inner[0] = {(a0, b0)}
+  acc = wt_inner_product_ext(t, 7, ext_make(0, 0), pr, 0);      // innerW[1] is empty: ReduceExtension(0)
+  pr.a[0] = a.a;
+  pr.b[0] = b.b;
+  pr.a[1] = a.b;
+  pr.b[1] = b.a;
+  Ext p1 = wt_inner_product_ext(t, 1, acc, pr, 2);              // inner[1] = {(a0, b1), (a1, b0)}
+  return alg_make(p0, p1);
+}
+GPV_DEV ExtAlg wt_scalar_mul_alg(WTrace& t, Ext a, ExtAlg b) { Ext c0 = wt_mul_ext(t, a, b.a); Ext c1 = wt_mul_ext(t, a, b.b); return alg_make(c0, c1); }  // :77-86
+GPV_DEV ExtAlg wires_alg(const u64* __restrict__ wires, u32 start) { return alg_make(ws_ld(wires, start), ws_ld(wires, start + 1)); }  // vars.go:29-41
+// PartialInterpolateExtAlgebra (:88-125) over the points [lo, hi) of the gate's subgroup; domain[i] = g^i
+__device__ __noinline__ void wt_partial_interpolate(WTrace& t, u64 g, u32 lo, u32 hi, const u64* __restrict__ wires, const u64* __restrict__ weights,
+                                                    ExtAlg point, ExtAlg& ev, ExtAlg& prod) {
+  u64 x = 1;
+#pragma unroll 1
+  for (u32 i = 0; i < lo; i++) x = gl_mul(x, g);
+#pragma unroll 1
+  for (u32 i = lo; i < hi; i++) {
+    ExtAlg term = wt_sub_alg(t, point, alg_make(ext_make(x, 0), ext_make(0, 0)));
+    ExtAlg weighted = wt_scalar_mul_alg(t, ext_make(weights[i], 0), wires_alg(wires, 1 + 2 * i));
+    ev = wt_mul_alg(t, ev, term);
+    ExtAlg tmp = wt_mul_alg(t, weighted, prod);
+    ev = wt_add_alg(t, ev, tmp);
+    prod = wt_mul_alg(t, prod, term);
+    x = gl_mul(x, g);
+  }
+}
+// poseidon/goldilocks.go, extension layers
+__device__ __noinline__ Ext wt_sbox_ext(WTrace& t, Ext x) {  // :147-152
+  Ext x2 = wt_mul_ext(t, x, x);
+  Ext x4 = wt_mul_ext(t, x2, x2);
+  Ext x3 = wt_mul_ext(t, x, x2);
+  return wt_mul_ext(t, x4, x3);
+}
+GPV_DEV void wt_constant_layer_ext(WTrace& t, Ext* s, int round) {  // :127-136
+#pragma unroll 1
+  for (int i = 0; i < 12; i++) s[i] = wt_add_ext(t, s[i], ext_make(PGL_ARC[i + 12 * round], 0));
+}
+__device__ __noinline__ void wt_mds_layer_ext(WTrace& t, Ext* s) {  // :185-201, :218-229
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  Ext out[12];
+#pragma unroll 1
+  for (int r = 0; r < 12; r++) {
+    Ext res = ext_make(0, 0);
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) {
+      Ext res1 = wt_mul_ext(t, s[(i + r) % 12], ext_make(C[i], 0));
+      res = wt_add_ext(t, res, res1);
+    }
+    Ext last = wt_mul_ext(t, s[r], ext_make(r == 0 ? 8 : 0, 0));
+    out[r] = wt_add_ext(t, res, last);
+  }
+#pragma unroll 1
+  for (int r = 0; r < 12; r++) s[r] = out[r];
+}
+__device__ __noinline__ void wt_mds_partial_layer_init_ext(WTrace& t, Ext* s) {  // :277-298
+  Ext res[12];
+#pragma unroll 1
+  for (int i = 0; i < 12; i++) res[i] = ext_make(0, 0);
+  res[0] = s[0];
+#pragma unroll 1
+  for (int r = 1; r < 12; r++)
+#pragma unroll 1
+    for (int d = 1; d < 12; d++) {
+      Ext m = wt_mul_ext(t, s[r], ext_make(PGL_INIT[(r - 1) * 11 + (d - 1)], 0));
+      res[d] = wt_add_ext(t, res[d], m);
+    }
+#pragma unroll 1
+  for (int i = 0; i < 12; i++) s[i] = res[i];
+}
+__device__ __noinline__ void wt_mds_partial_layer_fast_ext(WTrace& t, Ext* s, int r) {  // :333-357
+  Ext d = wt_mul_ext(t, s[0], ext_make(25, 0));  // MDS0TO0
+#pragma unroll 1
+  for (int i = 1; i < 12; i++) {
+    Ext m = wt_mul_ext(t, s[i], ext_make(PGL_WHAT[r * 11 + i - 1], 0));
+    d = wt_add_ext(t, d, m);
+  }
+  const Ext s0 = s[0];
+  s[0] = d;
+#pragma unroll 1
+  for (int i = 1; i < 12; i++) {
+    Ext m = wt_mul_ext(t, s0, ext_make(PGL_VS[r * 11 + i - 1], 0));
+    s[i] = wt_add_ext(t, m, s[i]);
+  }
+}
+// ReduceWithPowers over consecutive extension elements of a word array
+GPV_DEV Ext wt_reduce_with_powers_ext(WTrace& t, const u64* __restrict__ a, u32 n, Ext s) {
+  return wt_reduce_with_powers_words(t, a, a + 2 * n, ext_make(0, 0), s);
+}
+
+// One gate's EvalUnfiltered into out[0 .. n_constraints). consts: localConstants after RemovePrefix (evaluate_gates.go:67).
+__device__ __noinline__ u32 wt_gate_unfiltered(WTrace& t, const DevGate& g, const u64* __restrict__ consts, const u64* __restrict__ wires,
+                                               const u64* __restrict__ pih, const u64* __restrict__ weights, u64* __restrict__ out,
+                                               u64* __restrict__ tmp) {
+  u32 k = 0;
+  const Ext one = ext_make(1, 0), zero = ext_make(0, 0);
+  switch (g.kind) {
+    case 0: break;  // NoopGate
+    case 1:         // constant_gate.go:57-69
+#pragma unroll 1
+      for (u32 i = 0; i < g.p0; i++) ws_st(out, k++, wt_sub_ext(t, ws_ld(consts, i), ws_ld(wires, i)));
+      break;
+    case 2:  // public_input_gate.go:32-51
+#pragma unroll 1
+      for (u32 i = 0; i < 4; i++) ws_st(out, k++, wt_sub_ext(t, ws_ld(wires, i), ext_make(pih[i], 0)));
+      break;
+    case 3: {  // base_sum_gate.go:66-96
+      Ext computed = wt_reduce_with_powers_ext(t, wires + 2, g.p0, ext_make(g.p1, 0));
+      ws_st(out, k++, wt_sub_ext(t, computed, ws_ld(wires, 0)));
+#pragma unroll 1
+      for (u32 l = 0; l < g.p0; l++) {
+        Ext limb = ws_ld(wires, 1 + l), acc = one;
+#pragma unroll 1
+        for (u32 i = 0; i < g.p1; i++) {
+          Ext d = wt_sub_ext(t, limb, ext_make(i, 0));
+          acc = wt_mul_ext(t, acc, d);
+        }
+        ws_st(out, k++, acc);
+      }
+      break;
+    }
+    case 4: {  // arithmetic_gate.go:60-84
+      const Ext c0 = ws_ld(consts, 0), c1 = ws_ld(consts, 1);
+#pragma unroll 1
+      for (u32 i = 0; i < g.p0; i++) {
+        Ext mm = wt_mul_ext(t, ws_ld(wires, 4 * i), ws_ld(wires, 4 * i + 1));
+        Ext left = wt_mul_ext(t, mm, c0);
+        Ext right = wt_mul_ext(t, ws_ld(wires, 4 * i + 2), c1);
+        Ext computed = wt_add_ext(t, left, right);
+        ws_st(out, k++, wt_sub_ext(t, ws_ld(wires, 4 * i + 3), computed));
+      }
+      break;
+    }
+    case 5: {  // arithmetic_extension_gate.go:59-86
+      const Ext c0 = ws_ld(consts, 0), c1 = ws_ld(consts, 1);
+#pragma unroll 1
+      for (u32 i = 0; i < g.p0; i++) {
+        ExtAlg mul = wt_mul_alg(t, wires_alg(wires, 8 * i), wires_alg(wires, 8 * i + 2));
+        ExtAlg scaled = wt_scalar_mul_alg(t, c0, mul);
+        ExtAlg computed = wt_scalar_mul_alg(t, c1, wires_alg(wires, 8 * i + 4));
+        computed = wt_add_alg(t, computed, scaled);
+        ExtAlg d = wt_sub_alg(t, wires_alg(wires, 8 * i + 6), computed);
+        ws_st(out, k++, d.a);
+        ws_st(out, k++, d.b);
+      }
+      break;
+    }
+    case 6: {  // multiplication_extension_gate.go:55-76
+      const Ext c0 = ws_ld(consts, 0);
+#pragma unroll 1
+      for (u32 i = 0; i < g.p0; i++) {
+        ExtAlg mul = wt_mul_alg(t, wires_alg(wires, 6 * i), wires_alg(wires, 6 * i + 2));
+        ExtAlg computed = wt_scalar_mul_alg(t, c0, mul);
+        ExtAlg d = wt_sub_alg(t, wires_alg(wires, 6 * i + 4), computed);
+        ws_st(out, k++, d.a);
+        ws_st(out, k++, d.b);
+      }
+      break;
+    }
+    case 7:
+    case 8: {  // reducing_gate.go:77-110, reducing_extension_gate.go:77-109
+      const u32 n = g.p0;
+      const bool ext_coeffs = g.kind == 8;
+      const u32 start_accs = 6 + (ext_coeffs ? 2 * n : n);
+      const ExtAlg alpha = wires_alg(wires, 2);
+      ExtAlg acc = wires_alg(wires, 4);
+#pragma unroll 1
+      for (u32 i = 0; i < n; i++) {
+        ExtAlg coeff = ext_coeffs ? wires_alg(wires, 6 + 2 * i) : alg_make(ws_ld(wires, 6 + i), zero);
+        ExtAlg acc_i = wires_alg(wires, i == n - 1 ? 0 : start_accs + 2 * i);
+        ExtAlg x = wt_mul_alg(t, acc, alpha);
+        x = wt_add_alg(t, x, coeff);
+        x = wt_sub_alg(t, x, acc_i);
+        ws_st(out, k++, x.a);
+        ws_st(out, k++, x.b);
+        acc = acc_i;
+      }
+      break;
+    }
+    case 9: {  // exponentiation_gate.go:80-128
+      const u32 n = g.p0;
+      const Ext base = ws_ld(wires, 0);
+#pragma unroll 1
+      for (u32 i = 0; i < n; i++) {
+        Ext prev = one;
+        if (i != 0) {
+          Ext iv = ws_ld(wires, 2 + n + i - 1);
+          prev = wt_mul_ext(t, iv, iv);
+        }
+        Ext cur = ws_ld(wires, 1 + (n - i - 1));
+        Ext x = wt_mul_ext(t, cur, one);
+        x = wt_sub_ext(t, x, one);
+        Ext mul_by = wt_mul_ext(t, cur, base);
+        mul_by = wt_sub_ext(t, mul_by, x);
+        Ext diff = wt_mul_ext(t, prev, mul_by);
+        ws_st(out, k++, wt_sub_ext(t, diff, ws_ld(wires, 2 + n + i)));
+      }
+      ws_st(out, k++, wt_sub_ext(t, ws_ld(wires, 1 + n), ws_ld(wires, 2 + n + n - 1)));
+      break;
+    }
+    case 10: {  // random_access_gate.go:131-190
+      const u32 bits = g.p0, copies = g.p1, extra = g.p2, vec = 1u << bits;
+      const u32 routed = (2 + vec) * copies + extra;
+#pragma unroll 1
+      for (u32 cp = 0; cp < copies; cp++) {
+        const u32 base_w = (2 + vec) * cp, bit_w = routed + cp * bits;
+#pragma unroll 1
+        for (u32 i = 0; i < bits; i++) {
+          Ext b = ws_ld(wires, bit_w + i);
+          Ext sq = wt_mul_ext(t, b, b);
+          ws_st(out, k++, wt_sub_ext(t, sq, b));
+        }
+        Ext rec = wt_reduce_with_powers_ext(t, wires + 2 * bit_w, bits, ext_make(2, 0));
+        ws_st(out, k++, wt_sub_ext(t, rec, ws_ld(wires, base_w)));
+        u32 cnt = vec;
+#pragma unroll 1
+        for (u32 lvl = 0; lvl < bits; lvl++) {  // fold adjacent pairs, lowest bit first; the folded list lives in tmp (in place: i <= 2 i)
+          Ext b = ws_ld(wires, bit_w + lvl);
+          cnt >>= 1;
+#pragma unroll 1
+          for (u32 i = 0; i < cnt; i++) {
+            Ext x = lvl == 0 ? ws_ld(wires, base_w + 2 + 2 * i) : ws_ld(tmp, 2 * i);
+            Ext y = lvl == 0 ? ws_ld(wires, base_w + 2 + 2 * i + 1) : ws_ld(tmp, 2 * i + 1);
+            Ext diff = wt_sub_ext(t, y, x);
+            Ext m = wt_mul_ext(t, b, diff);
+            ws_st(tmp, i, wt_add_ext(t, x, m));
+          }
+        }
+        Ext item0 = bits == 0 ? ws_ld(wires, base_w + 2) : ws_ld(tmp, 0);
+        ws_st(out, k++, wt_sub_ext(t, item0, ws_ld(wires, base_w + 1)));
+      }
+#pragma unroll 1
+      for (u32 i = 0; i < extra; i++) ws_st(out, k++, wt_sub_ext(t, ws_ld(consts, i), ws_ld(wires, (2 + vec) * copies + i)));
+      break;
+    }
+    case 11: {  // coset_interpolation_gate.go:151-226
+      const u32 sb = g.p0, degree = g.p1, npts = 1u << sb, n_inter = (npts - 2) / (degree - 1);
+      const u32 start_point = 1 + 2 * npts, start_inter = start_point + 4;
+      const u64* w = weights + g.weights_off;
+      const ExtAlg point = wires_alg(wires, start_point), shifted = wires_alg(wires, start_inter + 4 * n_inter);
+      Ext neg_shift = wt_scalar_mul_ext(t, ws_ld(wires, 0), GLP - 1);
+      ExtAlg x = wt_scalar_mul_alg(t, neg_shift, shifted);
+      x = wt_add_alg(t, x, point);
+      ws_st(out, k++, x.a);
+      ws_st(out, k++, x.b);
+      u64 gen = 1753635133440165772ULL;
+#pragma unroll 1
+      for (u32 i = 0; i < 32 - sb; i++) gen = gl_sqr(gen);
+      ExtAlg ev = alg_make(zero, zero), prod = alg_make(one, zero);
+      wt_partial_interpolate(t, gen, 0, degree, wires, w, shifted, ev, prod);
+#pragma unroll 1
+      for (u32 i = 0; i < n_inter; i++) {
+        ExtAlg i_ev = wires_alg(wires, start_inter + 2 * i), i_prod = wires_alg(wires, start_inter + 2 * (n_inter + i));
+        ExtAlg d = wt_sub_alg(t, i_ev, ev);
+        ws_st(out, k++, d.a);
+        ws_st(out, k++, d.b);
+        d = wt_sub_alg(t, i_prod, prod);
+        ws_st(out, k++, d.a);
+        ws_st(out, k++, d.b);
+        const u32 lo = 1 + (degree - 1) * (i + 1), hi = lo + degree - 1 < npts ? lo + degree - 1 : npts;
+        ev = i_ev;
+        prod = i_prod;
+        wt_partial_interpolate(t, gen, lo, hi, wires, w, shifted, ev, prod);
+      }
+      ExtAlg d = wt_sub_alg(t, wires_alg(wires, start_point + 2), ev);
+      ws_st(out, k++, d.a);
+      ws_st(out, k++, d.b);
+      break;
+    }
+    case 12: {  // poseidon_gate.go:95-181
+      const Ext swap = ws_ld(wires, 24);
+      Ext swap_m1 = wt_sub_ext(t, swap, one);
+      ws_st(out, k++, wt_mul_ext(t, swap, swap_m1));
+#pragma unroll 1
+      for (u32 i = 0; i < 4; i++) {
+        Ext diff = wt_sub_ext(t, ws_ld(wires, i + 4), ws_ld(wires, i));
+        Ext expected = wt_mul_ext(t, swap, diff);
+        ws_st(out, k++, wt_sub_ext(t, expected, ws_ld(wires, 25 + i)));
+      }
+      Ext s[12];
+#pragma unroll 1
+      for (u32 i = 0; i < 4; i++) {
+        s[i] = wt_add_ext(t, ws_ld(wires, i), ws_ld(wires, 25 + i));
+        s[i + 4] = wt_sub_ext(t, ws_ld(wires, i + 4), ws_ld(wires, 25 + i));
+      }
+#pragma unroll 1
+      for (u32 i = 8; i < 12; i++) s[i] = ws_ld(wires, i);
+      int round = 0;
+#pragma unroll 1
+      for (u32 r = 0; r < 4; r++) {
+        wt_constant_layer_ext(t, s, round);
+        if (r != 0)
+#pragma unroll 1
+          for (u32 i = 0; i < 12; i++) {
+            Ext sbox_in = ws_ld(wires, 29 + (r - 1) * 12 + i);
+            ws_st(out, k++, wt_sub_ext(t, s[i], sbox_in));
+            s[i] = sbox_in;
+          }
+#pragma unroll 1
+        for (u32 i = 0; i < 12; i++) s[i] = wt_sbox_ext(t, s[i]);
+        wt_mds_layer_ext(t, s);
+        round++;
+      }
+#pragma unroll 1
+      for (u32 i = 0; i < 12; i++) s[i] = wt_add_ext(t, s[i], ext_make(PGL_FIRST[i], 0));  // :240-249
+      wt_mds_partial_layer_init_ext(t, s);
+      const u32 start_partial = 29 + 36;
+#pragma unroll 1
+      for (u32 r = 0; r < 22; r++) {
+        Ext sbox_in = ws_ld(wires, start_partial + r);
+        ws_st(out, k++, wt_sub_ext(t, s[0], sbox_in));
+        s[0] = wt_sbox_ext(t, sbox_in);
+        if (r != 21) s[0] = wt_add_ext(t, s[0], ext_make(PGL_PRC[r], 0));
+        wt_mds_partial_layer_fast_ext(t, s, (int)r);
+      }
+      round += 22;
+      const u32 start_full1 = start_partial + 22;
+#pragma unroll 1
+      for (u32 r = 0; r < 4; r++) {
+        wt_constant_layer_ext(t, s, round);
+#pragma unroll 1
+        for (u32 i = 0; i < 12; i++) {
+          Ext sbox_in = ws_ld(wires, start_full1 + r * 12 + i);
+          ws_st(out, k++, wt_sub_ext(t, s[i], sbox_in));
+          s[i] = sbox_in;
+        }
+#pragma unroll 1
+        for (u32 i = 0; i < 12; i++) s[i] = wt_sbox_ext(t, s[i]);
+        wt_mds_layer_ext(t, s);
+        round++;
+      }
+#pragma unroll 1
+      for (u32 i = 0; i < 12; i++) ws_st(out, k++, wt_sub_ext(t, s[i], ws_ld(wires, 12 + i)));
+      break;
+    }
+    case 13: {  // poseidon_mds_gate.go:43-99: all 12 output rows first (in tmp), then the differences
+      const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+#pragma unroll 1
+      for (u32 r = 0; r < 12; r++) {
+        ExtAlg res = alg_make(zero, zero);
+#pragma unroll 1
+        for (u32 i = 0; i < 12; i++) {
+          ExtAlg m = wt_scalar_mul_alg(t, ext_make(C[i], 0), wires_alg(wires, 2 * ((i + r) % 12)));
+          res = wt_add_alg(t, res, m);
+        }
+        ExtAlg m = wt_scalar_mul_alg(t, ext_make(r == 0 ? 8 : 0, 0), wires_alg(wires, 2 * r));
+        res = wt_add_alg(t, res, m);
+        ws_st(tmp, 2 * r, res.a);
+        ws_st(tmp, 2 * r + 1, res.b);
+      }
+#pragma unroll 1
+      for (u32 i = 0; i < 12; i++) {
+        ExtAlg d = wt_sub_alg(t, wires_alg(wires, 2 * (12 + i)), alg_make(ws_ld(tmp, 2 * i), ws_ld(tmp, 2 * i + 1)));
+        ws_st(out, k++, d.a);
+        ws_st(out, k++, d.b);
+      }
+      break;
+    }
+    default: break;
+  }
+  return k;
+}
+
+// One proof. ch: [n_challenge_words]; pih: the public-inputs hash (its own hints belong to slice 1). Returns false when the reference's
+// vanishing-polynomial assertion (plonk.go:248) fails -- the trace is what the solver would be handed either way.
+GPV_DEV bool dev_witness_plonk(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch, const u64* __restrict__ pih,
+                               u64* __restrict__ trace, u64* __restrict__ wsp, size_t* written) {
+  WTrace t;
+  t.p = trace;
+  const u32 nc = dc->num_challenges, nr = dc->num_routed, qdf = dc->qdf, npp = dc->num_pp, ngc = dc->num_gate_constraints;
+  WPlonkWs ws;
+  ws.gate_terms = wsp;
+  ws.unf = ws.gate_terms + 2 * ngc;
+  ws.s_ids = ws.unf + 2 * ngc;
+  ws.num = ws.s_ids + 2 * nr;
+  ws.den = ws.num + 2 * nr;
+  ws.head = ws.den + 2 * nr;
+  ws.tmp = ws.head + 2 * nc * (npp + 2);
+  const Ext zeta = ext_make(ch[dc->ch_zeta], ch[dc->ch_zeta + 1]), one = ext_make(1, 0);
+  const u64* consts = rec + dc->off_constants;
+  const u64* wires = rec + dc->off_wires;
+  Ext zeta_pow_n = zeta;  // expPowerOf2Extension :55-61
+#pragma unroll 1
+  for (u32 i = 0; i < dc->degree_bits; i++) zeta_pow_n = wt_mul_ext(t, zeta_pow_n, zeta_pow_n);
+  // EvaluateGateConstraints evaluate_gates.go:77-105
+#pragma unroll 1
+  for (u32 i = 0; i < ngc; i++) ws_st(ws.gate_terms, i, ext_make(0, 0));
+#pragma unroll 1
+  for (u32 row = 0; row < dc->n_gates; row++) {
+    const u32 sel = dc->selector_index[row];
+    const Ext s = ws_ld(consts, sel);
+    Ext filter = one;  // computeFilter :33-55
+#pragma unroll 1
+    for (u32 i = dc->group_start[sel]; i < dc->group_end[sel]; i++) {
+      if (i == row) continue;
+      Ext d = wt_sub_ext(t, ext_make(i, 0), s);
+      filter = wt_mul_ext(t, filter, d);
+    }
+    if (dc->n_groups > 1) {
+      Ext d = wt_sub_ext(t, ext_make(0xFFFFFFFFULL, 0), s);  // UNUSED_SELECTOR gates/types.go:3
+      filter = wt_mul_ext(t, filter, d);
+    }
+    const u32 n = wt_gate_unfiltered(t, dc->gates[row], consts + 2 * dc->n_groups, wires, pih, dc->weights, ws.unf, ws.tmp);
+#pragma unroll 1
+    for (u32 i = 0; i < n; i++) ws_st(ws.unf, i, wt_mul_ext(t, ws_ld(ws.unf, i), filter));
+#pragma unroll 1
+    for (u32 i = 0; i < n; i++) ws_st(ws.gate_terms, i, wt_add_ext(t, ws_ld(ws.gate_terms, i), ws_ld(ws.unf, i)));
+  }
+  // evalVanishingPoly :121-207
+#pragma unroll 1
+  for (u32 i = 0; i < nr; i++) ws_st(ws.s_ids, i, wt_scalar_mul_ext(t, zeta, dc->k_is[i]));
+  const u64 degree = (u64)1 << dc->degree_bits;
+  Ext eval_zero_poly = wt_sub_ext(t, zeta_pow_n, one);  // evalL0 :63-83
+  Ext scaled = wt_scalar_mul_ext(t, zeta, degree);
+  Ext denominator = wt_sub_ext(t, scaled, ext_make(degree, 0));
+  const Ext l0 = wt_div_ext(t, eval_zero_poly, denominator);
+  const u32 per = npp + 2;  // head: per challenge [z1 term | npp + 1 partial-product checks]
+#pragma unroll 1
+  for (u32 i = 0; i < nc; i++) {
+    const Ext z = ws_ld(rec + dc->off_zs, i);
+    Ext zm1 = wt_sub_ext(t, z, one);
+    ws_st(ws.head, i * per, wt_mul_ext(t, l0, zm1));
+    const Ext beta = ext_make(ch[dc->ch_betas + i], 0), gamma = ext_make(ch[dc->ch_gammas + i], 0);
+#pragma unroll 1
+    for (u32 j = 0; j < nr; j++) {
+      Ext wpg = wt_add_ext(t, ws_ld(wires, j), gamma);
+      Ext bs = wt_mul_ext(t, beta, ws_ld(ws.s_ids, j));
+      ws_st(ws.num, j, wt_add_ext(t, bs, wpg));
+      Ext bg = wt_mul_ext(t, beta, ws_ld(rec + dc->off_sigmas, j));
+      ws_st(ws.den, j, wt_add_ext(t, bg, wpg));
+    }
+    Ext acc_k = z;  // checkPartialProducts :85-119
+#pragma unroll 1
+    for (u32 k = 0; k <= npp; k++) {
+      Ext np = ws_ld(ws.num, k * qdf), dp = ws_ld(ws.den, k * qdf);
+#pragma unroll 1
+      for (u32 j = 1; j < qdf; j++) {
+        np = wt_mul_ext(t, np, ws_ld(ws.num, k * qdf + j));
+        dp = wt_mul_ext(t, dp, ws_ld(ws.den, k * qdf + j));
+      }
+      const Ext acc_next = k < npp ? ws_ld(rec + dc->off_pp, i * npp + k) : ws_ld(rec + dc->off_zs_next, i);
+      Ext a = wt_mul_ext(t, acc_k, np);
+      Ext b = wt_mul_ext(t, acc_next, dp);
+      ws_st(ws.head, i * per + 1 + k, wt_sub_ext(t, a, b));
+      acc_k = acc_next;
+    }
+  }
+  // the reverse reduction over [z1 terms | partial-product checks | gate constraints] (:185-204)
+  Ext reduced[GPV_MAX_CHALLENGES];
+#pragma unroll
+  for (u32 j = 0; j < GPV_MAX_CHALLENGES; j++) reduced[j] = ext_make(0, 0);
+  const u32 n_pp_terms = nc * (npp + 1), n_terms = nc + n_pp_terms + ngc;
+#pragma unroll 1
+  for (u32 i = n_terms; i-- > 0;) {
+    Ext term;
+    if (i >= nc + n_pp_terms) {
+      term = ws_ld(ws.gate_terms, i - nc - n_pp_terms);
+    } else if (i >= nc) {
+      const u32 x = i - nc;
+      term = ws_ld(ws.head, (x / (npp + 1)) * per + 1 + x % (npp + 1));
+    } else {
+      term = ws_ld(ws.head, i * per);
+    }
+#pragma unroll
+    for (u32 j = 0; j < GPV_MAX_CHALLENGES; j++)
+      if (j < nc) {
+        Ext sm = wt_scalar_mul_ext(t, reduced[j], ch[dc->ch_alphas + j]);
+        reduced[j] = wt_add_ext(t, term, sm);
+      }
+  }
+  const Ext zh = wt_sub_ext(t, zeta_pow_n, one);  // Verify :209-250
+  bool ok = true;
+#pragma unroll
+  for (u32 i = 0; i < GPV_MAX_CHALLENGES; i++)
+    if (i < nc) {
+      Ext r = wt_reduce_with_powers_ext(t, rec + dc->off_quot + 2 * i * qdf, qdf, zeta_pow_n);
+      Ext prod = wt_mul_ext(t, zh, r);
+      ok &= prod.a == reduced[i].a && prod.b == reduced[i].b;
+    }
+  *written = (size_t)(t.p - trace);
+  return ok;
+}

@@ -46,6 +46,24 @@ class PlonkChip:
         _lib.check(_lib.lib().gpv_plonk_verify(self.ctx.h, c.h, _lib.ptr(proofs.data), _lib.ptr(flat), proofs.n, _lib.ptr(mask)), self.ctx.h)
         return mask
 
+    def WitnessVerify(self, proofs, challenges):
+        """Witness slice 3 (gpv_witness_plonk): the outputs of every hint the reference calls in PlonkChip.Verify
+        (plonk.go:209-250), in call order, for the given challenges. Returns (trace [n][words], kinds [n_hints] = GPV_HINT_* per hint
+        call, consistent [n] = the reference's vanishing-polynomial assertion holds)."""
+        import ctypes
+        c = proofs.circuit
+        L = _lib.lib()
+        flat = challenges.flat if hasattr(challenges, "flat") else challenges
+        flat = _lib.u64c(flat).reshape(proofs.n, c.num_challenge_words)
+        words = L.gpv_witness_plonk_words(ctypes.c_void_p(c.h))
+        n_hints = L.gpv_witness_plonk_layout(ctypes.c_void_p(c.h), None, 0)
+        kinds = np.empty(n_hints, dtype=np.uint8)
+        L.gpv_witness_plonk_layout(ctypes.c_void_p(c.h), _lib.ptr(kinds), n_hints)
+        trace = np.empty((proofs.n, words), dtype=np.uint64)
+        cons = np.empty(proofs.n, dtype=np.uint8)
+        _lib.check(L.gpv_witness_plonk(self.ctx.h, c.h, _lib.ptr(proofs.data), _lib.ptr(flat), proofs.n, _lib.ptr(trace), _lib.ptr(cons)), self.ctx.h)
+        return trace, kinds, cons
+
     def EvaluateGateConstraints(self, proofs):
         """gates.EvaluateGatesChip.EvaluateGateConstraints (evaluate_gates.go:77): [n][num_gate_constraints][2]."""
         c = proofs.circuit

@@ -54,6 +54,24 @@ class VerifierChip:
         _lib.check(L.gpv_witness_challenges(self.ctx.h, c.h, _lib.ptr(proofs.data), proofs.n, _lib.ptr(trace), _lib.ptr(ch)), self.ctx.h)
         return trace, kinds, (ProofChallenges(c, ch) if with_challenges else None)
 
+    def WitnessVerify(self, proofs):
+        """The whole hint trace of Verify (verifier.go:143-178; gpv_witness_verify): rangeCheckProof | GetPublicInputsHash + GetChallenges |
+        PlonkChip.Verify | GetInstance + VerifyFriProof per proof, in call order, the challenges handed between the slices in HBM. Returns
+        (trace [n][words] uint64, kinds [n_hints] uint8, ProofChallenges, status [n] uint8 = GPV_WITNESS_* bits of the reference's
+        assertions that fail on the way)."""
+        import ctypes
+        c = proofs.circuit
+        L = _lib.lib()
+        words = L.gpv_witness_verify_words(ctypes.c_void_p(c.h))
+        n_hints = L.gpv_witness_verify_layout(ctypes.c_void_p(c.h), None, 0)
+        kinds = np.empty(n_hints, dtype=np.uint8)
+        L.gpv_witness_verify_layout(ctypes.c_void_p(c.h), _lib.ptr(kinds), n_hints)
+        trace = np.empty((proofs.n, words), dtype=np.uint64)
+        ch = np.empty((proofs.n, c.num_challenge_words), dtype=np.uint64)
+        status = np.empty(proofs.n, dtype=np.uint8)
+        _lib.check(L.gpv_witness_verify(self.ctx.h, c.h, _lib.ptr(proofs.data), proofs.n, _lib.ptr(trace), _lib.ptr(ch), _lib.ptr(status)), self.ctx.h)
+        return trace, kinds, ProofChallenges(c, ch), status
+
     def Verify(self, proofs, verifierData=None, detail=False):
         """verifier.go:143. The reference's Verify returns nothing -- "accepted" means its gnark circuit is satisfiable.
         Here: accept[n] (uint8). With detail=True also the failure mask [n] and the ProofChallenges."""

@@ -218,7 +218,34 @@ size_t gpv_witness_fri_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap);
 int gpv_witness_fri(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n, uint64_t* trace,
                     uint8_t* consistent);
 int gpv_witness_range_check(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint8_t* ok);
+/* Slice 3: plonk.PlonkChip.Verify (plonk/plonk.go:209-250) for the given challenges, evaluated literally: expPowerOf2Extension, every
+ * gate's computeFilter + EvalUnfiltered + filter products + per-index sums (plonk/gates/evaluate_gates.go:33-105 and the 14 gates, the
+ * extension-algebra products as InnerProductExtension calls, the Poseidon gate through the *Extension layers of poseidon/goldilocks.go),
+ * sIDs, evalL0 (one InverseHint), numerators / denominators / checkPartialProducts per challenge, the reverse reduction by alpha and the
+ * quotient recombination, op by op in call order (the verification kernel streams constraints into a power-of-alpha sum and never holds
+ * these values). 142 693 words / 55 636 hint calls per testdata/step proof (135 137 / 52 824 for decode_block). consistent[i] (may be
+ * NULL) = 0 where the reference's vanishing-polynomial assertion (plonk.go:248) fails. The public-inputs hash the PublicInputGate needs
+ * is recomputed natively (its hints are slice 1's). With slices 0-2 this is every hint call of VerifierChip.Verify: the trace of Verify
+ * is range_check | challenges | plonk | fri (verifier.go:148-178). */
+size_t gpv_witness_plonk_words(const gpv_circuit* c);
+size_t gpv_witness_plonk_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap);
+int gpv_witness_plonk(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, const uint64_t* challenges, size_t n, uint64_t* trace,
+                      uint8_t* consistent);
 size_t gpv_witness_challenges_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap);
+/* The whole of it: every hint call of VerifierChip.Verify (verifier/verifier.go:143-178) per proof, in call order =
+ * range_check | challenges | plonk | fri (1 349 735 words / 448 677 hint calls per testdata/step proof). The challenges slice 1 derives
+ * are handed to slices 3 and 2 in HBM. status[i] (may be NULL): GPV_WITNESS_* bits of the assertions of the reference that fail on the way
+ * (the trace is written either way; after GPV_WITNESS_RANGE the reference's hints would have panicked and the rest of that row is
+ * meaningless). challenges (may be NULL): [n][gpv_num_challenge_words]. The _dev form takes device pointers and leaves trace / challenges /
+ * status in HBM for a prover on the same GPU; it synchronises the context's stream (the lanes' word counts are checked against the host's
+ * layout before it returns). What is NOT in the trace: gnark's own hints (api.ToBinary inside BN254Chip.ToVec and the index
+ * decompositions), and the Merkle paths -- they run in the native BN254 field and call none of the reference's hint functions. */
+enum { GPV_WITNESS_RANGE = 1, GPV_WITNESS_PLONK = 2, GPV_WITNESS_FRI = 4 };
+size_t gpv_witness_verify_words(const gpv_circuit* c);
+size_t gpv_witness_verify_layout(const gpv_circuit* c, uint8_t* kinds, size_t cap);
+int gpv_witness_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint64_t* challenges, uint8_t* status);
+int gpv_witness_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs_dev, size_t n, uint64_t* trace_dev, uint64_t* challenges_dev,
+                           uint8_t* status_dev);
 int gpv_witness_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint64_t* challenges);
 /* Add/Sub/Mul/Inverse/DivExtension (goldilocks/quadratic_extension.go:31-140), [n][2]; ok[i] = 0 where the
  * reference's "operand != 0" assertion (:124-125) fails. ok may be NULL. */

@@ -317,6 +317,24 @@ size_t orc_witness_fri(const void* cv, const void* proof, const u64* challenges,
   if (consistent) *consistent = ok ? 1 : 0;
   return w.size();
 }
+// Witness slice 3 (orc_witness.h): the hint outputs of plonk.PlonkChip.Verify for supplied challenges, one proof; the public-inputs hash is
+// computed natively here (its own hints belong to slice 1). Same conventions as orc_witness_fri; *consistent = the assertion of plonk.go:248.
+size_t orc_witness_plonk(const void* cv, const void* proof, const u64* challenges, u64* trace, unsigned char* kinds, size_t* n_hints, int* consistent) {
+  const Circuit& c = *(const Circuit*)cv;
+  ProofView pv(&c, proof);
+  std::vector<u64> w;
+  std::vector<unsigned char> k;
+  wit::Sink sink = {&w, &k};
+  bool ok = true;
+  u64 h[4];
+  public_inputs_hash(pv, h);
+  wit::witness_plonk(pv, Challenges::unflatten(c, challenges), h, sink, &ok);
+  if (trace) memcpy(trace, w.data(), 8 * w.size());
+  if (kinds) memcpy(kinds, k.data(), k.size());
+  if (n_hints) *n_hints = k.size();
+  if (consistent) *consistent = ok ? 1 : 0;
+  return w.size();
+}
 // Witness slice 0: the SplitLimbsHint outputs of rangeCheckProof, one proof. Returns the number of words (trace may be NULL).
 size_t orc_witness_range_check(const void* cv, const void* proof, u64* trace) {
   const Circuit& c = *(const Circuit*)cv;

@@ -440,5 +440,401 @@ static inline void witness_fri(const ProofView& pv, const Challenges& ch, Sink& 
   }
 }
 
+
+// ---------------------------------------------------------------- slice 3: plonk.PlonkChip.Verify (plonk/plonk.go:55-250)
+// Every gl.Chip call of Verify, evalVanishingPoly, evalL0, checkPartialProducts, EvaluateGateConstraints / computeFilter / evalFiltered
+// (plonk/gates/evaluate_gates.go:33-105), the 14 gates' EvalUnfiltered, the extension-algebra helpers
+// (goldilocks/quadratic_extension_algebra.go:28-125) and the *Extension Poseidon layers (poseidon/goldilocks.go:127-357), in call order.
+typedef ExtAlg Alg;  // orc_field.h
+static inline Ext inner_product_ext(Sink& t, u64 constant, BigExt acc, const Ext (*pairs)[2], int n) {  // quadratic_extension.go:107-120
+  for (int i = 0; i < n; i++) {
+    Ext m = scalar_mul_ext(t, pairs[i][0], constant);
+    BigExt p = mul_ext_nr(bext(m), bext(pairs[i][1]));
+    acc.c[0] = big_add(p.c[0], acc.c[0]);
+    acc.c[1] = big_add(p.c[1], acc.c[1]);
+  }
+  return reduce_ext(t, acc);
+}
+static inline Alg add_alg(Sink& t, Alg a, Alg b) { Ext c0 = add_ext(t, a.c[0], b.c[0]); Ext c1 = add_ext(t, a.c[1], b.c[1]); return alg(c0, c1); }  // :28
+static inline Alg sub_alg(Sink& t, Alg a, Alg b) { Ext c0 = sub_ext(t, a.c[0], b.c[0]); Ext c1 = sub_ext(t, a.c[1], b.c[1]); return alg(c0, c1); }  // :39
+static inline Alg mul_alg(Sink& t, Alg a, Alg b) {  // :50-75 with D = 2
+  const Ext inner0[1][2] = {{a.c[0], b.c[0]}}, inner_w0[1][2] = {{a.c[1], b.c[1]}};
+  const Ext inner1[2][2] = {{a.c[0], b.c[1]}, {a.c[1], b.c[0]}};
+  Alg r;
+  Ext acc = inner_product_ext(t, GL_W, bext(0, 0), inner_w0, 1);
+  r.c[0] = inner_product_ext(t, 1, bext(acc), inner0, 1);
+  acc = inner_product_ext(t, GL_W, bext(0, 0), nullptr, 0);
+  r.c[1] = inner_product_ext(t, 1, bext(acc), inner1, 2);
+  return r;
+}
+static inline Alg scalar_mul_alg(Sink& t, Ext a, Alg b) { Ext c0 = mul_ext(t, a, b.c[0]); Ext c1 = mul_ext(t, a, b.c[1]); return alg(c0, c1); }  // :77-86
+static inline void partial_interpolate(Sink& t, const u64* domain, const Alg* values, const u64* weights, size_t n, Alg point, Alg* ev,
+                                       Alg* prod) {  // :88-125
+  for (size_t i = 0; i < n; i++) {
+    Alg term = sub_alg(t, point, alg(ext(domain[i], 0), ext_zero()));
+    Alg weighted = scalar_mul_alg(t, ext(weights[i], 0), values[i]);
+    *ev = mul_alg(t, *ev, term);
+    Alg tmp = mul_alg(t, weighted, *prod);
+    *ev = add_alg(t, *ev, tmp);
+    *prod = mul_alg(t, *prod, term);
+  }
+}
+// poseidon/goldilocks.go extension layers
+static inline Ext sbox_ext(Sink& t, Ext x) {  // :147-152
+  Ext x2 = mul_ext(t, x, x);
+  Ext x4 = mul_ext(t, x2, x2);
+  Ext x3 = mul_ext(t, x, x2);
+  return mul_ext(t, x4, x3);
+}
+static inline void constant_layer_ext(Sink& t, Ext s[12], int round) {  // :127-136
+  for (int i = 0; i < 12; i++) s[i] = add_ext(t, s[i], ext(orc_const::GL_ALL_ROUND_CONSTANTS[i + 12 * round], 0));
+}
+static inline void mds_layer_ext(Sink& t, Ext s[12]) {  // :185-201, :218-229
+  Ext out[12];
+  for (int r = 0; r < 12; r++) {
+    Ext res = ext_zero();
+    for (int i = 0; i < 12; i++) {
+      Ext res1 = mul_ext(t, s[(i + r) % 12], ext(orc_const::GL_MDS_CIRC[i], 0));
+      res = add_ext(t, res, res1);
+    }
+    Ext last = mul_ext(t, s[r], ext(orc_const::GL_MDS_DIAG[r], 0));
+    out[r] = add_ext(t, res, last);
+  }
+  for (int r = 0; r < 12; r++) s[r] = out[r];
+}
+static inline void mds_partial_layer_init_ext(Sink& t, Ext s[12]) {  // :277-298
+  Ext res[12];
+  for (int i = 0; i < 12; i++) res[i] = ext_zero();
+  res[0] = s[0];
+  for (int r = 1; r < 12; r++)
+    for (int d = 1; d < 12; d++) {
+      Ext m = mul_ext(t, s[r], ext(orc_const::GL_FAST_PARTIAL_ROUND_INITIAL_MATRIX[(r - 1) * 11 + (d - 1)], 0));
+      res[d] = add_ext(t, res[d], m);
+    }
+  for (int i = 0; i < 12; i++) s[i] = res[i];
+}
+static inline void mds_partial_layer_fast_ext(Sink& t, Ext s[12], int r) {  // :333-357
+  Ext d = mul_ext(t, s[0], ext(orc_const::GL_MDS0TO0, 0));
+  for (int i = 1; i < 12; i++) {
+    Ext m = mul_ext(t, s[i], ext(orc_const::GL_FAST_PARTIAL_ROUND_W_HATS[r * 11 + i - 1], 0));
+    d = add_ext(t, d, m);
+  }
+  Ext res[12];
+  res[0] = d;
+  for (int i = 1; i < 12; i++) {
+    Ext m = mul_ext(t, s[0], ext(orc_const::GL_FAST_PARTIAL_ROUND_VS[r * 11 + i - 1], 0));
+    res[i] = add_ext(t, m, s[i]);
+  }
+  for (int i = 0; i < 12; i++) s[i] = res[i];
+}
+static inline Alg alg_at(const Ext* wires, u64 start) { return alg(wires[start], wires[start + 1]); }  // vars.go:29-41
+static inline void put(std::vector<Ext>& out, Alg a) { out.push_back(a.c[0]); out.push_back(a.c[1]); }
+
+// One gate's EvalUnfiltered. `consts` is localConstants after RemovePrefix (evaluate_gates.go:67).
+static inline std::vector<Ext> gate_unfiltered(Sink& t, const Gate& g, const Ext* consts, const Ext* wires, const u64 pih[4]) {
+  std::vector<Ext> out;
+  switch (g.kind) {
+    case GATE_NOOP: break;
+    case GATE_CONSTANT:  // constant_gate.go:57-69
+      for (u64 i = 0; i < g.p[0]; i++) out.push_back(sub_ext(t, consts[i], wires[i]));
+      break;
+    case GATE_PUBLIC_INPUT:  // public_input_gate.go:32-51
+      for (int i = 0; i < 4; i++) out.push_back(sub_ext(t, wires[i], ext(pih[i], 0)));
+      break;
+    case GATE_BASE_SUM: {  // base_sum_gate.go:66-96
+      std::vector<Ext> limbs(wires + 1, wires + 1 + g.p[0]);
+      Ext computed = reduce_with_powers(t, limbs, ext(g.p[1], 0));
+      out.push_back(sub_ext(t, computed, wires[0]));
+      for (Ext limb : limbs) {
+        Ext acc = ext_one();
+        for (u64 i = 0; i < g.p[1]; i++) {
+          Ext d = sub_ext(t, limb, ext(i, 0));
+          acc = mul_ext(t, acc, d);
+        }
+        out.push_back(acc);
+      }
+      break;
+    }
+    case GATE_ARITHMETIC:  // arithmetic_gate.go:60-84
+      for (u64 i = 0; i < g.p[0]; i++) {
+        const Ext* w = wires + 4 * i;
+        Ext mm = mul_ext(t, w[0], w[1]);
+        Ext left = mul_ext(t, mm, consts[0]);
+        Ext right = mul_ext(t, w[2], consts[1]);
+        Ext computed = add_ext(t, left, right);
+        out.push_back(sub_ext(t, w[3], computed));
+      }
+      break;
+    case GATE_ARITHMETIC_EXT:  // arithmetic_extension_gate.go:59-86
+      for (u64 i = 0; i < g.p[0]; i++) {
+        Alg m0 = alg_at(wires, 8 * i), m1 = alg_at(wires, 8 * i + 2), addend = alg_at(wires, 8 * i + 4), output = alg_at(wires, 8 * i + 6);
+        Alg mul = mul_alg(t, m0, m1);
+        Alg scaled = scalar_mul_alg(t, consts[0], mul);
+        Alg computed = scalar_mul_alg(t, consts[1], addend);
+        computed = add_alg(t, computed, scaled);
+        put(out, sub_alg(t, output, computed));
+      }
+      break;
+    case GATE_MUL_EXT:  // multiplication_extension_gate.go:55-76
+      for (u64 i = 0; i < g.p[0]; i++) {
+        Alg m0 = alg_at(wires, 6 * i), m1 = alg_at(wires, 6 * i + 2), output = alg_at(wires, 6 * i + 4);
+        Alg mul = mul_alg(t, m0, m1);
+        Alg computed = scalar_mul_alg(t, consts[0], mul);
+        put(out, sub_alg(t, output, computed));
+      }
+      break;
+    case GATE_REDUCING:
+    case GATE_REDUCING_EXT: {  // reducing_gate.go:77-110, reducing_extension_gate.go:77-109
+      const u64 n = g.p[0];
+      const bool ext_coeffs = g.kind == GATE_REDUCING_EXT;
+      const u64 start_accs = 6 + (ext_coeffs ? 2 * n : n);
+      Alg alpha = alg_at(wires, 2), acc = alg_at(wires, 4);
+      for (u64 i = 0; i < n; i++) {
+        Alg coeff = ext_coeffs ? alg_at(wires, 6 + 2 * i) : alg(wires[6 + i], ext_zero());
+        Alg acc_i = alg_at(wires, i == n - 1 ? 0 : start_accs + 2 * i);
+        Alg tmp = mul_alg(t, acc, alpha);
+        tmp = add_alg(t, tmp, coeff);
+        tmp = sub_alg(t, tmp, acc_i);
+        put(out, tmp);
+        acc = acc_i;
+      }
+      break;
+    }
+    case GATE_EXPONENTIATION: {  // exponentiation_gate.go:80-128
+      const u64 n = g.p[0];
+      Ext base = wires[0], output = wires[1 + n];
+      const Ext* bits = wires + 1;
+      const Ext* inter = wires + 2 + n;
+      for (u64 i = 0; i < n; i++) {
+        Ext prev = i == 0 ? ext_one() : mul_ext(t, inter[i - 1], inter[i - 1]);
+        Ext cur = bits[n - i - 1];
+        Ext tmp = mul_ext(t, cur, ext_one());
+        tmp = sub_ext(t, tmp, ext_one());
+        Ext mul_by = mul_ext(t, cur, base);
+        mul_by = sub_ext(t, mul_by, tmp);
+        Ext diff = mul_ext(t, prev, mul_by);
+        out.push_back(sub_ext(t, diff, inter[i]));
+      }
+      out.push_back(sub_ext(t, output, inter[n - 1]));
+      break;
+    }
+    case GATE_RANDOM_ACCESS: {  // random_access_gate.go:131-190
+      const u64 nbits = g.p[0], copies = g.p[1], extra = g.p[2], vec = (u64)1 << nbits;
+      const u64 routed = (2 + vec) * copies + extra;
+      for (u64 cp = 0; cp < copies; cp++) {
+        const Ext* base = wires + (2 + vec) * cp;
+        Ext access = base[0], claimed = base[1];
+        std::vector<Ext> items(base + 2, base + 2 + vec), bits(wires + routed + cp * nbits, wires + routed + (cp + 1) * nbits);
+        for (Ext b : bits) {
+          Ext sq = mul_ext(t, b, b);
+          out.push_back(sub_ext(t, sq, b));
+        }
+        Ext rec = reduce_with_powers(t, bits, ext(2, 0));
+        out.push_back(sub_ext(t, rec, access));
+        for (Ext b : bits) {
+          std::vector<Ext> next;
+          for (size_t i = 0; i < items.size(); i += 2) {
+            Ext diff = sub_ext(t, items[i + 1], items[i]);
+            Ext m = mul_ext(t, b, diff);
+            next.push_back(add_ext(t, items[i], m));
+          }
+          items = next;
+        }
+        out.push_back(sub_ext(t, items[0], claimed));
+      }
+      for (u64 i = 0; i < extra; i++) out.push_back(sub_ext(t, consts[i], wires[(2 + vec) * copies + i]));
+      break;
+    }
+    case GATE_COSET_INTERPOLATION: {  // coset_interpolation_gate.go:151-226
+      const u64 sb = g.p[0], degree = g.p[1], npts = (u64)1 << sb, n_inter = (npts - 2) / (degree - 1);
+      const u64 start_point = 1 + 2 * npts, start_inter = start_point + 4;
+      Ext shift = wires[0];
+      Alg point = alg_at(wires, start_point), value = alg_at(wires, start_point + 2), shifted = alg_at(wires, start_inter + 4 * n_inter);
+      Ext neg_shift = scalar_mul_ext(t, shift, GL_P - 1);
+      Alg tmp = scalar_mul_alg(t, neg_shift, shifted);
+      tmp = add_alg(t, tmp, point);
+      put(out, tmp);
+      std::vector<u64> domain(npts);
+      u64 gen = gl_primitive_root_of_unity((unsigned)sb);
+      domain[0] = 1;
+      for (u64 i = 1; i < npts; i++) domain[i] = gl_mul(domain[i - 1], gen);
+      std::vector<Alg> values(npts);
+      for (u64 i = 0; i < npts; i++) values[i] = alg_at(wires, 1 + 2 * i);
+      Alg ev = alg(ext_zero(), ext_zero()), prod = alg(ext_one(), ext_zero());
+      partial_interpolate(t, domain.data(), values.data(), g.weights.data(), degree, shifted, &ev, &prod);
+      for (u64 i = 0; i < n_inter; i++) {
+        Alg i_ev = alg_at(wires, start_inter + 2 * i), i_prod = alg_at(wires, start_inter + 2 * (n_inter + i));
+        put(out, sub_alg(t, i_ev, ev));
+        put(out, sub_alg(t, i_prod, prod));
+        u64 lo = 1 + (degree - 1) * (i + 1), hi = lo + degree - 1 < npts ? lo + degree - 1 : npts;
+        ev = i_ev;
+        prod = i_prod;
+        partial_interpolate(t, domain.data() + lo, values.data() + lo, g.weights.data() + lo, hi - lo, shifted, &ev, &prod);
+      }
+      put(out, sub_alg(t, value, ev));
+      break;
+    }
+    case GATE_POSEIDON: {  // poseidon_gate.go:95-181
+      Ext swap = wires[24];
+      Ext swap_m1 = sub_ext(t, swap, ext_one());
+      out.push_back(mul_ext(t, swap, swap_m1));
+      for (int i = 0; i < 4; i++) {
+        Ext diff = sub_ext(t, wires[i + 4], wires[i]);
+        Ext expected = mul_ext(t, swap, diff);
+        out.push_back(sub_ext(t, expected, wires[25 + i]));
+      }
+      Ext s[12];
+      for (int i = 0; i < 4; i++) {
+        s[i] = add_ext(t, wires[i], wires[25 + i]);
+        s[i + 4] = sub_ext(t, wires[i + 4], wires[25 + i]);
+      }
+      for (int i = 8; i < 12; i++) s[i] = wires[i];
+      int round = 0;
+      for (int r = 0; r < 4; r++) {
+        constant_layer_ext(t, s, round);
+        if (r != 0)
+          for (int i = 0; i < 12; i++) {
+            Ext sbox_in = wires[29 + (r - 1) * 12 + i];
+            out.push_back(sub_ext(t, s[i], sbox_in));
+            s[i] = sbox_in;
+          }
+        for (int i = 0; i < 12; i++) s[i] = sbox_ext(t, s[i]);
+        mds_layer_ext(t, s);
+        round++;
+      }
+      for (int i = 0; i < 12; i++) s[i] = add_ext(t, s[i], ext(orc_const::GL_FAST_PARTIAL_FIRST_ROUND_CONSTANT[i], 0));  // :240-249
+      mds_partial_layer_init_ext(t, s);
+      const int start_partial = 29 + 36;
+      for (int r = 0; r < 21; r++) {
+        Ext sbox_in = wires[start_partial + r];
+        out.push_back(sub_ext(t, s[0], sbox_in));
+        s[0] = sbox_ext(t, sbox_in);
+        s[0] = add_ext(t, s[0], ext(orc_const::GL_FAST_PARTIAL_ROUND_CONSTANTS[r], 0));
+        mds_partial_layer_fast_ext(t, s, r);
+      }
+      {
+        Ext sbox_in = wires[start_partial + 21];
+        out.push_back(sub_ext(t, s[0], sbox_in));
+        s[0] = sbox_ext(t, sbox_in);
+        mds_partial_layer_fast_ext(t, s, 21);
+      }
+      round += 22;
+      const int start_full1 = start_partial + 22;
+      for (int r = 0; r < 4; r++) {
+        constant_layer_ext(t, s, round);
+        for (int i = 0; i < 12; i++) {
+          Ext sbox_in = wires[start_full1 + r * 12 + i];
+          out.push_back(sub_ext(t, s[i], sbox_in));
+          s[i] = sbox_in;
+        }
+        for (int i = 0; i < 12; i++) s[i] = sbox_ext(t, s[i]);
+        mds_layer_ext(t, s);
+        round++;
+      }
+      for (int i = 0; i < 12; i++) out.push_back(sub_ext(t, s[i], wires[12 + i]));
+      break;
+    }
+    case GATE_POSEIDON_MDS: {  // poseidon_mds_gate.go:43-99
+      Alg in[12], outs[12];
+      for (int i = 0; i < 12; i++) in[i] = alg_at(wires, 2 * i);
+      for (int r = 0; r < 12; r++) {
+        Alg res = alg(ext_zero(), ext_zero());
+        for (int i = 0; i < 12; i++) {
+          Alg m = scalar_mul_alg(t, ext(orc_const::GL_MDS_CIRC[i], 0), in[(i + r) % 12]);
+          res = add_alg(t, res, m);
+        }
+        Alg m = scalar_mul_alg(t, ext(orc_const::GL_MDS_DIAG[r], 0), in[r]);
+        outs[r] = add_alg(t, res, m);
+      }
+      for (int i = 0; i < 12; i++) put(out, sub_alg(t, alg_at(wires, 2 * (12 + i)), outs[i]));
+      break;
+    }
+    default: throw std::runtime_error("unknown gate kind");
+  }
+  return out;
+}
+
+// One proof: PlonkChip.Verify. `ok` is cleared when the reference's vanishing-polynomial assertion (plonk.go:248) fails.
+static inline void witness_plonk(const ProofView& pv, const Challenges& ch, const u64 pih[4], Sink& t, bool* ok) {
+  const Circuit& c = *pv.c;
+  const u64 nc = c.num_challenges, nr = c.num_routed_wires, qdf = c.quotient_degree_factor, npp = c.num_partial_products;
+  Ext zeta_pow_n = ch.zeta;  // expPowerOf2Extension :55-61
+  for (u64 i = 0; i < c.degree_bits; i++) zeta_pow_n = mul_ext(t, zeta_pow_n, zeta_pow_n);
+  std::vector<Ext> constants(c.num_constants), wires(c.num_wires);
+  for (u64 i = 0; i < c.num_constants; i++) constants[i] = pv.constant(i);
+  for (u64 i = 0; i < c.num_wires; i++) wires[i] = pv.wire(i);
+  // EvaluateGateConstraints evaluate_gates.go:77-105
+  std::vector<Ext> gate_terms(c.num_gate_constraints, ext_zero());
+  const u64 n_sel = c.group_start.size();
+  for (size_t row = 0; row < c.gates.size(); row++) {
+    const u64 sel = c.selector_indices[row];
+    Ext s = constants[sel], filter = ext_one();  // computeFilter :33-55
+    for (u64 i = c.group_start[sel]; i < c.group_end[sel]; i++) {
+      if (i == row) continue;
+      Ext d = sub_ext(t, ext(i, 0), s);
+      filter = mul_ext(t, filter, d);
+    }
+    if (n_sel > 1) {
+      Ext d = sub_ext(t, ext(0xFFFFFFFFULL, 0), s);
+      filter = mul_ext(t, filter, d);
+    }
+    std::vector<Ext> unf = gate_unfiltered(t, c.gates[row], constants.data() + n_sel, wires.data(), pih);
+    for (Ext& u : unf) u = mul_ext(t, u, filter);
+    if (unf.size() > gate_terms.size()) throw std::runtime_error("num_constraints() gave too low of a number");
+    for (size_t i = 0; i < unf.size(); i++) gate_terms[i] = add_ext(t, gate_terms[i], unf[i]);
+  }
+  std::vector<Ext> s_ids(nr);  // evalVanishingPoly :121-207
+  for (u64 i = 0; i < nr; i++) s_ids[i] = scalar_mul_ext(t, ch.zeta, c.k_is[i]);
+  const u64 degree = (u64)1 << c.degree_bits;
+  Ext eval_zero_poly = sub_ext(t, zeta_pow_n, ext_one());  // evalL0 :63-83
+  Ext scaled = scalar_mul_ext(t, ch.zeta, degree);
+  Ext denominator = sub_ext(t, scaled, ext(degree, 0));
+  Ext l0 = div_ext(t, eval_zero_poly, denominator);
+  std::vector<Ext> z1_terms, pp_terms;
+  for (u64 i = 0; i < nc; i++) {
+    Ext zm1 = sub_ext(t, pv.z(i), ext_one());
+    z1_terms.push_back(mul_ext(t, l0, zm1));
+    std::vector<Ext> num(nr), den(nr);
+    for (u64 j = 0; j < nr; j++) {
+      Ext wpg = add_ext(t, wires[j], ext(ch.gammas[i], 0));
+      Ext bs = mul_ext(t, ext(ch.betas[i], 0), s_ids[j]);
+      num[j] = add_ext(t, bs, wpg);
+      Ext bg = mul_ext(t, ext(ch.betas[i], 0), pv.sigma(j));
+      den[j] = add_ext(t, bg, wpg);
+    }
+    std::vector<Ext> accs;  // checkPartialProducts :85-119
+    accs.push_back(pv.z(i));
+    for (u64 k = 0; k < npp; k++) accs.push_back(pv.partial_product(i * npp + k));
+    accs.push_back(pv.z_next(i));
+    for (u64 k = 0; k <= npp; k++) {
+      Ext np = num[k * qdf], dp = den[k * qdf];
+      for (u64 j = 1; j < qdf; j++) {
+        np = mul_ext(t, np, num[k * qdf + j]);
+        dp = mul_ext(t, dp, den[k * qdf + j]);
+      }
+      Ext a = mul_ext(t, accs[k], np);
+      Ext b = mul_ext(t, accs[k + 1], dp);
+      pp_terms.push_back(sub_ext(t, a, b));
+    }
+  }
+  std::vector<Ext> terms = z1_terms;
+  terms.insert(terms.end(), pp_terms.begin(), pp_terms.end());
+  terms.insert(terms.end(), gate_terms.begin(), gate_terms.end());
+  std::vector<Ext> reduced(nc, ext_zero());
+  for (size_t i = terms.size(); i-- > 0;)
+    for (u64 j = 0; j < nc; j++) {
+      Ext sm = scalar_mul_ext(t, reduced[j], ch.alphas[j]);
+      reduced[j] = add_ext(t, terms[i], sm);
+    }
+  Ext zh = sub_ext(t, zeta_pow_n, ext_one());  // Verify :209-250
+  for (u64 i = 0; i < nc; i++) {
+    std::vector<Ext> chunk;
+    for (u64 k = 0; k < qdf; k++) chunk.push_back(pv.quotient_poly(i * qdf + k));
+    Ext r = reduce_with_powers(t, chunk, zeta_pow_n);
+    Ext prod = mul_ext(t, zh, r);
+    if (!(reduced[i] == prod)) *ok = false;
+  }
+}
+
 }  // namespace wit
 }  // namespace orc

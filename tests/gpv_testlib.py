@@ -512,6 +512,26 @@ class Oracle:
             cons[i] = c.value
         return trace, kinds, cons
 
+    def witness_plonk(self, oc, proofs, challenges):
+        """oracle/orc_witness.h witness_plonk: (trace [n][words], kinds [n_hints], consistent [n]) -- the hint outputs of PlonkChip.Verify
+        (plonk.go:209-250) for the supplied challenges."""
+        buf, n = self._proofs(oc, proofs)
+        rows = buf.reshape(n, -1)
+        ch = u64arr(challenges).reshape(n, oc.ncw)
+        f = self.lib.orc_witness_plonk
+        f.restype = ctypes.c_size_t
+        nh = ctypes.c_size_t()
+        words = f(ctypes.c_void_p(oc.h), _p(np.ascontiguousarray(rows[0])), _p(np.ascontiguousarray(ch[0])), None, None, ctypes.byref(nh), None)
+        trace = np.empty((n, words), dtype=np.uint64)
+        kinds = np.empty(nh.value, dtype=np.uint8)
+        cons = np.empty(n, dtype=np.uint8)
+        for i in range(n):
+            c = ctypes.c_int()
+            assert f(ctypes.c_void_p(oc.h), _p(np.ascontiguousarray(rows[i])), _p(np.ascontiguousarray(ch[i])), _p(trace[i]), _p(kinds), ctypes.byref(nh),
+                     ctypes.byref(c)) == words
+            cons[i] = c.value
+        return trace, kinds, cons
+
     def witness_range_check(self, oc, proofs):
         """oracle/orc_witness.h witness_range_check: [n][words] SplitLimbsHint outputs of rangeCheckProof (verifier.go:84-141)."""
         buf, n = self._proofs(oc, proofs)
@@ -1294,3 +1314,345 @@ def witness_fri_exact(ci, packed, challenges):
     for q in range(ci.num_query_rounds):
         w.query_round(ci, rec, ch, precomputed, points, q)
     return w.words, w.kinds, w.consistent
+
+
+# ---------------------------------------------------------------- witness slice 3: the hint outputs of plonk.PlonkChip.Verify
+# (plonk/plonk.go:55-250; plonk/gates/evaluate_gates.go:33-105 and the 14 gates' EvalUnfiltered; goldilocks/quadratic_extension_algebra.go:28-125;
+# poseidon/goldilocks.go:127-357 extension layers), exact integers, in the reference's call order.
+UNUSED_SELECTOR = 2**32 - 1
+
+
+class ExactPlonkWitness(ExactFriWitness):
+    def __init__(self):
+        self.words, self.kinds = [], []
+        self.K = _poseidon_gl_constants()
+
+    # ---- quadratic_extension.go:107-121 / quadratic_extension_algebra.go
+    def inner_product_ext(self, constant, acc, pairs):
+        acc = list(acc)
+        for a, b in pairs:
+            m = self.scalar_mul_ext(a, constant)
+            p = self.mul_ext_nr(m, b)
+            acc = [p[0] + acc[0], p[1] + acc[1]]
+        return self.reduce_ext(acc)
+
+    def add_alg(self, a, b): return [self.add_ext(a[0], b[0]), self.add_ext(a[1], b[1])]   # :28
+    def sub_alg(self, a, b): return [self.sub_ext(a[0], b[0]), self.sub_ext(a[1], b[1])]   # :39
+
+    def mul_alg(self, a, b):  # :50-75, D = 2
+        inner = [[(a[0], b[0])], [(a[0], b[1]), (a[1], b[0])]]
+        inner_w = [[(a[1], b[1])], []]
+        out = []
+        for i in range(2):
+            acc = self.inner_product_ext(GL_W, [0, 0], inner_w[i])
+            out.append(self.inner_product_ext(1, acc, inner[i]))
+        return out
+
+    def scalar_mul_alg(self, a, b): return [self.mul_ext(a, b[0]), self.mul_ext(a, b[1])]  # :77-86
+
+    def partial_interpolate(self, domain, values, weights, point, ev, prod):  # :88-125
+        for x, val, wt in zip(domain, values, weights):
+            term = self.sub_alg(point, [[x, 0], [0, 0]])
+            weighted = self.scalar_mul_alg([wt, 0], val)
+            ev = self.mul_alg(ev, term)
+            tmp = self.mul_alg(weighted, prod)
+            ev = self.add_alg(ev, tmp)
+            prod = self.mul_alg(prod, term)
+        return ev, prod
+
+    # ---- poseidon/goldilocks.go extension layers
+    def sbox_ext(self, x):  # :147-152
+        x2 = self.mul_ext(x, x)
+        x4 = self.mul_ext(x2, x2)
+        x3 = self.mul_ext(x, x2)
+        return self.mul_ext(x4, x3)
+
+    def constant_layer_ext(self, s, rnd):  # :127-136
+        return [self.add_ext(s[i], [self.K["GL_ALL_ROUND_CONSTANTS"][i + 12 * rnd], 0]) for i in range(12)]
+
+    def mds_layer_ext(self, s):  # :218-229 / :185-201
+        out = []
+        for r in range(12):
+            res = [0, 0]
+            for i in range(12):
+                res1 = self.mul_ext(s[(i + r) % 12], [self.K["GL_MDS_CIRC"][i], 0])
+                res = self.add_ext(res, res1)
+            res = self.add_ext(res, self.mul_ext(s[r], [self.K["GL_MDS_DIAG"][r], 0]))
+            out.append(res)
+        return out
+
+    def partial_first_constant_layer_ext(self, s):  # :240-249
+        return [self.add_ext(s[i], [self.K["GL_FAST_PARTIAL_FIRST_ROUND_CONSTANT"][i], 0]) for i in range(12)]
+
+    def mds_partial_layer_init_ext(self, s):  # :277-298
+        M = self.K["GL_FAST_PARTIAL_ROUND_INITIAL_MATRIX"]
+        res = [[0, 0] for _ in range(12)]
+        res[0] = s[0]
+        for r in range(1, 12):
+            for d in range(1, 12):
+                res[d] = self.add_ext(res[d], self.mul_ext(s[r], [M[(r - 1) * 11 + (d - 1)], 0]))
+        return res
+
+    def mds_partial_layer_fast_ext(self, s, r):  # :333-357
+        W, V = self.K["GL_FAST_PARTIAL_ROUND_W_HATS"], self.K["GL_FAST_PARTIAL_ROUND_VS"]
+        d = self.mul_ext(s[0], [25, 0])
+        for i in range(1, 12):
+            d = self.add_ext(d, self.mul_ext(s[i], [W[r * 11 + i - 1], 0]))
+        res = [d]
+        for i in range(1, 12):
+            res.append(self.add_ext(self.mul_ext(s[0], [V[r * 11 + i - 1], 0]), s[i]))
+        return res
+
+    # ---- gates (plonk/gates/*.go EvalUnfiltered)
+    def alg(self, wires, start): return [wires[start], wires[start + 1]]  # GetLocalExtAlgebra vars.go:29-41
+
+    def eval_unfiltered(self, gate, consts, wires, pih):
+        kind, (p0, p1, p2), weights = gate
+        c = []
+        if kind == GATE_NOOP:
+            pass
+        elif kind == GATE_CONSTANT:  # constant_gate.go:57-69
+            for i in range(p0):
+                c.append(self.sub_ext(consts[i], wires[i]))
+        elif kind == GATE_PUBLIC_INPUT:  # public_input_gate.go:32-51
+            for i in range(4):
+                c.append(self.sub_ext(wires[i], [pih[i], 0]))
+        elif kind == GATE_BASE_SUM:  # base_sum_gate.go:66-96
+            limbs = [wires[1 + i] for i in range(p0)]
+            computed = self.reduce_with_powers(limbs, [p1, 0])
+            c.append(self.sub_ext(computed, wires[0]))
+            for limb in limbs:
+                acc = [1, 0]
+                for i in range(p1):
+                    acc = self.mul_ext(acc, self.sub_ext(limb, [i, 0]))
+                c.append(acc)
+        elif kind == GATE_ARITHMETIC:  # arithmetic_gate.go:60-84
+            for i in range(p0):
+                m0, m1, addend, output = wires[4 * i:4 * i + 4]
+                left = self.mul_ext(self.mul_ext(m0, m1), consts[0])
+                computed = self.add_ext(left, self.mul_ext(addend, consts[1]))
+                c.append(self.sub_ext(output, computed))
+        elif kind == GATE_ARITHMETIC_EXT:  # arithmetic_extension_gate.go:59-86
+            for i in range(p0):
+                m0, m1, addend, output = (self.alg(wires, 8 * i + 2 * k) for k in range(4))
+                mul = self.mul_alg(m0, m1)
+                scaled = self.scalar_mul_alg(consts[0], mul)
+                computed = self.scalar_mul_alg(consts[1], addend)
+                computed = self.add_alg(computed, scaled)
+                c += self.sub_alg(output, computed)
+        elif kind == GATE_MUL_EXT:  # multiplication_extension_gate.go:55-76
+            for i in range(p0):
+                m0, m1, output = (self.alg(wires, 6 * i + 2 * k) for k in range(3))
+                mul = self.mul_alg(m0, m1)
+                computed = self.scalar_mul_alg(consts[0], mul)
+                c += self.sub_alg(output, computed)
+        elif kind in (GATE_REDUCING, GATE_REDUCING_EXT):  # reducing_gate.go:77-110, reducing_extension_gate.go:77-109
+            n = p0
+            alpha, acc = self.alg(wires, 2), self.alg(wires, 4)
+            ext_coeffs = kind == GATE_REDUCING_EXT
+            start_accs = 6 + (2 * n if ext_coeffs else n)
+            accs = [self.alg(wires, 0 if i == n - 1 else start_accs + 2 * i) for i in range(n)]
+            for i in range(n):
+                coeff = self.alg(wires, 6 + 2 * i) if ext_coeffs else [wires[6 + i], [0, 0]]
+                tmp = self.mul_alg(acc, alpha)
+                tmp = self.add_alg(tmp, coeff)
+                tmp = self.sub_alg(tmp, accs[i])
+                c += tmp
+                acc = accs[i]
+        elif kind == GATE_EXPONENTIATION:  # exponentiation_gate.go:80-128
+            n = p0
+            base, bits, output = wires[0], [wires[1 + i] for i in range(n)], wires[1 + n]
+            inter = [wires[2 + n + i] for i in range(n)]
+            for i in range(n):
+                prev = [1, 0] if i == 0 else self.mul_ext(inter[i - 1], inter[i - 1])
+                cur = bits[n - i - 1]
+                tmp = self.mul_ext(cur, [1, 0])
+                tmp = self.sub_ext(tmp, [1, 0])
+                mul_by = self.mul_ext(cur, base)
+                mul_by = self.sub_ext(mul_by, tmp)
+                diff = self.mul_ext(prev, mul_by)
+                c.append(self.sub_ext(diff, inter[i]))
+            c.append(self.sub_ext(output, inter[n - 1]))
+        elif kind == GATE_RANDOM_ACCESS:  # random_access_gate.go:131-190
+            bits_n, copies, extra = p0, p1, p2
+            vec = 1 << bits_n
+            routed = (2 + vec) * copies + extra
+            for cp in range(copies):
+                access, claimed = wires[(2 + vec) * cp], wires[(2 + vec) * cp + 1]
+                items = [wires[(2 + vec) * cp + 2 + i] for i in range(vec)]
+                bits = [wires[routed + cp * bits_n + i] for i in range(bits_n)]
+                for b in bits:
+                    c.append(self.sub_ext(self.mul_ext(b, b), b))
+                c.append(self.sub_ext(self.reduce_with_powers(bits, [2, 0]), access))
+                for b in bits:
+                    nxt = []
+                    for i in range(0, len(items), 2):
+                        x, y = items[i], items[i + 1]
+                        diff = self.sub_ext(y, x)
+                        nxt.append(self.add_ext(x, self.mul_ext(b, diff)))
+                    items = nxt
+                c.append(self.sub_ext(items[0], claimed))
+            for i in range(extra):
+                c.append(self.sub_ext(consts[i], wires[(2 + vec) * copies + i]))
+        elif kind == GATE_COSET_INTERPOLATION:  # coset_interpolation_gate.go:151-226
+            sb, degree = p0, p1
+            npts = 1 << sb
+            n_inter = (npts - 2) // (degree - 1)
+            start_point = 1 + 2 * npts
+            start_inter = start_point + 4
+            shift = wires[0]
+            point, value = self.alg(wires, start_point), self.alg(wires, start_point + 2)
+            shifted = self.alg(wires, start_inter + 4 * n_inter)
+            neg_shift = self.scalar_mul_ext(shift, GL_P - 1)
+            tmp = self.scalar_mul_alg(neg_shift, shifted)
+            tmp = self.add_alg(tmp, point)
+            c += tmp
+            g = pow(GL_POW2_GENERATOR, 1 << (32 - sb), GL_P)
+            domain = [pow(g, i, GL_P) for i in range(npts)]
+            values = [self.alg(wires, 1 + 2 * i) for i in range(npts)]
+            ev, prod = self.partial_interpolate(domain[:degree], values[:degree], weights[:degree], shifted, [[0, 0], [0, 0]], [[1, 0], [0, 0]])
+            for i in range(n_inter):
+                i_ev, i_prod = self.alg(wires, start_inter + 2 * i), self.alg(wires, start_inter + 2 * (n_inter + i))
+                c += self.sub_alg(i_ev, ev)
+                c += self.sub_alg(i_prod, prod)
+                lo = 1 + (degree - 1) * (i + 1)
+                hi = min(lo + degree - 1, npts)
+                ev, prod = self.partial_interpolate(domain[lo:hi], values[lo:hi], weights[lo:hi], shifted, i_ev, i_prod)
+            c += self.sub_alg(value, ev)
+        elif kind == GATE_POSEIDON:  # poseidon_gate.go:95-181
+            swap = wires[24]
+            c.append(self.mul_ext(swap, self.sub_ext(swap, [1, 0])))
+            for i in range(4):
+                diff = self.sub_ext(wires[i + 4], wires[i])
+                c.append(self.sub_ext(self.mul_ext(swap, diff), wires[25 + i]))
+            s = [None] * 12
+            for i in range(4):
+                s[i] = self.add_ext(wires[i], wires[25 + i])
+                s[i + 4] = self.sub_ext(wires[i + 4], wires[25 + i])
+            for i in range(8, 12):
+                s[i] = wires[i]
+            rnd = 0
+            for r in range(4):
+                s = self.constant_layer_ext(s, rnd)
+                if r != 0:
+                    for i in range(12):
+                        sbox_in = wires[29 + (r - 1) * 12 + i]
+                        c.append(self.sub_ext(s[i], sbox_in))
+                        s[i] = sbox_in
+                s = [self.sbox_ext(x) for x in s]
+                s = self.mds_layer_ext(s)
+                rnd += 1
+            s = self.partial_first_constant_layer_ext(s)
+            s = self.mds_partial_layer_init_ext(s)
+            start_partial = 29 + 36
+            for r in range(21):
+                sbox_in = wires[start_partial + r]
+                c.append(self.sub_ext(s[0], sbox_in))
+                s[0] = self.sbox_ext(sbox_in)
+                s[0] = self.add_ext(s[0], [self.K["GL_FAST_PARTIAL_ROUND_CONSTANTS"][r], 0])
+                s = self.mds_partial_layer_fast_ext(s, r)
+            sbox_in = wires[start_partial + 21]
+            c.append(self.sub_ext(s[0], sbox_in))
+            s[0] = self.sbox_ext(sbox_in)
+            s = self.mds_partial_layer_fast_ext(s, 21)
+            rnd += 22
+            start_full1 = start_partial + 22
+            for r in range(4):
+                s = self.constant_layer_ext(s, rnd)
+                for i in range(12):
+                    sbox_in = wires[start_full1 + r * 12 + i]
+                    c.append(self.sub_ext(s[i], sbox_in))
+                    s[i] = sbox_in
+                s = [self.sbox_ext(x) for x in s]
+                s = self.mds_layer_ext(s)
+                rnd += 1
+            for i in range(12):
+                c.append(self.sub_ext(s[i], wires[12 + i]))
+        elif kind == GATE_POSEIDON_MDS:  # poseidon_mds_gate.go:43-99
+            ins = [self.alg(wires, 2 * i) for i in range(12)]
+            outs = []
+            for r in range(12):
+                res = [[0, 0], [0, 0]]
+                for i in range(12):
+                    res = self.add_alg(res, self.scalar_mul_alg([self.K["GL_MDS_CIRC"][i], 0], ins[(i + r) % 12]))
+                res = self.add_alg(res, self.scalar_mul_alg([self.K["GL_MDS_DIAG"][r], 0], ins[r]))
+                outs.append(res)
+            for i in range(12):
+                c += self.sub_alg(self.alg(wires, 2 * (12 + i)), outs[i])
+        else:
+            raise ValueError("gate kind %d" % kind)
+        return c
+
+    def evaluate_gate_constraints(self, ci, consts, wires, pih):  # evaluate_gates.go:33-105
+        total = [[0, 0] for _ in range(ci.num_gate_constraints)]
+        n_sel = len(ci.groups)
+        for row, gate in enumerate(ci.gates):
+            sel = ci.selector_indices[row]
+            lo, hi = ci.groups[sel]
+            s = consts[sel]
+            filt = [1, 0]
+            for i in range(lo, hi):
+                if i != row:
+                    filt = self.mul_ext(filt, self.sub_ext([i, 0], s))
+            if n_sel > 1:
+                filt = self.mul_ext(filt, self.sub_ext([UNUSED_SELECTOR, 0], s))
+            unf = self.eval_unfiltered(gate, consts[n_sel:], wires, pih)
+            unf = [self.mul_ext(u, filt) for u in unf]
+            for i, u in enumerate(unf):
+                total[i] = self.add_ext(total[i], u)
+        return total
+
+
+def witness_plonk_exact(ci, packed, challenges, pih):
+    """(trace words, hint kinds, both vanishing-polynomial equalities hold) of one packed proof: PlonkChip.Verify, exact integers."""
+    w = ExactPlonkWitness()
+    rec = np.frombuffer(packed, dtype=np.uint64)
+    nc, npp, qdf, nr = ci.num_challenges, ci.num_partial_products, ci.quotient_degree_factor, ci.num_routed_wires
+    flat = [int(x) for x in challenges]
+    betas, gammas, alphas, zeta = flat[0:nc], flat[nc:2 * nc], flat[2 * nc:3 * nc], flat[3 * nc:3 * nc + 2]
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        out = [[int(rec[pos + 2 * i]), int(rec[pos + 2 * i + 1])] for i in range(n)]
+        pos += 2 * n
+        return out
+
+    consts, sigmas, wires, zs, zs_next, pps, quots = (take(ci.num_constants), take(nr), take(ci.num_wires), take(nc), take(nc), take(nc * npp),
+                                                      take(nc * qdf))
+    pih = [int(x) for x in pih]
+    zeta_pow_n = zeta
+    for _ in range(ci.degree_bits):                                               # expPowerOf2Extension plonk.go:55-61
+        zeta_pow_n = w.mul_ext(zeta_pow_n, zeta_pow_n)
+    terms_gates = w.evaluate_gate_constraints(ci, consts, wires, pih)             # evalVanishingPoly :121-207
+    s_ids = [w.scalar_mul_ext(zeta, k) for k in ci.k_is[:nr]]
+    degree = 1 << ci.degree_bits
+    ezp = w.sub_ext(zeta_pow_n, [1, 0])                                           # evalL0 :63-83
+    den = w.sub_ext(w.scalar_mul_ext(zeta, degree), [degree, 0])
+    l0 = w.div_ext(ezp, den)
+    z1_terms, pp_terms = [], []
+    for i in range(nc):
+        z1_terms.append(w.mul_ext(l0, w.sub_ext(zs[i], [1, 0])))
+        nums, dens = [], []
+        for j in range(nr):
+            wvpg = w.add_ext(wires[j], [gammas[i], 0])
+            nums.append(w.add_ext(w.mul_ext([betas[i], 0], s_ids[j]), wvpg))
+            dens.append(w.add_ext(w.mul_ext([betas[i], 0], sigmas[j]), wvpg))
+        accs = [zs[i]] + pps[i * npp:(i + 1) * npp] + [zs_next[i]]                 # checkPartialProducts :85-119
+        for k in range(npp + 1):
+            np_, dp_ = nums[k * qdf], dens[k * qdf]
+            for j in range(1, qdf):
+                np_ = w.mul_ext(np_, nums[k * qdf + j])
+                dp_ = w.mul_ext(dp_, dens[k * qdf + j])
+            pp_terms.append(w.sub_ext(w.mul_ext(accs[k], np_), w.mul_ext(accs[k + 1], dp_)))
+    terms = z1_terms + pp_terms + terms_gates
+    reduced = [[0, 0] for _ in range(nc)]
+    for t in reversed(terms):
+        for j in range(nc):
+            reduced[j] = w.add_ext(t, w.scalar_mul_ext(reduced[j], alphas[j]))
+    zh = w.sub_ext(zeta_pow_n, [1, 0])                                            # Verify :209-250
+    ok = True
+    for i in range(nc):
+        prod = w.mul_ext(zh, w.reduce_with_powers(quots[i * qdf:(i + 1) * qdf], zeta_pow_n))
+        ok &= prod == reduced[i]
+    return w.words, w.kinds, ok

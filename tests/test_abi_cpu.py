@@ -404,3 +404,35 @@ def test_witness_fri_layout_and_oracle_trace(gpv, name):
     got = np.empty(n_hints, dtype=np.uint8)
     L.gpv_witness_fri_layout(ctypes.c_void_p(circuit.h), gpv._lib.ptr(got), n_hints)
     assert n_hints == len(kinds) and (got == ok).all()
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_witness_plonk_layout_and_oracle_trace(gpv, name):
+    """Witness slice 3 (plonk.PlonkChip.Verify), the parts that need no GPU: the oracle's literal restatement
+    (oracle/orc_witness.h witness_plonk) == the exact-integer Python derivation (gpv_testlib.witness_plonk_exact: every hint output checked
+    against its defining equation, the reference's vanishing-polynomial assertion evaluated at the end -- it holds for the fixture and fails
+    for a tampered wire opening) word for word, and libgpv's host-side layout (gpv_witness_plonk_words / _layout) agrees with both."""
+    import ctypes
+    ci, packed, (common, vo, _) = T.load_fixture(name)
+    orc = T.oracle()
+    oc = orc.circuit(ci)
+    ch = orc.challenges(oc, packed)
+    pih = orc.public_inputs_hash(oc, packed)[0]
+    words, kinds, consistent = T.witness_plonk_exact(ci, packed, ch[0], pih)
+    assert consistent
+    tr, ok, cons = orc.witness_plonk(oc, packed, ch)
+    assert cons.tolist() == [1] and tr.shape == (1, len(words)) and (tr[0] == np.array(words, dtype=np.uint64)).all()
+    assert (ok == np.array(kinds, dtype=np.uint8)).all()
+    assert int((ok == 2).sum()) == 1  # one InverseHint: evalL0's DivExtension (plonk.go:75)
+    rec = np.frombuffer(packed, dtype=np.uint64).copy()
+    rec[2 * (ci.num_constants + ci.num_routed_wires) + 6] ^= np.uint64(1)  # a wire opening
+    w2, _, c2 = T.witness_plonk_exact(ci, rec.tobytes(), ch[0], pih)
+    tr2, _, cons2 = orc.witness_plonk(oc, rec.tobytes(), ch)
+    assert not c2 and cons2.tolist() == [0] and (tr2[0] == np.array(w2, dtype=np.uint64)).all()
+    circuit = _circuit(gpv, common, vo)
+    L = gpv._lib.lib()
+    assert L.gpv_witness_plonk_words(ctypes.c_void_p(circuit.h)) == len(words) == {"decode_block": 135137, "step": 142693}[name]
+    n_hints = L.gpv_witness_plonk_layout(ctypes.c_void_p(circuit.h), None, 0)
+    got = np.empty(n_hints, dtype=np.uint8)
+    L.gpv_witness_plonk_layout(ctypes.c_void_p(circuit.h), gpv._lib.ptr(got), n_hints)
+    assert n_hints == len(kinds) and (got == ok).all()

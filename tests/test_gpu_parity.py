@@ -1691,3 +1691,95 @@ def test_witness_fri_trace(gpv, api, orc, name):
     for i in (0, 3):
         words, ekinds, econs = T.witness_fri_exact(ci, batch[i].tobytes(), ch[i])
         assert (trace[i] == np.array(words, dtype=np.uint64)).all() and (kinds == np.array(ekinds, dtype=np.uint8)).all() and int(econs) == cons[i]
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_witness_plonk_trace(gpv, api, orc, name):
+    """gpv_witness_plonk: the ordered hint outputs of plonk.PlonkChip.Verify (plonk.go:209-250) -- the GPU's literal evaluation
+    (csrc/gpv_witness.cuh: every gate constraint materialised, filtered and summed per index; the Poseidon gate through the extension
+    layers; algebra products as InnerProductExtension calls) == the oracle's, word for word, on the fixture, on records with corrupted
+    constants / sigmas / wires / Zs / partial products / quotient openings and public inputs (the consistency flag must follow the
+    reference's assertion) and under foreign challenges; == the exact-integer derivation on the fixture and on a corrupted record; and the
+    flag agrees with the verification kernel's verdict (gpv_plonk_verify)."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    n = 12
+    batch, _ = T.synthetic_batch(ci, packed, n, seed=47, tamper_every=0)
+    w = batch.view(np.uint64).reshape(n, -1)
+    rng = np.random.default_rng(53)
+    n_open, qwords, fr_queries, qfr, n_gl = T.query_section_layout(ci)
+    ch = np.tile(orc.challenges(oc, packed), (n, 1))
+    nc, nr = ci.num_constants, ci.num_routed_wires
+    off_wires = 2 * (nc + nr)
+    off_zs = off_wires + 2 * ci.num_wires
+    w[1, 1] ^= np.uint64(1)                                                   # a selector constant
+    w[2, 2 * nc + 7] ^= np.uint64(1 << 20)                                    # a sigma
+    w[3, off_wires + 2 * 30] ^= np.uint64(1)                                  # a wire
+    w[4, off_zs] ^= np.uint64(1)                                              # Z(zeta)
+    w[5, off_zs + 4 * ci.num_challenges + 5] ^= np.uint64(1 << 33)            # a partial product
+    w[6, n_open - 3] ^= np.uint64(1)                                          # a quotient opening
+    w[7, 0:n_open] = rand_gl(rng, n_open)                                     # random openings altogether
+    w[8, n_gl - 1] ^= np.uint64(1)                                            # a public input (PublicInputGate sees another hash)
+    ch[9] = rand_gl(rng, ch.shape[1])                                         # foreign challenges
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    pchip = gpv.plonk.NewPlonkChip(api, common)
+    trace, kinds, cons = pchip.WitnessVerify(pb, ch)
+    otr, okinds, ocons = orc.witness_plonk(oc, batch, ch)
+    assert trace.shape == otr.shape and (kinds == okinds).all()
+    bad = np.nonzero((trace != otr).any(axis=1))[0]
+    assert bad.size == 0, (bad, np.nonzero(trace[bad[0]] != otr[bad[0]])[0][:4])
+    pi_seen = 0 if ci.num_public_inputs else 1                                 # decode_block has no public inputs: word n_gl - 1 is the PoW witness
+    assert cons.tolist() == ocons.tolist() and cons.tolist() == [1, 0, 0, 0, 0, 0, 0, 0, pi_seen, 0, 1, 1]
+    mask = pchip.Verify(pb, ch)
+    assert ((mask & 0x8) != 0).tolist() == [c == 0 for c in cons.tolist()]     # GPV_FAIL_PLONK_VANISH
+    for i in (0, 3, 8):
+        pih = orc.public_inputs_hash(oc, batch[i].tobytes())[0]
+        words, ekinds, econs = T.witness_plonk_exact(ci, batch[i].tobytes(), ch[i], pih)
+        assert (trace[i] == np.array(words, dtype=np.uint64)).all() and (kinds == np.array(ekinds, dtype=np.uint8)).all() and int(econs) == cons[i]
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_witness_verify_is_the_four_slices_in_order(gpv, api, orc, name):
+    """gpv_witness_verify: the hint trace of VerifierChip.Verify as a whole (verifier.go:143-178) == the oracle's rangeCheckProof trace,
+    then its GetPublicInputsHash + GetChallenges trace, then its PlonkChip.Verify trace, then its GetInstance + VerifyFriProof trace (the
+    latter two under the challenges the oracle derives itself), word for word and hint kind for hint kind; the status bits follow the
+    reference's assertions; gpv_witness_verify_dev leaves the same rows in HBM."""
+    import ctypes
+    torch = pytest.importorskip("torch")
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    n = 6
+    batch, _ = T.synthetic_batch(ci, packed, n, seed=59, tamper_every=0)
+    w = batch.view(np.uint64).reshape(n, -1)
+    n_open, qwords, fr_queries, qfr, n_gl = T.query_section_layout(ci)
+    w[1, 2 * (ci.num_constants + ci.num_routed_wires) + 8] ^= np.uint64(1)     # a wire opening: new challenges, plonk and FRI fail
+    w[2, n_open + 4] ^= np.uint64(1 << 9)                                       # a leaf element: FRI fails, plonk holds
+    w[3, 5] = np.uint64(2**64 - 1)                                              # not a field element: the range check fails
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    chip = gpv.verifier.NewVerifierChip(api, common)
+    trace, kinds, ch, status = chip.WitnessVerify(pb)
+    o_rc = orc.witness_range_check(oc, batch)
+    o_ch, k_ch, och = orc.witness_challenges(oc, batch)
+    assert (np.asarray(ch.flat).reshape(n, -1)[[0, 1, 2, 4, 5]] == och[[0, 1, 2, 4, 5]]).all()
+    o_pl, k_pl, c_pl = orc.witness_plonk(oc, batch, och)
+    o_fri, k_fri, c_fri = orc.witness_fri(oc, batch, och)
+    want = np.concatenate([o_rc, o_ch, o_pl, o_fri], axis=1)
+    assert trace.shape == want.shape == (n, {"decode_block": 1287673, "step": 1349735}[name])
+    good = [0, 1, 2, 4, 5]   # row 3 is outside the field: the reference's hints panic there, the rest of the row is not compared
+    bad = [i for i in good if (trace[i] != want[i]).any()]
+    assert not bad, (bad, np.nonzero(trace[bad[0]] != want[bad[0]])[0][:4])
+    assert (trace[3, :o_rc.shape[1]] == o_rc[3]).all()
+    want_kinds = np.concatenate([np.full(o_rc.shape[1] // 2, 3, dtype=np.uint8), k_ch, k_pl, k_fri])
+    assert kinds.shape == want_kinds.shape and (kinds == want_kinds).all()
+    assert status[[0, 4, 5]].tolist() == [0, 0, 0] and status[1] == 2 | 4 and status[2] == 4 and status[3] & 1
+    assert [int(s) for s in status[good]] == [(0 if c_pl[i] else 2) | (0 if c_fri[i] else 4) for i in good]
+    # device-resident form
+    L = gpv._lib.lib()
+    dproofs = torch.from_numpy(batch.view(np.uint8).reshape(-1).copy()).cuda()
+    dtrace = torch.zeros(trace.size, dtype=torch.int64, device="cuda")
+    dstatus = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    gpv._lib.check(L.gpv_witness_verify_dev(api.h, circuit.h, ctypes.c_void_p(dproofs.data_ptr()), n, ctypes.c_void_p(dtrace.data_ptr()), None,
+                                            ctypes.c_void_p(dstatus.data_ptr())), api.h)
+    assert (dtrace.cpu().numpy().view(np.uint64).reshape(n, -1)[good] == trace[good]).all() and dstatus.cpu().numpy().tolist() == status.tolist()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of the witness slice (gpv_witness_challenges, host buffers in and out): python tools/witness_rate.py [n]"""
+"""Throughput of the witness slices (gpv_witness_challenges / _plonk / _fri, host buffers in and out): python tools/witness_rate.py [n]"""
 import importlib
 import sys
 import time
@@ -15,7 +15,7 @@ import gpv_testlib as T  # noqa: E402
 gpv = importlib.import_module("gnark-plonky2-verifier_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ctx = gpv.default_context()
-print("# gpv_witness_challenges: hint trace of GetPublicInputsHash + GetChallenges, %d proofs per call, host buffers in and out (one lane per proof)" % n)
+print("# gpv_witness_challenges / _plonk / _fri: hint traces of VerifierChip.Verify, %d proofs per call, host buffers in and out" % n)
 for name in ("step", "decode_block"):
     d = T.GOLDEN / name
     common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
@@ -34,5 +34,20 @@ for name in ("step", "decode_block"):
     otr, _, _ = orc.witness_challenges(orc.circuit(ci), batch[:16])
     dto = (time.perf_counter() - t) / 16
     assert (trace[:16] == otr).all()
-    print("%-13s %d words / %d hint calls per proof: %.1f ms per call = %.0f proofs/s = %.2f G trace words/s (%.2f GB/s incl. the copy back); oracle, one thread: %.1f ms per proof"
+    print("%-13s challenges: %d words / %d hint calls per proof: %.1f ms per call = %.0f proofs/s = %.2f G trace words/s (%.2f GB/s incl. the copy back); oracle, one thread: %.1f ms per proof"
           % (name, trace.shape[1], len(kinds), dt * 1e3, n / dt, n * trace.shape[1] / dt / 1e9, 8 * n * trace.shape[1] / dt / 1e9, dto * 1e3))
+    oc = orc.circuit(ci)
+    ch = np.asarray(ch.flat if hasattr(ch, "flat") else ch, dtype=np.uint64).reshape(n, -1)
+    for label, run, oracle_run in (
+            ("plonk", gpv.plonk.NewPlonkChip(ctx, common).WitnessVerify, orc.witness_plonk),
+            ("fri", gpv.fri.NewChip(ctx, common).WitnessFriProof, orc.witness_fri)):
+        run(pb, ch)
+        t = time.perf_counter()
+        trace, kinds, cons = run(pb, ch)
+        dt = time.perf_counter() - t
+        t = time.perf_counter()
+        otr, _, _ = oracle_run(oc, batch[:16], ch[:16])
+        dto = (time.perf_counter() - t) / 16
+        assert (trace[:16] == otr).all() and cons.all()
+        print("%-13s %-10s: %d words / %d hint calls per proof: %.1f ms per call = %.0f proofs/s = %.2f G trace words/s (%.2f GB/s incl. the copy back); oracle, one thread: %.1f ms per proof"
+              % (name, label, trace.shape[1], len(kinds), dt * 1e3, n / dt, n * trace.shape[1] / dt / 1e9, 8 * n * trace.shape[1] / dt / 1e9, dto * 1e3))
