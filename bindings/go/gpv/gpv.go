@@ -566,3 +566,40 @@ func (ctx *Context) WitnessFri(c *Circuit, proofs []byte, challenges []uint64) (
 	}
 	return trace, cons
 }
+
+// WitnessPlonk: slice 3, the hint outputs of plonk.PlonkChip.Verify (plonk/plonk.go:209-250) for the given challenges; consistent[i] is
+// false where the reference's vanishing-polynomial assertion fails.
+func (c *Circuit) WitnessPlonkLayout() []uint8 {
+	n := int(C.gpv_witness_plonk_layout(c.h, nil, 0))
+	kinds := make([]uint8, n)
+	C.gpv_witness_plonk_layout(c.h, (*C.uint8_t)(unsafe.Pointer(&kinds[0])), C.size_t(n))
+	return kinds
+}
+func (ctx *Context) WitnessPlonk(c *Circuit, proofs []byte, challenges []uint64) ([]uint64, []bool) {
+	n := len(proofs) / c.ProofNBytes()
+	trace := make([]uint64, n*int(C.gpv_witness_plonk_words(c.h)))
+	cb := make([]byte, n)
+	check(C.gpv_witness_plonk(ctx.h, c.h, unsafe.Pointer(&proofs[0]), u64p(challenges), C.size_t(n), u64p(trace), (*C.uint8_t)(unsafe.Pointer(&cb[0]))), ctx.h)
+	cons := make([]bool, n)
+	for i := range cb {
+		cons[i] = cb[i] == 1
+	}
+	return trace, cons
+}
+
+// WitnessVerify: every hint call of VerifierChip.Verify (verifier/verifier.go:143-178) per proof = range_check | challenges | plonk | fri;
+// status[i] = GPV_WITNESS_* bits of the reference's assertions that fail on the way.
+func (c *Circuit) WitnessVerifyLayout() []uint8 {
+	n := int(C.gpv_witness_verify_layout(c.h, nil, 0))
+	kinds := make([]uint8, n)
+	C.gpv_witness_verify_layout(c.h, (*C.uint8_t)(unsafe.Pointer(&kinds[0])), C.size_t(n))
+	return kinds
+}
+func (ctx *Context) WitnessVerify(c *Circuit, proofs []byte) (trace []uint64, challenges []uint64, status []uint8) {
+	n := len(proofs) / c.ProofNBytes()
+	trace = make([]uint64, n*int(C.gpv_witness_verify_words(c.h)))
+	challenges = make([]uint64, n*c.NumChallengeWords())
+	status = make([]uint8, n)
+	check(C.gpv_witness_verify(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(trace), u64p(challenges), (*C.uint8_t)(unsafe.Pointer(&status[0]))), ctx.h)
+	return
+}

@@ -20,6 +20,11 @@ func (p *PlonkChip) Verify(proofs variables.Proof, challenges []uint64) []uint32
 	return p.ctx.PlonkVerify(p.circuit, proofs.Packed, challenges)
 }
 
+// WitnessVerify: the hint outputs the wrapping circuit's solver asks for in Verify, in call order (SURVEY 8f.3).
+func (p *PlonkChip) WitnessVerify(proofs variables.Proof, challenges []uint64) (trace []uint64, consistent []bool) {
+	return p.ctx.WitnessPlonk(p.circuit, proofs.Packed, challenges)
+}
+
 // EvaluateGateConstraints (plonk/gates/evaluate_gates.go:77-105): [n][NumGateConstraints][2].
 func (p *PlonkChip) EvaluateGateConstraints(proofs variables.Proof) []uint64 {
 	return p.ctx.GateConstraints(p.circuit, proofs.Packed)

@@ -88,6 +88,11 @@ func (c *VerifierChip) WitnessChallenges(proof variables.Proof) (trace []uint64,
 	return c.ctx.WitnessChallenges(proof.Circuit, proof.Packed)
 }
 
+// WitnessVerify: every hint call of Verify (verifier.go:143-178) in call order: range_check | challenges | plonk | fri.
+func (c *VerifierChip) WitnessVerify(proof variables.Proof) (trace []uint64, challenges []uint64, status []uint8) {
+	return c.ctx.WitnessVerify(proof.Circuit, proof.Packed)
+}
+
 // Device-resident batches (raw device addresses; asynchronous on the context's stream).
 func (c *VerifierChip) VerifyDevice(circuit *gpv.Circuit, proofsDev unsafe.Pointer, n int, acceptDev unsafe.Pointer) {
 	c.ctx.VerifyDev(circuit, proofsDev, n, acceptDev)

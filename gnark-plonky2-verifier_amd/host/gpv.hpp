@@ -301,6 +301,20 @@ class PlonkChip {
     gpv::check(gpv_plonk_verify(api_.h(), c_.h(), proofs.data(), challenges.data(), n, mask.data()), api_.h());
     return mask;
   }
+  // Witness slice 3: the hint outputs of PlonkChip.Verify in call order for the given challenges; consistent (optional):
+  // the vanishing-polynomial assertion (plonk.go:248) holds; kinds (optional): one GPV_HINT_* id per hint call
+  std::vector<uint64_t> WitnessVerify(const std::vector<uint8_t>& proofs, const std::vector<uint64_t>& challenges,
+                                      std::vector<uint8_t>* consistent = nullptr, std::vector<uint8_t>* kinds = nullptr) {
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint64_t> trace(n * gpv_witness_plonk_words(c_.h()));
+    if (consistent) consistent->resize(n);
+    if (kinds) {
+      kinds->resize(gpv_witness_plonk_layout(c_.h(), nullptr, 0));
+      gpv_witness_plonk_layout(c_.h(), kinds->data(), kinds->size());
+    }
+    gpv::check(gpv_witness_plonk(api_.h(), c_.h(), proofs.data(), challenges.data(), n, trace.data(), consistent ? consistent->data() : nullptr), api_.h());
+    return trace;
+  }
  private:
   gpv::Api& api_;
   const gpv::Circuit& c_;
@@ -366,6 +380,23 @@ class VerifierChip {
     }
     if (challenges) challenges->resize(n * c_.num_challenge_words());
     gpv::check(gpv_witness_challenges(api_.h(), c_.h(), proofs.data(), n, trace.data(), challenges ? challenges->data() : nullptr), api_.h());
+    return trace;
+  }
+  // The whole hint trace of Verify (verifier.go:143-178): range_check | challenges | plonk | fri per proof, [n][WitnessVerifyWords()];
+  // status (optional): GPV_WITNESS_* bits of the reference's assertions that fail on the way
+  size_t WitnessVerifyWords() const { return gpv_witness_verify_words(c_.h()); }
+  std::vector<uint64_t> WitnessVerify(const std::vector<uint8_t>& proofs, std::vector<uint8_t>* kinds = nullptr,
+                                      std::vector<uint64_t>* challenges = nullptr, std::vector<uint8_t>* status = nullptr) {
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint64_t> trace(n * WitnessVerifyWords());
+    if (kinds) {
+      kinds->resize(gpv_witness_verify_layout(c_.h(), nullptr, 0));
+      gpv_witness_verify_layout(c_.h(), kinds->data(), kinds->size());
+    }
+    if (challenges) challenges->resize(n * c_.num_challenge_words());
+    if (status) status->resize(n);
+    gpv::check(gpv_witness_verify(api_.h(), c_.h(), proofs.data(), n, trace.data(), challenges ? challenges->data() : nullptr,
+                                  status ? status->data() : nullptr), api_.h());
     return trace;
   }
   // Verify (verifier.go:143): accept[i] == 1 iff the reference's circuit is satisfiable for proof i

@@ -117,6 +117,23 @@ int main(int argc, char** argv) {
     size_t fwords = 0;
     for (uint8_t k : fkinds) fwords += k == GPV_HINT_REDUCE ? 5 : k == GPV_HINT_INVERSE ? 1 : 2;
     EXPECT(ftrace.size() == fwords && fcons[0] == 1);
+    std::vector<uint8_t> pcons, pkinds;
+    std::vector<uint64_t> ptrace = plonk::PlonkChip(api, circuit).WitnessVerify(proof, wch, &pcons, &pkinds);  // slice 3: PlonkChip.Verify
+    size_t pwords = 0, pinv = 0;
+    for (uint8_t k : pkinds) {
+      pwords += k == GPV_HINT_REDUCE ? 5 : k == GPV_HINT_INVERSE ? 1 : 2;
+      pinv += k == GPV_HINT_INVERSE;
+    }
+    EXPECT(ptrace.size() == pwords && pcons[0] == 1 && pinv == 1);
+    // the whole of Verify = the four slices in the reference's statement order
+    std::vector<uint8_t> vkinds, vstatus;
+    std::vector<uint64_t> vch;
+    std::vector<uint64_t> vtrace = chip.WitnessVerify(proof, &vkinds, &vch, &vstatus);
+    std::vector<uint64_t> cat = rtrace;
+    cat.insert(cat.end(), trace.begin(), trace.end());
+    cat.insert(cat.end(), ptrace.begin(), ptrace.end());
+    cat.insert(cat.end(), ftrace.begin(), ftrace.end());
+    EXPECT(vtrace == cat && vch == ch && vstatus[0] == 0 && vkinds.size() == rtrace.size() / 2 + kinds.size() + pkinds.size() + fkinds.size());
     uint64_t first;
     memcpy(&first, proof.data(), 8);
     EXPECT(rtrace[0] == first >> 32 && rtrace[1] == (first & 0xFFFFFFFFu));

@@ -51,3 +51,31 @@ for name in ("step", "decode_block"):
         assert (trace[:16] == otr).all() and cons.all()
         print("%-13s %-10s: %d words / %d hint calls per proof: %.1f ms per call = %.0f proofs/s = %.2f G trace words/s (%.2f GB/s incl. the copy back); oracle, one thread: %.1f ms per proof"
               % (name, label, trace.shape[1], len(kinds), dt * 1e3, n / dt, n * trace.shape[1] / dt / 1e9, 8 * n * trace.shape[1] / dt / 1e9, dto * 1e3))
+
+# The whole trace of Verify, device-resident (gpv_witness_verify_dev): proofs, trace and status stay in HBM
+import ctypes  # noqa: E402
+
+import torch  # noqa: E402
+
+L = gpv._lib.lib()
+print("# gpv_witness_verify_dev: range_check | challenges | plonk | fri, everything resident in HBM")
+for name in ("step", "decode_block"):
+    d = T.GOLDEN / name
+    common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
+    vo = gpv.variables.DeserializeVerifierOnlyCircuitData(gpv.types.ReadVerifierOnlyCircuitData(d / "verifier_only_circuit_data.json"))
+    circuit = gpv.variables.circuit_for(common, vo)
+    ci, packed, _ = T.load_fixture(name)
+    words = L.gpv_witness_verify_words(ctypes.c_void_p(circuit.h))
+    for m in (64, 256, 1024, 4096):
+        batch, _ = T.synthetic_batch(ci, packed, m, seed=5, tamper_every=0)
+        dproofs = torch.from_numpy(batch.view(np.uint8).reshape(-1).copy()).cuda()
+        dtrace = torch.empty(m * words, dtype=torch.int64, device="cuda")
+        dstatus = torch.empty(m, dtype=torch.uint8, device="cuda")
+        args = (ctx.h, circuit.h, ctypes.c_void_p(dproofs.data_ptr()), m, ctypes.c_void_p(dtrace.data_ptr()), None, ctypes.c_void_p(dstatus.data_ptr()))
+        gpv._lib.check(L.gpv_witness_verify_dev(*args), ctx.h)
+        t = time.perf_counter()
+        gpv._lib.check(L.gpv_witness_verify_dev(*args), ctx.h)
+        dt = time.perf_counter() - t
+        assert int(dstatus.sum()) == 0
+        print("%-13s %5d proofs: %8.1f ms = %7.0f proofs/s = %.2f G trace words/s (%.1f GB of trace)" % (name, m, dt * 1e3, m / dt, m * words / dt / 1e9, 8e-9 * m * words))
+        del dtrace
