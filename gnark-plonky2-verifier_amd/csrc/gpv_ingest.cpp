@@ -668,6 +668,8 @@ static int circuit_from_json_impl(const char* common_json, size_t common_len, co
     if (wused + weights.size() > GPV_MAX_WEIGHTS) return GPV_ECONFIG;
     for (uint64_t wv : weights) c.weights[wused++] = wv;
     if (kind == GPV_GATE_COSET_INTERPOLATION && (dg.p0 > 8 || weights.size() != (1ull << dg.p0))) return GPV_ECONFIG;
+    // domain[:g.degree] / values[:g.degree] (coset_interpolation_gate.go:182-189) panic when the degree exceeds the number of points
+    if (kind == GPV_GATE_COSET_INTERPOLATION && dg.p1 > (1u << dg.p0)) return GPV_ECONFIG;
     if (kind == GPV_GATE_RANDOM_ACCESS && dg.p0 > GPV_MAX_RA_BITS) return GPV_ECONFIG;
     if (kind == GPV_GATE_BASE_SUM && dg.p1 > 256) return GPV_ECONFIG;
     {

@@ -91,6 +91,18 @@ int main(int argc, char** argv) {
       size_t calls = gpv_witness_challenges_layout(c2, kinds.data(), kinds.size()), words = 0;
       for (uint8_t k : kinds) words += k == GPV_HINT_REDUCE ? 5 : 2;
       if (calls != kinds.size() || words != gpv_witness_challenges_words(c2)) other++;
+      if (getenv("GPV_FUZZ_TRACE")) { uint64_t d[40] = {0}; gpv_circuit_describe(c2, d, 40); for (int q = 0; q < 40; q++) fprintf(stderr, "%llu ", (unsigned long long)d[q]); fprintf(stderr, "\n"); }
+      // the other slices' walkers (plonk: every gate shape the ingest lets through; fri: every arity) and their concatenation
+      const size_t w_all = gpv_witness_range_check_words(c2) + words + gpv_witness_plonk_words(c2) + gpv_witness_fri_words(c2);
+      const size_t h_all = gpv_witness_range_check_words(c2) / 2 + calls + gpv_witness_plonk_layout(c2, nullptr, 0) + gpv_witness_fri_layout(c2, nullptr, 0);
+      if (w_all != gpv_witness_verify_words(c2) || h_all != gpv_witness_verify_layout(c2, nullptr, 0)) other++;
+      if (gpv_witness_plonk_words(c2) < (1u << 22)) {
+        std::vector<uint8_t> pk(gpv_witness_plonk_layout(c2, nullptr, 0));
+        gpv_witness_plonk_layout(c2, pk.data(), pk.size());
+        size_t pw = 0;
+        for (uint8_t k : pk) pw += k == GPV_HINT_REDUCE ? 5 : k == GPV_HINT_INVERSE ? 1 : 2;
+        if (pw != gpv_witness_plonk_words(c2)) other++;
+      }
     }
     size_t nb = gpv_proof_nbytes(c2);
     if (nb <= (64u << 20)) {

@@ -202,6 +202,14 @@ def test_config_errors(gpv):
     bad["fri_params"]["config"]["cap_height"] = 3  # fri/fri.go:118-126
     with pytest.raises(gpv.ConfigError):
         _circuit(gpv, bad, vo)
+    bad = json.loads(json.dumps(common))
+    k = next(i for i, g in enumerate(bad["gates"]) if g.startswith("CosetInterpolationGate"))
+    assert "degree: 6" in bad["gates"][k]
+    # domain[:degree] with more than 2^subgroup_bits entries: the reference panics (coset_interpolation_gate.go:182-189); found by the
+    # ingest fuzzer as an unbounded loop in the gate evaluators
+    bad["gates"][k] = bad["gates"][k].replace("degree: 6", "degree: 1000000000")
+    with pytest.raises(gpv.ConfigError):
+        _circuit(gpv, bad, vo)
     with pytest.raises(gpv.ShapeError):
         gpv.variables.Circuit(gpv.types.CommonCircuitData("{not json"), gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)))
 
