@@ -61,7 +61,7 @@ struct gpv_ctx {
   // the copy of chunk k+1 runs while chunk k is being verified
   // shared upper Merkle levels (gpv_k_crown.hip)
   int merkle_shared = 1;  // GPV_OPT_MERKLE_SHARED_LEVELS: 0 off, 1 from GPV_MERKLE_SHARED_FROM proofs up, 2 always
-  int fr_form = 0;        // GPV_OPT_FR_EVALUATION: 0 by launch size, 1 column scanning, 2 operand scanning (gpv_fr.cuh)
+  int fr_form = 0;        // GPV_OPT_FR_EVALUATION: 0 by launch size, 1 column scanning, 2 operand scanning (gpv_fr.cuh), 3 four lanes per permutation
   void* crown = nullptr;
   size_t crown_bytes = 0;
   uint8_t* stage = nullptr;
@@ -268,7 +268,7 @@ extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
     ctx->merkle_shared = value;
     return GPV_OK;
   }
-  if (option == GPV_OPT_FR_EVALUATION && value >= 0 && value <= 2) {
+  if (option == GPV_OPT_FR_EVALUATION && value >= 0 && value <= 3) {
     ctx->fr_form = value;
     return GPV_OK;
   }

@@ -4,6 +4,7 @@
 #include "gpv_launch.h"
 #include "gpv_fri.cuh"
 #include "gpv_transcript.cuh"
+#include "gpv_poseidon_quad.cuh"
 
 // Every BN254 kernel exists in the two evaluation orders of gpv_fr.cuh: the plain name is the column-scanning (throughput)
 // form, `_wide` the operand-scanning (latency) form; the launch wrappers pick by the number of lanes (gpvk_fr_chain_pays).
@@ -49,6 +50,35 @@ __global__ __launch_bounds__(64) void k_poseidon_bn254_two_to_one(const u64* __r
 }
 __global__ __launch_bounds__(64) void k_poseidon_bn254_two_to_one_wide(const u64* __restrict__ l, const u64* __restrict__ r, u64* __restrict__ out, size_t n) {
   poseidon_bn254_two_to_one_body<FrWide>(l, r, out, n);
+}
+// Four lanes per permutation (gpv_poseidon_quad.cuh): the latency form. One block stages the tables in LDS once.
+#define GPV_QUAD_BLOCK 256
+__global__ __launch_bounds__(GPV_QUAD_BLOCK) void k_poseidon_bn254_permute_quad(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+  __shared__ u32 lds[PBQ_WORDS];
+  pbq_stage_tables(lds);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i = t >> 2;
+  const u32 q = (u32)t & 3;
+  if (i >= n) return;
+  Fr s = poseidon_bn254_permute_quad(fr_from_canonical64(in + 16 * i + 4 * q), lds, q);
+  fr_to_canonical64(s, out + 16 * i + 4 * q);
+}
+__global__ __launch_bounds__(GPV_QUAD_BLOCK) void k_poseidon_bn254_hash_or_noop_quad(const u64* __restrict__ in, u32 len, u64* __restrict__ out, size_t n) {
+  __shared__ u32 lds[PBQ_WORDS];
+  pbq_stage_tables(lds);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i = t >> 2;
+  const u32 q = (u32)t & 3;
+  if (i >= n) return;
+  Fr h = poseidon_bn254_hash_or_noop_quad(in + (size_t)len * i, len, lds, q);
+  if (q == 0) fr_to_canonical64(h, out + 4 * i);
+}
+__global__ __launch_bounds__(GPV_QUAD_BLOCK) void k_poseidon_bn254_two_to_one_quad(const u64* __restrict__ l, const u64* __restrict__ r, u64* __restrict__ out, size_t n) {
+  __shared__ u32 lds[PBQ_WORDS];
+  pbq_stage_tables(lds);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i = t >> 2;
+  const u32 q = (u32)t & 3;
+  if (i >= n) return;
+  Fr h = poseidon_bn254_two_to_one_quad(fr_from_canonical64(l + 4 * i), fr_from_canonical64(r + 4 * i), lds, q);
+  if (q == 0) fr_to_canonical64(h, out + 4 * i);
 }
 __global__ void k_poseidon_bn254_to_vec(const u64* __restrict__ h, u64* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -175,6 +205,65 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_lower_wide(co
                                                                          u32 crown_levels, Verdict v) {
   merkle_climb_lower_body<HashBNWide>(dc, proofs, derived, n, order, digests, mid, crown_levels, v);
 }
+// Four lanes per (proof, query, tree): the same two phases with the quad permutation, for launches that leave most of the chip idle
+// (the digests travel in the same scratch; the walk is the per-path one, up to the cap -- sharing upper levels saves work, not latency).
+__global__ __launch_bounds__(GPV_QUAD_BLOCK) void k_merkle_leaves_quad(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+                                                                       MerkleOrder order, u32* __restrict__ digests, Verdict v) {
+  __shared__ u32 lds[PBQ_WORDS];
+  pbq_stage_tables(lds);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, item = t >> 2;
+  const u32 lane4 = (u32)t & 3;
+  const u32 nq = dc->num_queries;
+  const size_t items = n * nq;
+  if (item >= items) return;
+  const size_t p = item / nq;
+  const u32 q = (u32)(item - p * nq);
+  const u32 tree = order.cls[blockIdx.y];
+  if (lane4 == 0) atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_LEAVES], 1u);
+  const u64* rec = proofs + p * (dc->proof_nbytes / 8);
+  const u64* qrec = rec + dc->off_queries + (size_t)q * dc->query_words;
+  const u64* leaf;
+  u32 leaf_len;
+  if (tree < 4) {
+    leaf = qrec + dc->leaf_off[tree];
+    leaf_len = dc->leaf_len[tree];
+  } else {
+    leaf = qrec + dc->step_evals_off[tree - 4];
+    leaf_len = 2u << dc->arity_bits[tree - 4];
+  }
+  Fr d = poseidon_bn254_hash_or_noop_quad(leaf, leaf_len, lds, lane4);
+  if (lane4 == 0) HashBN::store_digest(digests + ((size_t)tree * items + item) * FR_LIMBS, d);
+}
+__global__ __launch_bounds__(GPV_QUAD_BLOCK) void k_merkle_climb_quad(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                      const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                                      const u32* __restrict__ digests, Verdict v, uint8_t* __restrict__ ok_out) {
+  __shared__ u32 lds[PBQ_WORDS];
+  pbq_stage_tables(lds);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, item = t >> 2;
+  const u32 lane4 = (u32)t & 3;
+  const u32 nq = dc->num_queries;
+  const size_t items = n * nq;
+  if (item >= items) return;
+  const size_t p = item / nq;
+  const u32 q = (u32)(item - p * nq);
+  const u32 tree = order.cls[blockIdx.y];
+  const u64* rec = proofs + p * (dc->proof_nbytes / 8);
+  const u64* d = derived + p * (dc->n_challenge_words + GPV_DERIVED_EXTRA);
+  MerklePath m = dev_merkle_path(dc, rec, d, q, tree);
+  Fr cur = HashBN::load_digest(digests + ((size_t)tree * items + item) * FR_LIMBS);
+#pragma unroll 1
+  for (u32 i = 0; i < m.n_sib; i++) {  // fri.go:105-116: bit = 1: hash(sibling, cur)
+    const Fr sib = fr_from_canonical64(m.sib + 4 * i);
+    const bool bit = (m.bits >> i) & 1;
+    cur = poseidon_bn254_two_to_one_quad(pbq_select(bit, sib, cur), pbq_select(bit, cur, sib), lds, lane4);
+  }
+  if (lane4 != 0) return;
+  const bool ok = dev_node_matches<HashBNWide>(cur, m.cap + 4 * m.cap_index);
+  if (ok_out) ok_out[item * dc->n_trees + tree] = ok;
+  if (!ok) atomicOr(&v.fail[p], tree < 4 ? (u32)GPV_FAIL_MERKLE_INITIAL : (u32)GPV_FAIL_MERKLE_STEP);
+  atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_CLIMB], 1u);
+  atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_CAP], 1u);
+}
 // Poseidon-Goldilocks configuration: ~20x less arithmetic per hash, so 256-lane blocks
 #define GPV_MERKLE_BLOCK_GL 256
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK_GL) void k_merkle_leaves_gl(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
@@ -213,18 +302,30 @@ static MerkleOrder merkle_order(const DevCircuit& c, bool leaves) {
 }
 
 void gpvk_poseidon_bn254_permute(hipStream_t st, const u64* in, u64* out, size_t n, int form) {
+  if (gpvk_fr_quad_pays(n, form)) {
+    GPVK_LAUNCH(k_poseidon_bn254_permute_quad, dim3(gpvk_blocks_for(4 * n, GPV_QUAD_BLOCK)), dim3(GPV_QUAD_BLOCK), 0, st, in, out, n);
+    return;
+  }
   if (gpvk_fr_chain_pays(n, form))
     GPVK_LAUNCH(k_poseidon_bn254_permute, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, out, n);
   else
     GPVK_LAUNCH(k_poseidon_bn254_permute_wide, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, out, n);
 }
 void gpvk_poseidon_bn254_hash_or_noop(hipStream_t st, const u64* in, u32 len, u64* out, size_t n, int form) {
+  if (gpvk_fr_quad_pays(n, form)) {
+    GPVK_LAUNCH(k_poseidon_bn254_hash_or_noop_quad, dim3(gpvk_blocks_for(4 * n, GPV_QUAD_BLOCK)), dim3(GPV_QUAD_BLOCK), 0, st, in, len, out, n);
+    return;
+  }
   if (gpvk_fr_chain_pays(n, form))
     GPVK_LAUNCH(k_poseidon_bn254_hash_or_noop, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
   else
     GPVK_LAUNCH(k_poseidon_bn254_hash_or_noop_wide, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, in, len, out, n);
 }
 void gpvk_poseidon_bn254_two_to_one(hipStream_t st, const u64* l, const u64* r, u64* out, size_t n, int form) {
+  if (gpvk_fr_quad_pays(n, form)) {
+    GPVK_LAUNCH(k_poseidon_bn254_two_to_one_quad, dim3(gpvk_blocks_for(4 * n, GPV_QUAD_BLOCK)), dim3(GPV_QUAD_BLOCK), 0, st, l, r, out, n);
+    return;
+  }
   if (gpvk_fr_chain_pays(n, form))
     GPVK_LAUNCH(k_poseidon_bn254_two_to_one, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, l, r, out, n);
   else
@@ -236,6 +337,11 @@ void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n
 size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n) { return n * hc.num_queries * hc.n_trees * FR_LIMBS; }
 void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, Verdict v, int form) {
   size_t items = n * hc.num_queries;
+  if (hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && gpvk_fr_quad_pays(items * hc.n_trees, form)) {
+    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_quad, dim3(gpvk_blocks_for(4 * items, GPV_QUAD_BLOCK), hc.n_trees), dim3(GPV_QUAD_BLOCK), 0, st, dcd, proofs, n,
+                merkle_order(hc, true), digests, v);
+    return;
+  }
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs, n,
                 merkle_order(hc, true), digests, v);
@@ -249,6 +355,11 @@ void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit&
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
                        const u32* digests, Verdict v, uint8_t* ok_out, int form) {
   size_t items = n * hc.num_queries;
+  if (hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && gpvk_fr_quad_pays(items * hc.n_trees, form)) {
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_quad, dim3(gpvk_blocks_for(4 * items, GPV_QUAD_BLOCK), hc.n_trees), dim3(GPV_QUAD_BLOCK), 0, st, dcd, proofs,
+                derived, n, merkle_order(hc, false), digests, v, ok_out);
+    return;
+  }
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs,
                 derived, n, merkle_order(hc, false), digests, v, ok_out);

@@ -127,10 +127,12 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
  * node instead of once per query path (the paths of a proof's queries meet near the cap; inputs are compared word for
  * word and a proof whose paths disagree is re-hashed path by path, so accept bits are identical); 0 = every path on its
  * own, literally fri/fri.go:97-144.
- * GPV_OPT_FR_EVALUATION: the BN254 kernels exist in two evaluation orders of the same Montgomery rows with bit-identical
- * results -- column scanning (fewest instructions, needs a launch that fills the chip about three times) and operand scanning
- * (lower latency per permutation). 0 (default) = chosen per launch by its number of hashing lanes, 1 = always column
- * scanning, 2 = always operand scanning.
+ * GPV_OPT_FR_EVALUATION: the BN254 kernels exist in three forms with identical results -- column scanning (fewest instructions,
+ * needs a launch that fills the chip about three times), operand scanning (lower latency per permutation) and four lanes per
+ * permutation (half that latency again; for launches that leave most of the chip idle: up to about 200 proofs of the reference's
+ * circuits -- a single proof verifies in 4.3 ms instead of 8.7). 0 (default) = chosen per launch by its number of hashing lanes,
+ * 1 = always column scanning, 2 = always operand scanning, 3 = always four lanes per permutation (Poseidon-BN254 kernels and
+ * per-path Merkle walks; the shared upper levels keep form 2).
  * GPV_OPT_HOST_CHUNK_FIRST / GPV_OPT_HOST_CHUNK_MAX: gpv_verify uploads a host batch in chunks of first, first, 2 first, 4 first, ...
  * proofs capped at max and verifies them as they arrive, two in flight (defaults 1024 / 8192; 1 .. 2^24). */
 enum { GPV_OPT_TRANSCRIPT_VARIANT = 1, GPV_OPT_MERKLE_SHARED_LEVELS = 2, GPV_OPT_FR_EVALUATION = 3, GPV_OPT_HOST_CHUNK_FIRST = 4,

@@ -183,10 +183,11 @@ def test_poseidon_bn254_hashes(gpv, api, orc):
     assert (chip.ToVec(h) == orc.poseidon_bn254_to_vec(h)).all()
 
 
-@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("form", [1, 2, 3])
 def test_fr_evaluation_orders_are_identical(gpv, api, orc, form):
     """GPV_OPT_FR_EVALUATION: the BN254 kernels exist as column-scanning (1) and operand-scanning (2) forms of the same Montgomery
-    rows, chosen per launch by its size. Forced either way, at sizes where the automatic choice would pick the other one, every
+    rows and with four lanes per permutation (3: gpv_poseidon_quad.cuh, the latency form of small launches), chosen per launch by
+    its size. Forced each way, at sizes where the automatic choice would pick another one, every
     primitive, every Merkle chain (per-path and with the shared upper levels) and the whole verification still match the oracle."""
     chip = gpv.poseidon.NewBN254Chip(api)
     rng = np.random.default_rng(60 + form)
