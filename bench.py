@@ -463,6 +463,7 @@ def main():
         if not args.no_config_legs and n_ranks == 1:
             line["fri_verify_4096"] = bench_fri_verify(gpv, T, ctx, dev, max(2, min(args.steps, 5)))
             line["merkle_only_4096"] = bench_merkle_only(gpv, T, ctx, dev, max(2, min(args.steps, 5)))
+            line["single_proof"] = bench_single_proof(gpv, T, ctx, dev)
         if not args.no_poseidon_gl:
             line["poseidon_gl"] = bench_poseidon_gl(gpv, T, ctx, dev)
         if not args.no_heterogeneous and n_ranks == 1:
@@ -532,6 +533,36 @@ def bench_fri_verify(gpv, T, ctx, dev, steps, n=4096):
     return {"config": "BASELINE config 3: fri.VerifyFriProof on testdata/step, 28 queries x %d proofs, challenges supplied" % n,
             "entry_point": "gpv_fri_verify_dev", "proofs": n, "steps": steps, "proofs_per_s": n / dt, "ms_per_step": 1e3 * dt,
             "query_rounds_per_s": n * wl.ci.num_query_rounds / dt, "stage_ms": stage, "checked": "mask == 0 exactly for the untampered proofs"}
+
+
+def bench_single_proof(gpv, T, ctx, dev):
+    """The reference's own use: VerifierChip.Verify of ONE proof (BASELINE config 1 is that call on the Go CPU path). Latency of
+    gpv_verify_dev at n = 1 for both fixtures, record resident in HBM, and of a tampered copy (which must be rejected). The small-launch
+    form of the BN254 kernels (four lanes per permutation, csrc/gpv_poseidon_quad.cuh) is what runs here."""
+    out = {}
+    for name in ("step", "decode_block"):
+        wl = Workload(gpv, T, name, dev)
+        chip = gpv.verifier.NewVerifierChip(ctx, wl.common)
+        good = wl.rec.repeat(1, 1).contiguous()
+        bad = good.clone()
+        bad.view(-1)[wl.ci.num_constants * 2 + 3] ^= 1  # a sigma opening
+        acc = torch.zeros(1, dtype=torch.uint8, device=dev)
+        res = {}
+        for label, batch, want in (("valid", good, 1), ("tampered", bad, 0)):
+            for _ in range(3):
+                chip.VerifyDevice(wl.circuit, batch.data_ptr(), 1, acc.data_ptr())
+            ctx.synchronize()
+            reps = 20
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                chip.VerifyDevice(wl.circuit, batch.data_ptr(), 1, acc.data_ptr())
+            ctx.synchronize()
+            res[label + "_ms"] = (time.perf_counter() - t0) / reps * 1e3
+            if int(acc.item()) != want:
+                raise SystemExit("single_proof: %s %s proof: accept = %d" % (name, label, int(acc.item())))
+        out[name] = res
+    out["entry_point"] = "gpv_verify_dev, n = 1, record resident in HBM; accept checked (valid: 1, tampered: 0)"
+    return out
 
 
 def bench_merkle_only(gpv, T, ctx, dev, steps, n=4096):
