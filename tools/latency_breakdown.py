@@ -60,3 +60,14 @@ for n in (1, 8, 32, 64, 96, 128, 192, 256, 384, 512, 768, 1024):
         assert int(acc.sum().item()) == n
     ctx.set_option(3, 0)
     print("%5d   %7.2f  %7.2f  %7.2f" % (n, row[0], row[1], row[2]), flush=True)
+print("# gpv_verify on a host (pageable) buffer, ms per call")
+for n in (1, 16, 128):
+    b = np.tile(np.frombuffer(packed, dtype=np.uint8), n)
+    pb = gpv.variables.ProofBatch(circuit, b)
+    for _ in range(3): chip.Verify(pb, vo)
+    reps = 20
+    t = time.perf_counter()
+    for _ in range(reps): a = chip.Verify(pb, vo)
+    dt = (time.perf_counter() - t) / reps
+    assert int(a.sum()) == n
+    print("%5d   %7.2f" % (n, dt * 1e3), flush=True)
