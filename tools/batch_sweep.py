@@ -1,4 +1,5 @@
-"""Batch-size sweep of gpv_verify_dev with the shared upper Merkle levels forced on (2) and off (0): python tools/batch_sweep.py"""
+"""Batch-size sweep of gpv_verify_dev with the shared upper Merkle levels chosen by size (1, the default), forced on (2) and off (0):
+python tools/batch_sweep.py"""
 import importlib, sys, time
 import numpy as np, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -15,10 +16,10 @@ chip = gpv.verifier.NewVerifierChip(ctx, common)
 dev = torch.device("cuda:0")
 rec = torch.from_numpy(np.frombuffer(packed, dtype=np.int64).copy()).to(dev)
 print("# n  shared_levels  ms_per_step  proofs_per_s")
-for n in (1, 16, 64, 256, 1024, 2048, 4096, 8192, 16384):
+for n in (1, 16, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
     batch = rec.repeat(n, 1).contiguous()
     acc = torch.zeros(n, dtype=torch.uint8, device=dev)
-    for mode in (2, 0):
+    for mode in (1, 2, 0):
         ctx.set_option(2, mode)
         for _ in range(2): chip.VerifyDevice(circuit, batch.data_ptr(), n, acc.data_ptr())
         torch.cuda.synchronize()
@@ -27,4 +28,5 @@ for n in (1, 16, 64, 256, 1024, 2048, 4096, 8192, 16384):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / reps
         assert int(acc.sum().item()) == n
-        print("%6d   %d   %8.2f   %9.0f" % (n, mode, dt * 1e3, n / dt))
+        print("%6d   %d   %8.2f   %9.0f" % (n, mode, dt * 1e3, n / dt), flush=True)
+ctx.set_option(2, 1)
