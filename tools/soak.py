@@ -51,7 +51,7 @@ def work(tid):
             torch.cuda.synchronize()
             chip = gpv.verifier.NewVerifierChip(ctx, common)
             ctx.set_option(2, int(rng.choice([0, 1, 2])))
-            ctx.set_option(3, int(rng.choice([0, 1, 2])))  # GPV_OPT_FR_EVALUATION: by size / column scanning / operand scanning
+            ctx.set_option(3, int(rng.choice([0, 1, 2, 3])))  # GPV_OPT_FR_EVALUATION: by size / column scanning / operand scanning / four lanes per permutation
             reps = int(rng.integers(2, 6))
             for _ in range(reps):
                 if ch is None:
