@@ -78,11 +78,11 @@ __device__ __forceinline__ void gpvk_side_stream_priority() { __builtin_amdgcn_s
 #define GPV_FR_CHAIN_MIN_LANES ((size_t)3 << 18)
 // form: GPV_OPT_FR_EVALUATION -- 0 by size, 1 column scanning, 2 operand scanning
 static inline bool gpvk_fr_chain_pays(size_t lanes, int form) { return form == 1 || (form == 0 && lanes >= GPV_FR_CHAIN_MIN_LANES); }
-// form 3 / small launches: four lanes per permutation (gpv_poseidon_quad.cuh): 1.9 x fewer instructions in a wave's stream, 2.1 x more
+// form 3 / small launches: four lanes per permutation (gpv_poseidon_quad.cuh): 1.7 x fewer instructions in a wave's stream, 2.4 x more
 // lane-instructions in total. Measured on the whole verification (profiles/r03_latency_breakdown.txt, step, ms per call, one lane per
-// permutation / four): 1 proof 8.73 / 4.30, 32: 7.41 / 4.77, 96: 7.59 / 5.23, 192: 7.95 / 6.85, 256: 8.01 / 7.69, 384: 8.20 / 10.46 --
-// it pays while the quads leave the SIMDs with about two waves each: up to 36 864 paths (219 `step` proofs).
-#define GPV_FR_QUAD_MAX_LANES ((size_t)36 << 10)
+// permutation / four): 1 proof 8.75 / 3.99, 32: 7.42 / 4.34, 96: 7.88 / 5.01, 192: 8.06 / 6.63, 256: 8.15 / 7.54, 384: 8.33 / 10.10 --
+// it pays while the quads leave the SIMDs with two to three waves each: up to 45 056 paths (268 `step` proofs).
+#define GPV_FR_QUAD_MAX_LANES ((size_t)44 << 10)
 static inline bool gpvk_fr_quad_pays(size_t lanes, int form) { return form == 3 || (form == 0 && lanes <= GPV_FR_QUAD_MAX_LANES); }
 
 // gpv_k_prim.hip

@@ -9,10 +9,10 @@
 //                  results are exchanged with DPP quad_perm moves (36 v_mov_dpp), and lane i evaluates mix row i (one row instead
 //                  of four);
 //   partial rounds (two per window, the same algebra as gpv_poseidon.cuh): the S-boxes of s_0 are serial and run redundantly in
-//                  all four lanes; the 4- and 5-product rows are split one product per lane (the fifth rides in lane 0), summed
-//                  across the quad in their 18 unreduced 64-bit columns and reduced once; the three s_k updates run in lanes 1..3
-//                  at the same time.
-// ~66 k instructions per permutation in the wave's instruction stream instead of ~126 k. The lane-dependent round constants and
+//                  all four lanes; the 4- and 5-product rows are split one product per lane (the fifth rides in lane 0), reduced in
+//                  each lane and the four residues added across the quad (18 DPP adds + a carry sweep); the three s_k updates run in
+//                  lanes 1..3 at the same time.
+// ~73 k instructions per permutation in the wave's instruction stream instead of ~126 k. The lane-dependent round constants and
 // matrix entries cannot come from SGPRs any more: the block stages all tables in LDS (19.4 KB) and every lane reads its own.
 // Results are the same field elements as the one-lane forms (redundant representatives may differ; every consumer canonicalises).
 #pragma once
@@ -56,18 +56,26 @@ GPV_DEV Fr pbq_select(bool take_a, const Fr& a, const Fr& b) {
   for (int i = 0; i < FR_LIMBS; i++) r.l[i] = take_a ? a.l[i] : b.l[i];
   return r;
 }
-// all four lanes receive the quad's column sums (butterfly: lane ^ 1, then lane ^ 2)
-template <int CTRL>
-GPV_DEV u64 pbq_dpp64(u64 x) {
-  u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)(u32)x, CTRL, 0xf, 0xf, true);
-  u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)(u32)(x >> 32), CTRL, 0xf, 0xf, true);
-  return ((u64)hi << 32) | lo;
-}
-GPV_DEV void pbq_quad_sum(FrCols& c) {
+// Every lane receives the sum of the quad's four values (two DPP butterfly steps per limb: lane ^ 1, then lane ^ 2), carry-normalised
+// (limbs 0..7 < 2^29). Inputs normalised: a limb-wise sum of four stays below 2^31.
+GPV_DEV Fr pbq_quad_add(const Fr& x) {
+  Fr r;
 #pragma unroll
-  for (int k = 0; k < 2 * FR_LIMBS - 1; k++) c.t[k] += pbq_dpp64<0xB1>(c.t[k]);  // quad_perm:[1,0,3,2]
+  for (int i = 0; i < FR_LIMBS; i++) {
+    u32 v = x.l[i];
+    v += (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
+    v += (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);  // quad_perm:[2,3,0,1]
+    r.l[i] = v;
+  }
+  u32 carry = 0;
 #pragma unroll
-  for (int k = 0; k < 2 * FR_LIMBS - 1; k++) c.t[k] += pbq_dpp64<0x4E>(c.t[k]);  // quad_perm:[2,3,0,1]
+  for (int i = 0; i < FR_LIMBS - 1; i++) {
+    const u32 v = r.l[i] + carry;
+    r.l[i] = v & FR_MASK;
+    carry = v >> FR_BITS;
+  }
+  r.l[FR_LIMBS - 1] += carry;
+  return r;
 }
 // bn254.go:39-45 on the quad: `s` is this lane's state element (Montgomery form, normalised, < 2.2 r), q = lane & 3.
 GPV_DEV Fr poseidon_bn254_permute_quad(Fr s, const u32* __restrict__ lds, u32 q) {
@@ -89,17 +97,15 @@ GPV_DEV Fr poseidon_bn254_permute_quad(Fr s, const u32* __restrict__ lds, u32 q)
     for (int w = 0; w < 28; w++) {
       const int a = 2 * w, b = 2 * w + 1;
       const Fr ta = pbq_bcast<0>(pbn_exp5_add<FrWide>(s, pbq_load(lds, PBQ_C, 20 + a), 1u));
-      FrCols c;
-      frc_zero(c);
-      frc_mac(c, pbq_select(q == 0, ta, s), pbq_load(lds, PBQ_S, 7 * a + q));  // s_0a = S[7a] t_a + sum_k S[7a+k] s_k: one product per lane
-      pbq_quad_sum(c);
-      const Fr s0a = frc_reduce(c);
+      // s_0a = S[7a] t_a + sum_k S[7a+k] s_k: one product per lane, each reduced in its own lane, the four residues added across the quad
+      // (a sum of residues instead of a residue of the sum: < sum/R + 4 r instead of + r, which the next squaring absorbs)
+      const Fr s0a = pbq_quad_add(FrWide::mul(pbq_select(q == 0, ta, s), pbq_load(lds, PBQ_S, 7 * a + q)));
       const Fr tb = pbn_exp5_add<FrWide>(s0a, pbq_load(lds, PBQ_C, 20 + b), 1u);  // identical in the four lanes
+      FrCols c;
       frc_zero(c);
       frc_mac(c, pbq_select(q == 0, tb, s), pbq_load(lds, PBQ_S, 7 * b + q));
       frc_mac(c, ta, pbq_select(q == 0, pbq_load(lds, PBQ_X, w), fr_zero()));       // + X_w t_a, in lane 0
-      pbq_quad_sum(c);
-      const Fr s0n = frc_reduce(c);
+      const Fr s0n = pbq_quad_add(frc_reduce(c));
       const Fr upd = FrWide::dot2_add(ta, pbq_load(lds, PBQ_S, 7 * a + 3 + q), tb, pbq_load(lds, PBQ_S, 7 * b + 3 + q), s);  // lanes 1..3
       s = pbq_select(q == 0, s0n, upd);
     }
