@@ -473,6 +473,9 @@ func (ctx *Context) FriVerifyDev(c *Circuit, proofsDev, challengesDev unsafe.Poi
 func (ctx *Context) PoseidonGLDev(statesDev, outDev unsafe.Pointer, n int) {
 	check(C.gpv_poseidon_gl_permute_dev(ctx.h, (*C.uint64_t)(statesDev), (*C.uint64_t)(outDev), C.size_t(n)), ctx.h)
 }
+func (ctx *Context) PoseidonGLCoopDev(statesDev, outDev unsafe.Pointer, n int) {
+	check(C.gpv_poseidon_gl_permute_coop_dev(ctx.h, (*C.uint64_t)(statesDev), (*C.uint64_t)(outDev), C.size_t(n)), ctx.h)
+}
 func (ctx *Context) PoseidonBN254Dev(statesDev, outDev unsafe.Pointer, n int) {
 	check(C.gpv_poseidon_bn254_permute_dev(ctx.h, (*C.uint64_t)(statesDev), (*C.uint64_t)(outDev), C.size_t(n)), ctx.h)
 }
@@ -602,4 +605,11 @@ func (ctx *Context) WitnessVerify(c *Circuit, proofs []byte) (trace []uint64, ch
 	status = make([]uint8, n)
 	check(C.gpv_witness_verify(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(trace), u64p(challenges), (*C.uint8_t)(unsafe.Pointer(&status[0]))), ctx.h)
 	return
+}
+
+// WitnessVerifyDev: the same on device-resident proofs; trace [n][WitnessVerifyWords], challenges (may be nil) and status (may be nil)
+// stay in HBM for a prover on the same GPU. Synchronises the context's stream.
+func (c *Circuit) WitnessVerifyWords() int { return int(C.gpv_witness_verify_words(c.h)) }
+func (ctx *Context) WitnessVerifyDev(c *Circuit, proofsDev unsafe.Pointer, n int, traceDev, challengesDev, statusDev unsafe.Pointer) {
+	check(C.gpv_witness_verify_dev(ctx.h, c.h, proofsDev, C.size_t(n), (*C.uint64_t)(traceDev), (*C.uint64_t)(challengesDev), (*C.uint8_t)(statusDev)), ctx.h)
 }

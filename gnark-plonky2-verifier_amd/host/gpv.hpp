@@ -21,6 +21,9 @@
 
 #include "../../include/gpv.h"
 
+namespace verifier {
+class VerifierGroup;
+}
 namespace gpv {
 
 struct Error : std::runtime_error {
@@ -38,19 +41,41 @@ inline void check(int rc, gpv_ctx* ctx = nullptr) {
 class Api {
  public:
   explicit Api(int device = 0) { check(gpv_ctx_create(&h_, device)); }
-  ~Api() { if (h_) gpv_ctx_destroy(h_); }
+  ~Api() { if (h_ && owned_) gpv_ctx_destroy(h_); }
   Api(const Api&) = delete;
+  Api(Api&& o) noexcept : h_(o.h_), owned_(o.owned_) { o.h_ = nullptr; }
   Api& operator=(const Api&) = delete;
   gpv_ctx* h() const { return h_; }
+  // GPV_OPT_* (transcript variant, shared Merkle levels, BN254 evaluation form, host chunk schedule)
+  void set_option(int option, int value) { check(gpv_ctx_set_option(h_, option, value), h_); }
+  // run on the caller's HIP stream (hipStream_t) instead of the context's own; the *Device entry points are enqueued there
+  void set_stream(void* hip_stream) { check(gpv_ctx_set_stream(h_, hip_stream), h_); }
+  void synchronize() { check(gpv_ctx_synchronize(h_), h_); }
+  // per-kernel-class timings (HIP events on the launch streams; kinds listed in include/gpv.h)
+  void timing_enable(bool on) { check(gpv_timing_enable(h_, on ? 1 : 0), h_); }
+  void timing_reset() { check(gpv_timing_reset(h_), h_); }
+  std::pair<double, uint64_t> timing_get(int kind) {
+    double ms = 0;
+    uint64_t launches = 0;
+    check(gpv_timing_get(h_, kind, &ms, &launches), h_);
+    return {ms, launches};
+  }
  private:
+  friend class ::verifier::VerifierGroup;
+  explicit Api(gpv_ctx* borrowed, bool) : h_(borrowed), owned_(false) {}
   gpv_ctx* h_ = nullptr;
+  bool owned_ = true;
 };
 
 // types.CommonCircuitData + variables.VerifierOnlyCircuitData
 class Circuit {
  public:
-  Circuit(const std::string& common_json, const std::string& verifier_only_json) {
-    check(gpv_circuit_from_json(common_json.data(), common_json.size(), verifier_only_json.data(), verifier_only_json.size(), &h_));
+  // flags = 0: the reference's shapes only (anything else -> GPV_ECONFIG, like its panics); GPV_CIRCUIT_BEYOND_REFERENCE admits the rest
+  Circuit(const std::string& common_json, const std::string& verifier_only_json, unsigned flags = 0) {
+    if (flags == 0)
+      check(gpv_circuit_from_json(common_json.data(), common_json.size(), verifier_only_json.data(), verifier_only_json.size(), &h_));
+    else
+      check(gpv_circuit_from_json_ex(common_json.data(), common_json.size(), verifier_only_json.data(), verifier_only_json.size(), flags, &h_));
   }
   ~Circuit() { if (h_) gpv_circuit_destroy(h_); }
   Circuit(const Circuit&) = delete;
@@ -58,6 +83,25 @@ class Circuit {
   gpv_circuit* h() const { return h_; }
   size_t proof_nbytes() const { return gpv_proof_nbytes(h_); }
   size_t num_challenge_words() const { return gpv_num_challenge_words(h_); }
+  size_t num_gate_constraints() const { return gpv_num_gate_constraints(h_); }
+  size_t hash_kind() const { return gpv_circuit_hash_kind(h_); }  // GPV_HASH_KIND_*
+  std::vector<uint64_t> describe() const {                          // the flat circuit description ("blob")
+    std::vector<uint64_t> blob(gpv_circuit_describe(h_, nullptr, 0));
+    gpv_circuit_describe(h_, blob.data(), blob.size());
+    return blob;
+  }
+  // the same for many proofs on n_threads host threads (ingest at rate): n consecutive records
+  std::vector<uint8_t> pack_proofs(const std::vector<std::string>& proof_jsons, int n_threads) const {
+    std::vector<const char*> ptr(proof_jsons.size());
+    std::vector<size_t> len(proof_jsons.size());
+    for (size_t i = 0; i < proof_jsons.size(); i++) {
+      ptr[i] = proof_jsons[i].data();
+      len[i] = proof_jsons[i].size();
+    }
+    std::vector<uint8_t> out(proof_nbytes() * proof_jsons.size());
+    check(gpv_proof_pack_json_batch(h_, ptr.data(), len.data(), proof_jsons.size(), out.data(), n_threads));
+    return out;
+  }
   // variables.DeserializeProofWithPublicInputs(types.ReadProofWithPublicInputs(...)): one packed record
   std::vector<uint8_t> pack_proof(const std::string& proof_json) const {
     std::vector<uint8_t> out(proof_nbytes());
@@ -101,6 +145,15 @@ class Chip {
   Vars MulAddExtension(const Vars& a, const Vars& b, const Vars& c) { return op3(GPV_OP_MULADD, a, b, &c); }   // :75
   Vars SubMulExtension(const Vars& a, const Vars& b, const Vars& c) { return op3(GPV_OP_SUBMUL, a, b, &c); }   // :89
   Vars ScalarMulExtension(const Vars& a, const Vars& b) { return op3(GPV_OP_SCALARMUL, a, b, nullptr); }       // :96, b base field
+  // QuadraticExtensionAlgebraVariable ops (quadratic_extension_algebra.go:28-86): n x 2 x 2 words; ScalarMul: a = n x 2 extension scalars
+  Vars AddExtensionAlgebra(const Vars& a, const Vars& b) { return alg(GPV_OP_ADD, a, b); }
+  Vars SubExtensionAlgebra(const Vars& a, const Vars& b) { return alg(GPV_OP_SUB, a, b); }
+  Vars MulExtensionAlgebra(const Vars& a, const Vars& b) { return alg(GPV_OP_MUL, a, b); }
+  Vars ScalarMulExtensionAlgebra(const Vars& scalar, const Vars& b) {
+    Vars out(b.size());
+    gpv::check(gpv_gl2alg_op(api_.h(), GPV_OP_SCALARMUL, b.data(), scalar.data(), out.data(), b.size() / 4), api_.h());
+    return out;
+  }
   Vars ExpExtension(const Vars& a, uint64_t exponent) {                                                        // :143
     Vars out(a.size());
     gpv::check(gpv_gl2_exp(api_.h(), a.data(), exponent, out.data(), a.size() / 2), api_.h());
@@ -115,6 +168,11 @@ class Chip {
   Vars op3(int o, const Vars& a, const Vars& b, const Vars* c) {
     Vars out(a.size());
     gpv::check(gpv_gl2_op3(api_.h(), o, a.data(), b.data(), c ? c->data() : nullptr, out.data(), a.size() / 2), api_.h());
+    return out;
+  }
+  Vars alg(int o, const Vars& a, const Vars& b) {
+    Vars out(a.size());
+    gpv::check(gpv_gl2alg_op(api_.h(), o, a.data(), b.data(), out.data(), a.size() / 4), api_.h());
     return out;
   }
   HintResult hint(int which, const Vars& in, size_t words_in, size_t words_out) {
@@ -150,6 +208,16 @@ class GoldilocksChip {
     gpv::check(gpv_poseidon_gl_permute(api_.h(), states.data(), out.data(), states.size() / 12), api_.h());
     return out;
   }
+  Words PoseidonCooperative(const Words& states) {  // the same permutation, 16 lanes per state (the transcript's low-latency kernel)
+    Words out(states.size());
+    gpv::check(gpv_poseidon_gl_permute_coop(api_.h(), states.data(), out.data(), states.size() / 12), api_.h());
+    return out;
+  }
+  // device-resident states [n][12] -> out [n][12], enqueued on the context's stream
+  void PoseidonDevice(const uint64_t* states_dev, uint64_t* out_dev, size_t n) { gpv::check(gpv_poseidon_gl_permute_dev(api_.h(), states_dev, out_dev, n), api_.h()); }
+  void PoseidonCooperativeDevice(const uint64_t* states_dev, uint64_t* out_dev, size_t n) {
+    gpv::check(gpv_poseidon_gl_permute_coop_dev(api_.h(), states_dev, out_dev, n), api_.h());
+  }
   Words HashNToMNoPad(const Words& in, size_t len, size_t nbOutputs) {  // goldilocks.go:41, n x len -> n x nbOutputs
     size_t n = len ? in.size() / len : 0;
     Words out(nbOutputs * n);
@@ -173,6 +241,7 @@ class BN254Chip {
     gpv::check(gpv_poseidon_bn254_permute(api_.h(), states.data(), out.data(), states.size() / 16), api_.h());
     return out;
   }
+  void PoseidonDevice(const uint64_t* states_dev, uint64_t* out_dev, size_t n) { gpv::check(gpv_poseidon_bn254_permute_dev(api_.h(), states_dev, out_dev, n), api_.h()); }
   Words HashOrNoop(const Words& in, size_t len) {  // bn254.go:79
     size_t n = len ? in.size() / len : 0;
     Words out(4 * n);
@@ -301,6 +370,13 @@ class PlonkChip {
     gpv::check(gpv_plonk_verify(api_.h(), c_.h(), proofs.data(), challenges.data(), n, mask.data()), api_.h());
     return mask;
   }
+  // EvaluateGatesChip.EvaluateGateConstraints (evaluate_gates.go:77-105): [n][num_gate_constraints][2]
+  std::vector<uint64_t> EvaluateGateConstraints(const std::vector<uint8_t>& proofs) {
+    size_t n = proofs.size() / c_.proof_nbytes();
+    std::vector<uint64_t> out(n * c_.num_gate_constraints() * 2);
+    gpv::check(gpv_gate_constraints(api_.h(), c_.h(), proofs.data(), n, out.data()), api_.h());
+    return out;
+  }
   // Witness slice 3: the hint outputs of PlonkChip.Verify in call order for the given challenges; consistent (optional):
   // the vanishing-polynomial assertion (plonk.go:248) holds; kinds (optional): one GPV_HINT_* id per hint call
   std::vector<uint64_t> WitnessVerify(const std::vector<uint8_t>& proofs, const std::vector<uint64_t>& challenges,
@@ -318,6 +394,26 @@ class PlonkChip {
  private:
   gpv::Api& api_;
   const gpv::Circuit& c_;
+};
+// One entry of the gate registry (plonk/gates/gates.go:20-35): kind = GPV_GATE_*, p0..p2 the parameters of its id string
+struct Gate {
+  int kind;
+  uint64_t p0 = 0, p1 = 0, p2 = 0;
+  std::vector<uint64_t> weights;  // coset-interpolation barycentric weights
+  // EvalUnfiltered (gates.go:11-18) on n variable sets: constants [n][n_constants][2] (selector prefix stripped), wires [n][n_wires][2],
+  // publicInputsHash [n][4] -> [n][count][2]; *count receives the gate's number of constraints
+  std::vector<uint64_t> EvalUnfiltered(gpv::Api& api, const std::vector<uint64_t>& constants, size_t n_constants, const std::vector<uint64_t>& wires,
+                                       size_t n_wires, const std::vector<uint64_t>& publicInputsHash, size_t* count) const {
+    const size_t n = publicInputsHash.size() / 4, max_out = 256;  // the widest gate of the registry (PoseidonGate) has 123 constraints
+    std::vector<uint64_t> out(n * max_out * 2);
+    size_t n_out = 0;
+    gpv::check(gpv_gate_eval_unfiltered(api.h(), kind, p0, p1, p2, weights.data(), weights.size(), constants.data(), n_constants, wires.data(), n_wires,
+                                        publicInputsHash.data(), out.data(), max_out, &n_out, n), api.h());
+    std::vector<uint64_t> packed(n * n_out * 2);
+    for (size_t i = 0; i < n; i++) std::copy(out.begin() + i * max_out * 2, out.begin() + i * max_out * 2 + n_out * 2, packed.begin() + i * n_out * 2);
+    if (count) *count = n_out;
+    return packed;
+  }
 };
 }  // namespace plonk
 
@@ -382,6 +478,18 @@ class VerifierChip {
     gpv::check(gpv_witness_challenges(api_.h(), c_.h(), proofs.data(), n, trace.data(), challenges ? challenges->data() : nullptr), api_.h());
     return trace;
   }
+  // Device-resident forms (proofs / challenges / outputs in HBM), enqueued on the context's stream
+  void VerifyDevice(const void* proofs_dev, size_t n, uint8_t* accept_dev) { gpv::check(gpv_verify_dev(api_.h(), c_.h(), proofs_dev, n, accept_dev), api_.h()); }
+  void GetChallengesDevice(const void* proofs_dev, size_t n, uint64_t* challenges_dev) {
+    gpv::check(gpv_challenges_dev(api_.h(), c_.h(), proofs_dev, n, challenges_dev), api_.h());
+  }
+  void VerifyWithChallengesDevice(const void* proofs_dev, const uint64_t* challenges_dev, size_t n, uint8_t* accept_dev) {
+    gpv::check(gpv_verify_given_challenges_dev(api_.h(), c_.h(), proofs_dev, challenges_dev, n, accept_dev), api_.h());
+  }
+  // the whole hint trace left in HBM for a prover on the same GPU (synchronises the stream); challenges_dev / status_dev may be null
+  void WitnessVerifyDevice(const void* proofs_dev, size_t n, uint64_t* trace_dev, uint64_t* challenges_dev, uint8_t* status_dev) {
+    gpv::check(gpv_witness_verify_dev(api_.h(), c_.h(), proofs_dev, n, trace_dev, challenges_dev, status_dev), api_.h());
+  }
   // The whole hint trace of Verify (verifier.go:143-178): range_check | challenges | plonk | fri per proof, [n][WitnessVerifyWords()];
   // status (optional): GPV_WITNESS_* bits of the reference's assertions that fail on the way
   size_t WitnessVerifyWords() const { return gpv_witness_verify_words(c_.h()); }
@@ -435,7 +543,15 @@ class VerifierGroup {
   }
   int world() const { return gpv_group_world(g_); }
   int local() const { return gpv_group_local(g_); }
+  int rank(int local_index) const { return gpv_group_rank(g_, local_index); }
+  // the context of a local rank (options, timing, primitives); owned by the group
+  gpv::Api context(int local_index) { return gpv::Api(gpv_group_ctx(g_, local_index), false); }
+  static size_t AcceptSlotBytes(size_t n_total, int world) { return gpv_accept_slot_bytes(n_total, world); }  // one rank's slot of the all-gather
   void set_option(int option, int value) { check(gpv_group_set_option(g_, option, value)); }
+  // device-resident shards: shard_dev[i] = the block of local rank i on its device, accept_all_dev[i] = n_total bytes there
+  void VerifyDevice(const std::vector<const void*>& shard_dev, size_t n_total, const std::vector<uint8_t*>& accept_all_dev) {
+    check(gpv_group_verify_dev(g_, c_.h(), shard_dev.data(), n_total, accept_all_dev.data()));
+  }
   // `proofs`: the records of this process's blocks, back to back (the whole batch for the in-process form)
   std::vector<uint8_t> Verify(const std::vector<uint8_t>& proofs, size_t n_total) {
     std::vector<uint8_t> accept(n_total);

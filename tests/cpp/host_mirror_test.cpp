@@ -157,6 +157,41 @@ int main(int argc, char** argv) {
     five[4 * proof.size() + 8 * 900] ^= 1;
     std::vector<uint8_t> acc = grp.Verify(five, 5);
     EXPECT(acc == (std::vector<uint8_t>{1, 0, 1, 1, 0}) && grp.RankVerdict(0, 5) == acc && grp.world() == 1);
+    EXPECT(grp.rank(0) == 0 && verifier::VerifierGroup::AcceptSlotBytes(5, 1) >= 1);
+    gpv::Api rank_ctx = grp.context(0);  // borrowed: options / timing / primitives of that rank
+    EXPECT(poseidon::NewGoldilocksChip(rank_ctx).Poseidon(poseidon::Words(12, 0))[0] == 4330397376401421145ULL);
+  }
+  // the rest of the header through the mirror: options, timing, circuit inspection, batch ingest, the gate evaluator, the algebra ops
+  {
+    EXPECT(circuit.hash_kind() == GPV_HASH_KIND_POSEIDON_BN254 && circuit.describe().size() > 32 && circuit.num_gate_constraints() == 123);
+    std::string pj = slurp(dir + "/proof_with_public_inputs.json");
+    std::vector<uint8_t> two = circuit.pack_proofs({pj, pj}, 2);
+    EXPECT(two.size() == 2 * proof.size() && std::equal(proof.begin(), proof.end(), two.begin() + proof.size()));
+    verifier::VerifierChip vchip(api, circuit);
+    api.timing_enable(true);
+    api.timing_reset();
+    for (int form = 0; form <= 3; form++) {  // GPV_OPT_FR_EVALUATION: by size / column scanning / operand scanning / four lanes per permutation
+      api.set_option(GPV_OPT_FR_EVALUATION, form);
+      EXPECT(vchip.Verify(two) == (std::vector<uint8_t>{1, 1}));
+    }
+    api.set_option(GPV_OPT_FR_EVALUATION, 0);
+    api.synchronize();
+    EXPECT(api.timing_get(7).second == 4 && api.timing_get(7).first > 0);  // four launches of the leaf hashing
+    api.timing_enable(false);
+    plonk::PlonkChip pchip(api, circuit);
+    std::vector<uint64_t> gc = pchip.EvaluateGateConstraints(proof);
+    EXPECT(gc.size() == 2 * circuit.num_gate_constraints());
+    // ArithmeticGate { num_ops: 1 } (arithmetic_gate.go:60-84): output - (m0 m1 c0 + addend c1) with c0 = 2, c1 = 3, wires (5, 7, 11, 103)
+    plonk::Gate arith{GPV_GATE_ARITHMETIC, 1};
+    size_t count = 0;
+    std::vector<uint64_t> un = arith.EvalUnfiltered(api, {2, 0, 3, 0}, 2, {5, 0, 7, 0, 11, 0, 103, 0}, 4, {0, 0, 0, 0}, &count);
+    EXPECT(count == 1 && un == (std::vector<uint64_t>{0, 0}));
+    poseidon::Words st(24);
+    for (size_t i = 0; i < st.size(); i++) st[i] = 1000003 * i + 17;
+    EXPECT(pgl.PoseidonCooperative(st) == pgl.Poseidon(st));
+    goldilocks::Vars one_alg = {1, 0, 0, 0}, x_alg = {3, 5, 7, 11};
+    EXPECT(gl.MulExtensionAlgebra(one_alg, x_alg) == x_alg && gl.SubExtensionAlgebra(gl.AddExtensionAlgebra(x_alg, one_alg), one_alg) == x_alg);
+    EXPECT(gl.ScalarMulExtensionAlgebra({1, 0}, x_alg) == x_alg);
   }
   printf("host mirror ok\n");
   return 0;

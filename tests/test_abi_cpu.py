@@ -41,6 +41,26 @@ def test_library_exports_every_declared_symbol(gpv):
 
 
 @pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a GPU")
+def test_go_shim_covers_the_header():
+    """bindings/go cannot be compiled here (no Go toolchain): at least its cgo calls must name exactly the functions include/gpv.h
+    declares -- every C.gpv_* used is declared, every declared entry point is wrapped (the shim drifted behind the mirrors)."""
+    import re
+    hdr = (T.ROOT / "include" / "gpv.h").read_text()
+    declared = set(re.findall(r"\b(gpv_[a-z0-9_]+)\s*\(", hdr)) - {"gpv_group", "gpv_ctx", "gpv_circuit"}
+    used = set()
+    for f in (T.ROOT / "bindings" / "go").rglob("*.go"):
+        used |= set(re.findall(r"C\.(gpv_[a-z0-9_]+)\(", f.read_text()))
+    assert used - declared == set(), sorted(used - declared)
+    assert declared - used == set(), sorted(declared - used)
+    # the compiled C++ mirror (host/gpv.hpp) and the Python mirror describe the same surface
+    cpp = set(re.findall(r"\b(gpv_[a-z0-9_]+)\s*\(", (T.ROOT / "gnark-plonky2-verifier_amd" / "host" / "gpv.hpp").read_text()))
+    assert declared - cpp == set(), sorted(declared - cpp)
+    py = set()
+    for f in (T.ROOT / "gnark-plonky2-verifier_amd").glob("*.py"):
+        py |= set(re.findall(r"\b(gpv_[a-z0-9_]+)\b", f.read_text()))
+    assert declared - py == set(), sorted(declared - py)
+
+
 def test_no_cpu_fallback(gpv):
     with pytest.raises(gpv.DeviceError):
         gpv.Context(0)
