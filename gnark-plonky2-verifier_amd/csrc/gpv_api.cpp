@@ -26,7 +26,8 @@
 #include "gpv_launch.h"
 
 // ================================================================ context
-enum { TK_MERKLE = 0, TK_PGL = 1, TK_TRANSCRIPT = 2, TK_PLONK = 3, TK_FRI = 4, TK_RANGE = 5, TK_PBN = 6, TK_LEAVES = 7, TK_LOWER = 8, TK_COUNT = 9 };
+enum { TK_MERKLE = 0, TK_PGL = 1, TK_TRANSCRIPT = 2, TK_PLONK = 3, TK_FRI = 4, TK_RANGE = 5, TK_PBN = 6, TK_LEAVES = 7, TK_LOWER = 8, TK_WIT_CHALLENGES = 9,
+       TK_WIT_PLONK = 10, TK_WIT_FRI = 11, TK_WIT_RANGE = 12, TK_COUNT = 13 };
 
 struct TimingRec {
   int kind;
@@ -987,6 +988,37 @@ extern "C" int gpv_public_inputs_hash(gpv_ctx* ctx, const gpv_circuit* c, const 
 }
 
 // Witness slice 1 (csrc/gpv_witness.cuh): the hint outputs of GetPublicInputsHash + GetChallenges in the reference's call order.
+// scratch of slice 1's two passes: the permutation log, the segment table on the device, the mismatch flag
+struct WitChallengesScratch {
+  DevBuf<u64> log, seg;
+  DevBuf<u32> bad;
+  std::vector<uint64_t> off, len;  // host copies: must outlive the upload
+  u32 n_segments = 0;
+  int prepare(gpv_ctx* ctx, const gpv_circuit* c, size_t n, hipStream_t st) {
+    gpvi_witness_challenges_segments(c, &off, &len);
+    n_segments = (u32)off.size();
+    HIP_TRY(ctx, log.alloc((size_t)n_segments * GPV_WIT_LOG_WORDS * n));
+    HIP_TRY(ctx, seg.alloc(2 * (size_t)n_segments));
+    HIP_TRY(ctx, bad.alloc(1));
+    HIP_TRY(ctx, hipMemcpyAsync(seg.p, off.data(), 8 * (size_t)n_segments, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(seg.p + n_segments, len.data(), 8 * (size_t)n_segments, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(bad.p, 0, sizeof(u32), st));
+    return GPV_OK;
+  }
+  void launch(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, u64* challenges) {
+    gpvk_witness_challenges(st, dcd, proofs, n, trace, words_per_proof, challenges, log.p, n_segments, seg.p, seg.p + n_segments, bad.p);
+  }
+  // after the stream has been synchronised
+  int check(gpv_ctx* ctx) {
+    u32 flag = 0;
+    HIP_TRY(ctx, hipMemcpy(&flag, bad.p, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) {  // the kernels' walk and the host's layout are written separately: they must agree word for word
+      ctx_error(ctx, "witness trace (challenges): %s differs from the host layout", flag & 1 ? "the number of permutations" : "a segment's word count");
+      return GPV_EDEVICE;
+    }
+    return GPV_OK;
+  }
+};
 extern "C" int gpv_witness_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint64_t* challenges) {
   REQUIRE(ctx, ctx && c && proofs && trace);
   ENTER(ctx);
@@ -998,24 +1030,18 @@ extern "C" int gpv_witness_challenges(gpv_ctx* ctx, const gpv_circuit* c, const 
   const DevCircuit* dcd;
   rc = circuit_on_device(ctx, c, &dcd);
   if (rc != GPV_OK) return rc;
-  DevBuf<u64> dtrace, dch, dwritten;
+  DevBuf<u64> dtrace, dch;
+  WitChallengesScratch ws;
   HIP_TRY(ctx, dtrace.alloc(words * n));
   HIP_TRY(ctx, dch.alloc(ncw * n));
-  HIP_TRY(ctx, dwritten.alloc(n));
-  HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * n, ctx->stream));
-  gpvk_witness_challenges(ctx->stream, dcd, (const u64*)hb.proofs.p, n, dtrace.p, words, challenges ? dch.p : nullptr, dwritten.p);
+  rc = ws.prepare(ctx, c, n, ctx->stream);
+  if (rc != GPV_OK) return rc;
+  ws.launch(ctx->stream, dcd, (const u64*)hb.proofs.p, n, dtrace.p, words, challenges ? dch.p : nullptr);
   CHECK_LAUNCH(ctx);
-  std::vector<u64> written(n);
-  HIP_TRY(ctx, hipMemcpyAsync(written.data(), dwritten.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(trace, dtrace.p, 8 * words * n, hipMemcpyDeviceToHost, ctx->stream));
   if (challenges) HIP_TRY(ctx, hipMemcpyAsync(challenges, dch.p, 8 * ncw * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  for (size_t i = 0; i < n; i++)
-    if (written[i] != words) {  // the kernel's walk and the host's layout are written separately: they must agree word for word
-      ctx_error(ctx, "witness trace of proof %zu has %llu words, the layout says %zu", i, (unsigned long long)written[i], words);
-      return GPV_EDEVICE;
-    }
-  return GPV_OK;
+  return ws.check(ctx);
 }
 
 // Witness slice 2 (csrc/gpv_witness.cuh): the hint outputs of fri.Chip.GetInstance + VerifyFriProof for caller-supplied challenges.
@@ -1133,6 +1159,7 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
   for (u32 s = 0; s < c->dc.num_steps; s++) REQUIRE(ctx, c->dc.arity_bits[s] <= 5);
   DevBuf<u64> dwritten, dws, dch_own;
   DevBuf<uint8_t> dflags;  // [3][n]: range ok, plonk consistent, fri consistent
+  WitChallengesScratch wcs;
   HIP_TRY(ctx, dwritten.alloc((2 + nq) * n));
   HIP_TRY(ctx, dws.alloc(wsw * n));
   HIP_TRY(ctx, dflags.alloc(3 * n));
@@ -1143,14 +1170,28 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
   hipStream_t main_st = ctx->stream, side = ctx->side;
   HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * (2 + nq) * n, main_st));
   HIP_TRY(ctx, hipMemsetAsync(dflags.p, 1, 3 * n, main_st));
-  u64 *wr_ch = dwritten.p, *wr_pl = dwritten.p + n, *wr_fri = dwritten.p + 2 * n;
-  gpvk_witness_challenges(main_st, dcd, dproofs, n, dtrace + w_rc, total, dch, wr_ch);
+  u64 *wr_pl = dwritten.p + n, *wr_fri = dwritten.p + 2 * n;
+  {
+    int rc = wcs.prepare(ctx, c, n, main_st);
+    if (rc != GPV_OK) return rc;
+    Timed t(ctx, TK_WIT_CHALLENGES, main_st);
+    wcs.launch(main_st, dcd, dproofs, n, dtrace + w_rc, total, dch);
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_st));
   HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
-  gpvk_witness_plonk(side, dcd, dproofs, dch, n, dtrace + w_rc + w_ch, total, dws.p, wsw, dflags.p + n, wr_pl);
+  {
+    Timed t(ctx, TK_WIT_PLONK, side);
+    gpvk_witness_plonk(side, dcd, dproofs, dch, n, dtrace + w_rc + w_ch, total, dws.p, wsw, dflags.p + n, wr_pl);
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));
-  gpvk_witness_fri(main_st, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch + w_pl, total, prefix, round, dflags.p + 2 * n, wr_fri);
-  gpvk_witness_range_check(main_st, dcd, dproofs, n, dtrace, total, dflags.p);
+  {
+    Timed t(ctx, TK_WIT_FRI, main_st);
+    gpvk_witness_fri(main_st, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch + w_pl, total, prefix, round, dflags.p + 2 * n, wr_fri);
+  }
+  {
+    Timed t(ctx, TK_WIT_RANGE, main_st);
+    gpvk_witness_range_check(main_st, dcd, dproofs, n, dtrace, total, dflags.p);
+  }
   HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_side_done, 0));
   CHECK_LAUNCH(ctx);
   std::vector<u64> written((2 + nq) * n);
@@ -1158,8 +1199,12 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
   HIP_TRY(ctx, hipMemcpyAsync(written.data(), dwritten.p, 8 * written.size(), hipMemcpyDeviceToHost, main_st));
   HIP_TRY(ctx, hipMemcpyAsync(flags.data(), dflags.p, flags.size(), hipMemcpyDeviceToHost, main_st));
   HIP_TRY(ctx, hipStreamSynchronize(main_st));
+  {
+    int rc = wcs.check(ctx);
+    if (rc != GPV_OK) return rc;
+  }
   for (size_t i = 0; i < n; i++) {
-    bool good = written[i] == w_ch && written[n + i] == w_pl;
+    bool good = written[n + i] == w_pl;
     for (size_t q = 0; q < nq; q++) good &= written[2 * n + i * nq + q] == round + (q == 0 ? prefix : 0);
     if (!good) {
       ctx_error(ctx, "witness trace of proof %zu: a lane's word count differs from the host layout", i);

@@ -1,5 +1,6 @@
 // Host-side shared declarations of libgpv.so (not part of the public ABI).
 #pragma once
+#include <vector>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -23,3 +24,4 @@ void gpv_set_global_error(const char* fmt, ...);
 const char* gpv_get_global_error();
 void gpv_circuit_release_device(gpv_circuit* c);
 void gpvi_witness_fri_sizes(const gpv_circuit* c, size_t* prefix_words, size_t* round_words);  // gpv_ingest.cpp
+void gpvi_witness_challenges_segments(const gpv_circuit* c, std::vector<uint64_t>* seg_off, std::vector<uint64_t>* seg_len);  // gpv_ingest.cpp

@@ -764,6 +764,7 @@ namespace {
 struct WitLayout {
   std::vector<uint8_t>* kinds;
   size_t hints = 0, words = 0;
+  std::vector<size_t> seg_start;  // slice 1: where every permutation's segment (its Reduce records + the permutation) starts
   void push(uint8_t kind, size_t w) {
     if (kinds) kinds->push_back(kind);
     hints++;
@@ -794,6 +795,7 @@ struct WitLayout {
   // challenger.go:42-49, :89-98, :146-166
   uint32_t n_in = 0, n_out = 0;
   void duplexing() {
+    seg_start.push_back(words);
     for (uint32_t i = 0; i < n_in; i++) reduce();
     n_in = 0;
     poseidon();
@@ -1027,7 +1029,10 @@ WitLayout witness_challenges_layout(const DevCircuit& c, std::vector<uint8_t>* k
   WitLayout L;
   L.kinds = kinds;
   for (uint32_t i = 0; i < c.num_pi; i++) L.reduce();  // HashNoPad goldilocks.go:72-86
-  for (uint32_t i = 0; i < c.num_pi; i += 8) L.poseidon();
+  for (uint32_t i = 0; i < c.num_pi; i += 8) {
+    L.seg_start.push_back(L.words);
+    L.poseidon();
+  }
   const size_t hash_words = c.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS ? 4 : 5, cap = (size_t)1 << c.cap_height;
   L.observe(hash_words);  // circuit digest, verifier.go:56
   L.observe(4);           // public-inputs hash
@@ -1059,6 +1064,13 @@ extern "C" size_t gpv_witness_fri_layout(const gpv_circuit* c, uint8_t* kinds, s
   FriWitSizes z = witness_fri_layout(c->dc, kinds ? &k : nullptr);
   if (kinds) memcpy(kinds, k.data(), k.size() < cap ? k.size() : cap);
   return z.hints;
+}
+// slice 1's segments for the two-pass kernels (csrc/gpv_witness.cuh): offset and length of every permutation's share of the trace
+void gpvi_witness_challenges_segments(const gpv_circuit* c, std::vector<uint64_t>* seg_off, std::vector<uint64_t>* seg_len) {
+  WitLayout L = witness_challenges_layout(c->dc, nullptr);
+  seg_off->assign(L.seg_start.begin(), L.seg_start.end());
+  seg_len->resize(seg_off->size());
+  for (size_t i = 0; i < seg_off->size(); i++) (*seg_len)[i] = (i + 1 < seg_off->size() ? (*seg_off)[i + 1] : L.words) - (*seg_off)[i];
 }
 // sizes the kernel launch needs (gpv_api.cpp)
 void gpvi_witness_fri_sizes(const gpv_circuit* c, size_t* prefix_words, size_t* round_words) {

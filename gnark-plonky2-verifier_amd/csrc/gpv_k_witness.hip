@@ -1,20 +1,38 @@
-// Witness generator kernels: protocol slice 1, the hint outputs of GetPublicInputsHash + GetChallenges (gpv_witness.cuh).
+// Witness generator kernels: the hint outputs of VerifierChip.Verify, slice by slice (gpv_witness.cuh).
 #include "../../include/gpv.h"
 #include "gpv_launch.h"
 #include "gpv_witness.cuh"
 
-// One lane per proof: ~130 dependent literal permutations, ~700 k words of trace per proof written through the lane's own cursor.
-__global__ __launch_bounds__(64) void k_witness_challenges(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
-                                                           u64* __restrict__ trace, size_t words_per_proof, u64* __restrict__ challenges,
-                                                           u64* __restrict__ written) {
+// Slice 1 in two passes (gpv_witness.cuh): the native transcript logs every permutation's input, then one lane per (proof, permutation)
+// writes that permutation's literal trace at its fixed offset. `bad` is set when a lane's word count (or the number of logged
+// permutations) differs from the host's layout.
+__global__ __launch_bounds__(64) void k_witness_challenges_log(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+                                                               u64* __restrict__ log, u32 n_segments, u64* __restrict__ challenges,
+                                                               u32* __restrict__ bad) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64* rec = proofs + i * (dc->proof_nbytes / 8);
-  written[i] = dev_witness_challenges(dc, rec, trace + i * words_per_proof, challenges ? challenges + i * dc->n_challenge_words : nullptr);
+  const u32 logged = dev_witness_challenges_log(dc, rec, log + i * (size_t)n_segments * GPV_WIT_LOG_WORDS,
+                                                challenges ? challenges + i * dc->n_challenge_words : nullptr);
+  if (logged != n_segments) atomicOr(bad, 1u);
 }
-void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof,
-                             u64* challenges, u64* written) {
-  GPVK_LAUNCH(k_witness_challenges, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, trace, words_per_proof, challenges, written);
+__global__ __launch_bounds__(64) void k_witness_challenges_fill(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+                                                                const u64* __restrict__ log, u32 n_segments, const u64* __restrict__ seg_off,
+                                                                const u64* __restrict__ seg_len, u64* __restrict__ trace, size_t words_per_proof,
+                                                                u32* __restrict__ bad) {
+  size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= n * n_segments) return;
+  const size_t p = item / n_segments;
+  const u32 seg = (u32)(item - p * n_segments);
+  const size_t wrote = dev_witness_challenges_fill(dc, proofs + p * (dc->proof_nbytes / 8), log + item * GPV_WIT_LOG_WORDS, trace + p * words_per_proof,
+                                                   seg_off[seg], seg, n_segments);
+  if (wrote != seg_len[seg]) atomicOr(bad, 2u);
+}
+void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, u64* challenges,
+                             u64* log, u32 n_segments, const u64* seg_off, const u64* seg_len, u32* bad) {
+  GPVK_LAUNCH(k_witness_challenges_log, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, log, n_segments, challenges, bad);
+  GPVK_LAUNCH(k_witness_challenges_fill, dim3(gpvk_blocks_for(n * n_segments, 64)), dim3(64), 0, st, dcd, proofs, n, log, n_segments, seg_off, seg_len, trace,
+              words_per_proof, bad);
 }
 
 // rangeCheckProof (verifier/verifier.go:84-141): RangeCheck / RangeCheckQE of every proof element except the public inputs, in the order

@@ -149,8 +149,11 @@ void gpvk_scatter_challenges(hipStream_t st, const u64* ch, u64* derived, u32 nc
 void gpvk_gather_challenges(hipStream_t st, const u64* derived, u64* ch, u32 ncw, size_t n);
 void gpvk_gather_pih(hipStream_t st, const u64* derived, u64* out, u32 ncw, size_t n);
 // gpv_k_witness.hip
-void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof,
-                             u64* challenges, u64* written);
+// slice 1: log [n][n_segments][GPV_WIT_LOG_WORDS] scratch; seg_off / seg_len [n_segments] from the host layout (gpvi_witness_challenges_segments);
+// *bad != 0 afterwards = the kernels' walk and the layout disagree
+#define GPV_WIT_LOG_WORDS 21
+void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, u64* challenges,
+                             u64* log, u32 n_segments, const u64* seg_off, const u64* seg_len, u32* bad);
 void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
                       size_t words_per_proof, size_t prefix_words, size_t round_words, uint8_t* consistent, u64* written);
 void gpvk_witness_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, uint8_t* ok);

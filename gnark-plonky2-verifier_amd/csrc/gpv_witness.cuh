@@ -1,5 +1,6 @@
 // Witness values of the wrapping circuit, protocol slice 1: the outputs of the reference's gnark hints while
-// VerifierChip.Verify runs GetPublicInputsHash and GetChallenges (verifier/verifier.go:41-82, :148-150), in call order, one lane per proof.
+// VerifierChip.Verify runs GetPublicInputsHash and GetChallenges (verifier/verifier.go:41-82, :148-150), in call order (slices 2 and 3 --
+// FRI, plonk -- follow further down).
 //
 // The reference proves this verification inside a gnark circuit; what its solver asks the hint functions for (goldilocks/base.go:223-243
 // MulAddHint, :284-294 ReduceHint, :339-359 SplitLimbsHint) is the non-deterministic part of that circuit's witness. Which values are
@@ -160,23 +161,54 @@ GPV_DEV void wt_poseidon(WTrace& t, u64* s) {  // :30-37
   wt_full_rounds(t, s, 26);
 }
 
-// ---------------------------------------------------------------- challenger/challenger.go, literally (elements are buffered and
-// reduced at the duplexing, :146-166 -- the order of the hints depends on it)
-struct WitChallenger {
-  WTrace* t;
+// ---------------------------------------------------------------- challenger/challenger.go: two passes
+// The sponge is one chain, but what the reference's solver is handed per PERMUTATION depends only on that permutation's input state --
+// and the input states are cheap to get: the verification kernels' textbook permutation produces them without visiting a single hinted
+// value. So the slice runs in two passes:
+//   pass 1 (k_witness_challenges_log, one lane per proof): the transcript with the native permutation; at every duplexing
+//          (challenger.go:146-166) and every permutation of the public-inputs hash it logs one entry
+//              [n_red | raw[8] | state[12]]
+//          -- the buffered raw inputs the reference reduces there (`n_red` of them) and the sponge state the permutation starts from;
+//          it also yields the challenges;
+//   pass 2 (k_witness_challenges_fill, one lane per (proof, permutation)): the n_red Reduce records, then the LITERAL permutation of
+//          that state (5 190 words), written at the segment's offset -- which depends on the circuit only (host layout,
+//          csrc/gpv_ingest.cpp). The Reduce records of the public inputs (goldilocks.go:76-78, before the first permutation) are spread
+//          over the lanes of the proof.
+// 139 / 130 lanes per step / decode_block proof instead of one: the slice's latency drops from 78 ms (134 dependent literal
+// permutations) to one literal permutation + the native transcript.
+#ifndef GPV_WIT_LOG_WORDS
+#define GPV_WIT_LOG_WORDS 21
+#endif
+struct WitLogChallenger {
+  u64* log;  // next entry
   u64 sponge[12];
   u64 in_buf[8];
-  u32 n_in, n_out;
-  GPV_DEV void init(WTrace* tr) {
-    t = tr;
+  u32 n_in, n_out, n_logged;
+  GPV_DEV void init(u64* l) {
+    log = l;
     for (int i = 0; i < 12; i++) sponge[i] = 0;
     n_in = 0;
     n_out = 0;
+    n_logged = 0;
   }
-  GPV_DEV void duplexing() {
-    for (u32 i = 0; i < n_in; i++) sponge[i] = wt_reduce(*t, wb_from(in_buf[i]));
+  GPV_DEV void log_entry(u32 n_red, const u64* raw, const u64* state) {
+    log[0] = n_red;
+    for (int i = 0; i < 8; i++) log[1 + i] = i < (int)n_red ? raw[i] : 0;
+    for (int i = 0; i < 12; i++) log[9 + i] = state[i];
+    log += GPV_WIT_LOG_WORDS;
+    n_logged++;
+  }
+  GPV_DEV void permute() {
+    PglState st;
+    for (int i = 0; i < 12; i++) st.s[i] = sponge[i];
+    st = poseidon_gl_permute_call(st);
+    for (int i = 0; i < 12; i++) sponge[i] = st.s[i];
+  }
+  GPV_DEV void duplexing() {  // :146-166: the buffered elements are reduced HERE -- the order of the hints depends on it
+    for (u32 i = 0; i < n_in; i++) sponge[i] = gl_canon(in_buf[i]);
+    log_entry(n_in, in_buf, sponge);
     n_in = 0;
-    wt_poseidon(*t, sponge);
+    permute();
     n_out = 8;
   }
   GPV_DEV void observe(u64 v) {  // :42-49
@@ -204,31 +236,28 @@ struct WitChallenger {
   }
 };
 
-// One proof. challenges (may be null): [n_challenge_words] in the layout of gpv_challenges. Returns the words written.
-GPV_DEV size_t dev_witness_challenges(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, u64* __restrict__ trace,
-                                      u64* __restrict__ challenges) {
-  WTrace t;
-  t.p = trace;
+// Pass 1, one proof. log: [n_segments][GPV_WIT_LOG_WORDS]; challenges (may be null): [n_challenge_words] in the layout of gpv_challenges.
+// Returns the number of entries logged.
+GPV_DEV u32 dev_witness_challenges_log(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, u64* __restrict__ log,
+                                       u64* __restrict__ challenges) {
   const u64* frs = rec + dc->n_gl_words;
-  // GetPublicInputsHash verifier.go:41-43 -> HashNoPad goldilocks.go:72-86: every input reduced first, then the rate-8 sponge
+  WitLogChallenger ch;
+  ch.init(log);
+  // GetPublicInputsHash verifier.go:41-43 -> HashNoPad goldilocks.go:72-86: every input reduced first (pass 2 emits those records),
+  // then the rate-8 overwrite sponge
   u64 pih[4];
   {
     const u64* pi = rec + dc->off_pi;
     const u32 n = dc->num_pi;
-    u64 s[12];
-    for (int k = 0; k < 12; k++) s[k] = 0;
-    // the reference reduces ALL inputs before the first permutation (goldilocks.go:76-78); two passes over the inputs keep that
-    // order without a buffer: pass 1 emits the hints, pass 2 recomputes the (hint-free) remainders for the sponge
-    for (u32 i = 0; i < n; i++) wt_reduce(t, wb_from(pi[i]));
     for (u32 i = 0; i < n; i += 8) {
       for (u32 j = 0; j < 8; j++)
-        if (i + j < n) s[j] = gl_canon(pi[i + j]);
-      wt_poseidon(t, s);
+        if (i + j < n) ch.sponge[j] = gl_canon(pi[i + j]);
+      ch.log_entry(0, ch.in_buf, ch.sponge);
+      ch.permute();
     }
-    for (int k = 0; k < 4; k++) pih[k] = s[k];
+    for (int k = 0; k < 4; k++) pih[k] = ch.sponge[k];
+    for (int k = 0; k < 12; k++) ch.sponge[k] = 0;  // the challenger starts from its own zero state (challenger.go:23-40)
   }
-  WitChallenger ch;
-  ch.init(&t);
   u64 dummy;
   u64* out = challenges ? challenges : &dummy;
   const u32 step = challenges ? 1u : 0u;
@@ -256,7 +285,28 @@ GPV_DEV size_t dev_witness_challenges(const DevCircuit* __restrict__ dc, const u
   out[k] = ch.challenge();  // pow response
   k += step;
   for (u32 q = 0; q < dc->num_queries; q++, k += step) out[k] = ch.challenge();
-  return (size_t)(t.p - trace);
+  return ch.n_logged;
+}
+// Pass 2, one (proof, segment) lane: the segment's Reduce records and literal permutation at `seg_off`, plus this lane's share of the
+// public inputs' Reduce records (one per input, 7 words each, at the head of the trace). Returns the words the segment took.
+GPV_DEV size_t dev_witness_challenges_fill(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ entry,
+                                           u64* __restrict__ trace, size_t seg_off, u32 seg, u32 n_segments) {
+  {
+    const u64* pi = rec + dc->off_pi;
+    for (u32 i = seg; i < dc->num_pi; i += n_segments) {
+      WTrace t;
+      t.p = trace + (size_t)7 * i;
+      wt_reduce(t, wb_from(pi[i]));
+    }
+  }
+  WTrace t;
+  t.p = trace + seg_off;
+  const u32 n_red = (u32)entry[0];
+  for (u32 i = 0; i < n_red; i++) wt_reduce(t, wb_from(entry[1 + i]));
+  u64 s[12];
+  for (int i = 0; i < 12; i++) s[i] = entry[9 + i];
+  wt_poseidon(t, s);
+  return (size_t)(t.p - (trace + seg_off));
 }
 
 // ================================================================ slice 2: fri.Chip.GetInstance + VerifyFriProof (fri/fri.go:40-61, :500-548)
