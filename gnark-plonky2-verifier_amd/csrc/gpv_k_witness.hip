@@ -3,18 +3,21 @@
 #include "gpv_launch.h"
 #include "gpv_witness.cuh"
 
-// Slice 1 in two passes (gpv_witness.cuh): the native transcript logs every permutation's input, then one lane per (proof, permutation)
+// Slice 1 in two passes (gpv_witness.cuh): the native (cooperative) transcript logs every permutation's input, then one lane per (proof, permutation)
 // writes that permutation's literal trace at its fixed offset. `bad` is set when a lane's word count (or the number of logged
 // permutations) differs from the host's layout.
-__global__ __launch_bounds__(64) void k_witness_challenges_log(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
-                                                               u64* __restrict__ log, u32 n_segments, u64* __restrict__ challenges,
-                                                               u32* __restrict__ bad) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// pass 1, cooperative: one 16-lane group per proof, four proofs per wave; round constants staged in LDS
+__global__ __launch_bounds__(64) void k_witness_challenges_log_coop(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+                                                                    u64* __restrict__ log, u32 n_segments, u64* __restrict__ challenges,
+                                                                    u32* __restrict__ bad) {
+  __shared__ u64 lds_rc[360];
+  pgl_coop_stage_constants(lds_rc);
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / PGL_COOP_LANES;
+  if (i >= n) return;  // whole 16-lane groups leave together
   const u64* rec = proofs + i * (dc->proof_nbytes / 8);
-  const u32 logged = dev_witness_challenges_log(dc, rec, log + i * (size_t)n_segments * GPV_WIT_LOG_WORDS,
-                                                challenges ? challenges + i * dc->n_challenge_words : nullptr);
-  if (logged != n_segments) atomicOr(bad, 1u);
+  const u32 logged = dev_witness_challenges_log_coop(dc, rec, log + i * (size_t)n_segments * GPV_WIT_LOG_WORDS,
+                                                     challenges ? challenges + i * dc->n_challenge_words : nullptr, lds_rc);
+  if ((threadIdx.x & (PGL_COOP_LANES - 1)) == 0 && logged != n_segments) atomicOr(bad, 1u);
 }
 __global__ __launch_bounds__(64) void k_witness_challenges_fill(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
                                                                 const u64* __restrict__ log, u32 n_segments, const u64* __restrict__ seg_off,
@@ -30,7 +33,7 @@ __global__ __launch_bounds__(64) void k_witness_challenges_fill(const DevCircuit
 }
 void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, u64* challenges,
                              u64* log, u32 n_segments, const u64* seg_off, const u64* seg_len, u32* bad) {
-  GPVK_LAUNCH(k_witness_challenges_log, dim3(gpvk_blocks_for(n, 64)), dim3(64), 0, st, dcd, proofs, n, log, n_segments, challenges, bad);
+  GPVK_LAUNCH(k_witness_challenges_log_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 64)), dim3(64), 0, st, dcd, proofs, n, log, n_segments, challenges, bad);
   GPVK_LAUNCH(k_witness_challenges_fill, dim3(gpvk_blocks_for(n * n_segments, 64)), dim3(64), 0, st, dcd, proofs, n, log, n_segments, seg_off, seg_len, trace,
               words_per_proof, bad);
 }

@@ -165,7 +165,8 @@ GPV_DEV void wt_poseidon(WTrace& t, u64* s) {  // :30-37
 // The sponge is one chain, but what the reference's solver is handed per PERMUTATION depends only on that permutation's input state --
 // and the input states are cheap to get: the verification kernels' textbook permutation produces them without visiting a single hinted
 // value. So the slice runs in two passes:
-//   pass 1 (k_witness_challenges_log, one lane per proof): the transcript with the native permutation; at every duplexing
+//   pass 1 (k_witness_challenges_log_coop, one 16-lane group per proof): the transcript with the native cooperative permutation
+//          (gpv_poseidon_coop.cuh -- pass 1 is the one dependent chain left in this slice); at every duplexing
 //          (challenger.go:146-166) and every permutation of the public-inputs hash it logs one entry
 //              [n_red | raw[8] | state[12]]
 //          -- the buffered raw inputs the reference reduces there (`n_red` of them) and the sponge state the permutation starts from;
@@ -175,116 +176,117 @@ GPV_DEV void wt_poseidon(WTrace& t, u64* s) {  // :30-37
 //          csrc/gpv_ingest.cpp). The Reduce records of the public inputs (goldilocks.go:76-78, before the first permutation) are spread
 //          over the lanes of the proof.
 // 139 / 130 lanes per step / decode_block proof instead of one: the slice's latency drops from 78 ms (134 dependent literal
-// permutations) to one literal permutation + the native transcript.
+// permutations) to 3 ms: the cooperative native transcript + one literal permutation.
 #ifndef GPV_WIT_LOG_WORDS
 #define GPV_WIT_LOG_WORDS 21
 #endif
-struct WitLogChallenger {
-  u64* log;  // next entry
-  u64 sponge[12];
-  u64 in_buf[8];
+// Pass 1: lane k of the 16-lane group holds sponge word k (and the raw element buffered at position k). Every lane of the group runs this
+// with the same arguments; the elements are written into the state as they arrive (nothing reads it between an observe and the duplexing,
+// where the reference overwrites it, challenger.go:154-156) and the raw values are kept for the log.
+struct WitLogCoopChallenger {
+  PglCoop c;
+  u64* log;
+  u64 x, raw;  // this lane's sponge word; the raw element buffered at position g since the last duplexing
   u32 n_in, n_out, n_logged;
-  GPV_DEV void init(u64* l) {
-    log = l;
-    for (int i = 0; i < 12; i++) sponge[i] = 0;
-    n_in = 0;
-    n_out = 0;
-    n_logged = 0;
-  }
-  GPV_DEV void log_entry(u32 n_red, const u64* raw, const u64* state) {
-    log[0] = n_red;
-    for (int i = 0; i < 8; i++) log[1 + i] = i < (int)n_red ? raw[i] : 0;
-    for (int i = 0; i < 12; i++) log[9 + i] = state[i];
+  GPV_DEV void log_entry(u32 n_red) {
+    if (c.g == 0) log[0] = n_red;
+    if (c.g < 8) log[1 + c.g] = (u32)c.g < n_red ? raw : 0;
+    if (c.g < 12) log[9 + c.g] = x;
     log += GPV_WIT_LOG_WORDS;
     n_logged++;
   }
-  GPV_DEV void permute() {
-    PglState st;
-    for (int i = 0; i < 12; i++) st.s[i] = sponge[i];
-    st = poseidon_gl_permute_call(st);
-    for (int i = 0; i < 12; i++) sponge[i] = st.s[i];
-  }
-  GPV_DEV void duplexing() {  // :146-166: the buffered elements are reduced HERE -- the order of the hints depends on it
-    for (u32 i = 0; i < n_in; i++) sponge[i] = gl_canon(in_buf[i]);
-    log_entry(n_in, in_buf, sponge);
+  GPV_DEV void duplexing() {
+    log_entry(n_in);
     n_in = 0;
-    permute();
+    x = pgl_coop_permute<GlLatency>(c, x);
     n_out = 8;
   }
-  GPV_DEV void observe(u64 v) {  // :42-49
+  GPV_DEV void observe(u64 v) {
     n_out = 0;
-    in_buf[n_in++] = v;
+    if ((u32)c.g == n_in) {
+      raw = v;
+      x = gl_canon(v);
+    }
+    n_in++;
     if (n_in == 8) duplexing();
   }
-  GPV_DEV u64 challenge() {  // :89-98
+  GPV_DEV u64 challenge() {
     if (n_in != 0 || n_out == 0) duplexing();
-    return sponge[--n_out];
+    u64 r = pgl_coop_word(c, x, (int)n_out - 1);
+    n_out--;
+    return r;
   }
-  GPV_DEV void observe_hash(const u64* h, u32 hash_kind) {  // :57-65
+  GPV_DEV void observe_hash(const u64* h, u32 hash_kind) {
     if (hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS) {
       for (int i = 0; i < 4; i++) observe(h[i]);
       return;
     }
-    u64 c[4] = {h[0], h[1], h[2], h[3]};
-    fr_words_reduce(c);
+    u64 w[4] = {h[0], h[1], h[2], h[3]};
+    fr_words_reduce(w);
     u64 v[5];
-    fr_canonical_to_vec(c, v);  // BN254Chip.ToVec bn254.go:106-120 (gnark's ToBinary: not one of the reference's hints)
+    fr_canonical_to_vec(w, v);
     for (int i = 0; i < 5; i++) observe(v[i]);
   }
   GPV_DEV void observe_cap(const u64* cap, u32 n, u32 hash_kind) {
+#pragma unroll 1
     for (u32 i = 0; i < n; i++) observe_hash(cap + 4 * i, hash_kind);
   }
 };
-
-// Pass 1, one proof. log: [n_segments][GPV_WIT_LOG_WORDS]; challenges (may be null): [n_challenge_words] in the layout of gpv_challenges.
-// Returns the number of entries logged.
-GPV_DEV u32 dev_witness_challenges_log(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, u64* __restrict__ log,
-                                       u64* __restrict__ challenges) {
+GPV_DEV u32 dev_witness_challenges_log_coop(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, u64* __restrict__ log,
+                                            u64* __restrict__ challenges, const u64* lds_rc) {
   const u64* frs = rec + dc->n_gl_words;
-  WitLogChallenger ch;
-  ch.init(log);
-  // GetPublicInputsHash verifier.go:41-43 -> HashNoPad goldilocks.go:72-86: every input reduced first (pass 2 emits those records),
-  // then the rate-8 overwrite sponge
+  WitLogCoopChallenger ch;
+  ch.c = pgl_coop_init(lds_rc);
+  ch.log = log;
+  ch.x = 0;
+  ch.raw = 0;
+  ch.n_in = 0;
+  ch.n_out = 0;
+  ch.n_logged = 0;
+  const bool writer = ch.c.g == 0 && challenges != nullptr;
   u64 pih[4];
   {
     const u64* pi = rec + dc->off_pi;
     const u32 n = dc->num_pi;
+#pragma unroll 1
     for (u32 i = 0; i < n; i += 8) {
-      for (u32 j = 0; j < 8; j++)
-        if (i + j < n) ch.sponge[j] = gl_canon(pi[i + j]);
-      ch.log_entry(0, ch.in_buf, ch.sponge);
-      ch.permute();
+      const u32 j = i + (u32)ch.c.g;
+      if (ch.c.g < 8 && j < n) ch.x = gl_canon(pi[j]);
+      ch.log_entry(0);
+      ch.x = pgl_coop_permute<GlLatency>(ch.c, ch.x);
     }
-    for (int k = 0; k < 4; k++) pih[k] = ch.sponge[k];
-    for (int k = 0; k < 12; k++) ch.sponge[k] = 0;  // the challenger starts from its own zero state (challenger.go:23-40)
+    for (int k = 0; k < 4; k++) pih[k] = pgl_coop_word(ch.c, ch.x, k);
+    ch.x = 0;  // the challenger starts from its own zero state
   }
-  u64 dummy;
-  u64* out = challenges ? challenges : &dummy;
-  const u32 step = challenges ? 1u : 0u;
-  u32 k = 0;
   ch.observe_hash(dc->digest, dc->hash_kind);
   for (int i = 0; i < 4; i++) ch.observe(pih[i]);
   const u32 cap_len = 1u << dc->cap_height, nc = dc->num_challenges;
   ch.observe_cap(frs + 4 * dc->fr_wires_cap, cap_len, dc->hash_kind);
-  for (u32 i = 0; i < 2 * nc; i++, k += step) out[k] = ch.challenge();  // betas, gammas
+  for (u32 i = 0; i < nc; i++) { u64 v = ch.challenge(); if (writer) challenges[dc->ch_betas + i] = v; }
+  for (u32 i = 0; i < nc; i++) { u64 v = ch.challenge(); if (writer) challenges[dc->ch_gammas + i] = v; }
   ch.observe_cap(frs + 4 * dc->fr_zs_pp_cap, cap_len, dc->hash_kind);
-  for (u32 i = 0; i < nc; i++, k += step) out[k] = ch.challenge();  // alphas
+  for (u32 i = 0; i < nc; i++) { u64 v = ch.challenge(); if (writer) challenges[dc->ch_alphas + i] = v; }
   ch.observe_cap(frs + 4 * dc->fr_quot_cap, cap_len, dc->hash_kind);
-  for (u32 i = 0; i < 2; i++, k += step) out[k] = ch.challenge();  // zeta
+  for (u32 i = 0; i < 2; i++) { u64 v = ch.challenge(); if (writer) challenges[dc->ch_zeta + i] = v; }
   const OpeningRanges orr = opening_ranges(dc);
+#pragma unroll 1
   for (u32 w = orr.a0; w < orr.a1; w++) ch.observe(rec[w]);
+#pragma unroll 1
   for (u32 w = orr.b0; w < orr.b1; w++) ch.observe(rec[w]);
+#pragma unroll 1
   for (u32 w = orr.c0; w < orr.c1; w++) ch.observe(rec[w]);
-  for (u32 i = 0; i < 2; i++, k += step) out[k] = ch.challenge();  // fri alpha
+  for (u32 i = 0; i < 2; i++) { u64 v = ch.challenge(); if (writer) challenges[dc->ch_fri_alpha + i] = v; }
+#pragma unroll 1
   for (u32 s = 0; s < dc->num_steps; s++) {
     ch.observe_cap(frs + 4 * (dc->fr_commit_caps + s * cap_len), cap_len, dc->hash_kind);
-    for (u32 i = 0; i < 2; i++, k += step) out[k] = ch.challenge();
+    for (u32 i = 0; i < 2; i++) { u64 v = ch.challenge(); if (writer) challenges[dc->ch_fri_betas + 2 * s + i] = v; }
   }
+#pragma unroll 1
   for (u32 w = 0; w < 2 * dc->final_len; w++) ch.observe(rec[dc->off_final + w]);
   ch.observe(rec[dc->off_pow]);
-  out[k] = ch.challenge();  // pow response
-  k += step;
-  for (u32 q = 0; q < dc->num_queries; q++, k += step) out[k] = ch.challenge();
+  { u64 v = ch.challenge(); if (writer) challenges[dc->ch_pow] = v; }
+#pragma unroll 1
+  for (u32 q = 0; q < dc->num_queries; q++) { u64 v = ch.challenge(); if (writer) challenges[dc->ch_queries + q] = v; }
   return ch.n_logged;
 }
 // Pass 2, one (proof, segment) lane: the segment's Reduce records and literal permutation at `seg_off`, plus this lane's share of the
