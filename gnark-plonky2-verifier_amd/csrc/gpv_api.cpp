@@ -1098,16 +1098,21 @@ extern "C" int gpv_witness_plonk(gpv_ctx* ctx, const gpv_circuit* c, const void*
   const DevCircuit* dcd;
   rc = circuit_on_device(ctx, c, &dcd);
   if (rc != GPV_OK) return rc;
-  DevBuf<u64> dtrace, dch, dwritten, dws;
+  DevBuf<u64> dtrace, dch, dwritten, dws, dtab;
   DevBuf<uint8_t> dcons;
+  std::vector<uint64_t> tab;
+  gpvi_witness_plonk_table(c, &tab);
   HIP_TRY(ctx, dtrace.alloc(words * n));
   HIP_TRY(ctx, dch.alloc(ncw * n));
   HIP_TRY(ctx, dwritten.alloc(n));
   HIP_TRY(ctx, dws.alloc(wsw * n));
   HIP_TRY(ctx, dcons.alloc(n));
+  HIP_TRY(ctx, dtab.alloc(tab.size()));
+  HIP_TRY(ctx, hipMemcpyAsync(dtab.p, tab.data(), 8 * tab.size(), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(dch.p, challenges, 8 * ncw * n, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * n, ctx->stream));
-  gpvk_witness_plonk(ctx->stream, dcd, (const u64*)hb.proofs.p, dch.p, n, dtrace.p, words, dws.p, wsw, dcons.p, dwritten.p);
+  HIP_TRY(ctx, hipMemsetAsync(dcons.p, 1, n, ctx->stream));
+  gpvk_witness_plonk(ctx->stream, dcd, c->dc, (const u64*)hb.proofs.p, dch.p, n, dtrace.p, words, dtab.p, dws.p, wsw, dcons.p, dwritten.p);
   CHECK_LAUNCH(ctx);
   std::vector<u64> written(n);
   HIP_TRY(ctx, hipMemcpyAsync(written.data(), dwritten.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1157,9 +1162,13 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
   gpvi_witness_fri_sizes(c, &prefix, &round);
   const size_t nq = c->dc.num_queries, w_fri = prefix + nq * round, total = w_rc + w_ch + w_pl + w_fri, wsw = gpv_wit_plonk_ws_words(c->dc);
   for (u32 s = 0; s < c->dc.num_steps; s++) REQUIRE(ctx, c->dc.arity_bits[s] <= 5);
-  DevBuf<u64> dwritten, dws, dch_own;
+  DevBuf<u64> dwritten, dws, dch_own, dtab;
   DevBuf<uint8_t> dflags;  // [3][n]: range ok, plonk consistent, fri consistent
   WitChallengesScratch wcs;
+  std::vector<uint64_t> tab;
+  gpvi_witness_plonk_table(c, &tab);
+  HIP_TRY(ctx, dtab.alloc(tab.size()));
+  HIP_TRY(ctx, hipMemcpyAsync(dtab.p, tab.data(), 8 * tab.size(), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, dwritten.alloc((2 + nq) * n));
   HIP_TRY(ctx, dws.alloc(wsw * n));
   HIP_TRY(ctx, dflags.alloc(3 * n));
@@ -1181,7 +1190,7 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
   HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
   {
     Timed t(ctx, TK_WIT_PLONK, side);
-    gpvk_witness_plonk(side, dcd, dproofs, dch, n, dtrace + w_rc + w_ch, total, dws.p, wsw, dflags.p + n, wr_pl);
+    gpvk_witness_plonk(side, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch, total, dtab.p, dws.p, wsw, dflags.p + n, wr_pl);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));
   {

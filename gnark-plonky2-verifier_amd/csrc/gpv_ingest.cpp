@@ -884,6 +884,7 @@ FriWitSizes witness_fri_layout(const DevCircuit& c, std::vector<uint8_t>* kinds)
 }
 // ---- slice 3: plonk.PlonkChip.Verify (csrc/gpv_witness.cuh, third part), the same walk without the arithmetic
 struct PlonkWitLayout : FriWitLayout {
+  std::vector<uint64_t> tab;  // [off_sids | reduce_off | final_off | gate_off[n_gates] | gate_acc_off[n_gates]] (csrc/gpv_witness.cuh WPlonkTab)
   void add_ext() { ext2_mul_add(); }
   void sub_ext() { ext2_mul_add(); }
   void scalar_mul_ext() { ext2_mul_add(); }
@@ -999,16 +1000,20 @@ struct PlonkWitLayout : FriWitLayout {
 PlonkWitLayout witness_plonk_layout(const DevCircuit& c, std::vector<uint8_t>* kinds) {
   PlonkWitLayout L;
   L.kinds = kinds;
+  L.tab.assign(3 + 2 * (size_t)c.n_gates, 0);
   for (uint32_t i = 0; i < c.degree_bits; i++) L.mul_ext();  // expPowerOf2Extension plonk.go:55-61
   for (uint32_t row = 0; row < c.n_gates; row++) {           // EvaluateGateConstraints evaluate_gates.go:77-105
+    L.tab[3 + row] = L.words;
     const uint32_t sel = c.selector_index[row];
     for (uint32_t i = c.group_start[sel]; i < c.group_end[sel]; i++)
       if (i != row) { L.sub_ext(); L.mul_ext(); }
     if (c.n_groups > 1) { L.sub_ext(); L.mul_ext(); }
     const uint32_t n = L.gate(c.gates[row]);
     for (uint32_t i = 0; i < n; i++) L.mul_ext();
+    L.tab[3 + c.n_gates + row] = L.words;
     for (uint32_t i = 0; i < n; i++) L.add_ext();
   }
+  L.tab[0] = L.words;
   for (uint32_t i = 0; i < c.num_routed; i++) L.scalar_mul_ext();  // evalVanishingPoly :121-207
   L.sub_ext(); L.scalar_mul_ext(); L.sub_ext(); L.div_ext();       // evalL0 :63-83
   for (uint32_t i = 0; i < c.num_challenges; i++) {
@@ -1020,7 +1025,9 @@ PlonkWitLayout witness_plonk_layout(const DevCircuit& c, std::vector<uint8_t>* k
     }
   }
   const size_t n_terms = (size_t)c.num_challenges * (c.num_pp + 2) + c.num_gate_constraints;
+  L.tab[1] = L.words;
   for (size_t i = 0; i < n_terms * c.num_challenges; i++) { L.scalar_mul_ext(); L.add_ext(); }
+  L.tab[2] = L.words;
   L.sub_ext();                                                     // Verify :209-250
   for (uint32_t i = 0; i < c.num_challenges; i++) { L.reduce_with_powers(c.qdf); L.mul_ext(); }
   return L;
@@ -1072,6 +1079,8 @@ void gpvi_witness_challenges_segments(const gpv_circuit* c, std::vector<uint64_t
   seg_len->resize(seg_off->size());
   for (size_t i = 0; i < seg_off->size(); i++) (*seg_len)[i] = (i + 1 < seg_off->size() ? (*seg_off)[i + 1] : L.words) - (*seg_off)[i];
 }
+// slice 3's offsets for the three-phase kernels (csrc/gpv_witness.cuh WPlonkTab)
+void gpvi_witness_plonk_table(const gpv_circuit* c, std::vector<uint64_t>* tab) { *tab = witness_plonk_layout(c->dc, nullptr).tab; }
 // sizes the kernel launch needs (gpv_api.cpp)
 void gpvi_witness_fri_sizes(const gpv_circuit* c, size_t* prefix_words, size_t* round_words) {
   FriWitSizes z = witness_fri_layout(c->dc, nullptr);

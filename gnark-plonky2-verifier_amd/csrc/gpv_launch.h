@@ -157,14 +157,16 @@ void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* p
 void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
                       size_t words_per_proof, size_t prefix_words, size_t round_words, uint8_t* consistent, u64* written);
 void gpvk_witness_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, uint8_t* ok);
-// per-proof workspace of k_witness_plonk in words (gpv_witness.cuh WPlonkWs): gate_terms + one gate's constraints + sIDs + numerators +
-// denominators + per challenge [z1 term | partial-product checks] + GPV_WIT_PLONK_TMP, all extension elements
+// per-proof workspace of the plonk witness kernels in words (gpv_witness.cuh WPlonkWs): filtered constraints and tmp per gate + gate_terms +
+// sIDs + numerators + denominators + per challenge [z1 term | partial-product checks] + zeta^n, all extension elements
 #define GPV_WIT_PLONK_TMP 64  // the folded list of a random-access gate (2^(bits-1) <= 32) / the 12 algebra outputs of a PoseidonMds gate (24)
 static inline size_t gpv_wit_plonk_ws_words(const DevCircuit& c) {
-  return 2 * ((size_t)2 * c.num_gate_constraints + 3 * (size_t)c.num_routed + (size_t)c.num_challenges * (c.num_pp + 2) + GPV_WIT_PLONK_TMP);
+  return 2 * ((size_t)c.n_gates * (c.num_gate_constraints + GPV_WIT_PLONK_TMP) + c.num_gate_constraints + 3 * (size_t)c.num_routed +
+              (size_t)c.num_challenges * (c.num_pp + 2) + 1);
 }
-void gpvk_witness_plonk(hipStream_t st, const DevCircuit* dcd, const u64* proofs, const u64* challenges, size_t n, u64* trace, size_t words_per_proof,
-                        u64* ws, size_t ws_words, uint8_t* consistent, u64* written);
+// tab: [3 + 2 n_gates] words from gpvi_witness_plonk_table (device copy); consistent preset to 1, written to 0
+void gpvk_witness_plonk(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
+                        size_t words_per_proof, const u64* tab, u64* ws, size_t ws_words, uint8_t* consistent, u64* written);
 // gpv_k_plonk.hip
 void gpvk_gate_eval_unfiltered(hipStream_t st, DevGate g, const u64* weights, const u64* constants, u32 n_constants, const u64* wires,
                                u32 n_wires, const u64* pih, u64* out, u32 max_out, size_t n);

@@ -540,12 +540,8 @@ GPV_DEV bool dev_witness_fri(const DevCircuit* __restrict__ dc, const u64* __res
 // (plonk/gates/evaluate_gates.go:33-105), the 14 gates' EvalUnfiltered, the extension-algebra helpers
 // (goldilocks/quadratic_extension_algebra.go:28-125) and the *Extension Poseidon layers (poseidon/goldilocks.go:127-357), op by op in call
 // order: every gate constraint is materialised, multiplied by its filter and added into the per-index sum (the verification kernel,
-// dev_plonk_verify, streams constraints into a running power-of-alpha sum and never holds them). One lane per proof; the values the
-// reference keeps in Go slices live in a per-proof workspace in HBM (WPlonkWs).
-struct WPlonkWs {  // extension elements as word pairs
-  u64 *gate_terms, *unf, *s_ids, *num, *den, *head, *tmp;
-};
-// (sized on the host by gpv_wit_plonk_ws_words, gpv_launch.h)
+// dev_plonk_verify, streams constraints into a running power-of-alpha sum and never holds them). The values the reference keeps in Go
+// slices live in a per-proof workspace in HBM (WPlonkWs further down; sized on the host by gpv_wit_plonk_ws_words, gpv_launch.h).
 GPV_DEV Ext ws_ld(const u64* a, u32 i) { return ext_make(a[2 * i], a[2 * i + 1]); }
 GPV_DEV void ws_st(u64* a, u32 i, Ext v) {
   a[2 * i] = v.a;
@@ -941,51 +937,88 @@ __device__ __noinline__ u32 wt_gate_unfiltered(WTrace& t, const DevGate& g, cons
   return k;
 }
 
-// One proof. ch: [n_challenge_words]; pih: the public-inputs hash (its own hints belong to slice 1). Returns false when the reference's
-// vanishing-polynomial assertion (plonk.go:248) fails -- the trace is what the solver would be handed either way.
-GPV_DEV bool dev_witness_plonk(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch, const u64* __restrict__ pih,
-                               u64* __restrict__ trace, u64* __restrict__ wsp, size_t* written) {
+// PlonkChip.Verify of one proof is cut where the trace has fixed offsets and the INPUTS of a piece are at hand (the same idea as slice 1):
+//   phase 1  one lane per gate: computeFilter + EvalUnfiltered + the filter products of that gate (its filtered constraints go to the
+//            workspace), and one lane for everything that does not depend on the gates: expPowerOf2Extension, the sIDs, evalL0 and, per
+//            challenge, the Z1 term, numerators / denominators and checkPartialProducts (terms to the workspace);
+//   phase 2  one lane per constraint index i: the chain constraints[i] = AddExtension(constraints[i], gate's i-th) over the gates, each
+//            record at its place behind the gate's own segment;
+//   phase 3  one lane per challenge: the reverse reduction by alpha (the two challenges' records interleave term by term), Z_H and the
+//            quotient recombination with the assertion of plonk.go:248.
+// Offsets: WPlonkTab (host layout, csrc/gpv_ingest.cpp). Record sizes used for the interleaved places: an AddExtension / SubExtension /
+// ScalarMulExtension is two MulAdd records = 12 words, a MulExtension / MulAddExtension two Reduce records = 14 words.
+struct WPlonkTab {  // u64 table: [off_sids | reduce_off | final_off | gate_off[n_gates] | gate_acc_off[n_gates]]
+  const u64* t;
+  u32 n_gates;
+  GPV_DEV size_t off_sids() const { return t[0]; }
+  GPV_DEV size_t reduce_off() const { return t[1]; }
+  GPV_DEV size_t final_off() const { return t[2]; }
+  GPV_DEV size_t gate_off(u32 g) const { return t[3 + g]; }
+  GPV_DEV size_t gate_acc_off(u32 g) const { return t[3 + n_gates + g]; }
+};
+// workspace of one proof, in words (extension elements as word pairs): filtered constraints [n_gates][ngc] | tmp [n_gates][GPV_WIT_PLONK_TMP]
+// | gate_terms [ngc] | sIDs, numerators, denominators [3 nr] | head [nc (npp + 2)] | zeta^n [1]
+struct WPlonkWs {
+  u64 *filt, *tmp, *gate_terms, *s_ids, *num, *den, *head, *zpn;
+  GPV_DEV WPlonkWs(const DevCircuit* dc, u64* base) {
+    const u32 ngc = dc->num_gate_constraints, nr = dc->num_routed, G = dc->n_gates;
+    filt = base;
+    tmp = filt + 2 * (size_t)G * ngc;
+    gate_terms = tmp + 2 * (size_t)G * GPV_WIT_PLONK_TMP;
+    s_ids = gate_terms + 2 * ngc;
+    num = s_ids + 2 * nr;
+    den = num + 2 * nr;
+    head = den + 2 * nr;
+    zpn = head + 2 * dc->num_challenges * (dc->num_pp + 2);
+  }
+};
+// phase 1, gate `row`. Returns the words written.
+GPV_DEV size_t dev_witness_plonk_gate(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, u32 row, u64* __restrict__ trace,
+                                      const WPlonkTab& tab, u64* __restrict__ wsp) {
+  WPlonkWs ws(dc, wsp);
+  const u32 ngc = dc->num_gate_constraints;
+  u64* filt = ws.filt + 2 * (size_t)row * ngc;
+  WTrace t;
+  t.p = trace + tab.gate_off(row);
+  u64* const start = t.p;
+  const u64* consts = rec + dc->off_constants;
+  const u32 sel = dc->selector_index[row];
+  const Ext s = ws_ld(consts, sel);
+  Ext filter = ext_make(1, 0);  // computeFilter evaluate_gates.go:33-55
+#pragma unroll 1
+  for (u32 i = dc->group_start[sel]; i < dc->group_end[sel]; i++) {
+    if (i == row) continue;
+    Ext d = wt_sub_ext(t, ext_make(i, 0), s);
+    filter = wt_mul_ext(t, filter, d);
+  }
+  if (dc->n_groups > 1) {
+    Ext d = wt_sub_ext(t, ext_make(0xFFFFFFFFULL, 0), s);  // UNUSED_SELECTOR gates/types.go:3
+    filter = wt_mul_ext(t, filter, d);
+  }
+  u64 pih[4] = {0, 0, 0, 0};
+  if (dc->gates[row].kind == 2) dev_public_inputs_hash(dc, rec, pih);  // PublicInputGate: recomputed natively (its hints are slice 1's)
+  const u32 n = wt_gate_unfiltered(t, dc->gates[row], consts + 2 * dc->n_groups, rec + dc->off_wires, pih, dc->weights, filt,
+                                   ws.tmp + 2 * (size_t)row * GPV_WIT_PLONK_TMP);
+#pragma unroll 1
+  for (u32 i = 0; i < n; i++) ws_st(filt, i, wt_mul_ext(t, ws_ld(filt, i), filter));
+  return (size_t)(t.p - start);
+}
+// phase 1, the lane of everything that does not depend on the gates
+GPV_DEV size_t dev_witness_plonk_perm(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch,
+                                      u64* __restrict__ trace, const WPlonkTab& tab, u64* __restrict__ wsp) {
+  WPlonkWs ws(dc, wsp);
+  const u32 nc = dc->num_challenges, nr = dc->num_routed, qdf = dc->qdf, npp = dc->num_pp;
+  const Ext zeta = ext_make(ch[dc->ch_zeta], ch[dc->ch_zeta + 1]), one = ext_make(1, 0);
+  const u64* wires = rec + dc->off_wires;
   WTrace t;
   t.p = trace;
-  const u32 nc = dc->num_challenges, nr = dc->num_routed, qdf = dc->qdf, npp = dc->num_pp, ngc = dc->num_gate_constraints;
-  WPlonkWs ws;
-  ws.gate_terms = wsp;
-  ws.unf = ws.gate_terms + 2 * ngc;
-  ws.s_ids = ws.unf + 2 * ngc;
-  ws.num = ws.s_ids + 2 * nr;
-  ws.den = ws.num + 2 * nr;
-  ws.head = ws.den + 2 * nr;
-  ws.tmp = ws.head + 2 * nc * (npp + 2);
-  const Ext zeta = ext_make(ch[dc->ch_zeta], ch[dc->ch_zeta + 1]), one = ext_make(1, 0);
-  const u64* consts = rec + dc->off_constants;
-  const u64* wires = rec + dc->off_wires;
   Ext zeta_pow_n = zeta;  // expPowerOf2Extension :55-61
 #pragma unroll 1
   for (u32 i = 0; i < dc->degree_bits; i++) zeta_pow_n = wt_mul_ext(t, zeta_pow_n, zeta_pow_n);
-  // EvaluateGateConstraints evaluate_gates.go:77-105
-#pragma unroll 1
-  for (u32 i = 0; i < ngc; i++) ws_st(ws.gate_terms, i, ext_make(0, 0));
-#pragma unroll 1
-  for (u32 row = 0; row < dc->n_gates; row++) {
-    const u32 sel = dc->selector_index[row];
-    const Ext s = ws_ld(consts, sel);
-    Ext filter = one;  // computeFilter :33-55
-#pragma unroll 1
-    for (u32 i = dc->group_start[sel]; i < dc->group_end[sel]; i++) {
-      if (i == row) continue;
-      Ext d = wt_sub_ext(t, ext_make(i, 0), s);
-      filter = wt_mul_ext(t, filter, d);
-    }
-    if (dc->n_groups > 1) {
-      Ext d = wt_sub_ext(t, ext_make(0xFFFFFFFFULL, 0), s);  // UNUSED_SELECTOR gates/types.go:3
-      filter = wt_mul_ext(t, filter, d);
-    }
-    const u32 n = wt_gate_unfiltered(t, dc->gates[row], consts + 2 * dc->n_groups, wires, pih, dc->weights, ws.unf, ws.tmp);
-#pragma unroll 1
-    for (u32 i = 0; i < n; i++) ws_st(ws.unf, i, wt_mul_ext(t, ws_ld(ws.unf, i), filter));
-#pragma unroll 1
-    for (u32 i = 0; i < n; i++) ws_st(ws.gate_terms, i, wt_add_ext(t, ws_ld(ws.gate_terms, i), ws_ld(ws.unf, i)));
-  }
+  ws_st(ws.zpn, 0, zeta_pow_n);
+  size_t wrote = (size_t)(t.p - trace);
+  t.p = trace + tab.off_sids();
+  u64* const start = t.p;
   // evalVanishingPoly :121-207
 #pragma unroll 1
   for (u32 i = 0; i < nr; i++) ws_st(ws.s_ids, i, wt_scalar_mul_ext(t, zeta, dc->k_is[i]));
@@ -1025,11 +1058,35 @@ GPV_DEV bool dev_witness_plonk(const DevCircuit* __restrict__ dc, const u64* __r
       acc_k = acc_next;
     }
   }
-  // the reverse reduction over [z1 terms | partial-product checks | gate constraints] (:185-204)
-  Ext reduced[GPV_MAX_CHALLENGES];
-#pragma unroll
-  for (u32 j = 0; j < GPV_MAX_CHALLENGES; j++) reduced[j] = ext_make(0, 0);
+  return wrote + (size_t)(t.p - start);
+}
+// phase 2, constraint index i: constraints[i] over the gates (evaluate_gates.go:97-102)
+GPV_DEV size_t dev_witness_plonk_acc(const DevCircuit* __restrict__ dc, u32 i, u64* __restrict__ trace, const WPlonkTab& tab, u64* __restrict__ wsp) {
+  WPlonkWs ws(dc, wsp);
+  const u32 ngc = dc->num_gate_constraints;
+  Ext acc = ext_make(0, 0);
+  size_t wrote = 0;
+#pragma unroll 1
+  for (u32 g = 0; g < dc->n_gates; g++) {
+    if (i >= dc->gates[g].n_constraints) continue;
+    WTrace t;
+    t.p = trace + tab.gate_acc_off(g) + (size_t)12 * i;
+    acc = wt_add_ext(t, acc, ws_ld(ws.filt + 2 * (size_t)g * ngc, i));
+    wrote += 12;
+  }
+  ws_st(ws.gate_terms, i, acc);
+  return wrote;
+}
+// phase 3, challenge j: the reverse reduction over [z1 terms | partial-product checks | gate constraints] (:185-204), then Verify :209-250.
+// *ok is cleared when the vanishing-polynomial assertion (plonk.go:248) fails.
+GPV_DEV size_t dev_witness_plonk_reduce(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch, u32 j,
+                                        u64* __restrict__ trace, const WPlonkTab& tab, u64* __restrict__ wsp, bool* ok) {
+  WPlonkWs ws(dc, wsp);
+  const u32 nc = dc->num_challenges, qdf = dc->qdf, npp = dc->num_pp, ngc = dc->num_gate_constraints, per = npp + 2;
   const u32 n_pp_terms = nc * (npp + 1), n_terms = nc + n_pp_terms + ngc;
+  const u64 alpha = ch[dc->ch_alphas + j];
+  Ext reduced = ext_make(0, 0);
+  size_t wrote = 0;
 #pragma unroll 1
   for (u32 i = n_terms; i-- > 0;) {
     Ext term;
@@ -1041,22 +1098,25 @@ GPV_DEV bool dev_witness_plonk(const DevCircuit* __restrict__ dc, const u64* __r
     } else {
       term = ws_ld(ws.head, i * per);
     }
-#pragma unroll
-    for (u32 j = 0; j < GPV_MAX_CHALLENGES; j++)
-      if (j < nc) {
-        Ext sm = wt_scalar_mul_ext(t, reduced[j], ch[dc->ch_alphas + j]);
-        reduced[j] = wt_add_ext(t, term, sm);
-      }
+    WTrace t;
+    t.p = trace + tab.reduce_off() + ((size_t)(n_terms - 1 - i) * nc + j) * 24;
+    Ext sm = wt_scalar_mul_ext(t, reduced, alpha);
+    reduced = wt_add_ext(t, term, sm);
+    wrote += 24;
   }
-  const Ext zh = wt_sub_ext(t, zeta_pow_n, one);  // Verify :209-250
-  bool ok = true;
-#pragma unroll
-  for (u32 i = 0; i < GPV_MAX_CHALLENGES; i++)
-    if (i < nc) {
-      Ext r = wt_reduce_with_powers_ext(t, rec + dc->off_quot + 2 * i * qdf, qdf, zeta_pow_n);
-      Ext prod = wt_mul_ext(t, zh, r);
-      ok &= prod.a == reduced[i].a && prod.b == reduced[i].b;
-    }
-  *written = (size_t)(t.p - trace);
-  return ok;
+  const Ext zeta_pow_n = ws_ld(ws.zpn, 0);
+  Ext zh = ext_sub(zeta_pow_n, ext_make(1, 0));  // Z_H(zeta): the record belongs to lane 0, the value is the same field element
+  if (j == 0) {
+    WTrace t;
+    t.p = trace + tab.final_off();
+    zh = wt_sub_ext(t, zeta_pow_n, ext_make(1, 0));
+    wrote += 12;
+  }
+  WTrace t;
+  t.p = trace + tab.final_off() + 12 + (size_t)j * (qdf + 1) * 14;
+  u64* const start = t.p;
+  Ext r = wt_reduce_with_powers_ext(t, rec + dc->off_quot + 2 * j * qdf, qdf, zeta_pow_n);
+  Ext prod = wt_mul_ext(t, zh, r);
+  if (!(prod.a == reduced.a && prod.b == reduced.b)) *ok = false;
+  return wrote + (size_t)(t.p - start);
 }
