@@ -1784,3 +1784,41 @@ def test_witness_verify_is_the_four_slices_in_order(gpv, api, orc, name):
     gpv._lib.check(L.gpv_witness_verify_dev(api.h, circuit.h, ctypes.c_void_p(dproofs.data_ptr()), n, ctypes.c_void_p(dtrace.data_ptr()), None,
                                             ctypes.c_void_p(dstatus.data_ptr())), api.h)
     assert (dtrace.cpu().numpy().view(np.uint64).reshape(n, -1)[good] == trace[good]).all() and dstatus.cpu().numpy().tolist() == status.tolist()
+
+
+@pytest.mark.parametrize("shape", BEYOND_SHAPES, ids=lambda s: "%s-%s-cap%d%s-%s" % (s[0], "".join(map(str, s[1])), s[2], "-salted" if s[3] else "", "gl" if s[4] else "bn"))
+def test_witness_on_shapes_beyond_the_reference(gpv, api, orc, shape):
+    """The witness generator on the shapes of SURVEY 8f.2 / 8f.4 (other FRI arities incl. 32, other cap heights, salted leaves, Poseidon-
+    Goldilocks hashes in the transcript): every slice == the oracle's literal restatement word for word -- the FRI and plonk slices under the
+    synthetic record's supplied challenges (the valid record must come out consistent), the challenges slice and the concatenated trace
+    under the record's own transcript. PARITY UNPINNED like the shapes themselves."""
+    name, arity, cap, hiding, hk = shape
+    ci, packed, (common, vo, pj), ch0 = T.synthetic_shape_fixture(name, arity, cap, hiding, hk)
+    cj = gpv.types.CommonCircuitData(json.dumps(common))
+    circuit = gpv.variables.Circuit(cj, gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo)), beyond_reference=True)
+    oc = orc.circuit(ci)
+    n = 4
+    words = np.tile(np.frombuffer(packed, dtype=np.uint64), (n, 1)).copy()
+    q0, qwords, f0, qfr, n_gl = T.query_section_layout(ci)
+    step_off = sum(ci.leaf_len(o) for o in range(4))
+    words[1, q0 + 2 * qwords + 7] ^= np.uint64(1)                   # a leaf word of query 2
+    words[2, q0 + 5 * qwords + step_off + 3] ^= np.uint64(1)        # a step evaluation of query 5
+    words[3, 2 * ci.num_constants + 5] ^= np.uint64(1)              # a sigma opening
+    chs = np.tile(ch0.reshape(1, -1), (n, 1)).copy()
+    batch = words.view(np.uint8).reshape(n, -1)
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    chip = gpv.verifier.NewVerifierChip(api, cj)
+    tr, ok = chip.WitnessRangeCheck(pb)
+    assert (tr == orc.witness_range_check(oc, batch)).all() and ok.all()
+    tr, kinds, cons = gpv.fri.NewChip(api, cj).WitnessFriProof(pb, chs)
+    otr, okinds, ocons = orc.witness_fri(oc, batch, chs)
+    assert tr.shape == otr.shape and (tr == otr).all() and (kinds == okinds).all() and cons.tolist() == ocons.tolist() and cons[0] == 1 and not cons[1] and not cons[2]
+    tr, kinds, cons = gpv.plonk.NewPlonkChip(api, cj).WitnessVerify(pb, chs)
+    otr, okinds, ocons = orc.witness_plonk(oc, batch, chs)
+    assert tr.shape == otr.shape and (tr == otr).all() and (kinds == okinds).all() and cons.tolist() == ocons.tolist() == [1, 1, 1, 0]
+    tr, kinds, ch = chip.WitnessChallenges(pb)
+    otr, okinds, och = orc.witness_challenges(oc, batch)
+    assert tr.shape == otr.shape and (tr == otr).all() and (kinds == okinds).all() and (np.asarray(ch.flat).reshape(n, -1) == och).all()
+    trace, kinds, ch, status = chip.WitnessVerify(pb)
+    want = np.concatenate([orc.witness_range_check(oc, batch), otr, orc.witness_plonk(oc, batch, och)[0], orc.witness_fri(oc, batch, och)[0]], axis=1)
+    assert trace.shape == want.shape and (trace == want).all()
