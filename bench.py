@@ -464,6 +464,7 @@ def main():
             line["fri_verify_4096"] = bench_fri_verify(gpv, T, ctx, dev, max(2, min(args.steps, 5)))
             line["merkle_only_4096"] = bench_merkle_only(gpv, T, ctx, dev, max(2, min(args.steps, 5)))
             line["single_proof"] = bench_single_proof(gpv, T, ctx, dev)
+            line["witness_verify_1024"] = bench_witness(gpv, T, ctx, dev)
         if not args.no_poseidon_gl:
             line["poseidon_gl"] = bench_poseidon_gl(gpv, T, ctx, dev)
         if not args.no_heterogeneous and n_ranks == 1:
@@ -563,6 +564,37 @@ def bench_single_proof(gpv, T, ctx, dev):
         out[name] = res
     out["entry_point"] = "gpv_verify_dev, n = 1, record resident in HBM; accept checked (valid: 1, tampered: 0)"
     return out
+
+
+def bench_witness(gpv, T, ctx, dev, n=1024):
+    """the hint trace of VerifierChip.Verify (range_check | challenges | plonk | fri, 1.35 M words per testdata/step proof) for n
+    proofs, everything resident in HBM (gpv_witness_verify_dev). The status bytes of the timed run must be zero exactly for the untampered
+    proofs (a tampered query-section word breaks a FRI consistency assertion)."""
+    import ctypes
+    wl = Workload(gpv, T, "step", dev)
+    L = gpv._lib.lib()
+    words = L.gpv_witness_verify_words(ctypes.c_void_p(wl.circuit.h))
+    if torch.cuda.mem_get_info(dev)[0] < 8 * n * words + (8 << 30):
+        return {"skipped": "not enough free HBM for %d x %d trace words" % (n, words)}
+    batch, tam = wl.cloned_batch(0, n, n)
+    trace = torch.empty(n * words, dtype=torch.int64, device=dev)
+    status = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    args = (ctx.h, wl.circuit.h, ctypes.c_void_p(batch.data_ptr()), n, ctypes.c_void_p(trace.data_ptr()), None, ctypes.c_void_p(status.data_ptr()))
+    gpv._lib.check(L.gpv_witness_verify_dev(*args), ctx.h)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gpv._lib.check(L.gpv_witness_verify_dev(*args), ctx.h)  # synchronises: the lanes' word counts are checked against the host layout
+    dt = (time.perf_counter() - t0) / reps
+    km = {nm: ctx.timing_get(k)[0] for nm, k in (("challenges", 9), ("plonk", 10), ("fri", 11), ("range_check", 12))}
+    ctx.timing_enable(False)
+    if not ((status.cpu().numpy() == 0) == ~tam).all():
+        raise SystemExit("witness_verify: status bytes do not match the tamper mask")
+    return {"entry_point": "gpv_witness_verify_dev", "proofs": n, "trace_words_per_proof": int(words), "ms_per_call": 1e3 * dt, "proofs_per_s": n / dt,
+            "trace_words_per_s": n * words / dt, "store_GBs": 8 * n * words / dt / 1e9, "store_frac_of_hbm_peak": 8 * n * words / dt / 1e9 / HBM_PEAK_GBS,
+            "kernel_ms": km, "checked": "status == 0 exactly for the untampered proofs"}
 
 
 def bench_merkle_only(gpv, T, ctx, dev, steps, n=4096):
