@@ -3,13 +3,29 @@ then the three evaluation forms of the BN254 kernels (GPV_OPT_FR_EVALUATION: 2 o
 launch size) over the small batch sizes.   python tools/latency_breakdown.py"""
 import importlib, sys, time
 import numpy as np, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import gpv_testlib as T
 gpv = importlib.import_module("gnark-plonky2-verifier_amd")
 ctx = gpv.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 dev = torch.device("cuda:0")
 KINDS = (("merkle_walk", 0), ("transcript", 2), ("plonk", 3), ("fri_query", 4), ("range_check", 5), ("merkle_leaves", 7), ("merkle_climb_lower", 8))
+if "--one" in sys.argv:  # a single proof, 30 calls per fixture and nothing else: the run to put under rocprofv3 --kernel-trace --stats
+    for name in ("step", "decode_block"):
+        d = T.GOLDEN / name
+        common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
+        vo = gpv.variables.DeserializeVerifierOnlyCircuitData(gpv.types.ReadVerifierOnlyCircuitData(d / "verifier_only_circuit_data.json"))
+        circuit = gpv.variables.circuit_for(common, vo)
+        ci, packed, _ = T.load_fixture(name)
+        chip = gpv.verifier.NewVerifierChip(ctx, common)
+        rec = torch.from_numpy(np.frombuffer(packed, dtype=np.int64).copy()).to(dev).repeat(1, 1).contiguous()
+        acc = torch.zeros(1, dtype=torch.uint8, device=dev)
+        for _ in range(30): chip.VerifyDevice(circuit, rec.data_ptr(), 1, acc.data_ptr())
+        torch.cuda.synchronize()
+        assert int(acc.item()) == 1
+    sys.exit(0)
 for name in ("step", "decode_block"):
     d = T.GOLDEN / name
     common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
