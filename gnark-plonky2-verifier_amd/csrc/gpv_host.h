@@ -24,5 +24,6 @@ void gpv_set_global_error(const char* fmt, ...);
 const char* gpv_get_global_error();
 void gpv_circuit_release_device(gpv_circuit* c);
 void gpvi_witness_fri_sizes(const gpv_circuit* c, size_t* prefix_words, size_t* round_words);  // gpv_ingest.cpp
+int gpvi_proof_pack_json_tree(const gpv_circuit* circ, const char* proof_json, size_t proof_len, void* out_packed);  // gpv_ingest.cpp
 void gpvi_witness_plonk_table(const gpv_circuit* c, std::vector<uint64_t>* tab);  // gpv_ingest.cpp
 void gpvi_witness_challenges_segments(const gpv_circuit* c, std::vector<uint64_t>* seg_off, std::vector<uint64_t>* seg_len);  // gpv_ingest.cpp

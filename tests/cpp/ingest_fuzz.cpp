@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
   const char junk[] = "{}[],:\"\\0123456789-eE.tfn \n\x00\xff";
   for (int it = 0; it < iters; it++) {
     std::string m = p;
-    int kind = rng() % 6;
+    int kind = rng() % 8;  // 6, 7: a digit replaced by a digit -- the text stays canonical, so the streaming route keeps the proof
     int nmut = 1 + rng() % 4;
     for (int k = 0; k < nmut; k++) {
       size_t pos = rng() % m.size();
@@ -34,11 +34,19 @@ int main(int argc, char** argv) {
       else if (kind == 2) m.insert(pos, std::string(1 + rng() % 8, junk[rng() % (sizeof junk - 1)]));
       else if (kind == 3) m.resize(pos);                       // truncation
       else if (kind == 4) m[pos] = (char)(rng() & 0xff);
-      else { size_t q = rng() % m.size(); std::swap(m[pos], m[q]); }
+      else if (kind == 5) { size_t q = rng() % m.size(); std::swap(m[pos], m[q]); }
+      else {
+        while (pos < m.size() && (m[pos] < '0' || m[pos] > '9')) pos++;
+        if (pos < m.size()) m[pos] = (char)('0' + rng() % 10);
+      }
       if (m.empty()) m = "x";
     }
     int rc = gpv_proof_pack_json(ci, m.data(), m.size(), out.data());
     if (rc == 0) ok++; else if (rc == GPV_ESHAPE) shape++; else other++;
+    // the streaming route (tried first by gpv_proof_pack_json) and the tree route alone must agree on the verdict and on every byte
+    std::vector<uint8_t> out2(out.size(), 0xAB);
+    int rc2 = gpvi_proof_pack_json_tree(ci, m.data(), m.size(), out2.data());
+    if (rc2 != rc || (rc == 0 && memcmp(out.data(), out2.data(), out.size()))) other++;
   }
   // the circuit parsers too
   long cok = 0, cerr = 0;

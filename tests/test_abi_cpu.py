@@ -464,3 +464,31 @@ def test_witness_plonk_layout_and_oracle_trace(gpv, name):
     got = np.empty(n_hints, dtype=np.uint8)
     L.gpv_witness_plonk_layout(ctypes.c_void_p(circuit.h), gpv._lib.ptr(got), n_hints)
     assert n_hints == len(kinds) and (got == ok).all()
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_streaming_and_tree_ingest_agree(gpv, name):
+    """gpv_proof_pack_json has two routes: a streaming pass for proofs in the canonical member order (what plonky2's serde writer and Go's
+    encoding/json produce) and the tree (DOM) route for everything else, which also owns every error. Same record either way: the fixture
+    text (pretty-printed, canonical: streaming), its compact re-serialisation (streaming), the same object with sorted keys and with an extra
+    member (tree), and canonical texts with one damaged token (streaming gives up, the tree route reports the shape error)."""
+    ci, packed, (common, vo, pj) = T.load_fixture(name)
+    circuit = _circuit(gpv, common, vo)
+    text = (T.GOLDEN / name / "proof_with_public_inputs.json").read_text()
+    obj = json.loads(text)
+
+    def pack(t):
+        return gpv.variables.DeserializeProofWithPublicInputs(gpv.types.ProofWithPublicInputsRaw(t), circuit).data.tobytes()
+
+    want = pack(text)
+    assert want == bytes(packed)
+    assert pack(json.dumps(obj)) == want
+    assert pack(json.dumps(obj, sort_keys=True, indent=1)) == want
+    extra = json.loads(text)
+    extra["proof"]["openings"]["comment"] = [1, 2, 3]
+    assert pack(json.dumps(extra)) == want
+    cut = text.rindex("]")
+    for bad in (text.replace('"pow_witness": ', '"pow_witness": -', 1), text.replace('"pow_witness": ', '"pow_witness": 1e', 1),
+                text[:cut] + ", 7" + text[cut:], text + " x"):
+        with pytest.raises(gpv.ShapeError):
+            pack(bad)
