@@ -20,6 +20,7 @@
 
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gpv_internal.h"
@@ -360,7 +361,10 @@ static int circuit_on_device(gpv_ctx* ctx, const gpv_circuit* c, const DevCircui
     void* p = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMalloc(&p, sizeof(DevCircuit)));
-    hipError_t e = hipMemcpy(p, &c->dc, sizeof(DevCircuit), hipMemcpyHostToDevice);  // synchronous: visible to every stream
+    hipError_t e = hipMemcpy(p, &c->dc, sizeof(DevCircuit), hipMemcpyHostToDevice);
+    // a pageable-source hipMemcpy may return when the staging copy is done, and it runs on the legacy default stream, which the contexts'
+    // non-blocking streams do not wait for: make the descriptor visible to every stream before the pointer is published
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
       hipFree(p);
       ctx_error(ctx, "upload of the circuit descriptor failed: %s", hipGetErrorString(e));
@@ -444,7 +448,11 @@ static int ensure_scratch(gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
     if (cb > ctx->crown_bytes) {
       if (ctx->crown) { hipStreamSynchronize(ctx->stream); hipFree(ctx->crown); ctx->crown = nullptr; ctx->crown_bytes = 0; }
       HIP_TRY(ctx, hipMalloc(&ctx->crown, cb));
-      HIP_TRY(ctx, hipMemset(ctx->crown, 0, cb));  // no stamp of an earlier life of this memory may look current
+      // no stamp of an earlier life of this memory may look current. On the context's OWN stream: the streams are non-blocking, so a
+      // plain hipMemset (legacy default stream, asynchronous for device memory) is not ordered before the kernels that follow -- under
+      // three concurrent contexts the first large batch of a context was occasionally rejected wholesale (stamps zeroed under the
+      // running level kernels; fail-closed, but wrong). Found by tools/soak.py, profiles/r03n_soak.txt.
+      HIP_TRY(ctx, hipMemsetAsync(ctx->crown, 0, cb, ctx->stream));
       ctx->crown_bytes = cb;
       ctx->crown_gen = 0;
     }
@@ -1570,6 +1578,44 @@ extern "C" int gpv_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs
   HIP_TRY(ctx, hipMemcpyAsync(accept, acc_dev, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GPV_OK;
+}
+
+// JSON proofs -> verdicts (types.ReadProofWithPublicInputs + variables.DeserializeProofWithPublicInputs + VerifierChip.Verify, the
+// reference's verifier_test.go:13-41 flow) as one pipeline: host threads pack block k + 1 (gpv_proof_pack_json_batch) while the GPU
+// verifies block k (gpv_verify's chunked upload). Ingest is the slower side (48 k proofs/s on 16 threads against 118 k on the GPU), so
+// the verification hides under it. A proof that does not parse fails the call (GPV_ESHAPE with its index), like the reference's panic.
+extern "C" int gpv_verify_json(gpv_ctx* ctx, const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n, int n_threads,
+                               uint8_t* accept) {
+  REQUIRE(ctx, ctx && c && accept && (n == 0 || (proof_jsons && proof_lens)));
+  if (n == 0) return GPV_OK;
+  if (n_threads < 1) n_threads = 1;
+  const size_t nbytes = c->dc.proof_nbytes, block = 2048;
+  std::vector<uint8_t> buf[2];
+  auto pack = [&](size_t k) -> int {  // block k into buf[k & 1]
+    const size_t lo = k * block, m = n - lo < block ? n - lo : block;
+    buf[k & 1].resize(m * nbytes);
+    return gpv_proof_pack_json_batch(c, proof_jsons + lo, proof_lens + lo, m, buf[k & 1].data(), n_threads);
+  };
+  const size_t blocks = (n + block - 1) / block;
+  int rc = pack(0);
+  if (rc != GPV_OK) ctx_error(ctx, "in the block of proofs starting at 0: %s", gpv_get_global_error());
+  for (size_t k = 0; k < blocks && rc == GPV_OK; k++) {
+    int rc_next = GPV_OK;
+    std::string err_next;
+    std::thread packer;
+    if (k + 1 < blocks) packer = std::thread([&] {
+      rc_next = pack(k + 1);
+      if (rc_next != GPV_OK) err_next = gpv_get_global_error();  // thread-local text of the packing thread
+    });
+    const size_t lo = k * block, m = n - lo < block ? n - lo : block;
+    rc = gpv_verify(ctx, c, buf[k & 1].data(), m, accept + lo);
+    if (packer.joinable()) packer.join();
+    if (rc == GPV_OK && rc_next != GPV_OK) {
+      ctx_error(ctx, "in the block of proofs starting at %zu: %s", (k + 1) * block, err_next.c_str());
+      rc = rc_next;
+    }
+  }
+  return rc;
 }
 
 // ---- internal accessors for gpv_group.cpp (one worker per context)

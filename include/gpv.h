@@ -319,6 +319,12 @@ int gpv_merkle_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, co
 /* VerifierChip.Verify (verifier/verifier.go:143-170) per proof: accept[i] = 1 iff the reference circuit would be
  * satisfiable for proof i. */
 int gpv_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept);
+/* The same from the reference's input format: n proof_with_public_inputs.json texts (types.ReadProofWithPublicInputs +
+ * variables.DeserializeProofWithPublicInputs + Verify, verifier/verifier_test.go:13-41). One pipeline: n_threads host threads pack block
+ * k + 1 while the GPU verifies block k; ingest is the slower side (48 k proofs/s on 16 threads), the verification hides under it. A text
+ * that does not parse fails the call with GPV_ESHAPE (the reference panics); the message names the block and the proof. */
+int gpv_verify_json(gpv_ctx* ctx, const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n, int n_threads,
+                    uint8_t* accept);
 /* Same, plus the diagnostic mask and the derived challenges (either may be NULL). */
 int gpv_verify_detail(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept,
                       uint32_t* fail_mask, uint64_t* challenges);

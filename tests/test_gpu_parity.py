@@ -1822,3 +1822,44 @@ def test_witness_on_shapes_beyond_the_reference(gpv, api, orc, shape):
     trace, kinds, ch, status = chip.WitnessVerify(pb)
     want = np.concatenate([orc.witness_range_check(oc, batch), otr, orc.witness_plonk(oc, batch, och)[0], orc.witness_fri(oc, batch, och)[0]], axis=1)
     assert trace.shape == want.shape and (trace == want).all()
+
+
+def test_fresh_contexts_started_concurrently(gpv, orc):
+    """Three host threads, each creating a NEW context and sending a large batch through the shared upper Merkle levels straight away, several
+    times over: the scratch a context allocates on its first large batch (the stamps of the shared levels are zeroed there) must be ready
+    before its kernels run. The streams are non-blocking, so a memset on the legacy default stream was not ordered before them -- under
+    concurrent start-up a context's first batch was occasionally rejected wholesale (tools/soak.py found it; fail-closed, but wrong)."""
+    import threading
+    torch = pytest.importorskip("torch")
+    common, vo, circuit, proofs = _load(gpv, "step")
+    ci, packed, _ = T.load_fixture("step")
+    n = 1500
+    batch, tampered = T.synthetic_batch(ci, packed, n, seed=77, tamper_every=5)
+    expect = (~tampered).astype(np.uint8)
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(batch.copy()).to(dev)
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(tid):
+        for rnd in range(5):
+            ctx = gpv.Context(0)
+            try:
+                ctx.set_option(2, 2)
+                acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize()
+                chip = gpv.verifier.NewVerifierChip(ctx, common)
+                chip.VerifyDevice(circuit, t.data_ptr(), n, acc.data_ptr())
+                ctx.synchronize()
+                got = acc.cpu().numpy()
+                if not (got == expect).all():
+                    errors.append((tid, rnd, int(got.sum()), int(expect.sum())))
+            finally:
+                ctx.close()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors

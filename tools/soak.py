@@ -50,8 +50,9 @@ def work(tid):
             acc = torch.zeros(n, dtype=torch.uint8, device=dev)
             torch.cuda.synchronize()
             chip = gpv.verifier.NewVerifierChip(ctx, common)
-            ctx.set_option(2, int(rng.choice([0, 1, 2])))
-            ctx.set_option(3, int(rng.choice([0, 1, 2, 3])))  # GPV_OPT_FR_EVALUATION: by size / column scanning / operand scanning / four lanes per permutation
+            opt_shared, opt_form = int(rng.choice([0, 1, 2])), int(rng.choice([0, 1, 2, 3]))
+            ctx.set_option(2, opt_shared)
+            ctx.set_option(3, opt_form)  # GPV_OPT_FR_EVALUATION: by size / column scanning / operand scanning / four lanes per permutation
             reps = int(rng.integers(2, 6))
             for _ in range(reps):
                 if ch is None:
@@ -63,7 +64,7 @@ def work(tid):
                 ctx.synchronize()
                 got = acc.cpu().numpy()
                 if not (got == expect).all():
-                    errors.append((tid, label, n, int((got != expect).sum())))
+                    errors.append((tid, label, n, int((got != expect).sum()), "shared %d form %d" % (opt_shared, opt_form), "accepted %d expected %d" % (int(got.sum()), int(expect.sum()))))
                     return
             with lock:
                 counts[label] = counts.get(label, 0) + reps * n
