@@ -613,3 +613,27 @@ func (c *Circuit) WitnessVerifyWords() int { return int(C.gpv_witness_verify_wor
 func (ctx *Context) WitnessVerifyDev(c *Circuit, proofsDev unsafe.Pointer, n int, traceDev, challengesDev, statusDev unsafe.Pointer) {
 	check(C.gpv_witness_verify_dev(ctx.h, c.h, proofsDev, C.size_t(n), (*C.uint64_t)(traceDev), (*C.uint64_t)(challengesDev), (*C.uint8_t)(statusDev)), ctx.h)
 }
+
+// VerifyJSON: n proof_with_public_inputs.json texts -> accept bits in one pipeline (gpv_verify_json): host threads pack block k + 1 while
+// the GPU verifies block k -- the reference's verifier_test.go flow for a batch.
+func (ctx *Context) VerifyJSON(c *Circuit, proofJSONs [][]byte, nThreads int) []bool {
+	n := len(proofJSONs)
+	ptrs := make([]*C.char, n)
+	lens := make([]C.size_t, n)
+	for i, p := range proofJSONs {
+		ptrs[i] = (*C.char)(C.CBytes(p))
+		lens[i] = C.size_t(len(p))
+	}
+	defer func() {
+		for _, p := range ptrs {
+			C.free(unsafe.Pointer(p))
+		}
+	}()
+	acc := make([]byte, n)
+	check(C.gpv_verify_json(ctx.h, c.h, (**C.char)(unsafe.Pointer(&ptrs[0])), &lens[0], C.size_t(n), C.int(nThreads), (*C.uint8_t)(unsafe.Pointer(&acc[0]))), ctx.h)
+	out := make([]bool, n)
+	for i := range acc {
+		out[i] = acc[i] == 1
+	}
+	return out
+}

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "gpv_poseidon_bn254_permute", "gpv_poseidon_bn254_permute_dev", "gpv_poseidon_bn254_hash_or_noop",
     "gpv_poseidon_bn254_two_to_one", "gpv_poseidon_bn254_to_vec", "gpv_gate_eval_unfiltered",
     "gpv_public_inputs_hash", "gpv_challenges", "gpv_plonk_verify", "gpv_gate_constraints", "gpv_fri_verify",
-    "gpv_merkle_verify", "gpv_verify", "gpv_verify_detail", "gpv_verify_dev", "gpv_challenges_dev",
+    "gpv_merkle_verify", "gpv_verify", "gpv_verify_json", "gpv_verify_detail", "gpv_verify_dev", "gpv_challenges_dev",
     "gpv_merkle_verify_dev", "gpv_fri_verify_dev", "gpv_timing_enable", "gpv_timing_reset", "gpv_timing_get",
     "gpv_verify_given_challenges", "gpv_verify_given_challenges_dev",
     "gpv_shard_bounds", "gpv_accept_slot_bytes", "gpv_group_create", "gpv_group_unique_id", "gpv_group_create_rank", "gpv_group_destroy",
@@ -104,6 +104,7 @@ def lib():
         L.gpv_witness_plonk_layout.argtypes = [vp, vp, sz]
         L.gpv_witness_plonk_layout.restype = sz
         L.gpv_witness_plonk.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+        L.gpv_verify_json.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), sz, i32, vp]
         L.gpv_witness_verify_words.argtypes = [vp]
         L.gpv_witness_verify_words.restype = sz
         L.gpv_witness_verify_layout.argtypes = [vp, vp, sz]

@@ -66,6 +66,8 @@ struct gpv_ctx {
   int fr_form = 0;        // GPV_OPT_FR_EVALUATION: 0 by launch size, 1 column scanning, 2 operand scanning (gpv_fr.cuh), 3 four lanes per permutation
   void* crown = nullptr;
   size_t crown_bytes = 0;
+  void* json_stage[2] = {nullptr, nullptr};  // pinned blocks of gpv_verify_json
+  size_t json_stage_bytes = 0;
   uint8_t* stage = nullptr;
   size_t stage_bytes = 0;
   uint8_t* stage_accept = nullptr;
@@ -243,6 +245,8 @@ extern "C" int gpv_ctx_destroy(gpv_ctx* ctx) {
   if (ctx->twin) gpv_ctx_destroy(ctx->twin);
   if (ctx->ev_twin_done) hipEventDestroy(ctx->ev_twin_done);
   if (ctx->crown) hipFree(ctx->crown);
+  for (void* p : ctx->json_stage)
+    if (p) hipHostFree(p);
   if (ctx->stage) hipFree(ctx->stage);
   if (ctx->stage_accept) hipFree(ctx->stage_accept);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
@@ -1590,11 +1594,24 @@ extern "C" int gpv_verify_json(gpv_ctx* ctx, const gpv_circuit* c, const char* c
   if (n == 0) return GPV_OK;
   if (n_threads < 1) n_threads = 1;
   const size_t nbytes = c->dc.proof_nbytes, block = 2048;
-  std::vector<uint8_t> buf[2];
+  {  // two pinned blocks, kept in the context: the packers write where the upload DMA reads (pageable blocks cost a staging copy per upload)
+    ENTER(ctx);
+    const size_t want = (n < block ? n : block) * nbytes;
+    if (want > ctx->json_stage_bytes) {
+      for (void*& p : ctx->json_stage) {
+        if (p) hipHostFree(p);
+        p = nullptr;
+      }
+      ctx->json_stage_bytes = 0;
+      HIP_TRY(ctx, hipHostMalloc(&ctx->json_stage[0], want, hipHostMallocDefault));
+      HIP_TRY(ctx, hipHostMalloc(&ctx->json_stage[1], want, hipHostMallocDefault));
+      ctx->json_stage_bytes = want;
+    }
+  }
+  uint8_t* buf[2] = {(uint8_t*)ctx->json_stage[0], (uint8_t*)ctx->json_stage[1]};
   auto pack = [&](size_t k) -> int {  // block k into buf[k & 1]
     const size_t lo = k * block, m = n - lo < block ? n - lo : block;
-    buf[k & 1].resize(m * nbytes);
-    return gpv_proof_pack_json_batch(c, proof_jsons + lo, proof_lens + lo, m, buf[k & 1].data(), n_threads);
+    return gpv_proof_pack_json_batch(c, proof_jsons + lo, proof_lens + lo, m, buf[k & 1], n_threads);
   };
   const size_t blocks = (n + block - 1) / block;
   int rc = pack(0);
@@ -1608,7 +1625,7 @@ extern "C" int gpv_verify_json(gpv_ctx* ctx, const gpv_circuit* c, const char* c
       if (rc_next != GPV_OK) err_next = gpv_get_global_error();  // thread-local text of the packing thread
     });
     const size_t lo = k * block, m = n - lo < block ? n - lo : block;
-    rc = gpv_verify(ctx, c, buf[k & 1].data(), m, accept + lo);
+    rc = gpv_verify(ctx, c, buf[k & 1], m, accept + lo);
     if (packer.joinable()) packer.join();
     if (rc == GPV_OK && rc_next != GPV_OK) {
       ctx_error(ctx, "in the block of proofs starting at %zu: %s", (k + 1) * block, err_next.c_str());

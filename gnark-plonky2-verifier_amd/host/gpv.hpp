@@ -507,6 +507,18 @@ class VerifierChip {
                                   status ? status->data() : nullptr), api_.h());
     return trace;
   }
+  // JSON texts -> verdicts in one pipeline (gpv_verify_json): host threads pack block k + 1 while the GPU verifies block k
+  std::vector<uint8_t> VerifyJSON(const std::vector<std::string>& proof_jsons, int n_threads = 8) {
+    std::vector<const char*> ptr(proof_jsons.size());
+    std::vector<size_t> len(proof_jsons.size());
+    for (size_t i = 0; i < proof_jsons.size(); i++) {
+      ptr[i] = proof_jsons[i].data();
+      len[i] = proof_jsons[i].size();
+    }
+    std::vector<uint8_t> accept(proof_jsons.size());
+    gpv::check(gpv_verify_json(api_.h(), c_.h(), ptr.data(), len.data(), proof_jsons.size(), n_threads, accept.data()), api_.h());
+    return accept;
+  }
   // Verify (verifier.go:143): accept[i] == 1 iff the reference's circuit is satisfiable for proof i
   std::vector<uint8_t> Verify(const std::vector<uint8_t>& proofs) {
     size_t n = proofs.size() / c_.proof_nbytes();

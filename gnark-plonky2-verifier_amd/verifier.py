@@ -54,6 +54,18 @@ class VerifierChip:
         _lib.check(L.gpv_witness_challenges(self.ctx.h, c.h, _lib.ptr(proofs.data), proofs.n, _lib.ptr(trace), _lib.ptr(ch)), self.ctx.h)
         return trace, kinds, (ProofChallenges(c, ch) if with_challenges else None)
 
+    def VerifyJSON(self, circuit, raws, n_threads=8):
+        """verifier_test.go:13-41 for n proof_with_public_inputs.json texts in one pipeline (gpv_verify_json): host threads pack block k + 1
+        while the GPU verifies block k. raws: types.ProofWithPublicInputsRaw objects. Returns accept [n]; a text that does not parse raises
+        ShapeError (the reference panics)."""
+        import ctypes
+        n = len(raws)
+        texts = (ctypes.c_char_p * n)(*[r.text for r in raws])
+        lens = (ctypes.c_size_t * n)(*[len(r.text) for r in raws])
+        accept = np.empty(n, dtype=np.uint8)
+        _lib.check(_lib.lib().gpv_verify_json(self.ctx.h, circuit.h, texts, lens, n, n_threads, _lib.ptr(accept)), self.ctx.h)
+        return accept
+
     def WitnessVerify(self, proofs):
         """The whole hint trace of Verify (verifier.go:143-178; gpv_witness_verify): rangeCheckProof | GetPublicInputsHash + GetChallenges |
         PlonkChip.Verify | GetInstance + VerifyFriProof per proof, in call order, the challenges handed between the slices in HBM. Returns

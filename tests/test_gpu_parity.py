@@ -1863,3 +1863,22 @@ def test_fresh_contexts_started_concurrently(gpv, orc):
     for x in th:
         x.join()
     assert not errors, errors
+
+
+def test_verify_json_pipeline(gpv, api):
+    """gpv_verify_json: JSON texts -> verdicts with ingest and verification overlapped, across more than one block (2048 proofs per block),
+    canonical and re-ordered texts mixed, one proof tampered in the JSON itself; a text that does not parse fails the call."""
+    common, vo, circuit, proofs = _load(gpv, "decode_block")
+    text = (T.GOLDEN / "decode_block" / "proof_with_public_inputs.json").read_text()
+    obj = json.loads(text)
+    bad = json.loads(text)
+    bad["proof"]["openings"]["wires"][3][0] ^= 1
+    variants = [text, json.dumps(obj), json.dumps(obj, sort_keys=True), json.dumps(bad)]
+    n = 2048 + 700
+    raws = [gpv.types.ProofWithPublicInputsRaw(variants[3] if i % 97 == 5 else variants[i % 3]) for i in range(n)]
+    chip = gpv.verifier.NewVerifierChip(api, common)
+    acc = chip.VerifyJSON(circuit, raws, n_threads=8)
+    assert acc.tolist() == [0 if i % 97 == 5 else 1 for i in range(n)]
+    raws[2500] = gpv.types.ProofWithPublicInputsRaw('{"proof": {}}')
+    with pytest.raises(gpv.ShapeError):
+        chip.VerifyJSON(circuit, raws, n_threads=8)
