@@ -376,7 +376,7 @@ def main():
                    "merkle_shared_levels": "off: every path hashed on its own" if args.per_path_merkle else "on (default): the last 3 levels of each tree hashed once per distinct node, inputs compared "
                                            "word for word; accept bits identical to the per-path walk (GPV_OPT_MERKLE_SHARED_LEVELS)",
                    "bn254_fr_rows": "chosen per launch (GPV_OPT_FR_EVALUATION = 0): column scanning for launches of >= 3 * 2^18 hashing lanes "
-                                    "(this workload from ~4700 proofs per GPU up), operand scanning below; bit-identical results"},
+                                    "(this workload from ~4700 proofs per GPU up), operand scanning below, four lanes per permutation for launches of <= 45 056 paths (about 270 proofs); identical results"},
     }
     if rank == 0:
         leaf_perms, climb_perms = perms_per_proof(ci)
