@@ -173,20 +173,45 @@ func (c *Circuit) HashKind() int { return int(C.gpv_circuit_hash_kind(c.h)) }
 // PackProofs converts n proof JSON documents on nThreads host threads (gpv_proof_pack_json_batch).
 func (c *Circuit) PackProofs(proofJSONs [][]byte, nThreads int) []byte {
 	n := len(proofJSONs)
+	if n == 0 {
+		return nil // &slice[0] of an empty slice panics; the C ABI answers n == 0 with GPV_OK
+	}
 	out := make([]byte, n*c.ProofNBytes())
-	ptrs := make([]*C.char, n)
-	lens := make([]C.size_t, n)
-	for i, p := range proofJSONs {
-		ptrs[i] = (*C.char)(C.CBytes(p)) // C copies: cgo must not hold Go pointers to Go pointers
+	ptrs, lens, free := cTexts(proofJSONs)
+	defer free()
+	check(C.gpv_proof_pack_json_batch(c.h, (**C.char)(unsafe.Pointer(&ptrs[0])), &lens[0], C.size_t(n), unsafe.Pointer(&out[0]), C.int(nThreads)), nil)
+	return out
+}
+
+// PackProofsStatus is PackProofs with a status per proof (gpv_proof_pack_json_batch_status): a document that does not parse -- where
+// types.ReadProofWithPublicInputs / DeserializeProofWithPublicInputs panic -- gets its error code and an all-zero record.
+func (c *Circuit) PackProofsStatus(proofJSONs [][]byte, nThreads int) ([]byte, []int32) {
+	n := len(proofJSONs)
+	if n == 0 {
+		return nil, nil
+	}
+	out := make([]byte, n*c.ProofNBytes())
+	status := make([]int32, n)
+	ptrs, lens, free := cTexts(proofJSONs)
+	defer free()
+	check(C.gpv_proof_pack_json_batch_status(c.h, (**C.char)(unsafe.Pointer(&ptrs[0])), &lens[0], C.size_t(n), unsafe.Pointer(&out[0]), C.int(nThreads),
+		(*C.int32_t)(unsafe.Pointer(&status[0]))), nil)
+	return out, status
+}
+
+// cTexts copies the documents into C memory (cgo must not hold Go pointers to Go pointers); call free when done.
+func cTexts(docs [][]byte) ([]*C.char, []C.size_t, func()) {
+	ptrs := make([]*C.char, len(docs))
+	lens := make([]C.size_t, len(docs))
+	for i, p := range docs {
+		ptrs[i] = (*C.char)(C.CBytes(p))
 		lens[i] = C.size_t(len(p))
 	}
-	defer func() {
+	return ptrs, lens, func() {
 		for _, p := range ptrs {
 			C.free(unsafe.Pointer(p))
 		}
-	}()
-	check(C.gpv_proof_pack_json_batch(c.h, (**C.char)(unsafe.Pointer(&ptrs[0])), &lens[0], C.size_t(n), unsafe.Pointer(&out[0]), C.int(nThreads)), nil)
-	return out
+	}
 }
 
 // SetOption: GPV_OPT_TRANSCRIPT_VARIANT (1) / GPV_OPT_MERKLE_SHARED_LEVELS (2) / GPV_OPT_FR_EVALUATION (3).
@@ -618,17 +643,11 @@ func (ctx *Context) WitnessVerifyDev(c *Circuit, proofsDev unsafe.Pointer, n int
 // the GPU verifies block k -- the reference's verifier_test.go flow for a batch.
 func (ctx *Context) VerifyJSON(c *Circuit, proofJSONs [][]byte, nThreads int) []bool {
 	n := len(proofJSONs)
-	ptrs := make([]*C.char, n)
-	lens := make([]C.size_t, n)
-	for i, p := range proofJSONs {
-		ptrs[i] = (*C.char)(C.CBytes(p))
-		lens[i] = C.size_t(len(p))
+	if n == 0 {
+		return nil
 	}
-	defer func() {
-		for _, p := range ptrs {
-			C.free(unsafe.Pointer(p))
-		}
-	}()
+	ptrs, lens, free := cTexts(proofJSONs)
+	defer free()
 	acc := make([]byte, n)
 	check(C.gpv_verify_json(ctx.h, c.h, (**C.char)(unsafe.Pointer(&ptrs[0])), &lens[0], C.size_t(n), C.int(nThreads), (*C.uint8_t)(unsafe.Pointer(&acc[0]))), ctx.h)
 	out := make([]bool, n)
@@ -636,4 +655,24 @@ func (ctx *Context) VerifyJSON(c *Circuit, proofJSONs [][]byte, nThreads int) []
 		out[i] = acc[i] == 1
 	}
 	return out
+}
+
+// VerifyJSONStatus is VerifyJSON with a status per proof (gpv_verify_json_status): a document that does not parse is status[i] != 0
+// (GPV_ESHAPE where the reference panics) and accept[i] = false; every other proof of the batch is still verified.
+func (ctx *Context) VerifyJSONStatus(c *Circuit, proofJSONs [][]byte, nThreads int) ([]bool, []int32) {
+	n := len(proofJSONs)
+	if n == 0 {
+		return nil, nil
+	}
+	ptrs, lens, free := cTexts(proofJSONs)
+	defer free()
+	acc := make([]byte, n)
+	status := make([]int32, n)
+	check(C.gpv_verify_json_status(ctx.h, c.h, (**C.char)(unsafe.Pointer(&ptrs[0])), &lens[0], C.size_t(n), C.int(nThreads),
+		(*C.uint8_t)(unsafe.Pointer(&acc[0])), (*C.int32_t)(unsafe.Pointer(&status[0]))), ctx.h)
+	out := make([]bool, n)
+	for i := range acc {
+		out[i] = acc[i] == 1
+	}
+	return out, status
 }

@@ -10,6 +10,8 @@ import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libgpv.so"
+# the same objects + the fault-injection hook of csrc/gpv_testhooks.h (csrc/Makefile); loaded by the fail-closed tests only
+TEST_LIB_PATH = PKG_DIR / "libgpv_test.so"
 
 GPV_OK, GPV_ESHAPE, GPV_ECONFIG, GPV_EDEVICE, GPV_EINVAL, GPV_ENOMEM, GPV_EPEER = 0, -1, -2, -3, -4, -5, -6
 
@@ -18,14 +20,14 @@ ABI_SYMBOLS = [
     "gpv_ctx_create", "gpv_ctx_destroy", "gpv_ctx_set_stream", "gpv_ctx_set_option", "gpv_ctx_synchronize", "gpv_last_error_message",
     "gpv_circuit_from_json", "gpv_circuit_from_json_ex", "gpv_circuit_destroy", "gpv_proof_nbytes", "gpv_num_challenge_words",
     "gpv_num_gate_constraints", "gpv_num_query_rounds", "gpv_num_merkle_trees", "gpv_circuit_hash_kind", "gpv_circuit_describe",
-    "gpv_proof_pack_json", "gpv_proof_pack_json_batch",
+    "gpv_proof_pack_json", "gpv_proof_pack_json_batch", "gpv_proof_pack_json_batch_status",
     "gpv_gl_op", "gpv_gl_hints", "gpv_witness_fri_words", "gpv_witness_fri_layout", "gpv_witness_fri", "gpv_witness_plonk_words", "gpv_witness_plonk_layout", "gpv_witness_plonk", "gpv_witness_verify_words", "gpv_witness_verify_layout", "gpv_witness_verify", "gpv_witness_verify_dev", "gpv_witness_range_check_words", "gpv_witness_range_check", "gpv_witness_challenges_words", "gpv_witness_challenges_layout", "gpv_witness_challenges", "gpv_gl2_op", "gpv_gl2_op3", "gpv_gl2_exp", "gpv_gl2_reduce_with_powers", "gpv_gl2alg_op",
     "gpv_poseidon_gl_hash_n_to_m_no_pad", "gpv_challenger_run", "gpv_poseidon_gl_permute", "gpv_poseidon_gl_permute_dev", "gpv_poseidon_gl_permute_coop",
     "gpv_poseidon_gl_permute_coop_dev", "gpv_poseidon_gl_hash_no_pad",
     "gpv_poseidon_bn254_permute", "gpv_poseidon_bn254_permute_dev", "gpv_poseidon_bn254_hash_or_noop",
     "gpv_poseidon_bn254_two_to_one", "gpv_poseidon_bn254_to_vec", "gpv_gate_eval_unfiltered",
     "gpv_public_inputs_hash", "gpv_challenges", "gpv_plonk_verify", "gpv_gate_constraints", "gpv_fri_verify",
-    "gpv_merkle_verify", "gpv_verify", "gpv_verify_json", "gpv_verify_detail", "gpv_verify_dev", "gpv_challenges_dev",
+    "gpv_merkle_verify", "gpv_verify", "gpv_verify_json", "gpv_verify_json_status", "gpv_verify_detail", "gpv_verify_dev", "gpv_challenges_dev",
     "gpv_merkle_verify_dev", "gpv_fri_verify_dev", "gpv_timing_enable", "gpv_timing_reset", "gpv_timing_get",
     "gpv_verify_given_challenges", "gpv_verify_given_challenges_dev",
     "gpv_shard_bounds", "gpv_accept_slot_bytes", "gpv_group_create", "gpv_group_unique_id", "gpv_group_create_rank", "gpv_group_destroy",
@@ -57,13 +59,40 @@ class DeviceError(GpvError):
 
 
 _lib = None
+_test_lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not LIB_PATH.exists():
-            raise DeviceError(GPV_EDEVICE, "%s not built -- run __graft_entry__.build() (hipcc, gfx950)" % LIB_PATH)
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+class test_library:
+    """`with _lib.test_library():` -- inside the block lib() is libgpv_test.so (product objects + gpvi_test_set_fault). Contexts, circuits
+    and groups must be created INSIDE the block and closed before it ends: the two libraries are separate images with separate state, and
+    a handle of one means nothing to the other. For tests/ only."""
+
+    def __enter__(self):
+        global _lib, _test_lib
+        if _test_lib is None:
+            _test_lib = _load(TEST_LIB_PATH)
+            _test_lib.gpvi_test_set_fault.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_uint]
+        self._saved = _lib
+        _lib = _test_lib
+        return _test_lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
+
+
+def _load(path):
+    if True:
+        if not path.exists():
+            raise DeviceError(GPV_EDEVICE, "%s not built -- run __graft_entry__.build() (hipcc, gfx950)" % path)
         # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if libgpv pulled in the system copy first,
         # torch would later fail with "No HIP GPUs are available". Loading torch first makes both share torch's runtime.
         # (C/C++/Go hosts without torch simply use the system ROCm runtime.)
@@ -71,7 +100,7 @@ def lib():
             import torch  # noqa: F401
         except Exception:
             pass
-        L = ctypes.CDLL(str(LIB_PATH))
+        L = ctypes.CDLL(str(path))
         vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
         L.gpv_ctx_create.argtypes = [ctypes.POINTER(vp), i32]
         L.gpv_ctx_destroy.argtypes = [vp]
@@ -92,6 +121,7 @@ def lib():
         L.gpv_circuit_describe.restype = sz
         L.gpv_proof_pack_json.argtypes = [vp, ctypes.c_char_p, sz, vp]
         L.gpv_proof_pack_json_batch.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), sz, vp, i32]
+        L.gpv_proof_pack_json_batch_status.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), sz, vp, i32, vp]
         L.gpv_gl_op.argtypes = [vp, i32, vp, vp, vp, vp, sz]
         L.gpv_gl_hints.argtypes = [vp, i32, vp, vp, vp, sz]
         L.gpv_witness_fri_words.argtypes = [vp]
@@ -105,6 +135,7 @@ def lib():
         L.gpv_witness_plonk_layout.restype = sz
         L.gpv_witness_plonk.argtypes = [vp, vp, vp, vp, sz, vp, vp]
         L.gpv_verify_json.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), sz, i32, vp]
+        L.gpv_verify_json_status.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), sz, i32, vp, vp]
         L.gpv_witness_verify_words.argtypes = [vp]
         L.gpv_witness_verify_words.restype = sz
         L.gpv_witness_verify_layout.argtypes = [vp, vp, sz]
@@ -170,8 +201,7 @@ def lib():
         L.gpv_group_verify.argtypes = [vp, vp, vp, sz, vp]
         L.gpv_group_verify_dev.argtypes = [vp, vp, ctypes.POINTER(vp), sz, ctypes.POINTER(vp)]
         L.gpv_group_read_rank_accept.argtypes = [vp, i32, vp, sz]
-        _lib = L
-    return _lib
+    return L
 
 
 def last_error(ctx_handle=None):
@@ -207,13 +237,14 @@ class Context:
 
     def __init__(self, device_id=0):
         h = ctypes.c_void_p()
-        check(lib().gpv_ctx_create(ctypes.byref(h), device_id))
+        self._L = lib()  # the library that owns the handle (tests may switch lib() to libgpv_test.so, test_library)
+        check(self._L.gpv_ctx_create(ctypes.byref(h), device_id))
         self.h = h.value
         self.device_id = device_id
 
     def close(self):
         if getattr(self, "h", None):
-            lib().gpv_ctx_destroy(ctypes.c_void_p(self.h))
+            self._L.gpv_ctx_destroy(ctypes.c_void_p(self.h))
             self.h = None
 
     def __del__(self):
@@ -273,6 +304,7 @@ class Group:
 
     def __init__(self, device_ids=None, rank=None, world=None, unique_id=None, device_id=0):
         h = ctypes.c_void_p()
+        self._L = lib()
         if rank is None:
             ids = (ctypes.c_int * len(device_ids))(*device_ids)
             check(lib().gpv_group_create(ctypes.byref(h), ids, len(device_ids)))
@@ -300,7 +332,7 @@ class Group:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().gpv_group_destroy(ctypes.c_void_p(self.h))
+            self._L.gpv_group_destroy(ctypes.c_void_p(self.h))
             self.h = None
 
     def __del__(self):

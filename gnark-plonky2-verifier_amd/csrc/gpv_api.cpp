@@ -118,8 +118,12 @@ void gpvk_note_launch(hipError_t e, const char* what) {
   EntryDepth enter_depth_;                                \
   HIP_TRY(ctx, hipSetDevice(ctx->device))
 
-// Fault injection for the fail-closed tests (gpv_testhooks.h): process-wide, armed only by tests.
+// Fault injection for the fail-closed tests (gpv_testhooks.h). Compiled ONLY into libgpv_test.so (-DGPV_TEST_HOOKS, csrc/Makefile): the
+// product library has neither the process-wide state nor the symbol (round 4) -- there the two queries below are
+// the identity, so the kernel translation units are shared by both builds.
+#ifdef GPV_TEST_HOOKS
 #include <atomic>
+#include "gpv_testhooks.h"
 static std::atomic<int> g_fault_stage{0}, g_fault_nth{-1}, g_fault_seen{0};
 static std::atomic<unsigned> g_fault_num{1}, g_fault_den{1};
 unsigned gpvk_fault_blocks(int stage, unsigned blocks) {
@@ -139,6 +143,10 @@ extern "C" int gpvi_test_set_fault(int stage, int nth, unsigned num, unsigned de
   g_fault_stage = stage;
   return GPV_OK;
 }
+#else
+unsigned gpvk_fault_blocks(int, unsigned blocks) { return blocks; }
+bool gpvi_fault_rank(int) { return false; }
+#endif
 
 #define HIP_TRY(ctx, expr)                                                                      \
   do {                                                                                          \
@@ -1585,17 +1593,21 @@ extern "C" int gpv_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs
 }
 
 // JSON proofs -> verdicts (types.ReadProofWithPublicInputs + variables.DeserializeProofWithPublicInputs + VerifierChip.Verify, the
-// reference's verifier_test.go:13-41 flow) as one pipeline: host threads pack block k + 1 (gpv_proof_pack_json_batch) while the GPU
+// reference's verifier_test.go:13-41 flow) as one pipeline: host threads pack block k + 1 (gpv_proof_pack_json_batch_status) while the GPU
 // verifies block k (gpv_verify's chunked upload). Ingest is the slower side (48 k proofs/s on 16 threads against 118 k on the GPU), so
-// the verification hides under it. A proof that does not parse fails the call (GPV_ESHAPE with its index), like the reference's panic.
-extern "C" int gpv_verify_json(gpv_ctx* ctx, const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n, int n_threads,
-                               uint8_t* accept) {
-  REQUIRE(ctx, ctx && c && accept && (n == 0 || (proof_jsons && proof_lens)));
-  if (n == 0) return GPV_OK;
+// the verification hides under it.
+// The context's lock is held for the WHOLE call (round 4): the two pinned blocks belong to the context, and until
+// round 3 the lock was dropped after their (re)allocation -- two host threads on one context packed into the same block and could be
+// handed each other's verdicts, or free the blocks under a running call. The mutex is recursive (the inner gpv_verify re-enters) and
+// the packer threads never touch the context.
+// status == NULL: a text that does not parse fails the call (its rc, the message names the proof), like the reference's panic
+// (types/deserialize.go:92-108). status != NULL: status[i] = that rc, accept[i] = 0, and every other proof is still verified.
+static int verify_json_core(gpv_ctx* ctx, const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n, int n_threads,
+                            uint8_t* accept, int32_t* status) {
+  ENTER(ctx);
   if (n_threads < 1) n_threads = 1;
   const size_t nbytes = c->dc.proof_nbytes, block = 2048;
   {  // two pinned blocks, kept in the context: the packers write where the upload DMA reads (pageable blocks cost a staging copy per upload)
-    ENTER(ctx);
     const size_t want = (n < block ? n : block) * nbytes;
     if (want > ctx->json_stage_bytes) {
       for (void*& p : ctx->json_stage) {
@@ -1609,30 +1621,68 @@ extern "C" int gpv_verify_json(gpv_ctx* ctx, const gpv_circuit* c, const char* c
     }
   }
   uint8_t* buf[2] = {(uint8_t*)ctx->json_stage[0], (uint8_t*)ctx->json_stage[1]};
-  auto pack = [&](size_t k) -> int {  // block k into buf[k & 1]
+  std::vector<int32_t> own_status;
+  if (!status) {
+    own_status.assign(n, GPV_OK);
+    status = own_status.data();
+  }
+  const bool abort_on_bad = !own_status.empty();
+  struct PackResult {
+    int rc = GPV_OK;
+    std::string err;
+  };
+  auto pack = [&](size_t k, PackResult* r) {  // block k into buf[k & 1]; runs on the packing thread: thread-local error text is copied out
     const size_t lo = k * block, m = n - lo < block ? n - lo : block;
-    return gpv_proof_pack_json_batch(c, proof_jsons + lo, proof_lens + lo, m, buf[k & 1], n_threads);
+    r->rc = gpv_proof_pack_json_batch_status(c, proof_jsons + lo, proof_lens + lo, m, buf[k & 1], n_threads, status + lo);
+    if (r->rc != GPV_OK) { r->err = gpv_get_global_error(); return; }
+    if (abort_on_bad)
+      for (size_t i = 0; i < m; i++)
+        if (status[lo + i] != GPV_OK) {
+          r->rc = status[lo + i];
+          r->err = gpv_get_global_error();  // "proof <i in block>: ..."
+          return;
+        }
   };
   const size_t blocks = (n + block - 1) / block;
-  int rc = pack(0);
-  if (rc != GPV_OK) ctx_error(ctx, "in the block of proofs starting at 0: %s", gpv_get_global_error());
+  PackResult cur;
+  pack(0, &cur);
+  int rc = cur.rc;
+  if (rc != GPV_OK) ctx_error(ctx, "in the block of proofs starting at 0: %s", cur.err.c_str());
   for (size_t k = 0; k < blocks && rc == GPV_OK; k++) {
-    int rc_next = GPV_OK;
-    std::string err_next;
+    PackResult next;
     std::thread packer;
-    if (k + 1 < blocks) packer = std::thread([&] {
-      rc_next = pack(k + 1);
-      if (rc_next != GPV_OK) err_next = gpv_get_global_error();  // thread-local text of the packing thread
-    });
+    if (k + 1 < blocks) {
+      try {
+        packer = std::thread([&, k] { pack(k + 1, &next); });
+      } catch (const std::exception& e) {  // nothing may cross the C boundary
+        ctx_error(ctx, "packing thread: %s", e.what());
+        return GPV_ENOMEM;
+      }
+    }
     const size_t lo = k * block, m = n - lo < block ? n - lo : block;
     rc = gpv_verify(ctx, c, buf[k & 1], m, accept + lo);
     if (packer.joinable()) packer.join();
-    if (rc == GPV_OK && rc_next != GPV_OK) {
-      ctx_error(ctx, "in the block of proofs starting at %zu: %s", (k + 1) * block, err_next.c_str());
-      rc = rc_next;
+    if (rc != GPV_OK) break;
+    for (size_t i = 0; i < m; i++)
+      if (status[lo + i] != GPV_OK) accept[lo + i] = 0;  // an all-zero record is rejected anyway; the verdict must not depend on that
+    if (next.rc != GPV_OK) {
+      ctx_error(ctx, "in the block of proofs starting at %zu: %s", (k + 1) * block, next.err.c_str());
+      rc = next.rc;
     }
   }
   return rc;
+}
+extern "C" int gpv_verify_json(gpv_ctx* ctx, const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n, int n_threads,
+                               uint8_t* accept) {
+  REQUIRE(ctx, ctx && c && accept && (n == 0 || (proof_jsons && proof_lens)));
+  if (n == 0) return GPV_OK;
+  return verify_json_core(ctx, c, proof_jsons, proof_lens, n, n_threads, accept, nullptr);
+}
+extern "C" int gpv_verify_json_status(gpv_ctx* ctx, const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
+                                      int n_threads, uint8_t* accept, int32_t* status) {
+  REQUIRE(ctx, ctx && c && accept && status && (n == 0 || (proof_jsons && proof_lens)));
+  if (n == 0) return GPV_OK;
+  return verify_json_core(ctx, c, proof_jsons, proof_lens, n, n_threads, accept, status);
 }
 
 // ---- internal accessors for gpv_group.cpp (one worker per context)

@@ -1411,33 +1411,69 @@ int gpvi_proof_pack_json_tree(const gpv_circuit* circ, const char* proof_json, s
   return GPV_OK;
 }
 
-extern "C" int gpv_proof_pack_json_batch(const gpv_circuit* circ, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
-                                         void* out_packed, int n_threads) {
-  if (!circ || !out_packed || (n && (!proof_jsons || !proof_lens))) return GPV_EINVAL;
+// Every text is converted; status[i] = GPV_OK or what gpv_proof_pack_json returned for text i (its record is all zero then). With
+// `first_msg` the error text of the lowest failing index is kept for the caller.
+static int pack_json_batch_core(const gpv_circuit* circ, const char* const* proof_jsons, const size_t* proof_lens, size_t n, void* out_packed,
+                                int n_threads, int32_t* status, size_t* first_bad, std::string* first_msg) {
   if (n_threads < 1) n_threads = 1;
   if ((size_t)n_threads > n) n_threads = n ? (int)n : 1;
   const size_t nbytes = circ->dc.proof_nbytes;
   std::atomic<size_t> next(0);
-  std::vector<int> rc(n, GPV_OK);
-  std::vector<std::string> msg(n);
+  std::atomic<size_t> lowest(n);
+  std::mutex msg_mu;
   auto work = [&]() {
     for (;;) {
       size_t i = next.fetch_add(1);
       if (i >= n) return;
-      rc[i] = gpv_proof_pack_json(circ, proof_jsons[i], proof_lens[i], (char*)out_packed + i * nbytes);
-      if (rc[i] != GPV_OK) msg[i] = gpv_get_global_error();  // thread-local text of this worker
+      void* rec = (char*)out_packed + i * nbytes;
+      int rc = proof_jsons[i] ? gpv_proof_pack_json(circ, proof_jsons[i], proof_lens[i], rec) : GPV_EINVAL;
+      status[i] = rc;
+      if (rc == GPV_OK) continue;
+      memset(rec, 0, nbytes);  // nothing half-written reaches a verifier
+      std::lock_guard<std::mutex> lk(msg_mu);
+      if (i < lowest.load()) {
+        lowest = i;
+        if (first_msg) *first_msg = proof_jsons[i] ? gpv_get_global_error() : "null text";  // thread-local text of this worker
+      }
     }
   };
-  std::vector<std::thread> th;
-  for (int t = 1; t < n_threads; t++) th.emplace_back(work);
-  work();
-  for (auto& t : th) t.join();
-  for (size_t i = 0; i < n; i++)
-    if (rc[i] != GPV_OK) {
-      gpv_set_global_error("proof %zu: %s", i, msg[i].c_str());
-      return rc[i];
-    }
+  try {
+    std::vector<std::thread> th;
+    struct Join {
+      std::vector<std::thread>& t;
+      ~Join() { for (auto& x : t) if (x.joinable()) x.join(); }
+    } join{th};
+    for (int t = 1; t < n_threads; t++) th.emplace_back(work);
+    work();
+  } catch (const std::exception& e) {  // std::thread could not start: nothing may cross the C boundary
+    gpv_set_global_error("host threads for the ingest: %s", e.what());
+    return GPV_ENOMEM;
+  }
+  if (first_bad) *first_bad = lowest.load();
   return GPV_OK;
+}
+extern "C" int gpv_proof_pack_json_batch(const gpv_circuit* circ, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
+                                         void* out_packed, int n_threads) {
+  if (!circ || !out_packed || (n && (!proof_jsons || !proof_lens))) return GPV_EINVAL;
+  std::vector<int32_t> status(n, GPV_OK);
+  size_t bad = n;
+  std::string msg;
+  int rc = pack_json_batch_core(circ, proof_jsons, proof_lens, n, out_packed, n_threads, status.data(), &bad, &msg);
+  if (rc != GPV_OK) return rc;
+  if (bad < n) {
+    gpv_set_global_error("proof %zu: %s", bad, msg.c_str());
+    return status[bad];
+  }
+  return GPV_OK;
+}
+extern "C" int gpv_proof_pack_json_batch_status(const gpv_circuit* circ, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
+                                                void* out_packed, int n_threads, int32_t* status) {
+  if (!circ || !out_packed || !status || (n && (!proof_jsons || !proof_lens))) return GPV_EINVAL;
+  size_t bad = n;
+  std::string msg;
+  int rc = pack_json_batch_core(circ, proof_jsons, proof_lens, n, out_packed, n_threads, status, &bad, &msg);
+  if (rc == GPV_OK && bad < n) gpv_set_global_error("proof %zu: %s", bad, msg.c_str());  // informative only: the call succeeded
+  return rc;
 }
 // VerifierChip.Verify as a whole (verifier.go:143-178): range_check | challenges | plonk | fri
 extern "C" size_t gpv_witness_verify_words(const gpv_circuit* c) {

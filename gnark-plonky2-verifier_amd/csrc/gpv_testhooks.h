@@ -1,6 +1,8 @@
-/* gpv_testhooks.h -- fault injection for the tests of the fail-closed verdict. NOT part of the public boundary (include/gpv.h):
- * exported by libgpv.so for tests/ only. Process-wide; disarm with stage = 0. */
+/* gpv_testhooks.h -- fault injection for the tests of the fail-closed verdict. NOT part of the public boundary (include/gpv.h) and NOT
+ * in the product library: only libgpv_test.so (the same objects, gpv_api.cpp recompiled with -DGPV_TEST_HOOKS; csrc/Makefile) defines
+ * and exports it. Process-wide; disarm with stage = 0. */
 #pragma once
+#pragma GCC visibility push(default)
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -12,3 +14,4 @@ int gpvi_test_set_fault(int stage, int nth, unsigned num, unsigned den);
 #ifdef __cplusplus
 }
 #endif
+#pragma GCC visibility pop

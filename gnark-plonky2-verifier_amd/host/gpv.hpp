@@ -102,6 +102,19 @@ class Circuit {
     check(gpv_proof_pack_json_batch(h_, ptr.data(), len.data(), proof_jsons.size(), out.data(), n_threads));
     return out;
   }
+  // the same with a status per proof: a text that does not parse gets its error code and an all-zero record, the rest is converted
+  std::vector<uint8_t> pack_proofs(const std::vector<std::string>& proof_jsons, int n_threads, std::vector<int32_t>* status) const {
+    std::vector<const char*> ptr(proof_jsons.size());
+    std::vector<size_t> len(proof_jsons.size());
+    for (size_t i = 0; i < proof_jsons.size(); i++) {
+      ptr[i] = proof_jsons[i].data();
+      len[i] = proof_jsons[i].size();
+    }
+    std::vector<uint8_t> out(proof_nbytes() * proof_jsons.size());
+    status->assign(proof_jsons.size(), GPV_OK);
+    check(gpv_proof_pack_json_batch_status(h_, ptr.data(), len.data(), proof_jsons.size(), out.data(), n_threads, status->data()));
+    return out;
+  }
   // variables.DeserializeProofWithPublicInputs(types.ReadProofWithPublicInputs(...)): one packed record
   std::vector<uint8_t> pack_proof(const std::string& proof_json) const {
     std::vector<uint8_t> out(proof_nbytes());
@@ -517,6 +530,19 @@ class VerifierChip {
     }
     std::vector<uint8_t> accept(proof_jsons.size());
     gpv::check(gpv_verify_json(api_.h(), c_.h(), ptr.data(), len.data(), proof_jsons.size(), n_threads, accept.data()), api_.h());
+    return accept;
+  }
+  // the same with a status per proof (gpv_verify_json_status): a malformed text is status[i] != GPV_OK, accept[i] = 0; the rest is verified
+  std::vector<uint8_t> VerifyJSON(const std::vector<std::string>& proof_jsons, int n_threads, std::vector<int32_t>* status) {
+    std::vector<const char*> ptr(proof_jsons.size());
+    std::vector<size_t> len(proof_jsons.size());
+    for (size_t i = 0; i < proof_jsons.size(); i++) {
+      ptr[i] = proof_jsons[i].data();
+      len[i] = proof_jsons[i].size();
+    }
+    std::vector<uint8_t> accept(proof_jsons.size());
+    status->assign(proof_jsons.size(), GPV_OK);
+    gpv::check(gpv_verify_json_status(api_.h(), c_.h(), ptr.data(), len.data(), proof_jsons.size(), n_threads, accept.data(), status->data()), api_.h());
     return accept;
   }
   // Verify (verifier.go:143): accept[i] == 1 iff the reference's circuit is satisfiable for proof i

@@ -40,6 +40,7 @@ class Circuit:
         else:
             _lib.check(L.gpv_circuit_from_json(common.text, len(common.text), vo.text, len(vo.text), ctypes.byref(h)))
         self.h = h.value
+        self._L = L  # the library that owns the handle (tests may switch lib() to libgpv_test.so, _lib.test_library)
         self.proof_nbytes = L.gpv_proof_nbytes(h)
         self.num_challenge_words = L.gpv_num_challenge_words(h)
         self.num_gate_constraints = L.gpv_num_gate_constraints(h)
@@ -57,7 +58,7 @@ class Circuit:
     def __del__(self):
         try:
             if self.h:
-                _lib.lib().gpv_circuit_destroy(ctypes.c_void_p(self.h))
+                self._L.gpv_circuit_destroy(ctypes.c_void_p(self.h))
                 self.h = None
         except Exception:
             pass
@@ -110,3 +111,15 @@ def DeserializeProofsWithPublicInputs(raws, circuit, n_threads=8):
     out = np.zeros(n * circuit.proof_nbytes, dtype=np.uint8)
     _lib.check(_lib.lib().gpv_proof_pack_json_batch(ctypes.c_void_p(circuit.h), texts, lens, n, _lib.ptr(out), n_threads))
     return ProofBatch(circuit, out)
+
+
+def DeserializeProofsWithPublicInputsStatus(raws, circuit, n_threads=8):
+    """The same with a status per proof (gpv_proof_pack_json_batch_status): returns (ProofBatch, status [n] int32). A text that does not
+    parse (the reference panics, types/deserialize.go:92-108) gets its error code and an all-zero record; the others are converted."""
+    n = len(raws)
+    texts = (ctypes.c_char_p * n)(*[r.text for r in raws])
+    lens = (ctypes.c_size_t * n)(*[len(r.text) for r in raws])
+    out = np.zeros(n * circuit.proof_nbytes, dtype=np.uint8)
+    status = np.zeros(n, dtype=np.int32)
+    _lib.check(_lib.lib().gpv_proof_pack_json_batch_status(ctypes.c_void_p(circuit.h), texts, lens, n, _lib.ptr(out), n_threads, _lib.ptr(status)))
+    return ProofBatch(circuit, out), status

@@ -66,6 +66,18 @@ class VerifierChip:
         _lib.check(_lib.lib().gpv_verify_json(self.ctx.h, circuit.h, texts, lens, n, n_threads, _lib.ptr(accept)), self.ctx.h)
         return accept
 
+    def VerifyJSONStatus(self, circuit, raws, n_threads=8):
+        """gpv_verify_json_status: the same with a status per proof -- a text that does not parse gets status[i] = its error code
+        (GPV_ESHAPE where the reference panics) and accept[i] = 0; every other proof of the batch is verified. Returns (accept, status)."""
+        import ctypes
+        n = len(raws)
+        texts = (ctypes.c_char_p * n)(*[r.text for r in raws])
+        lens = (ctypes.c_size_t * n)(*[len(r.text) for r in raws])
+        accept = np.empty(n, dtype=np.uint8)
+        status = np.zeros(n, dtype=np.int32)
+        _lib.check(_lib.lib().gpv_verify_json_status(self.ctx.h, circuit.h, texts, lens, n, n_threads, _lib.ptr(accept), _lib.ptr(status)), self.ctx.h)
+        return accept, status
+
     def WitnessVerify(self, proofs):
         """The whole hint trace of Verify (verifier.go:143-178; gpv_witness_verify): rangeCheckProof | GetPublicInputsHash + GetChallenges |
         PlonkChip.Verify | GetInstance + VerifyFriProof per proof, in call order, the challenges handed between the slices in HBM. Returns

@@ -37,6 +37,11 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* Everything declared here -- and nothing else -- is exported by libgpv.so: the library is built with -fvisibility=hidden and the
+ * linker export list csrc/libgpv.map, which the tests compare with this header in both directions. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -180,6 +185,12 @@ int gpv_proof_pack_json(const gpv_circuit* c, const char* proof_json, size_t pro
  * records. Returns the error of the lowest failing index (its number is in the error message). */
 int gpv_proof_pack_json_batch(const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
                               void* out_packed, int n_threads);
+/* The same with a status PER PROOF, for batches fed by untrusted provers: every text is converted, status[i] = GPV_OK or the error
+ * gpv_proof_pack_json gives for text i (GPV_ESHAPE where types/deserialize.go:92-108 / fri/fri_utils.go:167-228 panic; GPV_EINVAL for a
+ * NULL text), and a failed text leaves an all-zero record. The reference's panic is per proof because its API is per proof; a batch call
+ * that gave up at the first malformed text would let one prover void everybody's batch. Returns GPV_OK unless an argument is bad. */
+int gpv_proof_pack_json_batch_status(const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
+                                     void* out_packed, int n_threads, int32_t* status);
 
 /* ------------------------------------------------------------------ field / hash primitives */
 /* goldilocks.Chip Add/Sub/Mul/MulAdd/Inverse/Reduce/RangeCheck (goldilocks/base.go:162-400). b, c may be NULL when unused. */
@@ -325,6 +336,11 @@ int gpv_verify(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n,
  * that does not parse fails the call with GPV_ESHAPE (the reference panics); the message names the block and the proof. */
 int gpv_verify_json(gpv_ctx* ctx, const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n, int n_threads,
                     uint8_t* accept);
+/* The same with a status per proof: a text that does not parse gets status[i] = its error (GPV_ESHAPE / GPV_EINVAL) and accept[i] = 0,
+ * every other proof of the batch is verified as usual (status[i] = GPV_OK; accept[i] is the verdict). The return value covers the call
+ * (arguments, device), never a single proof. Like every context call, both forms hold the context's lock from start to end. */
+int gpv_verify_json_status(gpv_ctx* ctx, const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
+                           int n_threads, uint8_t* accept, int32_t* status);
 /* Same, plus the diagnostic mask and the derived challenges (either may be NULL). */
 int gpv_verify_detail(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint8_t* accept,
                       uint32_t* fail_mask, uint64_t* challenges);
@@ -405,5 +421,8 @@ int gpv_timing_get(gpv_ctx* ctx, int kind, double* avg_ms, uint64_t* launches);
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif /* GPV_H */

@@ -19,7 +19,7 @@ def _built_libraries():
     cross-compiles gfx950 without a GPU -- and never rebuild an existing library (on the GPU box the prebuilt files that
     travelled with the snapshot are the ones under test)."""
     lib = ROOT / "gnark-plonky2-verifier_amd" / "libgpv.so"
-    if not lib.exists():
+    if not lib.exists() or not (ROOT / "gnark-plonky2-verifier_amd" / "libgpv_test.so").exists():
         subprocess.check_call(["make", "-s", "-j", "8", "-C", str(ROOT / "gnark-plonky2-verifier_amd" / "csrc")])
     orc = ROOT / "oracle" / "liborc.so"
     if not orc.exists():
