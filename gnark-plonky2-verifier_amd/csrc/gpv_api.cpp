@@ -501,7 +501,7 @@ static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit*
   Timed t(ctx, TK_MERKLE, st);
   if (!ok_dev && merkle_shared_for(ctx, c, n)) {
     // per-path hashing up to GPV_CROWN_LEVELS below the cap, then every distinct upper node once
-    CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown);
+    CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown, ctx->crown_bytes);
     {
       Timed tl(ctx, TK_LOWER, st);
       gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS, verdict_of(ctx),

@@ -277,13 +277,14 @@ GPV_DEV Ext dev_fri_fold(u64 x, u32 idx_in, const u64* __restrict__ evals, Ext b
   u64 b1sq7 = gl_mul7(gl_sqr(beta.b));
   u64 cur = s;
   bool on_coset = false;
+  int hit = 0;
 #pragma unroll
   for (int i = 0; i < A; i++) {
     xi[i] = cur;
     u64 d0 = gl_sub(beta.a, cur);
     u64 nrm = gl_sub(gl_sqr(d0), b1sq7);
     // N_i = 0 iff beta - x_i = 0 (7 is a non-residue): the reference's InverseExtension assertion (fri.go:280-286)
-    if (nrm == 0) { on_coset = true; nrm = 1; }
+    if (nrm == 0) { on_coset = true; hit = i; nrm = 1; }
     inv[i] = nrm;
     cur = gl_mul(cur, g);
   }
@@ -297,7 +298,14 @@ GPV_DEV Ext dev_fri_fold(u64 x, u32 idx_in, const u64* __restrict__ evals, Ext b
   const u64 s_a = sp;
   inv[A] = gl_mul(s_am1, (u64)A);
   gl_batch_inv<A + 1>(inv);
-  if (on_coset) *fail |= 256;  // GPV_FAIL_FRI_INTERP
+  if (on_coset) {
+    // GPV_FAIL_FRI_INTERP. The value the reference hands on is NOT the interpolation then: hasQuotient of the matching point is 0, so
+    // lookupFromPoints = 0 and interpolate returns lookupVal = the y of that point (fri.go:299-311, Lookup quadratic_extension.go:203-210);
+    // the round's later assertions (:460-461, :496-497) are evaluated on it.
+    *fail |= 256;
+    const u32 r = bitrev((u32)hit, AB);
+    return ext_make(evals[2 * r], evals[2 * r + 1]);
+  }
   // sum_i y_i g^i conj(beta - x_i) / N_i, with y_i = evals[bitrev(i)]  (fri.go:337-342)
   Ext sum = ext_make(0, 0);
   u64 gi = 1;
@@ -370,10 +378,15 @@ GPV_DEV u32 dev_fri_query(const DevCircuit* __restrict__ dc, const u64* __restri
   Ext zeta_next = ext_scalar_mul(zeta, dc->root_degree);  // fri.go:46-50
   Ext d0 = ext_make(gl_sub(x, zeta.a), gl_neg(zeta.b));
   Ext d1 = ext_make(gl_sub(x, zeta_next.a), gl_neg(zeta_next.b));
-  if (ext_is_zero(d0) || ext_is_zero(d1)) fail |= 64;  // GPV_FAIL_FRI_DENOM (fri.go:241-242)
-  // sum = alpha^nc * (red0 - ro0)/d0 + (red1 - ro1)/d1, one shared inversion
-  Ext dinv = ext_inv(ext_mul(d0, d1));
-  Ext inv0 = ext_mul(dinv, d1), inv1 = ext_mul(dinv, d0);
+  // sum = alpha^nc * (red0 - ro0)/d0 + (red1 - ro1)/d1, one shared inversion.
+  // A zero denominator is GPV_FAIL_FRI_DENOM (fri.go:241-242), and the values go on as in the reference: InverseExtension of 0 yields 0
+  // (InverseHint of 0 is 0, goldilocks/base.go:316-336) while the OTHER denominator keeps its inverse -- the shared product would zero both.
+  const bool z0 = ext_is_zero(d0), z1 = ext_is_zero(d1);
+  if (z0 || z1) fail |= 64;
+  const Ext one_ = ext_make(1, 0);
+  Ext dinv = ext_inv(ext_mul(z0 ? one_ : d0, z1 ? one_ : d1));
+  Ext inv0 = z0 ? ext_make(0, 0) : ext_mul(dinv, z1 ? one_ : d1);
+  Ext inv1 = z1 ? ext_make(0, 0) : ext_mul(dinv, z0 ? one_ : d0);
   Ext apow = ext_make(1, 0);
 #pragma unroll 1
   for (u32 i = 0; i < nc; i++) apow = ext_mul(apow, alpha);

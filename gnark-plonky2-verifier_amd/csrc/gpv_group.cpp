@@ -363,8 +363,10 @@ static void exchange_check(gpv_group* g, Worker& w) {
   for (int r = 0; r < g->world; r++)
     if (w.peer_status[r]) { worker_fail(w, GPV_EPEER, "rank %d of the group failed to verify its block; the batch has no verdict", r); return; }
 }
-// Buffers of the exchange, allocated BEFORE any rank starts verifying: a rank that cannot allocate fails here, while no collective
-// has been enqueued by anybody yet.
+// Buffers of the exchange, allocated BEFORE any rank starts verifying. Within ONE process (gpv_group_create) a rank that cannot allocate
+// fails here while no collective has been enqueued by anybody. Across processes (gpv_group_create_rank) that is not true -- the other
+// processes are on their way into ncclAllGather whatever happens here -- so a failing process still joins the exchange with its flag
+// raised (join_as_failed below).
 static void exchange_prepare(gpv_group* g, Worker& w, size_t n_total, bool need_accept_all) {
   W_HIP(w, hipSetDevice(w.device));
   const size_t need = gpv_accept_slot_bytes(n_total, g->world) * (size_t)g->world;
@@ -433,6 +435,27 @@ static void gather_by_peer_copies(gpv_group* g, Worker& w, size_t n_total, uint8
   exchange_finish(g, w, n_total, accept_all_dev);
 }
 
+// One process per rank: this process cannot run its part (bad argument, allocation failure) but the other processes are entering the
+// all-gather. Take part with an all-zero slot and the status flag raised, so that every other rank's call returns GPV_EPEER instead of
+// blocking in the collective. Needs only the gather buffer; if even that cannot be had (device out of memory at the very first call, a
+// dead device) the job is stranded and only a job-level timeout of the launcher can help -- include/gpv.h says so.
+static void join_as_failed(gpv_group* g, size_t n_total) {
+  if (g->in_process || !wants_collective(g) || !g->comm_ready) return;
+  Worker& w = g->w[0];
+  const size_t slot = gpv_accept_slot_bytes(n_total, g->world), need = slot * (size_t)g->world;
+  if (hipSetDevice(w.device) != hipSuccess) return;
+  hipStream_t st = gpvi_ctx_stream(w.ctx);
+  if (need > w.bits_cap) {
+    if (w.bits) { hipStreamSynchronize(st); hipFree(w.bits); w.bits = nullptr; w.bits_cap = 0; }
+    if (hipMalloc((void**)&w.bits, need) != hipSuccess) return;
+    w.bits_cap = need;
+  }
+  uint8_t* mine = w.bits + (size_t)w.rank * slot;
+  hipMemsetAsync(mine, 0, slot, st);
+  hipMemsetAsync(mine + slot - GPV_SLOT_TRAILER, 1, 1, st);
+  if (g_rccl.AllGather(mine, w.bits, slot, ncclUint8, w.comm, st) == ncclSuccess) hipStreamSynchronize(st);
+}
+
 extern "C" int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const void* const* shard_dev, size_t n_total,
                                     uint8_t* const* accept_all_dev) {
   if (!g || !c || !shard_dev || !accept_all_dev) return GPV_EINVAL;
@@ -443,15 +466,15 @@ extern "C" int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const vo
     if (rc != GPV_OK) return rc;
   }
   const size_t first = g->w[0].rank;
-  for (auto& w : g->w) {  // argument checks before any rank starts: a rank that bailed out later would strand the others in the collective
+  for (auto& w : g->w) {  // argument checks before any rank starts (in-process groups: nobody has entered the collective yet)
     const size_t i = (size_t)w.rank - first;
     size_t lo, hi;
     gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
-    if (hi > lo && !shard_dev[i]) { group_error(g, "shard pointer %zu is NULL", i); return GPV_EINVAL; }
-    if (!accept_all_dev[i]) { group_error(g, "accept pointer %zu is NULL", i); return GPV_EINVAL; }
+    if (hi > lo && !shard_dev[i]) { group_error(g, "shard pointer %zu is NULL", i); join_as_failed(g, n_total); return GPV_EINVAL; }
+    if (!accept_all_dev[i]) { group_error(g, "accept pointer %zu is NULL", i); join_as_failed(g, n_total); return GPV_EINVAL; }
   }
   int rc = run_all(g, [&](Worker& w) { exchange_prepare(g, w, n_total, false); });
-  if (rc != GPV_OK) return rc;
+  if (rc != GPV_OK) { join_as_failed(g, n_total); return rc; }
   rc = run_all(g, [&](Worker& w) {
     const size_t i = (size_t)w.rank - first;
     size_t lo, hi;
@@ -493,10 +516,10 @@ extern "C" int gpv_group_verify(gpv_group* g, const gpv_circuit* c, const void* 
   for (auto& w : g->w) {  // argument checks before any rank starts
     size_t lo, hi;
     gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);
-    if (hi > lo && !proofs) { group_error(g, "proofs is NULL but rank %d owns %zu proofs", w.rank, hi - lo); return GPV_EINVAL; }
+    if (hi > lo && !proofs) { group_error(g, "proofs is NULL but rank %d owns %zu proofs", w.rank, hi - lo); join_as_failed(g, n_total); return GPV_EINVAL; }
   }
   int rc = run_all(g, [&](Worker& w) { exchange_prepare(g, w, n_total, true); });
-  if (rc != GPV_OK) return rc;
+  if (rc != GPV_OK) { join_as_failed(g, n_total); return rc; }
   rc = run_all(g, [&](Worker& w) {
     size_t lo, hi;
     gpv_shard_bounds(n_total, w.rank, g->world, &lo, &hi);

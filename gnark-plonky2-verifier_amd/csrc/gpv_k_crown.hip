@@ -350,27 +350,36 @@ __global__ void k_crown_finish_gl(const DevCircuit* __restrict__ dc, const u64* 
 }
 
 // work lists hold the shared nodes (at most one per path and level) plus one node per path that left the shared tree
+// bytes per path of the batch: its node below the crown | per level: 2 work-list entries (item, digest, stamp) | slot, pslot per level | pstate
+#define CROWN_STAMP_BYTES_PER_PATH ((size_t)GPV_CROWN_LEVELS * 2 * 4)
+#define CROWN_BYTES_PER_PATH (32 + (size_t)GPV_CROWN_LEVELS * (sizeof(CrownItem) + 32) * 2 + CROWN_STAMP_BYTES_PER_PATH + 2 * 4 * GPV_CROWN_LEVELS + 4)
 size_t gpvk_crown_bytes(const DevCircuit& hc, size_t n) {
   size_t cap = n * hc.n_trees * hc.num_queries;
-  return 256 + 32 * cap + GPV_CROWN_LEVELS * (sizeof(CrownItem) + 32 + 4) * 2 * cap + 2 * 4 * GPV_CROWN_LEVELS * cap + 4 * cap;
+  return 512 + CROWN_BYTES_PER_PATH * cap;  // counters | stamps, padded to 256 B | everything else
 }
-// slots and node indices travel as 31-bit numbers (bit 31 marks "sibling supplied by query ...")
 bool gpvk_crown_supported(const DevCircuit& hc, size_t n) {
   return hc.num_queries <= GPV_CROWN_MAXQ && hc.cap_height + GPV_CROWN_LEVELS <= 16 && hc.n_trees < 256 &&
          2 * n * hc.n_trees * hc.num_queries < 0x7FFFFFFFull;
 }
-CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base) {
-  size_t cap = n * hc.n_trees * hc.num_queries;
+// The generation stamps sit FIRST, at offsets that depend only on the size of the ALLOCATION (round 4): the scratch is
+// reused across batch sizes and circuits and is zeroed only when it is (re)allocated, and until round 3 every array was carved at an
+// offset that depended on this run's n -- for a smaller n a stamp word landed where an earlier, larger run had stored slots, items or
+// digests, and a stale word v with (v >> 2) == gen and (v & 3) == GPV_STAMP_OK would have read as a node hashed in this run. Now a
+// stamp word is only ever written as a stamp (zero, or the generation of some earlier run of this context, which is never reused).
+CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base, size_t alloc_bytes) {
+  const size_t cap = n * hc.n_trees * hc.num_queries;
+  const size_t cap_alloc = (alloc_bytes - 512) / CROWN_BYTES_PER_PATH;  // paths this allocation was sized for (>= cap: gpvk_crown_bytes)
   CrownBufs b;
   uint8_t* p = (uint8_t*)base;
   b.count = (u32*)p; p += 256;
+  for (int k = 0; k < GPV_CROWN_LEVELS; k++) b.stamp[k] = (u32*)p + (size_t)k * 2 * cap_alloc;
+  p += (CROWN_STAMP_BYTES_PER_PATH * cap_alloc + 255) / 256 * 256;
   b.mid = (u64*)p; p += 32 * cap;
   for (int k = 0; k < GPV_CROWN_LEVELS; k++) { b.res[k] = (u64*)p; p += 32 * 2 * cap; }
   for (int k = 0; k < GPV_CROWN_LEVELS; k++) { b.item[k] = (CrownItem*)p; p += sizeof(CrownItem) * 2 * cap; }
   b.slot = (u32*)p; p += 4 * GPV_CROWN_LEVELS * cap;
   b.pslot = (u32*)p; p += 4 * GPV_CROWN_LEVELS * cap;
   b.pstate = (u32*)p; p += 4 * cap;
-  for (int k = 0; k < GPV_CROWN_LEVELS; k++) { b.stamp[k] = (u32*)p; p += 4 * 2 * cap; }
   return b;
 }
 // after gpvk_merkle_climb_lower has filled b.mid on the same stream. `gen`: the run's generation (unique per use of this scratch, never

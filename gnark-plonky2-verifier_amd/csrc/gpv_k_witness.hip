@@ -83,7 +83,7 @@ void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& h
 }
 
 // Witness slice 3: PlonkChip.Verify in three phases (gpv_witness.cuh). written[p] += every lane's word count (the host compares the sum
-// with the layout); consistent[p] is cleared by the lane that sees the assertion of plonk.go:248 fail.
+// with the layout); consistent[p] is cleared by the lane that sees the assertion of plonk.go:248 (or evalL0's, :75-80) fail.
 __global__ __launch_bounds__(64) void k_witness_plonk_units(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ challenges,
                                                             size_t n, u64* __restrict__ trace, size_t words_per_proof, const u64* __restrict__ tab,
                                                             u64* __restrict__ ws, size_t ws_words, unsigned long long* __restrict__ written) {
@@ -124,6 +124,10 @@ __global__ __launch_bounds__(64) void k_witness_plonk_reduce(const DevCircuit* _
   const size_t wrote = dev_witness_plonk_reduce(dc, proofs + p * (dc->proof_nbytes / 8), challenges + p * dc->n_challenge_words, (u32)(item - p * nc),
                                                 trace + p * words_per_proof, t, ws + p * ws_words, &ok);
   atomicAdd(&written[p], (unsigned long long)wrote);
+  {  // evalL0 divides by n (zeta - 1) (plonk.go:63-83): zero iff zeta = 1 -- InverseExtension's "operand != 0" / hasQuotient == 1 (:75-80)
+    const u64* ch = challenges + p * dc->n_challenge_words;
+    if (gl_canon(ch[dc->ch_zeta]) == 1 && gl_canon(ch[dc->ch_zeta + 1]) == 0) ok = false;
+  }
   if (!ok) consistent[p] = 0;
 }
 // consistent: preset to 1 by the caller; written: preset to 0

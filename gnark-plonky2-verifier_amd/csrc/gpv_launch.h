@@ -127,7 +127,8 @@ struct CrownBufs {
 #define GPV_STAMP_CAP_MISMATCH 2u
 size_t gpvk_crown_bytes(const DevCircuit& hc, size_t n);
 bool gpvk_crown_supported(const DevCircuit& hc, size_t n);
-CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base);
+// alloc_bytes: size of the allocation at `base` (>= gpvk_crown_bytes(hc, n)); it alone fixes where the generation stamps live
+CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base, size_t alloc_bytes);
 void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
                              const u32* digests, u64* mid, u32 crown_levels, Verdict v, int form);
 void gpvk_crown(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, CrownBufs b,

@@ -398,7 +398,10 @@ GPV_DEV u64 wt_exp_from_bits_const_base(WTrace& t, u64 base, u32 bits, u32 n_bit
 }
 #define GPV_WIT_MAX_ARITY 32
 // computeEvaluation :314-384 + interpolate :261-312
-__device__ __noinline__ Ext wt_compute_evaluation(WTrace& t, u64 x, u32 idx_in, u32 ab, const u64* __restrict__ evals, Ext beta) {
+// *ok is cleared when beta is one of the coset points: DivExtension -> InverseExtension asserts "operand != 0" (quadratic_extension.go:124-125).
+// The hints run regardless (InverseHint of 0 is 0), and the value handed on is then the y of the matching point, not the interpolation
+// (lookupFromPoints = 0 -> Lookup returns lookupVal, fri.go:299-311).
+__device__ __noinline__ Ext wt_compute_evaluation(WTrace& t, u64 x, u32 idx_in, u32 ab, const u64* __restrict__ evals, Ext beta, bool* ok) {
   const u32 A = 1u << ab;
   u64 g = 1753635133440165772ULL;
 #pragma unroll 1
@@ -441,7 +444,14 @@ __device__ __noinline__ Ext wt_compute_evaluation(WTrace& t, u64 x, u32 idx_in, 
   }
   Ext interpolation = wt_mul_ext(t, lx, total);
 #pragma unroll 1
-  for (u32 i = 0; i < A; i++) wt_sub_ext(t, beta, xs[i]);  // the lookup loop :301-309 (IsZero / Lookup have no hints)
+  for (u32 i = 0; i < A; i++) {  // the lookup loop :299-311 (IsZero / Lookup have no hints)
+    Ext d = wt_sub_ext(t, beta, xs[i]);
+    if (ext_is_zero(d)) {
+      const u32 src = __brev(i) >> (32 - ab);
+      interpolation = ext_make(evals[2 * src], evals[2 * src + 1]);
+      *ok = false;
+    }
+  }
   return interpolation;
 }
 // ReduceWithPowers (:177-193) over extension elements stored as consecutive words, from the last one down
@@ -512,6 +522,7 @@ GPV_DEV bool dev_witness_fri(const DevCircuit* __restrict__ dc, const u64* __res
     Ext denominator = wt_sub_ext(t, ext_make(x, 0), points[b]);
     Ext e = wt_exp_ext(t, alpha, n_evals);
     total = wt_mul_ext(t, e, total);
+    ok &= !ext_is_zero(denominator);  // fri.go:241-242 (InverseExtension's "operand != 0"); InverseHint of 0 is 0, the trace goes on
     Ext inv = wt_inverse_ext(t, denominator);
     total = wt_mul_add_ext(t, numerator, inv, total);
   }
@@ -522,7 +533,7 @@ GPV_DEV bool dev_witness_fri(const DevCircuit* __restrict__ dc, const u64* __res
     const u32 ab = dc->arity_bits[s];
     const u32 idx_in = idx & ((1u << ab) - 1);
     ok &= evals[2 * idx_in] == old_eval.a && evals[2 * idx_in + 1] == old_eval.b;  // :460-461
-    old_eval = wt_compute_evaluation(t, x, idx_in, ab, evals, ext_make(ch[dc->ch_fri_betas + 2 * s], ch[dc->ch_fri_betas + 2 * s + 1]));
+    old_eval = wt_compute_evaluation(t, x, idx_in, ab, evals, ext_make(ch[dc->ch_fri_betas + 2 * s], ch[dc->ch_fri_betas + 2 * s + 1]), &ok);
 #pragma unroll 1
     for (u32 j = 0; j < ab; j++) x = wt_mul(t, x, x);  // :486-488
     idx >>= ab;

@@ -381,6 +381,10 @@ typedef struct gpv_group gpv_group;
 int gpv_group_create(gpv_group** out, const int* device_ids, int n_devices);
 /* One process per GPU (torch.distributed.run, MPI, a Go supervisor): rank 0 calls gpv_group_unique_id, the caller hands the
  * 128 bytes to every rank, each rank calls gpv_group_create_rank (ncclCommInitRank happens at the first verify call). */
+/* Failure across processes: a rank whose verification fails -- or whose call cannot even start (bad argument, allocation failure) --
+ * still takes part in the all-gather with its status flag raised, so the other processes return GPV_EPEER instead of waiting. What
+ * cannot be covered from inside one process: a rank that never makes the call, dies, or cannot allocate the gather buffer itself; the
+ * others then wait in ncclAllGather like in any collective job -- run the ranks under a launcher with a job-level timeout. */
 int gpv_group_unique_id(void* id128);
 int gpv_group_create_rank(gpv_group** out, int device_id, int rank, int world, const void* id128);
 int gpv_group_destroy(gpv_group* g);

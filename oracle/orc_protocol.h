@@ -589,18 +589,26 @@ static inline u64 exp_from_bits_const_base(u64 base, const int* bits, size_t n) 
   return product;
 }
 
-// fri.go:261-312
+// fri.go:261-312. When x is one of the points, DivExtension -> InverseExtension asserts "operand != 0" (quadratic_extension.go:124-125,
+// audit VUL-008): the circuit is unsatisfiable (FAIL_FRI_INTERP). The VALUE that flows on is still defined and it is not the
+// interpolation: hasQuotient of that point is 0, so lookupFromPoints = 0 and Lookup (:203-210: Select(b, y, x)) returns lookupVal = the
+// y of the matching point (:299-311). The later assertions of the round (fri.go:460-461, :496-497) see that value.
 static inline Ext fri_interpolate(Ext x, const Ext* xp, const Ext* yp, const Ext* w, size_t n, int* fail) {
   Ext lx = ext_one();
   for (size_t i = 0; i < n; i++) lx = ext_submul(x, xp[i], lx);
   Ext sum = ext_zero();
+  bool lookup_from_points = true;  // the product of the hasQuotient bits
   for (size_t i = 0; i < n; i++) {
     bool ok = true;
     Ext q = ext_div(w[i], ext_sub(x, xp[i]), &ok);
-    if (!ok) *fail |= FAIL_FRI_INTERP;
+    if (!ok) { *fail |= FAIL_FRI_INTERP; lookup_from_points = false; }
     sum = ext_add(ext_mul(yp[i], q), sum);
   }
-  return ext_mul(lx, sum);
+  Ext interpolation = ext_mul(lx, sum);
+  Ext lookup_val = ext_zero();
+  for (size_t i = 0; i < n; i++)
+    if (ext_is_zero(ext_sub(x, xp[i]))) lookup_val = yp[i];
+  return lookup_from_points ? interpolation : lookup_val;
 }
 
 // fri.go:314-384

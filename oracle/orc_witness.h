@@ -59,6 +59,7 @@ static inline Big big_mul64(Big a, u64 m) {
 struct Sink {
   std::vector<u64>* words;          // the trace
   std::vector<unsigned char>* kinds;  // one entry per hint call (may be null)
+  bool zero_inverse = false;          // an InverseExtension was handed zero: its "operand != 0" assertion fails (quadratic_extension.go:124-125)
   void emit(int kind, const u64* v, int n) {
     if (words) words->insert(words->end(), v, v + n);
     if (kinds) kinds->push_back((unsigned char)kind);
@@ -318,7 +319,8 @@ static inline Ext mul_add_ext(Sink& t, BigExt a, Ext b, Ext c) {                
 }
 static inline Ext sub_mul_ext(Sink& t, Ext a, Ext b, Ext c) { return reduce_ext(t, mul_ext_nr(sub_ext_nr(bext(a), b), bext(c))); }  // :89-93
 static inline Ext scalar_mul_ext(Sink& t, Ext a, u64 b) { u64 c0 = mul(t, a.c[0], b); u64 c1 = mul(t, a.c[1], b); return ext(c0, c1); }  // :96-104
-static inline Ext inverse_ext(Sink& t, Ext a) {  // :123-134
+static inline Ext inverse_ext(Sink& t, Ext a) {  // :123-134; the hints run whatever a is (InverseHint of 0 is 0, hasInv = 0)
+  if (a.c[0] == 0 && a.c[1] == 0) t.zero_inverse = true;  // :124-125 AssertIsEqual(aIsZero, 0)
   Ext f = ext(a.c[0], mul(t, a.c[1], GL_DTH_ROOT));
   Ext n = mul_ext(t, f, a);
   return scalar_mul_ext(t, f, inverse(t, n.c[0]));
@@ -383,11 +385,19 @@ static inline Ext compute_evaluation(Sink& t, u64 x, const std::vector<u64>& idx
     total = add_ext(t, m, total);
   }
   Ext interpolation = mul_ext(t, lx, total);
-  for (size_t i = 0; i < arity; i++) sub_ext(t, beta, xs[i]);  // the lookup loop :301-309 (IsZero / Lookup have no hints)
-  return interpolation;
+  // the lookup loop :299-311 (IsZero / Lookup have no hints): beta on the coset -> hasQuotient = 0 for that point -> the value that flows
+  // on is the y of the matching point, not the interpolation (Lookup, quadratic_extension.go:203-210)
+  bool on_coset = false;
+  Ext lookup_val = ext_zero();
+  for (size_t i = 0; i < arity; i++) {
+    Ext d = sub_ext(t, beta, xs[i]);
+    if (d.c[0] == 0 && d.c[1] == 0) { on_coset = true; lookup_val = permuted[i]; }
+  }
+  return on_coset ? lookup_val : interpolation;
 }
 // One proof: GetInstance, fromOpeningsAndAlpha, then every query round in order. `ok` is cleared when one of the reference's FRI
-// consistency assertions (:460-461, :496-497) fails -- the trace is the solver's either way.
+// assertions fails: consistency (:460-461, :496-497) or an InverseExtension of zero (:241-242 via friCombineInitial, :280-286 via
+// interpolate) -- the trace is the solver's either way.
 static inline void witness_fri(const ProofView& pv, const Challenges& ch, Sink& t, bool* ok) {
   const Circuit& c = *pv.c;
   Ext zeta_next = mul_ext(t, ext(gl_primitive_root_of_unity((unsigned)c.degree_bits), 0), ch.zeta);  // GetInstance fri.go:46-50
@@ -438,6 +448,7 @@ static inline void witness_fri(const ProofView& pv, const Challenges& ch, Sink& 
     for (u64 i = c.final_poly_len(); i-- > 0;) fin = mul_add_ext(t, bext(fin), ext(subgroup_x, 0), pv.final_coeff(i));
     if (!(fin == old_eval)) *ok = false;
   }
+  if (t.zero_inverse) *ok = false;
 }
 
 
@@ -754,7 +765,8 @@ static inline std::vector<Ext> gate_unfiltered(Sink& t, const Gate& g, const Ext
   return out;
 }
 
-// One proof: PlonkChip.Verify. `ok` is cleared when the reference's vanishing-polynomial assertion (plonk.go:248) fails.
+// One proof: PlonkChip.Verify. `ok` is cleared when the reference's vanishing-polynomial assertion (plonk.go:248) fails, or evalL0's
+// "hasQuotient == 1" / InverseExtension's "operand != 0" (plonk.go:75-80 at zeta = 1).
 static inline void witness_plonk(const ProofView& pv, const Challenges& ch, const u64 pih[4], Sink& t, bool* ok) {
   const Circuit& c = *pv.c;
   const u64 nc = c.num_challenges, nr = c.num_routed_wires, qdf = c.quotient_degree_factor, npp = c.num_partial_products;
@@ -834,6 +846,7 @@ static inline void witness_plonk(const ProofView& pv, const Challenges& ch, cons
     Ext prod = mul_ext(t, zh, r);
     if (!(reduced[i] == prod)) *ok = false;
   }
+  if (t.zero_inverse) *ok = false;  // evalL0's DivExtension by n (zeta - 1) = 0 (plonk.go:75-80)
 }
 
 }  // namespace wit

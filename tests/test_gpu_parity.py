@@ -1491,6 +1491,81 @@ def test_shared_merkle_levels_with_colliding_queries(gpv, api, orc, name):
         api.set_option(2, 1)
 
 
+# ---------------------------------------------------------------- the "denominator != 0" assertions
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_denominator_assertions_on_their_poles(gpv, api, orc, name):
+    """GPV_FAIL_PLONK_L0 (plonk.go:75-80), GPV_FAIL_FRI_DENOM (fri.go:241-242) and GPV_FAIL_FRI_INTERP (fri.go:280-286 via
+    quadratic_extension.go:124-125) had code on both sides and were driven by no test: random corruption reaches them with probability
+    2^-64. Supplied challenges reach them at will (T.pole_challenges: zeta = 1, zeta^n = 1, zeta / g zeta = the subgroup point of a query
+    round, beta_s = each of the 16 coset points of a round's step). Through gpv_plonk_verify, gpv_fri_verify and
+    gpv_verify_given_challenges, masks bit for bit == the oracle -- which includes the VALUES the reference hands on after a failed
+    assertion (InverseExtension of 0 is 0; interpolate returns the y of the matching point, fri.go:299-311), since the round's later
+    assertions are evaluated on them -- with the shared Merkle levels on and off and in all three BN254 forms; and the same rows through
+    the witness generator: trace == oracle == exact integers (InverseHint of 0 -> 0), consistency flag cleared."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    ch0 = orc.challenges(oc, packed)
+    labels, rows, bits = T.pole_challenges(ci, ch0)
+    k = len(labels)
+    batch = np.tile(np.frombuffer(packed, dtype=np.uint8), (k, 1))
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    opm, ofm = orc.plonk_verify(oc, batch, rows).astype(np.int64), orc.fri_verify(oc, batch, rows).astype(np.int64)
+    for want_bit, got in ((4, opm), (64, ofm), (256, ofm)):
+        assert ((got & want_bit) != 0).tolist() == (bits == want_bit).tolist(), want_bit      # each pole raises exactly its assertion
+    pchip, fchip, chip = gpv.plonk.NewPlonkChip(api, common), gpv.fri.NewChip(api, common), gpv.verifier.NewVerifierChip(api, common)
+    pm = pchip.Verify(pb, rows)
+    bad = np.nonzero(pm != opm)[0]
+    assert bad.size == 0, [(labels[i], hex(int(pm[i])), hex(int(opm[i]))) for i in bad[:4]]
+    try:
+        for shared in (2, 0):
+            api.set_option(2, shared)
+            for form in (1, 2, 3):
+                api.set_option(3, form)
+                fm = fchip.VerifyFriProof(pb, rows)
+                bad = np.nonzero(fm != ofm)[0]
+                assert bad.size == 0, (shared, form, [(labels[i], hex(int(fm[i])), hex(int(ofm[i]))) for i in bad[:4]])
+                acc, mask = chip.VerifyWithChallenges(pb, rows)
+                assert not acc.any() and mask.tolist() == (opm | ofm).tolist(), (shared, form)
+    finally:
+        api.set_option(2, 1)
+        api.set_option(3, 0)
+    # the same rows through the witness generator
+    trace, kinds, cons = fchip.WitnessFriProof(pb, rows)
+    otr, okinds, ocons = orc.witness_fri(oc, batch, rows)
+    assert (kinds == okinds).all() and (trace == otr).all() and cons.tolist() == ocons.tolist() and not cons.any()
+    for i in (labels.index("zeta = x of query 0"), int(np.nonzero(bits == 256)[0][3]), k - 1):
+        words, ekinds, econs = T.witness_fri_exact(ci, packed, rows[i])
+        assert (trace[i] == np.array(words, dtype=np.uint64)).all() and not econs, labels[i]
+    ptrace, pkinds, pcons = pchip.WitnessVerify(pb, rows)
+    optr, opkinds, opcons = orc.witness_plonk(oc, batch, rows)
+    assert (pkinds == opkinds).all() and (ptrace == optr).all() and pcons.tolist() == opcons.tolist() and pcons[0] == 0
+    words, ekinds, econs = T.witness_plonk_exact(ci, packed, rows[0], orc.public_inputs_hash(oc, packed).reshape(-1))
+    assert (ptrace[0] == np.array(words, dtype=np.uint64)).all() and not econs
+
+
+def test_interpolation_poles_with_arity_32(gpv, api, orc):
+    """The same for a circuit with an arity-32 reduction step (its own kernel variant, k_fri_query_a32): beta on each of the 32 coset
+    points. Beyond the reference (fri.go:431-433 panics): GPU == the oracle's literal n^2 form."""
+    ci, packed, (common_j, vo_j, pj), ch0 = T.synthetic_shape_fixture("step", [5, 4], 4, False, 0)
+    common = gpv.types.CommonCircuitData(json.dumps(common_j))
+    circuit = gpv.variables.Circuit(common, gpv.types.VerifierOnlyCircuitDataRaw(json.dumps(vo_j)), beyond_reference=True)
+    oc = orc.circuit(ci)
+    labels, rows, bits = T.pole_challenges(ci, ch0)
+    k = len(labels)
+    batch = np.tile(np.frombuffer(packed, dtype=np.uint8), (k, 1))
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    ofm = orc.fri_verify(oc, batch, rows).astype(np.int64)
+    assert ((ofm & 256) != 0).tolist() == (bits == 256).tolist() and (bits == 256).sum() == 32 + 16
+    fchip = gpv.fri.NewChip(api, common)
+    fm = fchip.VerifyFriProof(pb, rows)
+    bad = np.nonzero(fm != ofm)[0]
+    assert bad.size == 0, [(labels[i], hex(int(fm[i])), hex(int(ofm[i]))) for i in bad[:4]]
+    trace, kinds, cons = fchip.WitnessFriProof(pb, rows)
+    otr, okinds, ocons = orc.witness_fri(oc, batch, rows)
+    assert (trace == otr).all() and cons.tolist() == ocons.tolist()
+
+
 # ---------------------------------------------------------------- fail-closed verdict (VERDICT r2 next-step 3, SURVEY App. A.9)
 def _set_fault(gpv, stage, nth=-1, num=0, den=1):
     """Arms the hook of csrc/gpv_testhooks.h. Only libgpv_test.so has it (the product library neither defines nor exports it), so this
@@ -1559,6 +1634,20 @@ def _verdict_is_fail_closed(gpv, api, orc, shared):
                 assert 0.3 * n <= hit.sum() <= 0.7 * n, (name, int(hit.sum()))           # half a grid, about half of the proofs
             acc, mask, _ch = chip.Verify(pb, vo, detail=True)                            # and the next run is clean again
             assert acc.tolist() == [1] * n and not mask.any(), name
+        if shared == 2:
+            # the crown scratch is reused across batch sizes. A larger batch leaves slots / items / digests all over it; the
+            # smaller batch that follows, with a whole level launch skipped, must not find anything that reads as a current stamp.
+            big, _ = T.synthetic_batch(ci, packed, 2 * n + 37, seed=6, tamper_every=0)
+            assert chip.Verify(gpv.variables.ProofBatch(circuit, big), vo).all()
+            for nth in (0, 1, 2):
+                _set_fault(gpv, 9, nth, 0, 1)
+                try:
+                    acc, mask, _ch = chip.Verify(pb, vo, detail=True)
+                finally:
+                    _set_fault(gpv, 0)
+                assert not acc.any() and ((mask & T.FAIL_INCOMPLETE) != 0).all(), nth
+            acc, mask, _ch = chip.Verify(pb, vo, detail=True)
+            assert acc.all() and not mask.any()
         # the stage entry points check the stages they run
         chs = orc.challenges(orc.circuit(ci), batch)
         fchip = gpv.fri.NewChip(api, common)

@@ -282,3 +282,38 @@ def test_hint_functions_oracle():
     reference's MulAdd known answer (2^63 * 2^63 + 3 -> remainder 18446744068340842500, base_test.go:109-116)."""
     orc = T.oracle()
     check_hints(lambda h, rows, wi, wo: orc.gl_hints(h, rows, wi, wo))
+
+
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_denominator_assertions_on_their_poles(orc, name):
+    """the "denominator != 0" family (plonk.go:75-80, fri.go:241-242, fri.go:280-286 via quadratic_extension.go:124-125;
+    SURVEY App. A.9) had code on both sides and a test on neither. Supplied challenges reach every pole: the oracle must raise exactly the
+    bit of the assertion on each crafted row (and the other rows' bits are whatever the reference's later assertions give -- checked
+    against the exact-integer restatement through the witness, below), and its witness restatement must agree word for word with the
+    independent exact-integer one on pole rows: InverseHint of 0 is 0 (base.go:316-336), hasInv = 0, and interpolate hands on the y of the
+    matching point (fri.go:299-311), not the interpolation."""
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    ch0 = orc.challenges(oc, packed)
+    labels, rows, bits = T.pole_challenges(ci, ch0)
+    k = len(labels)
+    batch = np.tile(np.frombuffer(packed, dtype=np.uint8), (k, 1))
+    pm, fm = orc.plonk_verify(oc, batch, rows), orc.fri_verify(oc, batch, rows)
+    for i, (label, bit) in enumerate(zip(labels, bits)):
+        assert ((int(pm[i]) & 4) != 0) == (bit == 4), label
+        assert ((int(fm[i]) & 64) != 0) == (bit == 64), label
+        assert ((int(fm[i]) & 256) != 0) == (bit == 256), label
+        assert int(pm[i]) | int(fm[i]), label          # none of these rows is the proof's own transcript: every one is rejected
+    assert orc.plonk_verify(oc, batch[:1], ch0.reshape(1, -1))[0] == 0 and orc.fri_verify(oc, batch[:1], ch0.reshape(1, -1))[0] == 0
+    # the witness restatements on a pole of each family (the exact-integer one takes seconds per row)
+    otr, okinds, ocons = orc.witness_fri(oc, batch, rows)
+    assert not ocons.any()   # every row fails some FRI assertion (a pole, or the foreign zeta / beta)
+    pick = [labels.index("zeta = x of query 0"), next(i for i, b in enumerate(bits) if b == 256), len(labels) - 1]
+    for i in pick:
+        words, ekinds, econs = T.witness_fri_exact(ci, packed, rows[i])
+        assert (otr[i] == np.array(words, dtype=np.uint64)).all() and (okinds == np.array(ekinds, dtype=np.uint8)).all() and not econs, labels[i]
+    pih = orc.public_inputs_hash(oc, packed).reshape(-1)
+    ptr, pkinds, pcons = orc.witness_plonk(oc, batch[:3], rows[:3])
+    assert pcons.tolist() == [0, 0, 0]
+    words, ekinds, econs = T.witness_plonk_exact(ci, packed, rows[0], pih)
+    assert (ptr[0] == np.array(words, dtype=np.uint64)).all() and (pkinds == np.array(ekinds, dtype=np.uint8)).all() and not econs

@@ -21,7 +21,8 @@ ctx = gpv.default_context()
 orc = T.oracle()
 P = T.GL_P
 KINDS = ["one bit anywhere", "one bit in the hash section", "a hash replaced by its neighbour", "a query-section word", "two corruptions",
-         "a hash replaced by random 256 bits", "one bit of a supplied challenge"]
+         "a hash replaced by random 256 bits", "one bit of a supplied challenge",
+         "a supplied challenge on a pole (zeta = 1 / zeta or g zeta = a query's subgroup point / beta_s = a coset point of a query's step; often combined with a corrupted word)"]
 
 
 def mutate(ci, packed, ch0, rng, gl_hashes):
@@ -30,8 +31,9 @@ def mutate(ci, packed, ch0, rng, gl_hashes):
     q0, qwords, f0, qfr, n_gl = T.query_section_layout(ci)
     chs = None if ch0 is None else np.tile(np.asarray(ch0, dtype=np.uint64).reshape(1, -1), (n, 1)).copy()
     kinds = np.zeros(n, dtype=int)
+    poles = T.pole_challenges(ci, ch0)[1] if chs is not None else None
     for i in range(1, n):
-        k = int(rng.integers(0, 7 if chs is not None else 6))
+        k = int(rng.integers(0, 8 if chs is not None else 6))
         kinds[i] = k
         if k == 0:
             words[i, int(rng.integers(0, nw))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 64)))
@@ -48,8 +50,12 @@ def mutate(ci, packed, ch0, rng, gl_hashes):
         elif k == 5:
             w = n_gl + 4 * int(rng.integers(0, (nw - n_gl) // 4))
             words[i, w:w + 4] = rng.integers(0, 2**63, 4, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 4, dtype=np.uint64)
-        else:
+        elif k == 6:
             chs[i, int(rng.integers(0, chs.shape[1]))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 40)))
+        else:  # the "denominator != 0" assertions (plonk.go:75-80, fri.go:241-242, :280-286): reachable only through the challenges
+            chs[i] = poles[int(rng.integers(0, len(poles)))]
+            if rng.random() < 0.5:  # ... and what the later assertions make of the values handed on, on a corrupted record too
+                words[i, int(rng.integers(q0, n_gl))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 33)))
     noncanon = (words[:, :n_gl - ci.num_public_inputs] >= np.uint64(P)).any(axis=1)
     if gl_hashes:
         noncanon |= (words[:, n_gl:] >= np.uint64(P)).any(axis=1)
@@ -88,7 +94,7 @@ def run(label, circuit, common, ci, packed, ch0, gl_hashes, vo=None):
         assert bad.size == 0, (label, mode, "mask", bad[:5], kinds[bad[:5]])
     ctx.set_option(2, 1)
     print("%-58s %5d records (%4d accepted; by kind %s) agree with the oracle, shared levels on and off; oracle %.1f s"
-          % (label, n, int(oacc.sum()), np.bincount(kinds, minlength=7).tolist(), t_or), flush=True)
+          % (label, n, int(oacc.sum()), np.bincount(kinds, minlength=8).tolist(), t_or), flush=True)
 
 
 for name in ("decode_block", "step"):
