@@ -61,11 +61,40 @@ def executed_mads_per_perm(zero_head):
     the Montgomery step (a squaring 45 + 81). Per permutation (csrc/gpv_poseidon.cuh): 88 S-boxes = 176 squarings + 88
     multiply-with-addend, 60 four-product rows (32 mix rows + 28 partial-round rows), 28 five-product rows, 84 two-product updates;
     TwoToOne (zero_head) saves two S-boxes and turns four four-product rows into two-product ones. tools/isa_count.py counts the
-    same numbers in the shipped code object (profiles/r03_isa_counts.json)."""
+    same numbers in the shipped code object (profiles/r04_isa_counts.json)."""
     sqr, mul_add, dot4, dot5, dot2_add = 45 + 81, 81 + 9 + 81, 4 * 81 + 81, 5 * 81 + 81, 2 * 81 + 9 + 81
     total = 176 * sqr + 88 * mul_add + 60 * dot4 + 28 * dot5 + 84 * dot2_add
     if zero_head:
         total += -2 * (2 * sqr + mul_add) - 4 * dot4 + 4 * dot2_add
+    return total
+
+
+def library_build_id(gpv):
+    """GNU build id of the libgpv.so this process loaded (csrc/Makefile links with --build-id): profiles/traffic.json carries the id of the
+    build its PMC passes ran on, and the line quotes that traffic only when the two agree."""
+    try:
+        sys.path.insert(0, str(ROOT / "tools"))
+        import make_traffic_json
+        return make_traffic_json.build_id(gpv._lib.LIB_PATH)
+    except Exception:
+        return None
+
+
+def crown_nodes_per_proof(ci, query_indices):
+    """Distinct nodes the shared upper Merkle levels hash for ONE proof with these query indices (csrc/gpv_k_crown.hip): hash number h of
+    a path (1-based from the leaf) produces the node at position bits >> h; the last min(3, n_sib) hashes of every tree are shared, so a
+    level costs one permutation per DISTINCT position among the query rounds. (A valid proof: no path leaves the shared tree.)"""
+    nlog, total = ci.lde_bits, 0
+    idx = [int(q) & ((1 << nlog) - 1) for q in query_indices]
+    trees = [(0, nlog - ci.cap_height)] * 4
+    shift, bits = 0, nlog
+    for a in ci.arity_bits:
+        shift += a
+        bits -= a
+        trees.append((shift, bits - ci.cap_height))
+    for shift, n_sib in trees:
+        for h in range(max(n_sib - CROWN_LEVELS, 0) + 1, n_sib + 1):
+            total += len({(i >> shift) >> h for i in idx})
     return total
 
 
@@ -408,11 +437,18 @@ def main():
         # (FETCH_SIZE x2 on gfx950, WRITE_SIZE), recorded in profiles/traffic.json, and is only reported when that file was
         # measured on this exact configuration.
         traffic, traffic_source = None, None
+        lib_id = library_build_id(gpv)
         try:
-            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())[dom]
-            if tj["fixture"] == args.fixture and tj["proofs_per_gpu"] == n_local:
+            tfile = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+            tj = tfile[dom]
+            if tfile.get("_build_id") != lib_id:
+                # measured on another build of the library: not this code's traffic, so it is not quoted
+                traffic_source = "profiles/traffic.json was measured on library build %s, this run loaded build %s: not quoted" % (
+                    str(tfile.get("_build_id"))[:12], str(lib_id)[:12])
+            elif tj["fixture"] == args.fixture and tj["proofs_per_gpu"] == n_local:
                 traffic = tj["traffic_bytes_per_launch"]
-                traffic_source = "profiles/traffic.json: separate rocprofv3 --pmc passes (%s), not measured in this run" % tj.get("source", "see file")
+                traffic_source = "profiles/traffic.json (build %s = the loaded library): separate rocprofv3 --pmc passes (%s), not measured in this run" % (
+                    str(lib_id)[:12], tj.get("source", "see file"))
         except Exception:
             traffic = None
         line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -446,7 +482,7 @@ def main():
             "numerator": "executed multiply-adds (frac_algorithmic counts SURVEY 8d's 784 x 136 per permutation instead)",
             "peak_definition": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (model: max clock)",
             "executed_mads_per_perm": per_perm_exec[dom], "algorithmic_mads_per_perm": per_perm_alg,
-            "executed_mads_source": "exact by construction of the Fr rows (bench.py executed_mads_per_perm); static count of the shipped code object: profiles/r03_isa_counts.json (tools/isa_count.py)",
+            "executed_mads_source": "exact by construction of the Fr rows (bench.py executed_mads_per_perm); static count of the shipped code object: profiles/r04_isa_counts.json (tools/isa_count.py)",
             "executed_valu_per_perm": isa.get("pmc_valu_per_perm"), "executed_valu_source": isa.get("pmc_source"),
             "achieved_algorithmic": a_alg / 1e12, "frac_algorithmic": a_alg / MAD_PEAK_MODEL,
             "achieved_executed": a_exec / 1e12, "frac_executed": a_exec / MAD_PEAK_MODEL,
@@ -459,10 +495,24 @@ def main():
             "per_kernel_frac_algorithmic": {k: rate(v[2], v[0], per_perm_alg) / MAD_PEAK_MODEL for k, v in cand.items()},
             "bn254_leaf_perms_per_proof": leaf_perms, "bn254_sibling_perms_per_proof_reference": climb_perms,
             "sibling_walk_effective_frac_algorithmic": rate(climb_perms, merkle_ms, per_perm_alg) / MAD_PEAK_MODEL, "sibling_walk_ms": merkle_ms}
+        if not args.per_path_merkle:
+            # the STEP, not only its best kernel: every Poseidon-BN254 permutation the step executes (leaf digests + sibling walk below
+            # the shared levels + one per distinct shared node) x its executed multiply-adds, over the whole step's wall time -- the
+            # transcript / plonk / FRI field work (Goldilocks, hidden on the side stream) is not counted in the numerator
+            ch_row = chip.GetChallenges(wl.proof).flat[0]
+            crown = crown_nodes_per_proof(ci, ch_row[len(ch_row) - ci.num_query_rounds:])
+            step_mads = leaf_perms * executed_mads_per_perm(False) + (lower_perms + crown) * executed_mads_per_perm(True)
+            step_rate = step_mads * float(n_local) / (ms_per_step * 1e-3)
+            line["valu_roofline"].update({
+                "whole_step_executed_mads_per_proof": step_mads, "whole_step_bn254_perms_per_proof": {"leaves": leaf_perms, "walk_below_shared_levels": lower_perms, "shared_nodes": crown},
+                "whole_step_frac_executed": step_rate / MAD_PEAK_MODEL,
+                "whole_step_frac_executed_at_measured_clock": step_rate / peak_meas if peak_meas else None,
+                "whole_step_note": "executed BN254 multiply-adds of the whole step / (ms_per_step x peak); n_gpus = 1 timing (the all-gather is inside ms_per_step for N > 1)"})
         line["stage_ms"] = stage_ms
         if not args.no_config_legs and n_ranks == 1:
             line["fri_verify_4096"] = bench_fri_verify(gpv, T, ctx, dev, max(2, min(args.steps, 5)))
             line["merkle_only_4096"] = bench_merkle_only(gpv, T, ctx, dev, max(2, min(args.steps, 5)))
+            line["full_batch_65536"] = bench_full_batch(gpv, T, ctx, dev, args.fixture)
             line["single_proof"] = bench_single_proof(gpv, T, ctx, dev)
             line["witness_verify_1024"] = bench_witness(gpv, T, ctx, dev)
         if not args.no_poseidon_gl:
@@ -534,6 +584,26 @@ def bench_fri_verify(gpv, T, ctx, dev, steps, n=4096):
     return {"config": "BASELINE config 3: fri.VerifyFriProof on testdata/step, 28 queries x %d proofs, challenges supplied" % n,
             "entry_point": "gpv_fri_verify_dev", "proofs": n, "steps": steps, "proofs_per_s": n / dt, "ms_per_step": 1e3 * dt,
             "query_rounds_per_s": n * wl.ci.num_query_rounds / dt, "stage_ms": stage, "checked": "mask == 0 exactly for the untampered proofs"}
+
+
+def bench_full_batch(gpv, T, ctx, dev, fixture, n=65536, steps=3):
+    """BASELINE config 4 exactly as stated: 65 536 proofs -- the whole batch on ONE GPU (8.7 GB of records; the headline step is its per-GPU
+    shard of 8192). Same generator, same entry point (gpv_verify_dev), accept vector checked against the tamper mask."""
+    wl = Workload(gpv, T, fixture, dev)
+    need = n * len(wl.packed) + (12 << 30)
+    if torch.cuda.mem_get_info(dev)[0] < need:
+        return {"skipped": "not enough free HBM for %d records" % n}
+    batch, tam = wl.cloned_batch(0, n, n)
+    acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+    chip = gpv.verifier.NewVerifierChip(ctx, wl.common)
+    dt = _time_steps(ctx, lambda: chip.VerifyDevice(wl.circuit, batch.data_ptr(), n, acc.data_ptr()), steps)
+    if not (acc.cpu().numpy() == (~tam).astype(np.uint8)).all():
+        raise SystemExit("full_batch_65536: accept vector does not match the tamper mask")
+    del batch
+    torch.cuda.empty_cache()
+    return {"config": "BASELINE config 4 as stated: VerifierChip.Verify end-to-end, %d testdata/%s proofs on one GPU, 1 in 16 tampered" % (n, fixture),
+            "entry_point": "gpv_verify_dev", "proofs": n, "steps": steps, "proofs_per_s": n / dt, "ms_per_step": 1e3 * dt,
+            "record_bytes_in_hbm": n * len(wl.packed), "checked": "accept == the tamper mask, all %d proofs" % n}
 
 
 def bench_single_proof(gpv, T, ctx, dev):

@@ -26,8 +26,8 @@ type Context struct{ h *C.gpv_ctx }
 
 func lastError(ctx *C.gpv_ctx) string {
 	buf := make([]byte, 1024)
-	C.gpv_last_error_message(ctx, (*C.char)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)))
-	return C.GoString((*C.char)(unsafe.Pointer(&buf[0])))
+	C.gpv_last_error_message(ctx, (*C.char)(ptr(buf)), C.size_t(len(buf)))
+	return C.GoString((*C.char)(ptr(buf)))
 }
 
 func check(rc C.int, ctx *C.gpv_ctx) {
@@ -52,8 +52,8 @@ type Circuit struct{ h *C.gpv_circuit }
 // (types.ReadCommonCircuitData, variables.DeserializeVerifierOnlyCircuitData).
 func NewCircuit(commonJSON, verifierOnlyJSON []byte) *Circuit {
 	var h *C.gpv_circuit
-	check(C.gpv_circuit_from_json((*C.char)(unsafe.Pointer(&commonJSON[0])), C.size_t(len(commonJSON)),
-		(*C.char)(unsafe.Pointer(&verifierOnlyJSON[0])), C.size_t(len(verifierOnlyJSON)), &h), nil)
+	check(C.gpv_circuit_from_json((*C.char)(ptr(commonJSON)), C.size_t(len(commonJSON)),
+		(*C.char)(ptr(verifierOnlyJSON)), C.size_t(len(verifierOnlyJSON)), &h), nil)
 	return &Circuit{h}
 }
 
@@ -62,7 +62,7 @@ func (c *Circuit) ProofNBytes() int { return int(C.gpv_proof_nbytes(c.h)) }
 // PackProof converts proof_with_public_inputs.json into one packed record (variables.DeserializeProofWithPublicInputs).
 func (c *Circuit) PackProof(proofJSON []byte) []byte {
 	out := make([]byte, c.ProofNBytes())
-	check(C.gpv_proof_pack_json(c.h, (*C.char)(unsafe.Pointer(&proofJSON[0])), C.size_t(len(proofJSON)), unsafe.Pointer(&out[0])), nil)
+	check(C.gpv_proof_pack_json(c.h, (*C.char)(ptr(proofJSON)), C.size_t(len(proofJSON)), ptr(out)), nil)
 	return out
 }
 
@@ -70,7 +70,7 @@ func (c *Circuit) PackProof(proofJSON []byte) []byte {
 func (ctx *Context) Verify(c *Circuit, proofs []byte) []bool {
 	n := len(proofs) / c.ProofNBytes()
 	acc := make([]byte, n)
-	check(C.gpv_verify(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&acc[0]))), ctx.h)
+	check(C.gpv_verify(ctx.h, c.h, ptr(proofs), C.size_t(n), (*C.uint8_t)(ptr(acc))), ctx.h)
 	out := make([]bool, n)
 	for i := range acc {
 		out[i] = acc[i] == 1
@@ -81,14 +81,14 @@ func (ctx *Context) Verify(c *Circuit, proofs []byte) []bool {
 // PoseidonGL = poseidon.GoldilocksChip.Poseidon on n states of 12 words.
 func (ctx *Context) PoseidonGL(states []uint64) []uint64 {
 	out := make([]uint64, len(states))
-	check(C.gpv_poseidon_gl_permute(ctx.h, (*C.uint64_t)(unsafe.Pointer(&states[0])), (*C.uint64_t)(unsafe.Pointer(&out[0])), C.size_t(len(states)/12)), ctx.h)
+	check(C.gpv_poseidon_gl_permute(ctx.h, (*C.uint64_t)(ptr(states)), (*C.uint64_t)(ptr(out)), C.size_t(len(states)/12)), ctx.h)
 	return out
 }
 
 // PoseidonBN254 = poseidon.BN254Chip.Poseidon on n states of 4 Fr (4 limbs each).
 func (ctx *Context) PoseidonBN254(states []uint64) []uint64 {
 	out := make([]uint64, len(states))
-	check(C.gpv_poseidon_bn254_permute(ctx.h, (*C.uint64_t)(unsafe.Pointer(&states[0])), (*C.uint64_t)(unsafe.Pointer(&out[0])), C.size_t(len(states)/16)), ctx.h)
+	check(C.gpv_poseidon_bn254_permute(ctx.h, (*C.uint64_t)(ptr(states)), (*C.uint64_t)(ptr(out)), C.size_t(len(states)/16)), ctx.h)
 	return out
 }
 
@@ -99,7 +99,7 @@ func (ctx *Context) GlOp(op int, a, b, c []uint64) []uint64 {
 		if len(s) == 0 {
 			return nil
 		}
-		return (*C.uint64_t)(unsafe.Pointer(&s[0]))
+		return (*C.uint64_t)(ptr(s))
 	}
 	check(C.gpv_gl_op(ctx.h, C.int(op), p(a), p(b), p(c), p(out), C.size_t(len(a))), ctx.h)
 	return out
@@ -109,21 +109,21 @@ func (ctx *Context) GlOp(op int, a, b, c []uint64) []uint64 {
 func (ctx *Context) Challenges(c *Circuit, proofs []byte) []uint64 {
 	n := len(proofs) / c.ProofNBytes()
 	out := make([]uint64, n*int(C.gpv_num_challenge_words(c.h)))
-	check(C.gpv_challenges(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), (*C.uint64_t)(unsafe.Pointer(&out[0]))), ctx.h)
+	check(C.gpv_challenges(ctx.h, c.h, ptr(proofs), C.size_t(n), (*C.uint64_t)(ptr(out))), ctx.h)
 	return out
 }
 
 func (ctx *Context) FriVerify(c *Circuit, proofs []byte, challenges []uint64) []uint32 {
 	n := len(proofs) / c.ProofNBytes()
 	out := make([]uint32, n)
-	check(C.gpv_fri_verify(ctx.h, c.h, unsafe.Pointer(&proofs[0]), (*C.uint64_t)(unsafe.Pointer(&challenges[0])), C.size_t(n), (*C.uint32_t)(unsafe.Pointer(&out[0]))), ctx.h)
+	check(C.gpv_fri_verify(ctx.h, c.h, ptr(proofs), (*C.uint64_t)(ptr(challenges)), C.size_t(n), (*C.uint32_t)(ptr(out))), ctx.h)
 	return out
 }
 
 func (ctx *Context) PlonkVerify(c *Circuit, proofs []byte, challenges []uint64) []uint32 {
 	n := len(proofs) / c.ProofNBytes()
 	out := make([]uint32, n)
-	check(C.gpv_plonk_verify(ctx.h, c.h, unsafe.Pointer(&proofs[0]), (*C.uint64_t)(unsafe.Pointer(&challenges[0])), C.size_t(n), (*C.uint32_t)(unsafe.Pointer(&out[0]))), ctx.h)
+	check(C.gpv_plonk_verify(ctx.h, c.h, ptr(proofs), (*C.uint64_t)(ptr(challenges)), C.size_t(n), (*C.uint32_t)(ptr(out))), ctx.h)
 	return out
 }
 
@@ -134,7 +134,7 @@ func (ctx *Context) Gl2Op3(op int, a, b, c []uint64) []uint64 {
 		if len(s) == 0 {
 			return nil
 		}
-		return (*C.uint64_t)(unsafe.Pointer(&s[0]))
+		return (*C.uint64_t)(ptr(s))
 	}
 	check(C.gpv_gl2_op3(ctx.h, C.int(op), p(a), p(b), p(c), p(out), C.size_t(len(a)/2)), ctx.h)
 	return out
@@ -146,21 +146,25 @@ func (ctx *Context) ChallengerRun(script []uint32, in []uint64, nIn, nOut, n int
 	out := make([]uint64, nOut*n)
 	var pin *C.uint64_t
 	if len(in) > 0 {
-		pin = (*C.uint64_t)(unsafe.Pointer(&in[0]))
+		pin = (*C.uint64_t)(ptr(in))
 	}
-	check(C.gpv_challenger_run(ctx.h, (*C.uint32_t)(unsafe.Pointer(&script[0])), C.size_t(len(script)), pin, C.size_t(nIn),
-		(*C.uint64_t)(unsafe.Pointer(&out[0])), C.size_t(nOut), C.size_t(n)), ctx.h)
+	check(C.gpv_challenger_run(ctx.h, (*C.uint32_t)(ptr(script)), C.size_t(len(script)), pin, C.size_t(nIn),
+		(*C.uint64_t)(ptr(out)), C.size_t(nOut), C.size_t(n)), ctx.h)
 	return out
 }
 
 // ---------------------------------------------------------------- the rest of include/gpv.h (round 2; still UNCOMPILED)
 
-func u64p(s []uint64) *C.uint64_t {
+// ptr: address of a slice's first element, nil for an empty slice. &s[0] PANICS on an empty slice where the C ABI answers n == 0 with
+// GPV_OK (ADVICE r3): every slice argument of this file goes through here.
+func ptr[T any](s []T) unsafe.Pointer {
 	if len(s) == 0 {
 		return nil
 	}
-	return (*C.uint64_t)(unsafe.Pointer(&s[0]))
+	return unsafe.Pointer(&s[0])
 }
+
+func u64p(s []uint64) *C.uint64_t { return (*C.uint64_t)(ptr(s)) }
 
 func (c *Circuit) Close()                 { C.gpv_circuit_destroy(c.h) }
 func (c *Circuit) NumChallengeWords() int { return int(C.gpv_num_challenge_words(c.h)) }
@@ -179,7 +183,7 @@ func (c *Circuit) PackProofs(proofJSONs [][]byte, nThreads int) []byte {
 	out := make([]byte, n*c.ProofNBytes())
 	ptrs, lens, free := cTexts(proofJSONs)
 	defer free()
-	check(C.gpv_proof_pack_json_batch(c.h, (**C.char)(unsafe.Pointer(&ptrs[0])), &lens[0], C.size_t(n), unsafe.Pointer(&out[0]), C.int(nThreads)), nil)
+	check(C.gpv_proof_pack_json_batch(c.h, (**C.char)(ptr(ptrs)), &lens[0], C.size_t(n), ptr(out), C.int(nThreads)), nil)
 	return out
 }
 
@@ -194,8 +198,8 @@ func (c *Circuit) PackProofsStatus(proofJSONs [][]byte, nThreads int) ([]byte, [
 	status := make([]int32, n)
 	ptrs, lens, free := cTexts(proofJSONs)
 	defer free()
-	check(C.gpv_proof_pack_json_batch_status(c.h, (**C.char)(unsafe.Pointer(&ptrs[0])), &lens[0], C.size_t(n), unsafe.Pointer(&out[0]), C.int(nThreads),
-		(*C.int32_t)(unsafe.Pointer(&status[0]))), nil)
+	check(C.gpv_proof_pack_json_batch_status(c.h, (**C.char)(ptr(ptrs)), &lens[0], C.size_t(n), ptr(out), C.int(nThreads),
+		(*C.int32_t)(ptr(status))), nil)
 	return out, status
 }
 
@@ -223,7 +227,7 @@ func (ctx *Context) GlHints(hint int, in []uint64, wordsIn, wordsOut int) ([]uin
 	n := len(in) / wordsIn
 	out := make([]uint64, n*wordsOut)
 	okb := make([]byte, n)
-	check(C.gpv_gl_hints(ctx.h, C.int(hint), u64p(in), u64p(out), (*C.uint8_t)(unsafe.Pointer(&okb[0])), C.size_t(n)), ctx.h)
+	check(C.gpv_gl_hints(ctx.h, C.int(hint), u64p(in), u64p(out), (*C.uint8_t)(ptr(okb)), C.size_t(n)), ctx.h)
 	ok := make([]bool, n)
 	for i := range okb {
 		ok[i] = okb[i] == 1
@@ -236,7 +240,7 @@ func (ctx *Context) Gl2Op(op int, a, b []uint64) ([]uint64, []bool) {
 	n := len(a) / 2
 	out := make([]uint64, len(a))
 	okb := make([]byte, n)
-	check(C.gpv_gl2_op(ctx.h, C.int(op), u64p(a), u64p(b), u64p(out), (*C.uint8_t)(unsafe.Pointer(&okb[0])), C.size_t(n)), ctx.h)
+	check(C.gpv_gl2_op(ctx.h, C.int(op), u64p(a), u64p(b), u64p(out), (*C.uint8_t)(ptr(okb)), C.size_t(n)), ctx.h)
 	ok := make([]bool, n)
 	for i := range okb {
 		ok[i] = okb[i] == 1
@@ -311,14 +315,14 @@ func (ctx *Context) GateEvalUnfiltered(kind int, p0, p1, p2 uint64, weights, con
 func (ctx *Context) PublicInputsHash(c *Circuit, proofs []byte) []uint64 {
 	n := len(proofs) / c.ProofNBytes()
 	out := make([]uint64, 4*n)
-	check(C.gpv_public_inputs_hash(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(out)), ctx.h)
+	check(C.gpv_public_inputs_hash(ctx.h, c.h, ptr(proofs), C.size_t(n), u64p(out)), ctx.h)
 	return out
 }
 
 func (ctx *Context) GateConstraints(c *Circuit, proofs []byte) []uint64 {
 	n := len(proofs) / c.ProofNBytes()
 	out := make([]uint64, 2*n*int(C.gpv_num_gate_constraints(c.h)))
-	check(C.gpv_gate_constraints(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(out)), ctx.h)
+	check(C.gpv_gate_constraints(ctx.h, c.h, ptr(proofs), C.size_t(n), u64p(out)), ctx.h)
 	return out
 }
 
@@ -326,7 +330,7 @@ func (ctx *Context) GateConstraints(c *Circuit, proofs []byte) []uint64 {
 func (ctx *Context) MerkleVerify(c *Circuit, proofs []byte, challenges []uint64) []bool {
 	n := len(proofs) / c.ProofNBytes()
 	okb := make([]byte, n*c.NumQueryRounds()*c.NumMerkleTrees())
-	check(C.gpv_merkle_verify(ctx.h, c.h, unsafe.Pointer(&proofs[0]), u64p(challenges), C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&okb[0]))), ctx.h)
+	check(C.gpv_merkle_verify(ctx.h, c.h, ptr(proofs), u64p(challenges), C.size_t(n), (*C.uint8_t)(ptr(okb))), ctx.h)
 	ok := make([]bool, len(okb))
 	for i := range okb {
 		ok[i] = okb[i] == 1
@@ -340,8 +344,8 @@ func (ctx *Context) VerifyWithChallenges(c *Circuit, proofs []byte, challenges [
 	n := len(proofs) / c.ProofNBytes()
 	acc := make([]byte, n)
 	mask := make([]uint32, n)
-	check(C.gpv_verify_given_challenges(ctx.h, c.h, unsafe.Pointer(&proofs[0]), u64p(challenges), C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&acc[0])),
-		(*C.uint32_t)(unsafe.Pointer(&mask[0]))), ctx.h)
+	check(C.gpv_verify_given_challenges(ctx.h, c.h, ptr(proofs), u64p(challenges), C.size_t(n), (*C.uint8_t)(ptr(acc)),
+		(*C.uint32_t)(ptr(mask))), ctx.h)
 	out := make([]bool, n)
 	for i := range acc {
 		out[i] = acc[i] == 1
@@ -355,8 +359,8 @@ func (ctx *Context) VerifyDetail(c *Circuit, proofs []byte) ([]bool, []uint32, [
 	acc := make([]byte, n)
 	mask := make([]uint32, n)
 	ch := make([]uint64, n*c.NumChallengeWords())
-	check(C.gpv_verify_detail(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&acc[0])),
-		(*C.uint32_t)(unsafe.Pointer(&mask[0])), u64p(ch)), ctx.h)
+	check(C.gpv_verify_detail(ctx.h, c.h, ptr(proofs), C.size_t(n), (*C.uint8_t)(ptr(acc)),
+		(*C.uint32_t)(ptr(mask)), u64p(ch)), ctx.h)
 	out := make([]bool, n)
 	for i := range acc {
 		out[i] = acc[i] == 1
@@ -395,8 +399,8 @@ type Group struct{ h *C.gpv_group }
 func groupCheck(rc C.int, g *C.gpv_group) {
 	if rc != C.GPV_OK {
 		buf := make([]byte, 1024)
-		C.gpv_group_last_error_message(g, (*C.char)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)))
-		panic(&Error{Code: int(rc), Msg: C.GoString((*C.char)(unsafe.Pointer(&buf[0])))})
+		C.gpv_group_last_error_message(g, (*C.char)(ptr(buf)), C.size_t(len(buf)))
+		panic(&Error{Code: int(rc), Msg: C.GoString((*C.char)(ptr(buf)))})
 	}
 }
 
@@ -407,19 +411,19 @@ func NewGroup(deviceIDs []int) *Group {
 		ids[i] = C.int(d)
 	}
 	var h *C.gpv_group
-	groupCheck(C.gpv_group_create(&h, &ids[0], C.int(len(ids))), nil)
+	groupCheck(C.gpv_group_create(&h, (*C.int)(ptr(ids)), C.int(len(ids))), nil) // no devices: GPV_EINVAL from the C side, not a Go panic
 	return &Group{h}
 }
 
 // GroupUniqueID / NewGroupRank: one process per GPU; rank 0 creates the id, the caller hands it to the other ranks.
 func GroupUniqueID() [128]byte {
 	var id [128]byte
-	groupCheck(C.gpv_group_unique_id(unsafe.Pointer(&id[0])), nil)
+	groupCheck(C.gpv_group_unique_id(ptr(id)), nil)
 	return id
 }
 func NewGroupRank(device, rank, world int, id [128]byte) *Group {
 	var h *C.gpv_group
-	groupCheck(C.gpv_group_create_rank(&h, C.int(device), C.int(rank), C.int(world), unsafe.Pointer(&id[0])), nil)
+	groupCheck(C.gpv_group_create_rank(&h, C.int(device), C.int(rank), C.int(world), ptr(id)), nil)
 	return &Group{h}
 }
 func (g *Group) Close()     { C.gpv_group_destroy(g.h) }
@@ -431,7 +435,7 @@ func (g *Group) SetOption(option, value int) { groupCheck(C.gpv_group_set_option
 // verdict of all nTotal proofs, identical on every rank.
 func (g *Group) Verify(c *Circuit, proofs []byte, nTotal int) []bool {
 	acc := make([]byte, nTotal)
-	groupCheck(C.gpv_group_verify(g.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(nTotal), (*C.uint8_t)(unsafe.Pointer(&acc[0]))), g.h)
+	groupCheck(C.gpv_group_verify(g.h, c.h, ptr(proofs), C.size_t(nTotal), (*C.uint8_t)(ptr(acc))), g.h)
 	out := make([]bool, nTotal)
 	for i := range acc {
 		out[i] = acc[i] == 1
@@ -457,8 +461,8 @@ const (
 // other FRI arities / cap heights, hiding, Poseidon-Goldilocks hashes, lookup gates. Parity unpinned (DESIGN.md).
 func NewCircuitBeyondReference(commonJSON, verifierOnlyJSON []byte) *Circuit {
 	var h *C.gpv_circuit
-	check(C.gpv_circuit_from_json_ex((*C.char)(unsafe.Pointer(&commonJSON[0])), C.size_t(len(commonJSON)),
-		(*C.char)(unsafe.Pointer(&verifierOnlyJSON[0])), C.size_t(len(verifierOnlyJSON)), C.GPV_CIRCUIT_BEYOND_REFERENCE, &h), nil)
+	check(C.gpv_circuit_from_json_ex((*C.char)(ptr(commonJSON)), C.size_t(len(commonJSON)),
+		(*C.char)(ptr(verifierOnlyJSON)), C.size_t(len(verifierOnlyJSON)), C.GPV_CIRCUIT_BEYOND_REFERENCE, &h), nil)
 	return &Circuit{h}
 }
 
@@ -533,13 +537,13 @@ func (g *Group) VerifyDev(c *Circuit, shardDev []unsafe.Pointer, nTotal int, acc
 	for i, p := range acceptAllDev {
 		acc[i] = (*C.uint8_t)(p)
 	}
-	groupCheck(C.gpv_group_verify_dev(g.h, c.h, (*unsafe.Pointer)(unsafe.Pointer(&shardDev[0])), C.size_t(nTotal), &acc[0]), g.h)
+	groupCheck(C.gpv_group_verify_dev(g.h, c.h, (*unsafe.Pointer)(ptr(shardDev)), C.size_t(nTotal), (**C.uint8_t)(ptr(acc))), g.h)
 }
 
 // ReadRankAccept: the gathered verdict as local rank `local` holds it on its own device after Verify.
 func (g *Group) ReadRankAccept(local, nTotal int) []bool {
 	acc := make([]byte, nTotal)
-	groupCheck(C.gpv_group_read_rank_accept(g.h, C.int(local), (*C.uint8_t)(unsafe.Pointer(&acc[0])), C.size_t(nTotal)), g.h)
+	groupCheck(C.gpv_group_read_rank_accept(g.h, C.int(local), (*C.uint8_t)(ptr(acc)), C.size_t(nTotal)), g.h)
 	out := make([]bool, nTotal)
 	for i := range acc {
 		out[i] = acc[i] == 1
@@ -554,7 +558,7 @@ func (ctx *Context) WitnessRangeCheck(c *Circuit, proofs []byte) ([]uint64, []bo
 	n := len(proofs) / c.ProofNBytes()
 	trace := make([]uint64, n*int(C.gpv_witness_range_check_words(c.h)))
 	okb := make([]byte, n)
-	check(C.gpv_witness_range_check(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(trace), (*C.uint8_t)(unsafe.Pointer(&okb[0]))), ctx.h)
+	check(C.gpv_witness_range_check(ctx.h, c.h, ptr(proofs), C.size_t(n), u64p(trace), (*C.uint8_t)(ptr(okb))), ctx.h)
 	ok := make([]bool, n)
 	for i := range okb {
 		ok[i] = okb[i] == 1
@@ -564,14 +568,14 @@ func (ctx *Context) WitnessRangeCheck(c *Circuit, proofs []byte) ([]uint64, []bo
 func (c *Circuit) WitnessChallengesLayout() []uint8 {
 	n := int(C.gpv_witness_challenges_layout(c.h, nil, 0))
 	kinds := make([]uint8, n)
-	C.gpv_witness_challenges_layout(c.h, (*C.uint8_t)(unsafe.Pointer(&kinds[0])), C.size_t(n))
+	C.gpv_witness_challenges_layout(c.h, (*C.uint8_t)(ptr(kinds)), C.size_t(n))
 	return kinds
 }
 func (ctx *Context) WitnessChallenges(c *Circuit, proofs []byte) (trace []uint64, challenges []uint64) {
 	n := len(proofs) / c.ProofNBytes()
 	trace = make([]uint64, n*int(C.gpv_witness_challenges_words(c.h)))
 	challenges = make([]uint64, n*c.NumChallengeWords())
-	check(C.gpv_witness_challenges(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(trace), u64p(challenges)), ctx.h)
+	check(C.gpv_witness_challenges(ctx.h, c.h, ptr(proofs), C.size_t(n), u64p(trace), u64p(challenges)), ctx.h)
 	return trace, challenges
 }
 
@@ -580,14 +584,14 @@ func (ctx *Context) WitnessChallenges(c *Circuit, proofs []byte) (trace []uint64
 func (c *Circuit) WitnessFriLayout() []uint8 {
 	n := int(C.gpv_witness_fri_layout(c.h, nil, 0))
 	kinds := make([]uint8, n)
-	C.gpv_witness_fri_layout(c.h, (*C.uint8_t)(unsafe.Pointer(&kinds[0])), C.size_t(n))
+	C.gpv_witness_fri_layout(c.h, (*C.uint8_t)(ptr(kinds)), C.size_t(n))
 	return kinds
 }
 func (ctx *Context) WitnessFri(c *Circuit, proofs []byte, challenges []uint64) ([]uint64, []bool) {
 	n := len(proofs) / c.ProofNBytes()
 	trace := make([]uint64, n*int(C.gpv_witness_fri_words(c.h)))
 	cb := make([]byte, n)
-	check(C.gpv_witness_fri(ctx.h, c.h, unsafe.Pointer(&proofs[0]), u64p(challenges), C.size_t(n), u64p(trace), (*C.uint8_t)(unsafe.Pointer(&cb[0]))), ctx.h)
+	check(C.gpv_witness_fri(ctx.h, c.h, ptr(proofs), u64p(challenges), C.size_t(n), u64p(trace), (*C.uint8_t)(ptr(cb))), ctx.h)
 	cons := make([]bool, n)
 	for i := range cb {
 		cons[i] = cb[i] == 1
@@ -600,14 +604,14 @@ func (ctx *Context) WitnessFri(c *Circuit, proofs []byte, challenges []uint64) (
 func (c *Circuit) WitnessPlonkLayout() []uint8 {
 	n := int(C.gpv_witness_plonk_layout(c.h, nil, 0))
 	kinds := make([]uint8, n)
-	C.gpv_witness_plonk_layout(c.h, (*C.uint8_t)(unsafe.Pointer(&kinds[0])), C.size_t(n))
+	C.gpv_witness_plonk_layout(c.h, (*C.uint8_t)(ptr(kinds)), C.size_t(n))
 	return kinds
 }
 func (ctx *Context) WitnessPlonk(c *Circuit, proofs []byte, challenges []uint64) ([]uint64, []bool) {
 	n := len(proofs) / c.ProofNBytes()
 	trace := make([]uint64, n*int(C.gpv_witness_plonk_words(c.h)))
 	cb := make([]byte, n)
-	check(C.gpv_witness_plonk(ctx.h, c.h, unsafe.Pointer(&proofs[0]), u64p(challenges), C.size_t(n), u64p(trace), (*C.uint8_t)(unsafe.Pointer(&cb[0]))), ctx.h)
+	check(C.gpv_witness_plonk(ctx.h, c.h, ptr(proofs), u64p(challenges), C.size_t(n), u64p(trace), (*C.uint8_t)(ptr(cb))), ctx.h)
 	cons := make([]bool, n)
 	for i := range cb {
 		cons[i] = cb[i] == 1
@@ -620,7 +624,7 @@ func (ctx *Context) WitnessPlonk(c *Circuit, proofs []byte, challenges []uint64)
 func (c *Circuit) WitnessVerifyLayout() []uint8 {
 	n := int(C.gpv_witness_verify_layout(c.h, nil, 0))
 	kinds := make([]uint8, n)
-	C.gpv_witness_verify_layout(c.h, (*C.uint8_t)(unsafe.Pointer(&kinds[0])), C.size_t(n))
+	C.gpv_witness_verify_layout(c.h, (*C.uint8_t)(ptr(kinds)), C.size_t(n))
 	return kinds
 }
 func (ctx *Context) WitnessVerify(c *Circuit, proofs []byte) (trace []uint64, challenges []uint64, status []uint8) {
@@ -628,7 +632,7 @@ func (ctx *Context) WitnessVerify(c *Circuit, proofs []byte) (trace []uint64, ch
 	trace = make([]uint64, n*int(C.gpv_witness_verify_words(c.h)))
 	challenges = make([]uint64, n*c.NumChallengeWords())
 	status = make([]uint8, n)
-	check(C.gpv_witness_verify(ctx.h, c.h, unsafe.Pointer(&proofs[0]), C.size_t(n), u64p(trace), u64p(challenges), (*C.uint8_t)(unsafe.Pointer(&status[0]))), ctx.h)
+	check(C.gpv_witness_verify(ctx.h, c.h, ptr(proofs), C.size_t(n), u64p(trace), u64p(challenges), (*C.uint8_t)(ptr(status))), ctx.h)
 	return
 }
 
@@ -649,7 +653,7 @@ func (ctx *Context) VerifyJSON(c *Circuit, proofJSONs [][]byte, nThreads int) []
 	ptrs, lens, free := cTexts(proofJSONs)
 	defer free()
 	acc := make([]byte, n)
-	check(C.gpv_verify_json(ctx.h, c.h, (**C.char)(unsafe.Pointer(&ptrs[0])), &lens[0], C.size_t(n), C.int(nThreads), (*C.uint8_t)(unsafe.Pointer(&acc[0]))), ctx.h)
+	check(C.gpv_verify_json(ctx.h, c.h, (**C.char)(ptr(ptrs)), &lens[0], C.size_t(n), C.int(nThreads), (*C.uint8_t)(ptr(acc))), ctx.h)
 	out := make([]bool, n)
 	for i := range acc {
 		out[i] = acc[i] == 1
@@ -668,8 +672,8 @@ func (ctx *Context) VerifyJSONStatus(c *Circuit, proofJSONs [][]byte, nThreads i
 	defer free()
 	acc := make([]byte, n)
 	status := make([]int32, n)
-	check(C.gpv_verify_json_status(ctx.h, c.h, (**C.char)(unsafe.Pointer(&ptrs[0])), &lens[0], C.size_t(n), C.int(nThreads),
-		(*C.uint8_t)(unsafe.Pointer(&acc[0])), (*C.int32_t)(unsafe.Pointer(&status[0]))), ctx.h)
+	check(C.gpv_verify_json_status(ctx.h, c.h, (**C.char)(ptr(ptrs)), &lens[0], C.size_t(n), C.int(nThreads),
+		(*C.uint8_t)(ptr(acc)), (*C.int32_t)(ptr(status))), ctx.h)
 	out := make([]bool, n)
 	for i := range acc {
 		out[i] = acc[i] == 1

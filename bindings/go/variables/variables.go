@@ -4,6 +4,8 @@
 package variables
 
 import (
+	"sync"
+
 	"github.com/succinctlabs/gnark-plonky2-verifier/bindings/go/gpv"
 	"github.com/succinctlabs/gnark-plonky2-verifier/bindings/go/types"
 )
@@ -28,11 +30,16 @@ type ProofWithPublicInputs struct { // variables/circuit.go:16-19
 	PublicInputs []uint64 // [N][num_public_inputs], as stored in the record (not reduced: verifier.go:84-141 exempts them)
 }
 
-var circuits = map[string]*gpv.Circuit{}
+var (
+	circuitsMu sync.Mutex // goroutines deserialise concurrently; a gpv_circuit itself is immutable and shareable (include/gpv.h, Threading)
+	circuits   = map[string]*gpv.Circuit{}
+)
 
-// CircuitFor returns the (cached) gpv_circuit for a pair of circuit data.
+// CircuitFor returns the (cached) gpv_circuit for a pair of circuit data. Safe for concurrent use.
 func CircuitFor(common types.CommonCircuitData, vo VerifierOnlyCircuitData) *gpv.Circuit {
 	key := string(common.JSON) + "\x00" + string(vo.Raw.JSON)
+	circuitsMu.Lock()
+	defer circuitsMu.Unlock()
 	if c, ok := circuits[key]; ok {
 		return c
 	}

@@ -121,8 +121,8 @@ void gpvk_note_launch(hipError_t e, const char* what) {
 // Fault injection for the fail-closed tests (gpv_testhooks.h). Compiled ONLY into libgpv_test.so (-DGPV_TEST_HOOKS, csrc/Makefile): the
 // product library has neither the process-wide state nor the symbol (round 4) -- there the two queries below are
 // the identity, so the kernel translation units are shared by both builds.
-#ifdef GPV_TEST_HOOKS
 #include <atomic>
+#ifdef GPV_TEST_HOOKS
 #include "gpv_testhooks.h"
 static std::atomic<int> g_fault_stage{0}, g_fault_nth{-1}, g_fault_seen{0};
 static std::atomic<unsigned> g_fault_num{1}, g_fault_den{1};
@@ -147,6 +147,21 @@ extern "C" int gpvi_test_set_fault(int stage, int nth, unsigned num, unsigned de
 unsigned gpvk_fault_blocks(int, unsigned blocks) { return blocks; }
 bool gpvi_fault_rank(int) { return false; }
 #endif
+
+// SIMDs of the current device: the unit of the form-selection rule (gpv_launch.h). Cached per ordinal; a device that cannot be queried
+// counts as a whole MI355X (1024 SIMDs), which reproduces the thresholds of rounds 2 - 3.
+unsigned gpvk_device_simds() {
+  static std::atomic<unsigned> cache[GPV_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GPV_MAX_DEVICES) return 1024;
+  unsigned v = cache[dev].load(std::memory_order_relaxed);
+  if (v) return v;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  v = 4u * (unsigned)cus;
+  cache[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
 
 #define HIP_TRY(ctx, expr)                                                                      \
   do {                                                                                          \

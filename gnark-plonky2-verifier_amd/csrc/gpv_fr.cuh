@@ -54,7 +54,8 @@ GPV_DEV Fr fr_load(const u32* tab, int idx) {  // Montgomery-form table entry, i
 
 // ---------------------------------------------------------------- 64-bit column accumulators
 // Operand-scanning form (rounds 1b - 2f). The product path uses the column-scanning rows further down (fr_row); these stay
-// as the reference form of the arithmetic for the MFMA feasibility probe (gpv_k_mfma_probe.hip) and for A/B runs.
+// as the latency form (FrWide, small launches), as the reference form of the arithmetic for the MFMA feasibility probe
+// (tools/probe/gpvp_k_mfma.hip -- outside the product since round 3) and for A/B runs.
 struct FrCols {
   u64 t[2 * FR_LIMBS];
 };

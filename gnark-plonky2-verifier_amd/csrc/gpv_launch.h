@@ -70,20 +70,30 @@ unsigned gpvk_fault_blocks(int stage, unsigned blocks);
 __device__ __forceinline__ void gpvk_side_stream_priority() { __builtin_amdgcn_s_setprio(3); }
 #endif
 
-// Which evaluation order of the BN254 Fr rows a launch of `lanes` hashing lanes gets (gpv_fr.cuh: FrChain / FrWide). The
-// column-scanning kernels need four resident waves per SIMD (262 144 lanes fill the chip once) and win from about three chip
-// fills on; below that the operand-scanning kernels finish sooner. Step fixture (168 lanes per proof), ms per batch, column /
-// operand scanning: 21.6 / 20.4 at 2048 proofs, 30.0 / 29.0 at 3072, 37.3 / 36.7 at 4096, 45.2 / 45.5 at 5120, 69.1 / 71.5 at 8192,
-// 136.3 / 142.0 at 16384 (profiles/r02l_batch_sweep.txt); a single proof: 11.7 / 8.6.
-#define GPV_FR_CHAIN_MIN_LANES ((size_t)3 << 18)
-// form: GPV_OPT_FR_EVALUATION -- 0 by size, 1 column scanning, 2 operand scanning
-static inline bool gpvk_fr_chain_pays(size_t lanes, int form) { return form == 1 || (form == 0 && lanes >= GPV_FR_CHAIN_MIN_LANES); }
-// form 3 / small launches: four lanes per permutation (gpv_poseidon_quad.cuh): 1.7 x fewer instructions in a wave's stream, 2.4 x more
-// lane-instructions in total. Measured on the whole verification (profiles/r03_latency_breakdown.txt, step, ms per call, one lane per
-// permutation / four): 1 proof 8.75 / 3.99, 32: 7.42 / 4.34, 96: 7.88 / 5.01, 192: 8.06 / 6.63, 256: 8.15 / 7.54, 384: 8.33 / 10.10 --
-// it pays while the quads leave the SIMDs with two to three waves each: up to 45 056 paths (268 `step` proofs).
-#define GPV_FR_QUAD_MAX_LANES ((size_t)44 << 10)
-static inline bool gpvk_fr_quad_pays(size_t lanes, int form) { return form == 3 || (form == 0 && lanes <= GPV_FR_QUAD_MAX_LANES); }
+// Which evaluation order of the BN254 Fr rows a launch of `lanes` hashing lanes gets (gpv_fr.cuh: FrChain / FrWide / the four-lane form).
+// The rule is stated in OCCUPANCY of the device the launch goes to (round 4) -- waves the launch puts
+// on every SIMD, w = lanes / (64 x SIMDs), SIMDs = 4 x hipDeviceAttributeMultiprocessorCount of the current device -- so that a
+// partitioned or smaller device (CPX / a 64-CU partition, another SKU) picks by ITS size, not by the lane counts that happened to be
+// the crossovers of a whole MI355X:
+//   column scanning (FrChain) needs four resident waves per SIMD to hide its serial chain and wins from about three chip fills on:
+//       w >= GPV_FR_CHAIN_MIN_WAVES_PER_SIMD = 12          (on 1024 SIMDs: 786 432 lanes = the 3 * 2^18 of rounds 2 - 3)
+//   four lanes per permutation (gpv_poseidon_quad.cuh) pays while the quads leave the SIMDs with fewer than three waves each:
+//       4 w <= GPV_FR_QUAD_MAX_WAVES_PER_SIMD_X4 / 4 = 2.75   (on 1024 SIMDs: 45 056 paths = the 44 * 2^10 of round 3)
+//   operand scanning (FrWide) in between.
+// Measured on the step fixture (168 lanes per proof), ms per batch, column / operand scanning: 21.6 / 20.4 at 2048 proofs, 30.0 / 29.0 at
+// 3072, 37.3 / 36.7 at 4096, 45.2 / 45.5 at 5120, 69.1 / 71.5 at 8192, 136.3 / 142.0 at 16384 (profiles/r02l_batch_sweep.txt); one lane
+// per permutation / four, whole verification: 1 proof 8.75 / 3.99, 32: 7.42 / 4.34, 96: 7.88 / 5.01, 192: 8.06 / 6.63, 256: 8.15 / 7.54,
+// 384: 8.33 / 10.10 (profiles/r03_latency_breakdown.txt). A second geometry (12 trees, 4-word step leaves): profiles/r04_form_crossover.txt.
+#define GPV_FR_CHAIN_MIN_WAVES_PER_SIMD 12
+#define GPV_FR_QUAD_MAX_WAVES_PER_SIMD_X4 11  // 2.75 waves per SIMD, in quarters
+unsigned gpvk_device_simds();  // SIMDs of the CURRENT device (gpv_api.cpp; cached per device ordinal)
+// form: GPV_OPT_FR_EVALUATION -- 0 by occupancy, 1 column scanning, 2 operand scanning, 3 four lanes per permutation
+static inline bool gpvk_fr_chain_pays(size_t lanes, int form) {
+  return form == 1 || (form == 0 && lanes >= (size_t)GPV_FR_CHAIN_MIN_WAVES_PER_SIMD * 64 * gpvk_device_simds());
+}
+static inline bool gpvk_fr_quad_pays(size_t lanes, int form) {
+  return form == 3 || (form == 0 && 4 * 4 * lanes <= (size_t)GPV_FR_QUAD_MAX_WAVES_PER_SIMD_X4 * 64 * gpvk_device_simds());
+}
 
 // gpv_k_prim.hip
 void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n);

@@ -2008,7 +2008,7 @@ def test_verify_json_two_threads_one_context(gpv, api):
     obj = json.loads(text)
     bad1, bad2 = json.loads(text), json.loads(text)
     bad1["proof"]["openings"]["wires"][3][0] ^= 1
-    bad2["public_inputs"][0] ^= 1
+    bad2["proof"]["openings"]["plonk_zs"][0][0] ^= 1
     good = [text, json.dumps(obj)]
     jobs = {"small": (150, 5, 1, json.dumps(bad2)), "large": (2048 + 300, 7, 3, json.dumps(bad1))}
     chip = gpv.verifier.NewVerifierChip(api, common)   # ONE context

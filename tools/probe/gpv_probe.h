@@ -38,6 +38,13 @@ int gpvp_mfma_probe_permute(int device, int which, const uint64_t* states, uint6
 /* ms3[0] = every wave runs 4 x iters MFMAs, ms3[1] = every wave a VALU multiply-add chain of similar length, ms3[2] = per SIMD one
  * wave does the MFMAs and the other the VALU chain. */
 int gpvp_mfma_probe_overlap(int device, int iters, double* ms3, uint32_t* hw_ids, size_t n_ids);
+/* Output-stream write pattern (round 4): n_streams streams `stride_words` apart in a buffer of n_streams * stride_words words; every
+ * stream is written by lanes_per_stream adjacent lanes which, per step, each run `spin` dependent multiply-adds and then store chunk_words
+ * consecutive words (16-byte stores), together appending lanes_per_stream * chunk_words contiguous words; `steps` steps. store = 0: the
+ * same loop without the stores. stride_words must be even (16-byte alignment) and >= steps * lanes_per_stream * chunk_words.
+ * *ms = best of 3 launches. */
+int gpvp_stream_write(int device, int store, size_t n_streams, size_t stride_words, unsigned steps, unsigned lanes_per_stream, unsigned chunk_words,
+                      unsigned spin, double* ms);
 const char* gpvp_last_error(void);
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ def lib():
         L.gpvp_mfma_probe.argtypes = [i32, i32, vp, vp, vp, vp, sz, i32, dp]
         L.gpvp_mfma_probe_permute.argtypes = [i32, i32, vp, vp, sz, vp, sz, i32, dp]
         L.gpvp_mfma_probe_overlap.argtypes = [i32, i32, dp, vp, sz]
+        L.gpvp_stream_write.argtypes = [i32, i32, sz, sz, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, dp]
         L.gpvp_last_error.restype = ctypes.c_char_p
         _lib = L
     return _lib
@@ -57,6 +58,13 @@ def microbench_clocked(which, device=0):
 def row_mix_rate(chains, waves, device=0):
     v = ctypes.c_double()
     check(lib().gpvp_row_mix_rate(device, chains, waves, ctypes.byref(v)))
+    return v.value
+
+
+def stream_write(store, n_streams, stride_words, steps, lanes_per_stream, chunk_words, spin, device=0):
+    """ms of the output-stream write pattern (gpv_probe.h gpvp_stream_write)"""
+    v = ctypes.c_double()
+    check(lib().gpvp_stream_write(device, int(store), n_streams, stride_words, steps, lanes_per_stream, chunk_words, spin, ctypes.byref(v)))
     return v.value
 
 

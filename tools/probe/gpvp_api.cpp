@@ -109,6 +109,31 @@ extern "C" int gpvp_microbench_clocked(int device, int which, double* lane_ops_p
   return 0;
 }
 
+extern "C" int gpvp_stream_write(int device, int store, size_t n_streams, size_t stride_words, unsigned steps, unsigned lanes_per_stream,
+                                 unsigned chunk_words, unsigned spin, double* ms) {
+  if (!ms || !n_streams || !lanes_per_stream || !chunk_words || (chunk_words & 1) || (stride_words & 1) ||
+      stride_words < (size_t)steps * lanes_per_stream * chunk_words)
+    return -(int)hipErrorInvalidValue;
+  Streams s;
+  int rc = s.open(device);
+  if (rc) return rc;
+  DevBuf<u64> out;
+  P_TRY(out.alloc(n_streams * stride_words));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {
+    hipEventRecord(s.e0, s.main);
+    gpvk_stream_write(s.main, store, out.p, n_streams, stride_words, steps, lanes_per_stream, chunk_words, spin);
+    hipEventRecord(s.e1, s.main);
+    P_TRY(hipEventSynchronize(s.e1));
+    float t = 0;
+    hipEventElapsedTime(&t, s.e0, s.e1);
+    if (t < best) best = t;
+  }
+  P_LAUNCHED();
+  *ms = best;
+  return 0;
+}
+
 extern "C" int gpvp_row_mix_rate(int device, int chains, int waves, double* lane_mads_per_sec) {
   if (!lane_mads_per_sec || (chains != 1 && chains != 2) || (waves != 1 && waves != 2 && waves != 3 && waves != 4)) return -(int)hipErrorInvalidValue;
   Streams s;

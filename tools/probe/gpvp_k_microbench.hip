@@ -146,3 +146,40 @@ void gpvk_microbench_row_mix_n(hipStream_t st, int chains, int waves, u64* out, 
 #undef RM
 }
 void gpvk_clock_sample(hipStream_t st, u64* out, u32 spin_ticks) { GPVK_LAUNCH(k_clock_sample, dim3(1), dim3(64), 0, st, out, spin_ticks); }
+
+// ---------------------------------------------------------------- output-stream write patterns (round 4)
+// The witness kernels write 1.35 M words per proof as hundreds of thousands of concurrent output streams, each advancing 16 bytes at a
+// time between long stretches of arithmetic. This kernel reproduces the PATTERN without the arithmetic: n_streams streams `stride` words
+// apart; a stream is written by `lps` adjacent lanes; per step every lane runs `spin` dependent multiply-adds ("compute"), then stores
+// `cw` consecutive words (16-byte stores) so that the stream's lanes together append lps * cw contiguous words. store = 0 compiles the
+// same loop without the stores (the compute-only time).
+template <bool STORE>
+__global__ __launch_bounds__(64) void k_stream_write(u64* __restrict__ out, size_t n_streams, size_t stride, u32 steps, u32 lps, u32 cw, u32 spin) {
+  const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t s = lane / lps;
+  const u32 k = (u32)(lane - s * lps);
+  if (s >= n_streams) return;
+  u64* base = out + s * stride;
+  u64 x = lane * 0x9E3779B97F4A7C15ULL + 1;
+#pragma unroll 1
+  for (u32 st = 0; st < steps; st++) {
+#pragma unroll 1
+    for (u32 i = 0; i < spin; i++) x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+    u64* p = base + ((size_t)st * lps + k) * cw;
+    if (STORE) {
+#pragma unroll 1
+      for (u32 w = 0; w < cw; w += 2) {
+        ulonglong2 v = make_ulonglong2(x, x ^ w);
+        *reinterpret_cast<ulonglong2*>(p + w) = v;  // global_store_dwordx4
+      }
+    }
+  }
+  if (!STORE || x == 42) out[s * stride] = x;  // keeps the chain alive
+}
+void gpvk_stream_write(hipStream_t st, int store, u64* out, size_t n_streams, size_t stride, u32 steps, u32 lps, u32 cw, u32 spin) {
+  const size_t lanes = n_streams * lps;
+  if (store)
+    GPVK_LAUNCH(k_stream_write<true>, dim3(gpvk_blocks_for(lanes, 64)), dim3(64), 0, st, out, n_streams, stride, steps, lps, cw, spin);
+  else
+    GPVK_LAUNCH(k_stream_write<false>, dim3(gpvk_blocks_for(lanes, 64)), dim3(64), 0, st, out, n_streams, stride, steps, lps, cw, spin);
+}

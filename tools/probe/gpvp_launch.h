@@ -20,6 +20,7 @@ void gpvk_microbench(hipStream_t st, int which, u64* out, int blocks, int thread
 int gpvk_microbench_ops_per_iter();
 void gpvk_microbench_row_mix_n(hipStream_t st, int chains, int waves, u64* out, int waves_total, int iters);
 void gpvk_clock_sample(hipStream_t st, u64* out, u32 spin_ticks);
+void gpvk_stream_write(hipStream_t st, int store, u64* out, size_t n_streams, size_t stride, u32 steps, u32 lps, u32 cw, u32 spin);
 // gpvp_k_mfma.hip
 void gpvk_probe_row_valu(hipStream_t st, const u32* x, const u32* c_limbs, u64* out, int iters, size_t n);
 void gpvk_probe_row_mfma(hipStream_t st, const u32* x, const uint8_t* q, u64* out, int iters, size_t n, int parts);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): the rocprofv3 passes whose summaries are committed under profiles/.
-#   tools/profile_round.sh r03p            -> gpurun_out/r03p/{kernel_stats,pmc_sq,pmc_fetch,pmc_write}.txt + bench_under_rocprof.json
+#   tools/profile_round.sh r03p            -> gpurun_out/r03p/{kernel_stats,pmc_sq,pmc_fetch,pmc_write}.txt + bench_under_rocprof.json + traffic.json
 # Kernel trace + stats in one pass; every PMC set in its own pass with --kernel-trace only (the pool refuses --pmc together with
 # the HIP/HSA trace domains). The bench is cut down to the headline step (no CPU baseline, no side legs).
 set -u
@@ -24,5 +24,7 @@ cd /tmp
 ( echo "# rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 1 <headline step only>   (MI355X, $TAG; KB)"
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o p -- $B --steps 1 --warmup 1 > /dev/null 2> $OUT/write.err
   summ $OUT/write --pmc ) > $OUT/pmc_write.txt
+# HBM traffic of every kernel of the step, stamped with the build id of the library that was just profiled (bench.py checks it)
+python $ROOT/tools/make_traffic_json.py $OUT $TAG step 8192 > $OUT/traffic.json
 rm -rf $OUT/stats $OUT/sq $OUT/fetch $OUT/write
 for f in $OUT/*.err; do tail -n 2 $f; done
