@@ -404,8 +404,8 @@ def main():
                    "collective": collective,
                    "merkle_shared_levels": "off: every path hashed on its own" if args.per_path_merkle else "on (default): the last 3 levels of each tree hashed once per distinct node, inputs compared "
                                            "word for word; accept bits identical to the per-path walk (GPV_OPT_MERKLE_SHARED_LEVELS)",
-                   "bn254_fr_rows": "chosen per launch (GPV_OPT_FR_EVALUATION = 0): column scanning for launches of >= 3 * 2^18 hashing lanes "
-                                    "(this workload from ~4700 proofs per GPU up), operand scanning below, four lanes per permutation for launches of <= 45 056 paths (about 270 proofs); identical results"},
+                   "bn254_fr_rows": "chosen per launch by occupancy (GPV_OPT_FR_EVALUATION = 0): waves per SIMD of full-length lanes (4 Merkle paths per query round) >= 4.5 "
+                                    "column scanning (this workload from ~2600 proofs per GPU up), <= 0.5 four lanes per permutation (about 290 proofs), operand scanning in between; identical results"},
     }
     if rank == 0:
         leaf_perms, climb_perms = perms_per_proof(ci)

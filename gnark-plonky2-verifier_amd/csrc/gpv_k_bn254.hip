@@ -337,7 +337,7 @@ void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n
 size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n) { return n * hc.num_queries * hc.n_trees * FR_LIMBS; }
 void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, Verdict v, int form) {
   size_t items = n * hc.num_queries;
-  if (hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && gpvk_fr_quad_pays(items * hc.n_trees, form)) {
+  if (hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && gpvk_fr_quad_pays(gpvk_full_paths(hc, items), form)) {
     GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_quad, dim3(gpvk_blocks_for(4 * items, GPV_QUAD_BLOCK), hc.n_trees), dim3(GPV_QUAD_BLOCK), 0, st, dcd, proofs, n,
                 merkle_order(hc, true), digests, v);
     return;
@@ -345,7 +345,7 @@ void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit&
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs, n,
                 merkle_order(hc, true), digests, v);
-  else if (gpvk_fr_chain_pays(items * hc.n_trees, form))
+  else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form))
     GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
                 merkle_order(hc, true), digests, v);
   else
@@ -355,7 +355,7 @@ void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit&
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
                        const u32* digests, Verdict v, uint8_t* ok_out, int form) {
   size_t items = n * hc.num_queries;
-  if (hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && gpvk_fr_quad_pays(items * hc.n_trees, form)) {
+  if (hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && gpvk_fr_quad_pays(gpvk_full_paths(hc, items), form)) {
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_quad, dim3(gpvk_blocks_for(4 * items, GPV_QUAD_BLOCK), hc.n_trees), dim3(GPV_QUAD_BLOCK), 0, st, dcd, proofs,
                 derived, n, merkle_order(hc, false), digests, v, ok_out);
     return;
@@ -363,7 +363,7 @@ void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& 
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs,
                 derived, n, merkle_order(hc, false), digests, v, ok_out);
-  else if (gpvk_fr_chain_pays(items * hc.n_trees, form))
+  else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form))
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
                 merkle_order(hc, false), digests, v, ok_out);
   else
@@ -376,7 +376,7 @@ void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCir
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd,
                 proofs, derived, n, merkle_order(hc, false), digests, mid, crown_levels, v);
-  else if (gpvk_fr_chain_pays(items * hc.n_trees, form))
+  else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form))
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
                 derived, n, merkle_order(hc, false), digests, mid, crown_levels, v);
   else

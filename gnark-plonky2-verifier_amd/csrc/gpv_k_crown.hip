@@ -397,7 +397,7 @@ void gpvk_crown(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, con
     } else {
       GPVK_LAUNCH_STAGE(GPV_STAGE_CROWN_RECONCILE, k_crown_reconcile, dim3(gpvk_blocks_for(groups, 2)), dim3(64), 0, st, dcd, proofs, derived, n, b, k, v);
       // ~22 / 19 / 13 distinct nodes per tree on the three shared levels (28 uniform indices)
-      if (gpvk_fr_chain_pays(groups * 22, form))
+      if (gpvk_fr_chain_pays(groups * 22, form, GPV_FR_CHAIN_MIN_WAVES_X2_NODES))
         GPVK_LAUNCH_STAGE(GPV_STAGE_CROWN_LEVEL, k_crown_level, dim3(gpvk_blocks_for(cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k, gen);
       else
         GPVK_LAUNCH_STAGE(GPV_STAGE_CROWN_LEVEL, k_crown_level_wide, dim3(gpvk_blocks_for(cap, 64)), dim3(64), 0, st, dcd, proofs, derived, n, b, k, gen);

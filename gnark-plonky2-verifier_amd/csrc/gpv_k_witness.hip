@@ -3,6 +3,13 @@
 #include "gpv_launch.h"
 #include "gpv_witness.cuh"
 
+// Output staging (gpv_witness.cuh "the trace cursor") pays when other waves hide a flush event. Measured on testdata/step, ms per kernel,
+// unstaged / staged (profiles/r04_witness_rate.txt): challenges fill (139 lanes per proof) 3.0 / 3.1 at 64 proofs, 3.5 / 3.3 at 256
+// (0.5 waves per SIMD), 6.1 / 4.0 at 1024, 17.2 / 10.0 at 4096; FRI (28 lanes per proof) 2.0 / 3.0 at 64, 3.0 / 3.3 at 256, 3.8 / 3.6 at 1024
+// (0.44), 12.7 / 6.7 at 4096; plonk units (15 lanes per proof, the long pole is ONE lane's Poseidon gate) 3.8 / 6.9 at 64, 6.1 / 8.2 at 1024,
+// 18.4 / 12.9 at 4096 (0.94). quarter_waves: the threshold in quarters of a wave per SIMD.
+static bool gpvk_witness_staged(size_t lanes, unsigned quarter_waves) { return 4 * lanes >= (size_t)quarter_waves * 64 * gpvk_device_simds(); }
+
 // Slice 1 in two passes (gpv_witness.cuh): the native (cooperative) transcript logs every permutation's input, then one lane per (proof, permutation)
 // writes that permutation's literal trace at its fixed offset. `bad` is set when a lane's word count (or the number of logged
 // permutations) differs from the host's layout.
@@ -19,23 +26,29 @@ __global__ __launch_bounds__(64) void k_witness_challenges_log_coop(const DevCir
                                                      challenges ? challenges + i * dc->n_challenge_words : nullptr, lds_rc);
   if ((threadIdx.x & (PGL_COOP_LANES - 1)) == 0 && logged != n_segments) atomicOr(bad, 1u);
 }
+// Every lane of a wave stays in the kernel (the trace is written out by the wave together, gpv_witness.cuh "the trace cursor"): a lane
+// past the end repeats the last item -- the same words to the same addresses -- and only does not report.
 __global__ __launch_bounds__(64) void k_witness_challenges_fill(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
                                                                 const u64* __restrict__ log, u32 n_segments, const u64* __restrict__ seg_off,
                                                                 const u64* __restrict__ seg_len, u64* __restrict__ trace, size_t words_per_proof,
-                                                                u32* __restrict__ bad) {
+                                                                u32* __restrict__ bad, int staged) {
+  extern __shared__ u64 wt_lds[];  // GPV_WT_LDS_WORDS words when staged, none otherwise (dynamic: an unstaged launch keeps its occupancy)
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= n * n_segments) return;
-  const size_t p = item / n_segments;
-  const u32 seg = (u32)(item - p * n_segments);
-  const size_t wrote = dev_witness_challenges_fill(dc, proofs + p * (dc->proof_nbytes / 8), log + item * GPV_WIT_LOG_WORDS, trace + p * words_per_proof,
-                                                   seg_off[seg], seg, n_segments);
-  if (wrote != seg_len[seg]) atomicOr(bad, 2u);
+  const bool live = item < n * n_segments;
+  if (!live) item = n * n_segments - 1;
+  // segment-major: the 64 lanes of a wave write the SAME segment of 64 proofs, so they run in lockstep (same record counts, same branches)
+  const u32 seg = (u32)(item / n);
+  const size_t p = item - (size_t)seg * n;
+  const size_t wrote = dev_witness_challenges_fill(dc, proofs + p * (dc->proof_nbytes / 8), log + (p * n_segments + seg) * GPV_WIT_LOG_WORDS,
+                                                   trace + p * words_per_proof, seg_off[seg], seg, n_segments, staged ? wt_lds : nullptr);
+  if (live && wrote != seg_len[seg]) atomicOr(bad, 2u);
 }
 void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, u64* challenges,
                              u64* log, u32 n_segments, const u64* seg_off, const u64* seg_len, u32* bad) {
   GPVK_LAUNCH(k_witness_challenges_log_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 64)), dim3(64), 0, st, dcd, proofs, n, log, n_segments, challenges, bad);
-  GPVK_LAUNCH(k_witness_challenges_fill, dim3(gpvk_blocks_for(n * n_segments, 64)), dim3(64), 0, st, dcd, proofs, n, log, n_segments, seg_off, seg_len, trace,
-              words_per_proof, bad);
+  const bool staged = gpvk_witness_staged(n * n_segments, 2);
+  GPVK_LAUNCH(k_witness_challenges_fill, dim3(gpvk_blocks_for(n * n_segments, 64)), dim3(64), staged ? GPV_WT_LDS_WORDS * 8 : 0, st, dcd, proofs, n, log, n_segments,
+              seg_off, seg_len, trace, words_per_proof, bad, staged ? 1 : 0);
 }
 
 // rangeCheckProof (verifier/verifier.go:84-141): RangeCheck / RangeCheckQE of every proof element except the public inputs, in the order
@@ -64,52 +77,60 @@ void gpvk_witness_range_check(hipStream_t st, const DevCircuit* dcd, const u64* 
 // words the lane wrote (checked on the host against the layout).
 __global__ __launch_bounds__(64) void k_witness_fri(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ challenges,
                                                     size_t n, u64* __restrict__ trace, size_t words_per_proof, size_t prefix_words, size_t round_words,
-                                                    uint8_t* __restrict__ consistent, u64* __restrict__ written) {
+                                                    uint8_t* __restrict__ consistent, u64* __restrict__ written, int staged) {
+  extern __shared__ u64 wt_lds[];
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 nq = dc->num_queries;
-  if (item >= n * nq) return;
-  const size_t p = item / nq;
-  const u32 q = (u32)(item - p * nq);
+  const bool live = item < n * nq;
+  if (!live) item = n * nq - 1;  // stays for the wave's write-out; repeats the last item, reports nothing
+  // round-major: a wave holds the same query round of 64 proofs (the lanes of round 0 all carry the prefix; no wave waits for one lane)
+  const u32 q = (u32)(item / n);
+  const size_t p = item - (size_t)q * n;
   size_t wrote = 0;
   const bool ok = dev_witness_fri(dc, proofs + p * (dc->proof_nbytes / 8), challenges + p * dc->n_challenge_words, q, trace + p * words_per_proof,
-                                  prefix_words, round_words, &wrote);
-  written[item] = wrote;
+                                  prefix_words, round_words, &wrote, staged ? wt_lds : nullptr);
+  if (!live) return;
+  written[p * nq + q] = wrote;
   if (!ok) consistent[p] = 0;
 }
 void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
                       size_t words_per_proof, size_t prefix_words, size_t round_words, uint8_t* consistent, u64* written) {
-  GPVK_LAUNCH(k_witness_fri, dim3(gpvk_blocks_for(n * hc.num_queries, 64)), dim3(64), 0, st, dcd, proofs, challenges, n, trace, words_per_proof,
-              prefix_words, round_words, consistent, written);
+  const bool staged = gpvk_witness_staged(n * hc.num_queries, 2);
+  GPVK_LAUNCH(k_witness_fri, dim3(gpvk_blocks_for(n * hc.num_queries, 64)), dim3(64), staged ? GPV_WT_LDS_WORDS * 8 : 0, st, dcd, proofs, challenges, n, trace,
+              words_per_proof, prefix_words, round_words, consistent, written, staged ? 1 : 0);
 }
 
 // Witness slice 3: PlonkChip.Verify in three phases (gpv_witness.cuh). written[p] += every lane's word count (the host compares the sum
 // with the layout); consistent[p] is cleared by the lane that sees the assertion of plonk.go:248 (or evalL0's, :75-80) fail.
 __global__ __launch_bounds__(64) void k_witness_plonk_units(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ challenges,
                                                             size_t n, u64* __restrict__ trace, size_t words_per_proof, const u64* __restrict__ tab,
-                                                            u64* __restrict__ ws, size_t ws_words, unsigned long long* __restrict__ written) {
+                                                            u64* __restrict__ ws, size_t ws_words, unsigned long long* __restrict__ written, int staged) {
+  extern __shared__ u64 wt_lds[];
   const u32 units = dc->n_gates + 1;  // one lane per gate + the lane of what does not depend on the gates
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= n * units) return;
+  const bool live = item < n * units;
+  if (!live) item = n * units - 1;  // stays for the wave's write-out; repeats the last item, reports nothing
   // unit-major: the 64 lanes of a wave work on the SAME unit of 64 proofs (proof-major order put 14 different gates in one wave, which
   // then executed every gate's code one after the other: 4.7 ms instead of 2.x for 256 proofs)
   const u32 u = (u32)(item / n);
   const size_t p = item - (size_t)u * n;
   const u64* rec = proofs + p * (dc->proof_nbytes / 8);
   WPlonkTab t{tab, dc->n_gates};
-  const size_t wrote = u < dc->n_gates ? dev_witness_plonk_gate(dc, rec, u, trace + p * words_per_proof, t, ws + p * ws_words)
-                                       : dev_witness_plonk_perm(dc, rec, challenges + p * dc->n_challenge_words, trace + p * words_per_proof, t, ws + p * ws_words);
-  atomicAdd(&written[p], (unsigned long long)wrote);
+  const size_t wrote = u < dc->n_gates ? dev_witness_plonk_gate(dc, rec, u, trace + p * words_per_proof, t, ws + p * ws_words, staged ? wt_lds : nullptr)
+                                       : dev_witness_plonk_perm(dc, rec, challenges + p * dc->n_challenge_words, trace + p * words_per_proof, t, ws + p * ws_words, staged ? wt_lds : nullptr);
+  if (live) atomicAdd(&written[p], (unsigned long long)wrote);
 }
 __global__ __launch_bounds__(64) void k_witness_plonk_acc(const DevCircuit* __restrict__ dc, size_t n, u64* __restrict__ trace, size_t words_per_proof,
                                                           const u64* __restrict__ tab, u64* __restrict__ ws, size_t ws_words,
                                                           unsigned long long* __restrict__ written) {
   const u32 ngc = dc->num_gate_constraints;
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= n * ngc) return;
+  const bool live = item < n * ngc;
+  if (!live) item = n * ngc - 1;
   const size_t p = item / ngc;
   WPlonkTab t{tab, dc->n_gates};
-  const size_t wrote = dev_witness_plonk_acc(dc, (u32)(item - p * ngc), trace + p * words_per_proof, t, ws + p * ws_words);
-  atomicAdd(&written[p], (unsigned long long)wrote);
+  const size_t wrote = dev_witness_plonk_acc(dc, (u32)(item - p * ngc), trace + p * words_per_proof, t, ws + p * ws_words, nullptr);
+  if (live) atomicAdd(&written[p], (unsigned long long)wrote);
 }
 __global__ __launch_bounds__(64) void k_witness_plonk_reduce(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ challenges,
                                                              size_t n, u64* __restrict__ trace, size_t words_per_proof, const u64* __restrict__ tab,
@@ -117,12 +138,14 @@ __global__ __launch_bounds__(64) void k_witness_plonk_reduce(const DevCircuit* _
                                                              unsigned long long* __restrict__ written) {
   const u32 nc = dc->num_challenges;
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= n * nc) return;
+  const bool live = item < n * nc;
+  if (!live) item = n * nc - 1;
   const size_t p = item / nc;
   WPlonkTab t{tab, dc->n_gates};
   bool ok = true;
   const size_t wrote = dev_witness_plonk_reduce(dc, proofs + p * (dc->proof_nbytes / 8), challenges + p * dc->n_challenge_words, (u32)(item - p * nc),
-                                                trace + p * words_per_proof, t, ws + p * ws_words, &ok);
+                                                trace + p * words_per_proof, t, ws + p * ws_words, &ok, nullptr);
+  if (!live) return;
   atomicAdd(&written[p], (unsigned long long)wrote);
   {  // evalL0 divides by n (zeta - 1) (plonk.go:63-83): zero iff zeta = 1 -- InverseExtension's "operand != 0" / hasQuotient == 1 (:75-80)
     const u64* ch = challenges + p * dc->n_challenge_words;
@@ -134,8 +157,9 @@ __global__ __launch_bounds__(64) void k_witness_plonk_reduce(const DevCircuit* _
 void gpvk_witness_plonk(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
                         size_t words_per_proof, const u64* tab, u64* ws, size_t ws_words, uint8_t* consistent, u64* written) {
   unsigned long long* wr = (unsigned long long*)written;
-  GPVK_LAUNCH(k_witness_plonk_units, dim3(gpvk_blocks_for(n * (hc.n_gates + 1), 64)), dim3(64), 0, st, dcd, proofs, challenges, n, trace, words_per_proof, tab,
-              ws, ws_words, wr);
+  const bool staged = gpvk_witness_staged(n * (hc.n_gates + 1), 3);
+  GPVK_LAUNCH(k_witness_plonk_units, dim3(gpvk_blocks_for(n * (hc.n_gates + 1), 64)), dim3(64), staged ? GPV_WT_LDS_WORDS * 8 : 0, st, dcd, proofs, challenges, n, trace,
+              words_per_proof, tab, ws, ws_words, wr, staged ? 1 : 0);
   GPVK_LAUNCH(k_witness_plonk_acc, dim3(gpvk_blocks_for(n * hc.num_gate_constraints, 64)), dim3(64), 0, st, dcd, n, trace, words_per_proof, tab, ws, ws_words, wr);
   GPVK_LAUNCH(k_witness_plonk_reduce, dim3(gpvk_blocks_for(n * hc.num_challenges, 64)), dim3(64), 0, st, dcd, proofs, challenges, n, trace, words_per_proof, tab,
               ws, ws_words, consistent, wr);

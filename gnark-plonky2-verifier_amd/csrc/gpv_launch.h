@@ -70,30 +70,34 @@ unsigned gpvk_fault_blocks(int stage, unsigned blocks);
 __device__ __forceinline__ void gpvk_side_stream_priority() { __builtin_amdgcn_s_setprio(3); }
 #endif
 
-// Which evaluation order of the BN254 Fr rows a launch of `lanes` hashing lanes gets (gpv_fr.cuh: FrChain / FrWide / the four-lane form).
-// The rule is stated in OCCUPANCY of the device the launch goes to (round 4) -- waves the launch puts
-// on every SIMD, w = lanes / (64 x SIMDs), SIMDs = 4 x hipDeviceAttributeMultiprocessorCount of the current device -- so that a
-// partitioned or smaller device (CPX / a 64-CU partition, another SKU) picks by ITS size, not by the lane counts that happened to be
-// the crossovers of a whole MI355X:
-//   column scanning (FrChain) needs four resident waves per SIMD to hide its serial chain and wins from about three chip fills on:
-//       w >= GPV_FR_CHAIN_MIN_WAVES_PER_SIMD = 12          (on 1024 SIMDs: 786 432 lanes = the 3 * 2^18 of rounds 2 - 3)
-//   four lanes per permutation (gpv_poseidon_quad.cuh) pays while the quads leave the SIMDs with fewer than three waves each:
-//       4 w <= GPV_FR_QUAD_MAX_WAVES_PER_SIMD_X4 / 4 = 2.75   (on 1024 SIMDs: 45 056 paths = the 44 * 2^10 of round 3)
-//   operand scanning (FrWide) in between.
-// Measured on the step fixture (168 lanes per proof), ms per batch, column / operand scanning: 21.6 / 20.4 at 2048 proofs, 30.0 / 29.0 at
-// 3072, 37.3 / 36.7 at 4096, 45.2 / 45.5 at 5120, 69.1 / 71.5 at 8192, 136.3 / 142.0 at 16384 (profiles/r02l_batch_sweep.txt); one lane
-// per permutation / four, whole verification: 1 proof 8.75 / 3.99, 32: 7.42 / 4.34, 96: 7.88 / 5.01, 192: 8.06 / 6.63, 256: 8.15 / 7.54,
-// 384: 8.33 / 10.10 (profiles/r03_latency_breakdown.txt). A second geometry (12 trees, 4-word step leaves): profiles/r04_form_crossover.txt.
-#define GPV_FR_CHAIN_MIN_WAVES_PER_SIMD 12
-#define GPV_FR_QUAD_MAX_WAVES_PER_SIMD_X4 11  // 2.75 waves per SIMD, in quarters
+// Which evaluation order of the BN254 Fr rows a launch gets (gpv_fr.cuh: FrChain / FrWide / the four-lane form of gpv_poseidon_quad.cuh).
+// The rule is stated in OCCUPANCY of the device the launch goes to (round 4): w = full-length lanes /
+// (64 x SIMDs), SIMDs = 4 x hipDeviceAttributeMultiprocessorCount of the current device -- so that a partitioned or smaller device picks
+// by ITS size -- and in FULL-LENGTH lanes, so that another circuit geometry picks by its critical chains, not by how many short lanes
+// ride along: a Merkle launch counts the four initial-tree paths of every query round (every plonky2 proof has exactly those four
+// oracles, and their paths have the full length; the step trees' paths are shorter and their leaves smaller), a primitive launch counts
+// its items. Round 3's rule counted all lanes: right for `step` (6 trees), a factor 2 off for a geometry with 12 trees per query
+// (profiles/r04_form_crossover.txt, first table; the second table is this rule).
+//   four lanes per permutation   w <= 0.5   (the quads then put two waves on a SIMD; `step`, `decode_block` and the 12-tree geometry all
+//                                            cross over between 256 and 320 proofs = 0.44 .. 0.55)
+//   column scanning (FrChain)    w >= 4.5   (it needs four resident waves per SIMD to hide its serial chain; measured crossovers 2048 .. 3072
+//                                            proofs on both geometries = 3.5 .. 5.25; round 3 switched at 8.0, i.e. 4681 `step` proofs,
+//                                            which left 0.7 - 1.6 % at 3072 - 4096 proofs)
+//   operand scanning (FrWide)    in between.
+// The shared-level kernels (one hash per lane over a compacted node list) keep the threshold measured for them in round 2: 12 waves per SIMD.
+#define GPV_FR_CHAIN_MIN_WAVES_X2 9         // 4.5 waves per SIMD, in halves
+#define GPV_FR_QUAD_MAX_WAVES_X2 1          // 0.5
+#define GPV_FR_CHAIN_MIN_WAVES_X2_NODES 24  // k_crown_level: 12
 unsigned gpvk_device_simds();  // SIMDs of the CURRENT device (gpv_api.cpp; cached per device ordinal)
 // form: GPV_OPT_FR_EVALUATION -- 0 by occupancy, 1 column scanning, 2 operand scanning, 3 four lanes per permutation
-static inline bool gpvk_fr_chain_pays(size_t lanes, int form) {
-  return form == 1 || (form == 0 && lanes >= (size_t)GPV_FR_CHAIN_MIN_WAVES_PER_SIMD * 64 * gpvk_device_simds());
+static inline bool gpvk_fr_chain_pays(size_t full_lanes, int form, unsigned min_waves_x2 = GPV_FR_CHAIN_MIN_WAVES_X2) {
+  return form == 1 || (form == 0 && 2 * full_lanes >= (size_t)min_waves_x2 * 64 * gpvk_device_simds());
 }
-static inline bool gpvk_fr_quad_pays(size_t lanes, int form) {
-  return form == 3 || (form == 0 && 4 * 4 * lanes <= (size_t)GPV_FR_QUAD_MAX_WAVES_PER_SIMD_X4 * 64 * gpvk_device_simds());
+static inline bool gpvk_fr_quad_pays(size_t full_lanes, int form) {
+  return form == 3 || (form == 0 && 2 * full_lanes <= (size_t)GPV_FR_QUAD_MAX_WAVES_X2 * 64 * gpvk_device_simds());
 }
+// full-length Merkle paths of a launch over `items` = proofs x query rounds
+static inline size_t gpvk_full_paths(const DevCircuit& hc, size_t items) { return items * (hc.n_trees < 4 ? hc.n_trees : 4); }
 
 // gpv_k_prim.hip
 void gpvk_gl_op(hipStream_t st, int op, const u64* a, const u64* b, const u64* c, u64* out, size_t n);

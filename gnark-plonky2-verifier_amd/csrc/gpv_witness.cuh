@@ -56,24 +56,143 @@ GPV_DEV WBig wb_mul(const WBig& a, u64 m) {
   return r;
 }
 
+// ---------------------------------------------------------------- the trace cursor: output staged through LDS (round 4)
+// Every lane writes its own output stream (a permutation's records, a query round, a gate): hundreds of thousands of concurrent streams,
+// each advancing 16 bytes between long stretches of arithmetic. Written straight to HBM that pattern sustains 1.2 TB/s and more than
+// doubles the kernels' time (tools/stream_write_probe.py reproduces it without the arithmetic: +7.9 ms on the 23 GB of slice 1, against
+// +0.7 ms when eight lanes write one 128-byte line per store instruction; profiles/r04_stream_write_probe.txt). So a lane's words go to
+// an LDS ring first -- 32 rows of 64 words, the row of a word is its GLOBAL word index mod 32, so a 128-byte line of the stream is 16
+// consecutive rows wherever the stream starts (wt_index: which column) -- and the WAVE moves complete lines out together: per flush event eight store instructions, in each of which eight adjacent
+// lanes write one whole line of one stream (16 bytes each). An event fires when some lane's ring is about to overflow; every lane that
+// holds a complete aligned line takes part with it (lanes in lockstep: all of them, 7 events out of 8). A stream's unaligned head (after
+// a seek), its tail, and everything written while the wave is diverged go out lane by lane, as before.
+typedef __attribute__((address_space(3))) u64 wt_lds_u64;
+typedef __attribute__((address_space(1))) u64 wt_glb_u64;
+#define GPV_WT_SLOTS 32
+#define GPV_WT_LDS_WORDS (GPV_WT_SLOTS * 64)
+// A WTrace crosses every out-of-line call BY VALUE (f_call(WTrace t, ...) returns the updated cursor next to its result; the f(WTrace&, ...)
+// wrappers keep the call sites as they were): by reference it lived in scratch behind a generic pointer, and every emit paid a
+// flat load / wait / flat store round trip on its dependent path.
 struct WTrace {
-  u64* p;  // write cursor into this proof's trace
+  wt_glb_u64* p;     // next word of this lane's stream
+  wt_lds_u64* ring;  // the wave's ring
+  u32 nu;            // staged words: the ring holds [p - nu, p)
+  u32 lane;          // | GPV_WT_STAGED
 };
+#define GPV_WT_STAGED 0x100u
+// Where the word with global address q of lane `lane`'s stream sits in the ring: row = its word index mod 32, column = the lane rotated by
+// 8 per PAIR of rows. A lane's writes then stay in a bank of their own unless two lanes 8 apart sit 2 rows apart (the first layout, a
+// column per lane with padded rows, put lanes whose streams start 7 words apart -- proofs are 1 349 735 words apart -- into 4 banks:
+// 16-way conflicts on every write, 4 x the latency of the long units), and the eight lanes that read one line of one stream in a flush
+// (rows s .. s + 15, two each) read eight different columns.
+GPV_DEV u32 wt_index(const wt_glb_u64* q, u32 lane) {
+  const u32 g = (u32)((size_t)q >> 3);
+  return ((g & 31u) << 6) | ((lane + ((g & 30u) << 2)) & 63u);
+}
+// every staged word of this lane, 8 bytes at a time
+GPV_DEV void wt_drain(WTrace& t) {
+  wt_glb_u64* q = t.p - t.nu;
+#pragma unroll 1
+  for (; q != t.p; q++) *q = t.ring[wt_index(q, t.lane)];
+  t.nu = 0;
+}
+GPV_DEV void wt_flush_event_body(WTrace& t) {
+  if (__builtin_amdgcn_read_exec() != ~0ull) {  // diverged: no wave to share the work with
+    wt_drain(t);
+    return;
+  }
+  const u32 lane = t.lane & 63u;
+  wt_glb_u64* f = t.p - t.nu;
+  const u32 mis = (u32)((size_t)f >> 3) & 15;
+  if (mis) {  // the head of a stream up to its first line boundary
+    u32 head = 16 - mis;
+    if (head > t.nu) head = t.nu;
+#pragma unroll 1
+    for (u32 i = 0; i < head; i++, f++) *f = t.ring[wt_index(f, lane)];
+    t.nu -= head;
+  }
+  const bool has = t.nu >= 16;  // then f is line-aligned
+  // Three phases, each issued whole before its results are awaited (an event is on the dependent path of a lane's chain: at one wave per
+  // SIMD eight dependent read - read - store rounds cost 1 600 cycles per 16 words and tripled the latency of the long units):
+  // (1) every lane fetches the flush pointers of the eight streams it serves (ds_bpermute: no table, no write-then-read round trip),
+  // (2) the 16 ring reads, (3) the eight 16-byte stores -- eight adjacent lanes = one 128-byte line.
+  const u64 mine = (u64)(size_t)f | (has ? 1u : 0u);
+  const u32 c = lane & 7;
+  u64 e[8];
+#pragma unroll
+  for (u32 k = 0; k < 8; k++) {
+    const int j = (int)(8 * k + (lane >> 3));
+    const u32 lo = (u32)__shfl((int)(u32)mine, j, 64), hi = (u32)__shfl((int)(u32)(mine >> 32), j, 64);
+    e[k] = (u64)hi << 32 | lo;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // also: this wave's ring writes have left the LDS queue (in-order LDS)
+  u64 v0[8], v1[8];
+#pragma unroll
+  for (u32 k = 0; k < 8; k++) {
+    const u32 j = 8 * k + (lane >> 3);
+    const wt_glb_u64* src = (const wt_glb_u64*)(size_t)(e[k] & ~(u64)7) + 2 * c;
+    const u32 at = wt_index(src, j);  // an even row (16-byte aligned word pair), and row + 1 has the same column; a stream without a line: some valid ring address
+    v0[k] = t.ring[at];
+    v1[k] = t.ring[at + 64];
+  }
+#pragma unroll
+  for (u32 k = 0; k < 8; k++) {
+    if (e[k] & 1) {
+      typedef u64 __attribute__((ext_vector_type(2))) u64x2;
+      u64x2 v = {v0[k], v1[k]};
+      *(__attribute__((address_space(1))) u64x2*)((wt_glb_u64*)(size_t)(e[k] & ~(u64)7) + 2 * c) = v;  // global_store_dwordx4
+    }
+  }
+  asm volatile("" ::: "memory");  // the ring reads above stay ahead of the writes that follow (in-order LDS)
+  if (has) t.nu -= 16;
+}
+__device__ __noinline__ WTrace wt_flush_event_call(WTrace t) {
+  wt_flush_event_body(t);
+  return t;
+}
+GPV_DEV void wt_flush_event(WTrace& t) { t = wt_flush_event_call(t); }
+// Append the K <= 8 words of one hint record group. Staged: make room (a flush event if some lane's ring would overflow), then K LDS writes.
+// UNSTAGED (chosen per launch, wave-uniform): straight to the stream, as in round 3 -- one branch per group, so that adjacent stores still
+// merge. For launches too small to hide a flush event behind other waves (an event costs a lane's chain two LDS round trips plus, being
+// out of line, the wait for its own stores at the return) and for kernels whose long pole is one lane's latency.
+template <int K>
+GPV_DEV void wt_emit(WTrace& t, const u64 (&v)[K]) {
+  if (t.lane & GPV_WT_STAGED) {  // (not "ring != null": the ring starts at LDS offset 0)
+    if (__builtin_amdgcn_ballot_w64(t.nu + K > GPV_WT_SLOTS) != 0) wt_flush_event(t);
+#pragma unroll
+    for (int i = 0; i < K; i++) t.ring[wt_index(t.p + i, t.lane)] = v[i];
+    t.nu += K;
+  } else {
+#pragma unroll
+    for (int i = 0; i < K; i++) t.p[i] = v[i];
+  }
+  t.p += K;
+}
+// lds: the block's GPV_WT_LDS_WORDS words (one wave per block), or null = unstaged
+GPV_DEV WTrace wt_open(u64* lds, u64* at) {
+  WTrace t;
+  t.p = (wt_glb_u64*)at;
+  t.ring = (wt_lds_u64*)lds;
+  t.lane = __lane_id() | (lds ? GPV_WT_STAGED : 0u);
+  t.nu = 0;
+  return t;
+}
+GPV_DEV void wt_seek(WTrace& t, u64* at) {
+  wt_drain(t);
+  t.p = (wt_glb_u64*)at;
+}
+GPV_DEV size_t wt_words_since(const WTrace& t, const u64* start) { return (size_t)((const u64*)t.p - start); }
 GPV_DEV void wt_range_check(WTrace& t, u64 x) {  // base.go:362-400 -> SplitLimbsHint :339-359
-  t.p[0] = x >> 32;
-  t.p[1] = x & 0xFFFFFFFFu;
-  t.p += 2;
+  const u64 v[2] = {x >> 32, x & 0xFFFFFFFFu};
+  wt_emit(t, v);
 }
 GPV_DEV u64 wt_mul_add(WTrace& t, u64 a, u64 b, u64 c) {  // base.go:196-213 -> MulAddHint :223-243
   u64 lo = a * b, hi = __umul64hi(a, b);
   u64 s = lo + c;
   hi += s < lo;
   u64 q, r = gl_divmod128(s, hi, &q);  // operands < p: the quotient fits a word
-  t.p[0] = q;
-  t.p[1] = r;
-  t.p += 2;
-  wt_range_check(t, q);
-  wt_range_check(t, r);
+  const u64 v[6] = {q, r, q >> 32, q & 0xFFFFFFFFu, r >> 32, r & 0xFFFFFFFFu};  // MulAdd, then RangeCheck(quotient), RangeCheck(remainder)
+  wt_emit(t, v);
   return r;
 }
 GPV_DEV u64 wt_add(WTrace& t, u64 a, u64 b) { return wt_mul_add(t, a, 1, b); }  // base.go:162-164
@@ -81,11 +200,8 @@ GPV_DEV u64 wt_reduce(WTrace& t, const WBig& x) {  // base.go:246-281 -> ReduceH
   u64 rem = 0, q[4];
 #pragma unroll
   for (int k = 3; k >= 0; k--) rem = gl_divmod128(x.w[k], rem, &q[k]);  // schoolbook, top word first; rem < p keeps every digit in a word
-#pragma unroll
-  for (int k = 0; k < 4; k++) t.p[k] = q[k];
-  t.p[4] = rem;
-  t.p += 5;
-  wt_range_check(t, rem);
+  const u64 v[7] = {q[0], q[1], q[2], q[3], rem, rem >> 32, rem & 0xFFFFFFFFu};  // Reduce, then RangeCheck(remainder)
+  wt_emit(t, v);
   return rem;
 }
 
@@ -96,7 +212,7 @@ GPV_DEV u64 wt_sbox_monomial(WTrace& t, u64 x) {  // :138-145
   WBig x6 = wb_mul(wb_from(x3), x3);
   return wt_reduce(t, wb_mul(x6, x));
 }
-__device__ __noinline__ void wt_full_rounds(WTrace& t, u64* s, int round0) {  // :92-100
+GPV_DEV void wt_full_rounds_body(WTrace& t, u64* s, int round0) {  // :92-100
   const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};  // MDS_MATRIX_CIRC; MDS_MATRIX_DIAG = [8, 0, ...]
 #pragma unroll 1
   for (int rd = 0; rd < 4; rd++) {
@@ -117,7 +233,12 @@ __device__ __noinline__ void wt_full_rounds(WTrace& t, u64* s, int round0) {  //
     for (int i = 0; i < 12; i++) s[i] = r[i];
   }
 }
-__device__ __noinline__ void wt_partial_rounds(WTrace& t, u64* s) {  // :102-115
+__device__ __noinline__ WTrace wt_full_rounds_call(WTrace t, u64* s, int round0) {
+  wt_full_rounds_body(t, s, round0);
+  return t;
+}
+GPV_DEV void wt_full_rounds(WTrace& t, u64* s, int round0) { t = wt_full_rounds_call(t, s, round0); }
+GPV_DEV void wt_partial_rounds_body(WTrace& t, u64* s) {  // :102-115
 #pragma unroll 1
   for (int i = 0; i < 12; i++) s[i] = wt_add(t, s[i], PGL_FIRST[i]);  // partialFirstConstantLayer :231-238
   {                                                                   // mdsPartialLayerInit :251-275
@@ -155,6 +276,11 @@ __device__ __noinline__ void wt_partial_rounds(WTrace& t, u64* s) {  // :102-115
     for (int i = 0; i < 12; i++) s[i] = r[i];
   }
 }
+__device__ __noinline__ WTrace wt_partial_rounds_call(WTrace t, u64* s) {
+  wt_partial_rounds_body(t, s);
+  return t;
+}
+GPV_DEV void wt_partial_rounds(WTrace& t, u64* s) { t = wt_partial_rounds_call(t, s); }
 GPV_DEV void wt_poseidon(WTrace& t, u64* s) {  // :30-37
   wt_full_rounds(t, s, 0);
   wt_partial_rounds(t, s);
@@ -292,23 +418,24 @@ GPV_DEV u32 dev_witness_challenges_log_coop(const DevCircuit* __restrict__ dc, c
 // Pass 2, one (proof, segment) lane: the segment's Reduce records and literal permutation at `seg_off`, plus this lane's share of the
 // public inputs' Reduce records (one per input, 7 words each, at the head of the trace). Returns the words the segment took.
 GPV_DEV size_t dev_witness_challenges_fill(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ entry,
-                                           u64* __restrict__ trace, size_t seg_off, u32 seg, u32 n_segments) {
+                                           u64* __restrict__ trace, size_t seg_off, u32 seg, u32 n_segments, u64* lds) {
+  WTrace t = wt_open(lds, trace);
   {
     const u64* pi = rec + dc->off_pi;
     for (u32 i = seg; i < dc->num_pi; i += n_segments) {
-      WTrace t;
-      t.p = trace + (size_t)7 * i;
+      wt_seek(t, trace + (size_t)7 * i);
       wt_reduce(t, wb_from(pi[i]));
     }
   }
-  WTrace t;
-  t.p = trace + seg_off;
+  wt_seek(t, trace + seg_off);
   const u32 n_red = (u32)entry[0];
   for (u32 i = 0; i < n_red; i++) wt_reduce(t, wb_from(entry[1 + i]));
   u64 s[12];
   for (int i = 0; i < 12; i++) s[i] = entry[9 + i];
   wt_poseidon(t, s);
-  return (size_t)(t.p - (trace + seg_off));
+  const size_t wrote = wt_words_since(t, trace + seg_off);
+  wt_drain(t);
+  return wrote;
 }
 
 // ================================================================ slice 2: fri.Chip.GetInstance + VerifyFriProof (fri/fri.go:40-61, :500-548)
@@ -332,9 +459,8 @@ GPV_DEV u64 wt_mul(WTrace& t, u64 a, u64 b) { return wt_mul_add(t, a, b, 0); }  
 GPV_DEV u64 wt_sub(WTrace& t, u64 a, u64 b) { return wt_mul_add(t, b, GLP - 1, a); }      // base.go:174
 GPV_DEV u64 wt_inverse(WTrace& t, u64 x) {                                               // base.go:297-313 -> InverseHint :316-336
   u64 inv = gl_inv(x);
-  t.p[0] = inv;
-  t.p += 1;
-  wt_range_check(t, inv);
+  const u64 v[3] = {inv, inv >> 32, inv & 0xFFFFFFFFu};  // Inverse, then RangeCheck(inverse)
+  wt_emit(t, v);
   wt_mul(t, inv, x);
   return inv;
 }
@@ -365,10 +491,25 @@ GPV_DEV Ext wt_sub_mul_ext(WTrace& t, Ext a, Ext b, Ext c) {                    
   return wt_reduce_ext(t, wt_mul_ext_nr_add(wt_sub_ext_nr(wbe_from(a), b), c, ext_make(0, 0)));
 }
 GPV_DEV Ext wt_scalar_mul_ext(WTrace& t, Ext a, u64 b) { u64 c0 = wt_mul(t, a.a, b); u64 c1 = wt_mul(t, a.b, b); return ext_make(c0, c1); }      // :96-104
-__device__ __noinline__ Ext wt_inverse_ext(WTrace& t, Ext a) {  // :123-134
+GPV_DEV Ext wt_inverse_ext_body(WTrace& t, Ext a) {  // :123-134
   Ext f = ext_make(a.a, wt_mul(t, a.b, GLP - 1));               // DTH_ROOT = p - 1
   Ext n = wt_mul_ext(t, f, a);
   return wt_scalar_mul_ext(t, f, wt_inverse(t, n.a));
+}
+struct wt_inverse_ext_ret {
+  Ext v;
+  WTrace t;
+};
+__device__ __noinline__ wt_inverse_ext_ret wt_inverse_ext_call(WTrace t, Ext a) {
+  wt_inverse_ext_ret r;
+  r.v = wt_inverse_ext_body(t, a);
+  r.t = t;
+  return r;
+}
+GPV_DEV Ext wt_inverse_ext(WTrace& t, Ext a) {
+  wt_inverse_ext_ret r = wt_inverse_ext_call(t, a);
+  t = r.t;
+  return r.v;
 }
 GPV_DEV Ext wt_div_ext(WTrace& t, Ext a, Ext b) { Ext bi = wt_inverse_ext(t, b); return wt_mul_ext(t, a, bi); }  // :137-140
 GPV_DEV Ext wt_exp_ext(WTrace& t, Ext a, u64 e) {  // :143-171
@@ -401,7 +542,7 @@ GPV_DEV u64 wt_exp_from_bits_const_base(WTrace& t, u64 base, u32 bits, u32 n_bit
 // *ok is cleared when beta is one of the coset points: DivExtension -> InverseExtension asserts "operand != 0" (quadratic_extension.go:124-125).
 // The hints run regardless (InverseHint of 0 is 0), and the value handed on is then the y of the matching point, not the interpolation
 // (lookupFromPoints = 0 -> Lookup returns lookupVal, fri.go:299-311).
-__device__ __noinline__ Ext wt_compute_evaluation(WTrace& t, u64 x, u32 idx_in, u32 ab, const u64* __restrict__ evals, Ext beta, bool* ok) {
+GPV_DEV Ext wt_compute_evaluation_body(WTrace& t, u64 x, u32 idx_in, u32 ab, const u64* __restrict__ evals, Ext beta, bool* ok) {
   const u32 A = 1u << ab;
   u64 g = 1753635133440165772ULL;
 #pragma unroll 1
@@ -454,6 +595,21 @@ __device__ __noinline__ Ext wt_compute_evaluation(WTrace& t, u64 x, u32 idx_in, 
   }
   return interpolation;
 }
+struct wt_compute_evaluation_ret {
+  Ext v;
+  WTrace t;
+};
+__device__ __noinline__ wt_compute_evaluation_ret wt_compute_evaluation_call(WTrace t, u64 x, u32 idx_in, u32 ab, const u64* __restrict__ evals, Ext beta, bool* ok) {
+  wt_compute_evaluation_ret r;
+  r.v = wt_compute_evaluation_body(t, x, idx_in, ab, evals, beta, ok);
+  r.t = t;
+  return r;
+}
+GPV_DEV Ext wt_compute_evaluation(WTrace& t, u64 x, u32 idx_in, u32 ab, const u64* __restrict__ evals, Ext beta, bool* ok) {
+  wt_compute_evaluation_ret r = wt_compute_evaluation_call(t, x, idx_in, ab, evals, beta, ok);
+  t = r.t;
+  return r.v;
+}
 // ReduceWithPowers (:177-193) over extension elements stored as consecutive words, from the last one down
 GPV_DEV Ext wt_reduce_with_powers_words(WTrace& t, const u64* __restrict__ lo, const u64* __restrict__ hi, Ext acc, Ext s) {
 #pragma unroll 1
@@ -464,19 +620,18 @@ GPV_DEV Ext wt_reduce_with_powers_words(WTrace& t, const u64* __restrict__ lo, c
 // by the lane of query 0; round_words: length of one query round. Returns false when one of the reference's FRI consistency assertions
 // (:460-461, :496-497) fails -- the trace is what the solver would be handed either way.
 GPV_DEV bool dev_witness_fri(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch, u32 q,
-                             u64* __restrict__ trace, size_t prefix_words, size_t round_words, size_t* written) {
+                             u64* __restrict__ trace, size_t prefix_words, size_t round_words, size_t* written, u64* lds) {
   const Ext zeta = ext_make(ch[dc->ch_zeta], ch[dc->ch_zeta + 1]), alpha = ext_make(ch[dc->ch_fri_alpha], ch[dc->ch_fri_alpha + 1]);
   const OpeningRanges orr = opening_ranges(dc);
   Ext points[2], precomputed[2];
   size_t wrote = 0;
+  WTrace t = wt_open(lds, trace);
   if (q == 0) {  // GetInstance fri.go:46-50, then fromOpeningsAndAlpha :82-95: the zeta batch, then the zeta*g batch
-    WTrace t;
-    t.p = trace;
     points[1] = wt_mul_ext(t, ext_make(dc->root_degree, 0), zeta);
     Ext acc = wt_reduce_with_powers_words(t, rec + orr.b0, rec + orr.b1, ext_make(0, 0), alpha);
     precomputed[0] = wt_reduce_with_powers_words(t, rec + orr.a0, rec + orr.a1, acc, alpha);
     precomputed[1] = wt_reduce_with_powers_words(t, rec + orr.c0, rec + orr.c1, ext_make(0, 0), alpha);
-    wrote = (size_t)(t.p - trace);
+    wrote = wt_words_since(t, trace);
   } else {  // the same values without a trace
     points[1] = ext_scalar_mul(zeta, dc->root_degree);
     Ext acc = ext_make(0, 0);
@@ -488,9 +643,8 @@ GPV_DEV bool dev_witness_fri(const DevCircuit* __restrict__ dc, const u64* __res
     precomputed[1] = acc;
   }
   points[0] = zeta;
-  WTrace t;
-  t.p = trace + prefix_words + (size_t)q * round_words;
-  u64* const round_start = t.p;
+  u64* const round_start = trace + prefix_words + (size_t)q * round_words;
+  wt_seek(t, round_start);
   bool ok = true;
   const u64* qrec = rec + dc->off_queries + (size_t)q * dc->query_words;
   const u32 nlog = dc->lde_bits;
@@ -542,7 +696,8 @@ GPV_DEV bool dev_witness_fri(const DevCircuit* __restrict__ dc, const u64* __res
 #pragma unroll 1
   for (u32 i = dc->final_len; i-- > 0;) fin = wt_mul_add_ext(t, wbe_from(fin), ext_make(x, 0), ext_make(rec[dc->off_final + 2 * i], rec[dc->off_final + 2 * i + 1]));
   ok &= fin.a == old_eval.a && fin.b == old_eval.b;  // :496-497
-  *written = wrote + (size_t)(t.p - round_start);
+  *written = wrote + wt_words_since(t, round_start);
+  wt_drain(t);
   return ok;
 }
 
@@ -562,7 +717,7 @@ struct WPairs {
   Ext a[2], b[2];
 };
 // InnerProductExtension (quadratic_extension.go:107-120): per pair ScalarMulExtension(a, constant) then a lazy multiply-add; one ReduceExtension
-__device__ __noinline__ Ext wt_inner_product_ext(WTrace& t, u64 constant, Ext acc0, const WPairs& pr, int n) {
+GPV_DEV Ext wt_inner_product_ext_body(WTrace& t, u64 constant, Ext acc0, const WPairs& pr, int n) {
   WBigExt acc = wbe_from(acc0);
 #pragma unroll 1
   for (int i = 0; i < n; i++) {
@@ -575,9 +730,24 @@ __device__ __noinline__ Ext wt_inner_product_ext(WTrace& t, u64 constant, Ext ac
   }
   return wt_reduce_ext(t, acc);
 }
+struct wt_inner_product_ext_ret {
+  Ext v;
+  WTrace t;
+};
+__device__ __noinline__ wt_inner_product_ext_ret wt_inner_product_ext_call(WTrace t, u64 constant, Ext acc0, const WPairs& pr, int n) {
+  wt_inner_product_ext_ret r;
+  r.v = wt_inner_product_ext_body(t, constant, acc0, pr, n);
+  r.t = t;
+  return r;
+}
+GPV_DEV Ext wt_inner_product_ext(WTrace& t, u64 constant, Ext acc0, const WPairs& pr, int n) {
+  wt_inner_product_ext_ret r = wt_inner_product_ext_call(t, constant, acc0, pr, n);
+  t = r.t;
+  return r.v;
+}
 GPV_DEV ExtAlg wt_add_alg(WTrace& t, ExtAlg a, ExtAlg b) { Ext c0 = wt_add_ext(t, a.a, b.a); Ext c1 = wt_add_ext(t, a.b, b.b); return alg_make(c0, c1); }  // :28
 GPV_DEV ExtAlg wt_sub_alg(WTrace& t, ExtAlg a, ExtAlg b) { Ext c0 = wt_sub_ext(t, a.a, b.a); Ext c1 = wt_sub_ext(t, a.b, b.b); return alg_make(c0, c1); }  // :39
-__device__ __noinline__ ExtAlg wt_mul_alg(WTrace& t, ExtAlg a, ExtAlg b) {  // :50-75 with D = 2
+GPV_DEV ExtAlg wt_mul_alg_body(WTrace& t, ExtAlg a, ExtAlg b) {  // :50-75 with D = 2
   WPairs pr;
   pr.a[0] = a.b;
   pr.b[0] = b.b;
@@ -593,11 +763,25 @@ __device__ __noinline__ ExtAlg wt_mul_alg(WTrace& t, ExtAlg a, ExtAlg b) {  // :
   Ext p1 = wt_inner_product_ext(t, 1, acc, pr, 2);              // inner[1] = {(a0, b1), (a1, b0)}
   return alg_make(p0, p1);
 }
+struct wt_mul_alg_ret {
+  ExtAlg v;
+  WTrace t;
+};
+__device__ __noinline__ wt_mul_alg_ret wt_mul_alg_call(WTrace t, ExtAlg a, ExtAlg b) {
+  wt_mul_alg_ret r;
+  r.v = wt_mul_alg_body(t, a, b);
+  r.t = t;
+  return r;
+}
+GPV_DEV ExtAlg wt_mul_alg(WTrace& t, ExtAlg a, ExtAlg b) {
+  wt_mul_alg_ret r = wt_mul_alg_call(t, a, b);
+  t = r.t;
+  return r.v;
+}
 GPV_DEV ExtAlg wt_scalar_mul_alg(WTrace& t, Ext a, ExtAlg b) { Ext c0 = wt_mul_ext(t, a, b.a); Ext c1 = wt_mul_ext(t, a, b.b); return alg_make(c0, c1); }  // :77-86
 GPV_DEV ExtAlg wires_alg(const u64* __restrict__ wires, u32 start) { return alg_make(ws_ld(wires, start), ws_ld(wires, start + 1)); }  // vars.go:29-41
 // PartialInterpolateExtAlgebra (:88-125) over the points [lo, hi) of the gate's subgroup; domain[i] = g^i
-__device__ __noinline__ void wt_partial_interpolate(WTrace& t, u64 g, u32 lo, u32 hi, const u64* __restrict__ wires, const u64* __restrict__ weights,
-                                                    ExtAlg point, ExtAlg& ev, ExtAlg& prod) {
+GPV_DEV void wt_partial_interpolate_body(WTrace& t, u64 g, u32 lo, u32 hi, const u64* __restrict__ wires, const u64* __restrict__ weights, ExtAlg point, ExtAlg& ev, ExtAlg& prod) {
   u64 x = 1;
 #pragma unroll 1
   for (u32 i = 0; i < lo; i++) x = gl_mul(x, g);
@@ -612,18 +796,38 @@ __device__ __noinline__ void wt_partial_interpolate(WTrace& t, u64 g, u32 lo, u3
     x = gl_mul(x, g);
   }
 }
+__device__ __noinline__ WTrace wt_partial_interpolate_call(WTrace t, u64 g, u32 lo, u32 hi, const u64* __restrict__ wires, const u64* __restrict__ weights, ExtAlg point, ExtAlg& ev, ExtAlg& prod) {
+  wt_partial_interpolate_body(t, g, lo, hi, wires, weights, point, ev, prod);
+  return t;
+}
+GPV_DEV void wt_partial_interpolate(WTrace& t, u64 g, u32 lo, u32 hi, const u64* __restrict__ wires, const u64* __restrict__ weights, ExtAlg point, ExtAlg& ev, ExtAlg& prod) { t = wt_partial_interpolate_call(t, g, lo, hi, wires, weights, point, ev, prod); }
 // poseidon/goldilocks.go, extension layers
-__device__ __noinline__ Ext wt_sbox_ext(WTrace& t, Ext x) {  // :147-152
+GPV_DEV Ext wt_sbox_ext_body(WTrace& t, Ext x) {  // :147-152
   Ext x2 = wt_mul_ext(t, x, x);
   Ext x4 = wt_mul_ext(t, x2, x2);
   Ext x3 = wt_mul_ext(t, x, x2);
   return wt_mul_ext(t, x4, x3);
 }
+struct wt_sbox_ext_ret {
+  Ext v;
+  WTrace t;
+};
+__device__ __noinline__ wt_sbox_ext_ret wt_sbox_ext_call(WTrace t, Ext x) {
+  wt_sbox_ext_ret r;
+  r.v = wt_sbox_ext_body(t, x);
+  r.t = t;
+  return r;
+}
+GPV_DEV Ext wt_sbox_ext(WTrace& t, Ext x) {
+  wt_sbox_ext_ret r = wt_sbox_ext_call(t, x);
+  t = r.t;
+  return r.v;
+}
 GPV_DEV void wt_constant_layer_ext(WTrace& t, Ext* s, int round) {  // :127-136
 #pragma unroll 1
   for (int i = 0; i < 12; i++) s[i] = wt_add_ext(t, s[i], ext_make(PGL_ARC[i + 12 * round], 0));
 }
-__device__ __noinline__ void wt_mds_layer_ext(WTrace& t, Ext* s) {  // :185-201, :218-229
+GPV_DEV void wt_mds_layer_ext_body(WTrace& t, Ext* s) {  // :185-201, :218-229
   const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   Ext out[12];
 #pragma unroll 1
@@ -640,7 +844,12 @@ __device__ __noinline__ void wt_mds_layer_ext(WTrace& t, Ext* s) {  // :185-201,
 #pragma unroll 1
   for (int r = 0; r < 12; r++) s[r] = out[r];
 }
-__device__ __noinline__ void wt_mds_partial_layer_init_ext(WTrace& t, Ext* s) {  // :277-298
+__device__ __noinline__ WTrace wt_mds_layer_ext_call(WTrace t, Ext* s) {
+  wt_mds_layer_ext_body(t, s);
+  return t;
+}
+GPV_DEV void wt_mds_layer_ext(WTrace& t, Ext* s) { t = wt_mds_layer_ext_call(t, s); }
+GPV_DEV void wt_mds_partial_layer_init_ext_body(WTrace& t, Ext* s) {  // :277-298
   Ext res[12];
 #pragma unroll 1
   for (int i = 0; i < 12; i++) res[i] = ext_make(0, 0);
@@ -655,7 +864,12 @@ __device__ __noinline__ void wt_mds_partial_layer_init_ext(WTrace& t, Ext* s) { 
 #pragma unroll 1
   for (int i = 0; i < 12; i++) s[i] = res[i];
 }
-__device__ __noinline__ void wt_mds_partial_layer_fast_ext(WTrace& t, Ext* s, int r) {  // :333-357
+__device__ __noinline__ WTrace wt_mds_partial_layer_init_ext_call(WTrace t, Ext* s) {
+  wt_mds_partial_layer_init_ext_body(t, s);
+  return t;
+}
+GPV_DEV void wt_mds_partial_layer_init_ext(WTrace& t, Ext* s) { t = wt_mds_partial_layer_init_ext_call(t, s); }
+GPV_DEV void wt_mds_partial_layer_fast_ext_body(WTrace& t, Ext* s, int r) {  // :333-357
   Ext d = wt_mul_ext(t, s[0], ext_make(25, 0));  // MDS0TO0
 #pragma unroll 1
   for (int i = 1; i < 12; i++) {
@@ -670,15 +884,18 @@ __device__ __noinline__ void wt_mds_partial_layer_fast_ext(WTrace& t, Ext* s, in
     s[i] = wt_add_ext(t, m, s[i]);
   }
 }
+__device__ __noinline__ WTrace wt_mds_partial_layer_fast_ext_call(WTrace t, Ext* s, int r) {
+  wt_mds_partial_layer_fast_ext_body(t, s, r);
+  return t;
+}
+GPV_DEV void wt_mds_partial_layer_fast_ext(WTrace& t, Ext* s, int r) { t = wt_mds_partial_layer_fast_ext_call(t, s, r); }
 // ReduceWithPowers over consecutive extension elements of a word array
 GPV_DEV Ext wt_reduce_with_powers_ext(WTrace& t, const u64* __restrict__ a, u32 n, Ext s) {
   return wt_reduce_with_powers_words(t, a, a + 2 * n, ext_make(0, 0), s);
 }
 
 // One gate's EvalUnfiltered into out[0 .. n_constraints). consts: localConstants after RemovePrefix (evaluate_gates.go:67).
-__device__ __noinline__ u32 wt_gate_unfiltered(WTrace& t, const DevGate& g, const u64* __restrict__ consts, const u64* __restrict__ wires,
-                                               const u64* __restrict__ pih, const u64* __restrict__ weights, u64* __restrict__ out,
-                                               u64* __restrict__ tmp) {
+GPV_DEV u32 wt_gate_unfiltered_body(WTrace& t, const DevGate& g, const u64* __restrict__ consts, const u64* __restrict__ wires, const u64* __restrict__ pih, const u64* __restrict__ weights, u64* __restrict__ out, u64* __restrict__ tmp) {
   u32 k = 0;
   const Ext one = ext_make(1, 0), zero = ext_make(0, 0);
   switch (g.kind) {
@@ -947,6 +1164,21 @@ __device__ __noinline__ u32 wt_gate_unfiltered(WTrace& t, const DevGate& g, cons
   }
   return k;
 }
+struct wt_gate_unfiltered_ret {
+  u32 v;
+  WTrace t;
+};
+__device__ __noinline__ wt_gate_unfiltered_ret wt_gate_unfiltered_call(WTrace t, const DevGate& g, const u64* __restrict__ consts, const u64* __restrict__ wires, const u64* __restrict__ pih, const u64* __restrict__ weights, u64* __restrict__ out, u64* __restrict__ tmp) {
+  wt_gate_unfiltered_ret r;
+  r.v = wt_gate_unfiltered_body(t, g, consts, wires, pih, weights, out, tmp);
+  r.t = t;
+  return r;
+}
+GPV_DEV u32 wt_gate_unfiltered(WTrace& t, const DevGate& g, const u64* __restrict__ consts, const u64* __restrict__ wires, const u64* __restrict__ pih, const u64* __restrict__ weights, u64* __restrict__ out, u64* __restrict__ tmp) {
+  wt_gate_unfiltered_ret r = wt_gate_unfiltered_call(t, g, consts, wires, pih, weights, out, tmp);
+  t = r.t;
+  return r.v;
+}
 
 // PlonkChip.Verify of one proof is cut where the trace has fixed offsets and the INPUTS of a piece are at hand (the same idea as slice 1):
 //   phase 1  one lane per gate: computeFilter + EvalUnfiltered + the filter products of that gate (its filtered constraints go to the
@@ -985,13 +1217,12 @@ struct WPlonkWs {
 };
 // phase 1, gate `row`. Returns the words written.
 GPV_DEV size_t dev_witness_plonk_gate(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, u32 row, u64* __restrict__ trace,
-                                      const WPlonkTab& tab, u64* __restrict__ wsp) {
+                                      const WPlonkTab& tab, u64* __restrict__ wsp, u64* lds) {
   WPlonkWs ws(dc, wsp);
   const u32 ngc = dc->num_gate_constraints;
   u64* filt = ws.filt + 2 * (size_t)row * ngc;
-  WTrace t;
-  t.p = trace + tab.gate_off(row);
-  u64* const start = t.p;
+  u64* const start = trace + tab.gate_off(row);
+  WTrace t = wt_open(lds, start);
   const u64* consts = rec + dc->off_constants;
   const u32 sel = dc->selector_index[row];
   const Ext s = ws_ld(consts, sel);
@@ -1012,24 +1243,25 @@ GPV_DEV size_t dev_witness_plonk_gate(const DevCircuit* __restrict__ dc, const u
                                    ws.tmp + 2 * (size_t)row * GPV_WIT_PLONK_TMP);
 #pragma unroll 1
   for (u32 i = 0; i < n; i++) ws_st(filt, i, wt_mul_ext(t, ws_ld(filt, i), filter));
-  return (size_t)(t.p - start);
+  const size_t wrote_gate = wt_words_since(t, start);
+  wt_drain(t);
+  return wrote_gate;
 }
 // phase 1, the lane of everything that does not depend on the gates
 GPV_DEV size_t dev_witness_plonk_perm(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch,
-                                      u64* __restrict__ trace, const WPlonkTab& tab, u64* __restrict__ wsp) {
+                                      u64* __restrict__ trace, const WPlonkTab& tab, u64* __restrict__ wsp, u64* lds) {
   WPlonkWs ws(dc, wsp);
   const u32 nc = dc->num_challenges, nr = dc->num_routed, qdf = dc->qdf, npp = dc->num_pp;
   const Ext zeta = ext_make(ch[dc->ch_zeta], ch[dc->ch_zeta + 1]), one = ext_make(1, 0);
   const u64* wires = rec + dc->off_wires;
-  WTrace t;
-  t.p = trace;
+  WTrace t = wt_open(lds, trace);
   Ext zeta_pow_n = zeta;  // expPowerOf2Extension :55-61
 #pragma unroll 1
   for (u32 i = 0; i < dc->degree_bits; i++) zeta_pow_n = wt_mul_ext(t, zeta_pow_n, zeta_pow_n);
   ws_st(ws.zpn, 0, zeta_pow_n);
-  size_t wrote = (size_t)(t.p - trace);
-  t.p = trace + tab.off_sids();
-  u64* const start = t.p;
+  size_t wrote = wt_words_since(t, trace);
+  u64* const start = trace + tab.off_sids();
+  wt_seek(t, start);
   // evalVanishingPoly :121-207
 #pragma unroll 1
   for (u32 i = 0; i < nr; i++) ws_st(ws.s_ids, i, wt_scalar_mul_ext(t, zeta, dc->k_is[i]));
@@ -1069,35 +1301,40 @@ GPV_DEV size_t dev_witness_plonk_perm(const DevCircuit* __restrict__ dc, const u
       acc_k = acc_next;
     }
   }
-  return wrote + (size_t)(t.p - start);
+  wrote += wt_words_since(t, start);
+  wt_drain(t);
+  return wrote;
 }
 // phase 2, constraint index i: constraints[i] over the gates (evaluate_gates.go:97-102)
-GPV_DEV size_t dev_witness_plonk_acc(const DevCircuit* __restrict__ dc, u32 i, u64* __restrict__ trace, const WPlonkTab& tab, u64* __restrict__ wsp) {
+GPV_DEV size_t dev_witness_plonk_acc(const DevCircuit* __restrict__ dc, u32 i, u64* __restrict__ trace, const WPlonkTab& tab, u64* __restrict__ wsp,
+                                     u64* lds) {
   WPlonkWs ws(dc, wsp);
   const u32 ngc = dc->num_gate_constraints;
   Ext acc = ext_make(0, 0);
   size_t wrote = 0;
+  WTrace t = wt_open(lds, trace);
 #pragma unroll 1
   for (u32 g = 0; g < dc->n_gates; g++) {
     if (i >= dc->gates[g].n_constraints) continue;
-    WTrace t;
-    t.p = trace + tab.gate_acc_off(g) + (size_t)12 * i;
+    wt_seek(t, trace + tab.gate_acc_off(g) + (size_t)12 * i);
     acc = wt_add_ext(t, acc, ws_ld(ws.filt + 2 * (size_t)g * ngc, i));
     wrote += 12;
   }
+  wt_drain(t);
   ws_st(ws.gate_terms, i, acc);
   return wrote;
 }
 // phase 3, challenge j: the reverse reduction over [z1 terms | partial-product checks | gate constraints] (:185-204), then Verify :209-250.
 // *ok is cleared when the vanishing-polynomial assertion (plonk.go:248) fails.
 GPV_DEV size_t dev_witness_plonk_reduce(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch, u32 j,
-                                        u64* __restrict__ trace, const WPlonkTab& tab, u64* __restrict__ wsp, bool* ok) {
+                                        u64* __restrict__ trace, const WPlonkTab& tab, u64* __restrict__ wsp, bool* ok, u64* lds) {
   WPlonkWs ws(dc, wsp);
   const u32 nc = dc->num_challenges, qdf = dc->qdf, npp = dc->num_pp, ngc = dc->num_gate_constraints, per = npp + 2;
   const u32 n_pp_terms = nc * (npp + 1), n_terms = nc + n_pp_terms + ngc;
   const u64 alpha = ch[dc->ch_alphas + j];
   Ext reduced = ext_make(0, 0);
   size_t wrote = 0;
+  WTrace t = wt_open(lds, trace);
 #pragma unroll 1
   for (u32 i = n_terms; i-- > 0;) {
     Ext term;
@@ -1109,8 +1346,7 @@ GPV_DEV size_t dev_witness_plonk_reduce(const DevCircuit* __restrict__ dc, const
     } else {
       term = ws_ld(ws.head, i * per);
     }
-    WTrace t;
-    t.p = trace + tab.reduce_off() + ((size_t)(n_terms - 1 - i) * nc + j) * 24;
+    wt_seek(t, trace + tab.reduce_off() + ((size_t)(n_terms - 1 - i) * nc + j) * 24);
     Ext sm = wt_scalar_mul_ext(t, reduced, alpha);
     reduced = wt_add_ext(t, term, sm);
     wrote += 24;
@@ -1118,16 +1354,16 @@ GPV_DEV size_t dev_witness_plonk_reduce(const DevCircuit* __restrict__ dc, const
   const Ext zeta_pow_n = ws_ld(ws.zpn, 0);
   Ext zh = ext_sub(zeta_pow_n, ext_make(1, 0));  // Z_H(zeta): the record belongs to lane 0, the value is the same field element
   if (j == 0) {
-    WTrace t;
-    t.p = trace + tab.final_off();
+    wt_seek(t, trace + tab.final_off());
     zh = wt_sub_ext(t, zeta_pow_n, ext_make(1, 0));
     wrote += 12;
   }
-  WTrace t;
-  t.p = trace + tab.final_off() + 12 + (size_t)j * (qdf + 1) * 14;
-  u64* const start = t.p;
+  u64* const start = trace + tab.final_off() + 12 + (size_t)j * (qdf + 1) * 14;
+  wt_seek(t, start);
   Ext r = wt_reduce_with_powers_ext(t, rec + dc->off_quot + 2 * j * qdf, qdf, zeta_pow_n);
   Ext prod = wt_mul_ext(t, zh, r);
   if (!(prod.a == reduced.a && prod.b == reduced.b)) *ok = false;
-  return wrote + (size_t)(t.p - start);
+  wrote += wt_words_since(t, start);
+  wt_drain(t);
+  return wrote;
 }

@@ -134,9 +134,10 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
  * own, literally fri/fri.go:97-144.
  * GPV_OPT_FR_EVALUATION: the BN254 kernels exist in three forms with identical results -- column scanning (fewest instructions,
  * needs a launch that fills the chip about three times), operand scanning (lower latency per permutation) and four lanes per
- * permutation (half that latency again; for launches that leave most of the chip idle: up to about 270 proofs of the reference's
+ * permutation (half that latency again; for launches that leave most of the chip idle: up to about 290 proofs of the reference's
  * circuits -- a single proof verifies in 4.0 ms instead of 8.7). 0 (default) = chosen per launch by the occupancy it gives the device it runs
- * on (waves per SIMD = hashing lanes / (64 x 4 x its compute units): column scanning from 12, four lanes per permutation up to 2.75 / 4),
+ * on (waves per SIMD of full-length lanes = 4 Merkle paths per query round / (64 x 4 x its compute units): four lanes per permutation up to
+ * 0.5, column scanning from 4.5; profiles/r04_form_crossover.txt),
  * 1 = always column scanning, 2 = always operand scanning, 3 = always four lanes per permutation (Poseidon-BN254 kernels and
  * per-path Merkle walks; the shared upper levels keep form 2).
  * GPV_OPT_HOST_CHUNK_FIRST / GPV_OPT_HOST_CHUNK_MAX: gpv_verify uploads a host batch in chunks of first, first, 2 first, 4 first, ...

@@ -49,13 +49,14 @@ def ms_per_call(chip, circuit, t, chs, n, acc, reps):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-print("# tools/form_crossover.py (MI355X, %d SIMDs): ms per gpv_verify_given_challenges_dev call; * = fastest explicit form; rule: waves/SIMD >= 12 column scanning, 4 x waves/SIMD <= 2.75 four lanes, else operand scanning" % SIMDS)
+print("# tools/form_crossover.py (MI355X, %d SIMDs): ms per gpv_verify_given_challenges_dev call; * = fastest explicit form; rule (csrc/gpv_launch.h): w4 = waves per SIMD of full-length lanes "
+      "(4 Merkle paths per query round); w4 >= 4.5 column scanning, w4 <= 0.5 four lanes per permutation, else operand scanning" % SIMDS)
 for label in ("step", "decode_block rebuilt: 8 x arity 2, cap height 5 (12 trees per query, 4-word step leaves)"):
     circuit, common, ci, packed, ch = geometry("step" if label == "step" else "other")
     chip = gpv.verifier.NewVerifierChip(ctx, common)
     lanes_per_proof = ci.num_query_rounds * (4 + len(ci.arity_bits))
     print("## %s: %d hashing lanes per proof" % (label, lanes_per_proof))
-    print("%8s %10s %12s %12s %12s %12s   %s" % ("proofs", "waves/SIMD", "column", "operand", "four-lane", "rule (0)", "rule picks"))
+    print("%8s %10s %6s %12s %12s %12s %12s   %s" % ("proofs", "all lanes w", "w4", "column", "operand", "four-lane", "rule (0)", "rule picks"))
     for n in (16, 64, 128, 192, 256, 320, 512, 1024, 2048, 3072, 4096, 5120, 6144, 8192):
         batch, tampered = T.synthetic_batch(ci, packed, n, seed=n, tamper_every=7)
         t = torch.from_numpy(batch.copy()).to(dev)
@@ -63,6 +64,7 @@ for label in ("step", "decode_block rebuilt: 8 x arity 2, cap height 5 (12 trees
         acc = torch.zeros(n, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
         w = n * lanes_per_proof / (64.0 * SIMDS)
+        w4 = n * ci.num_query_rounds * 4 / (64.0 * SIMDS)
         reps = 3 if n >= 2048 else 8
         res = {}
         for form in (1, 2, 3, 0):
@@ -74,8 +76,8 @@ for label in ("step", "decode_block rebuilt: 8 x arity 2, cap height 5 (12 trees
             assert (acc.cpu().numpy() == (~tampered).astype(np.uint8)).all(), (label, n, form)
         ctx.set_option(3, 0)
         best = min((1, 2, 3), key=lambda f: res[f] if res[f] == res[f] else 1e9)
-        pick = "column" if w >= 12 else ("four-lane" if 4 * w <= 2.75 else "operand")
+        pick = "column" if w4 >= 4.5 else ("four-lane" if w4 <= 0.5 else "operand")
         cells = ["%10.3f%s" % (res[f], "*" if f == best else " ") for f in (1, 2, 3)]
-        print("%8d %10.2f %12s %12s %12s %11.3f    %s%s" % (n, w, cells[0], cells[1], cells[2], res[0], pick,
+        print("%8d %10.2f %6.2f %12s %12s %12s %11.3f    %s%s" % (n, w, w4, cells[0], cells[1], cells[2], res[0], pick,
                                                             "" if pick == {1: "column", 2: "operand", 3: "four-lane"}[best] else "   (fastest: %s, %+.1f %%)" % (
                                                                 {1: "column", 2: "operand", 3: "four-lane"}[best], 100 * (res[0] / res[best] - 1))), flush=True)
