@@ -55,10 +55,31 @@ def kernels(dis):
     return out
 
 
+# SIMD cycles per wave64 VALU instruction, measured with the shader clock sampled during the launch (profiles/r03p_microbench.txt,
+# tools/probe): the half-rate integer pipe 4.15 - 4.5 (4.3 used), a plain 32-bit op 2.47. Classification by opcode:
+HALF_RATE = ("v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshrrev_b64", "v_lshlrev_b64", "v_ashrrev_i64", "v_lshl_add_u64", "v_add_co_u32", "v_addc_co_u32",
+             "v_sub_co_u32", "v_subb_co_u32", "v_subrev_co_u32", "v_mad_u32_u24", "v_mad_i32_i24", "v_cmp_lt_u64", "v_cmp_gt_u64", "v_cmp_eq_u64", "v_cmp_ne_u64")
+CYC_HALF, CYC_FULL = 4.3, 2.47
+
+
+def base_op(op):
+    return re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+
+
 def count(ins):
     valu = sum(1 for _, op, _ in ins if op.startswith("v_"))
     return {"instructions": len(ins), "valu": valu, "v_mad_u64_u32": sum(1 for _, op, _ in ins if op.startswith("v_mad_u64_u32")),
             "s_nop": sum(1 for _, op, _ in ins if op == "s_nop")}
+
+
+def histogram(ins):
+    """VALU opcodes of a code range -> {opcode: count}, and the issue cycles they cost at the measured rates"""
+    h = {}
+    for _, op, _ in ins:
+        if op.startswith("v_"):
+            h[base_op(op)] = h.get(base_op(op), 0) + 1
+    cycles = sum(n * (CYC_HALF if op in HALF_RATE else CYC_FULL) for op, n in h.items())
+    return dict(sorted(h.items(), key=lambda kv: -kv[1])), cycles
 
 
 def loops(ins):
@@ -87,6 +108,7 @@ def analyse(name, ins):
         c = count(ins[s:e + 1])
         for label, want in res["expected_mads_per_trip"].items():
             if c["v_mad_u64_u32"] == want:
+                c["valu_opcodes"], c["valu_issue_cycles"] = histogram(ins[s:e + 1])
                 res["loops"][label] = c
     if not zero_head and {"window", "sbox", "mix_row"} <= set(res["loops"]):
         L = res["loops"]
@@ -125,6 +147,21 @@ def main():
                 "", p["instructions"], p["valu"], p["v_mad_u64_u32"], p["s_nop"]))
             ok &= p["v_mad_u64_u32"] == out["expected_mads_per_permutation"]["general"]
         ok &= not missing
+    # ---- the instruction budget of one partial-round WINDOW of the dominant kernel (11 Montgomery reductions, 2 493 multiply-adds): what is
+    # multiply-add, what is glue, and what the glue costs in issue cycles -- the derived ceiling of DESIGN.md section 5
+    dom = out["kernels"].get("k_merkle_climb_lower")
+    if dom and "window" in dom["loops"]:
+        w = dom["loops"]["window"]
+        h, cyc = w["valu_opcodes"], w["valu_issue_cycles"]
+        mad_cyc = h.get("v_mad_u64_u32", 0) * CYC_HALF
+        print("k_merkle_climb_lower, one partial-round window (2 rounds, 11 reductions): VALU opcodes")
+        for op, n in h.items():
+            c = CYC_HALF if op in HALF_RATE else CYC_FULL
+            print("    %-18s %5d  x %.2f cycles = %8.0f   (%.1f per reduction)" % (op, n, c, n * c, n / 11.0))
+        print("    issue cycles per window: %.0f, of which multiply-adds %.0f = %.3f; a stream of the multiply-adds ALONE would be the ceiling: "
+              "executed-MAD fraction at 100 %% VALU issue = %.3f" % (cyc, mad_cyc, mad_cyc / cyc, mad_cyc / cyc))
+        out["window_budget"] = {"kernel": "k_merkle_climb_lower", "valu_opcodes": h, "issue_cycles": cyc, "mad_issue_cycles": mad_cyc, "mad_fraction_of_issue": mad_cyc / cyc,
+                                "cycles_half_rate": CYC_HALF, "cycles_full_rate": CYC_FULL, "source": "profiles/r03p_microbench.txt"}
     if args.pmc_valu_per_perm:
         out["pmc_valu_per_perm"] = args.pmc_valu_per_perm
         out["pmc_source"] = args.pmc_source
