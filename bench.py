@@ -658,7 +658,7 @@ def bench_witness(gpv, T, ctx, dev, n=1024):
     for _ in range(reps):
         gpv._lib.check(L.gpv_witness_verify_dev(*args), ctx.h)  # synchronises: the lanes' word counts are checked against the host layout
     dt = (time.perf_counter() - t0) / reps
-    km = {nm: ctx.timing_get(k)[0] for nm, k in (("challenges", 9), ("plonk", 10), ("fri", 11), ("range_check", 12))}
+    km = {nm: ctx.timing_get(k)[0] for nm, k in (("transcript_pass", 13), ("challenges_fill", 9), ("plonk", 10), ("fri", 11), ("range_check", 12))}
     ctx.timing_enable(False)
     if not ((status.cpu().numpy() == 0) == ~tam).all():
         raise SystemExit("witness_verify: status bytes do not match the tamper mask")

@@ -28,7 +28,7 @@
 
 // ================================================================ context
 enum { TK_MERKLE = 0, TK_PGL = 1, TK_TRANSCRIPT = 2, TK_PLONK = 3, TK_FRI = 4, TK_RANGE = 5, TK_PBN = 6, TK_LEAVES = 7, TK_LOWER = 8, TK_WIT_CHALLENGES = 9,
-       TK_WIT_PLONK = 10, TK_WIT_FRI = 11, TK_WIT_RANGE = 12, TK_COUNT = 13 };
+       TK_WIT_PLONK = 10, TK_WIT_FRI = 11, TK_WIT_RANGE = 12, TK_WIT_TRANSCRIPT = 13, TK_COUNT = 14 };
 
 struct TimingRec {
   int kind;
@@ -45,6 +45,9 @@ struct gpv_ctx {
   // side stream + events: the latency-bound transcript (and plonk / FRI field work) overlaps the Merkle leaf hashing
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_cleared = nullptr, ev_transcript = nullptr, ev_side_done = nullptr;
+  // a second side stream: the FRI slice of the witness generator runs next to the challenges fill and the plonk slice (gpv_witness_verify)
+  hipStream_t side2 = nullptr;
+  hipEvent_t ev_side2_done = nullptr;
   u32* digests = nullptr;
   size_t digest_words = 0;
   int transcript_variant = 0;  // GPV_OPT_TRANSCRIPT_VARIANT
@@ -245,6 +248,8 @@ extern "C" int gpv_ctx_create(gpv_ctx** out, int device_id) {
       hipEventCreateWithFlags(&ctx->ev_cleared, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_transcript, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_side_done, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_side2_done, hipEventDisableTiming) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->upload, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) {
     gpv_set_global_error("side stream / event creation failed on device %d", device_id);
@@ -263,6 +268,8 @@ extern "C" int gpv_ctx_destroy(gpv_ctx* ctx) {
   if (ctx->fail) hipFree(ctx->fail);
   if (ctx->digests) hipFree(ctx->digests);
   if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
+  if (ctx->side2) { hipStreamSynchronize(ctx->side2); hipStreamDestroy(ctx->side2); }
+  if (ctx->ev_side2_done) hipEventDestroy(ctx->ev_side2_done);
   if (ctx->upload) { hipStreamSynchronize(ctx->upload); hipStreamDestroy(ctx->upload); }
   if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
   if (ctx->twin) gpv_ctx_destroy(ctx->twin);
@@ -1040,8 +1047,8 @@ struct WitChallengesScratch {
     HIP_TRY(ctx, hipMemsetAsync(bad.p, 0, sizeof(u32), st));
     return GPV_OK;
   }
-  void launch(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, u64* challenges) {
-    gpvk_witness_challenges(st, dcd, proofs, n, trace, words_per_proof, challenges, log.p, n_segments, seg.p, seg.p + n_segments, bad.p);
+  void launch(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, u64* challenges, int pass = 0) {
+    gpvk_witness_challenges(st, dcd, proofs, n, trace, words_per_proof, challenges, log.p, n_segments, seg.p, seg.p + n_segments, bad.p, pass);
   }
   // after the stream has been synchronised
   int check(gpv_ctx* ctx) {
@@ -1147,7 +1154,8 @@ extern "C" int gpv_witness_plonk(gpv_ctx* ctx, const gpv_circuit* c, const void*
   HIP_TRY(ctx, hipMemcpyAsync(dch.p, challenges, 8 * ncw * n, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * n, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(dcons.p, 1, n, ctx->stream));
-  gpvk_witness_plonk(ctx->stream, dcd, c->dc, (const u64*)hb.proofs.p, dch.p, n, dtrace.p, words, dtab.p, dws.p, wsw, dcons.p, dwritten.p);
+  gpvk_witness_plonk(ctx->stream, dcd, c->dc, (const u64*)hb.proofs.p, dch.p, n, dtrace.p, words, dtab.p, (u32)tab[3 + 2 * (size_t)c->dc.n_gates], dws.p, wsw, dcons.p,
+                     dwritten.p);
   CHECK_LAUNCH(ctx);
   std::vector<u64> written(n);
   HIP_TRY(ctx, hipMemcpyAsync(written.data(), dwritten.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1215,27 +1223,47 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
   HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * (2 + nq) * n, main_st));
   HIP_TRY(ctx, hipMemsetAsync(dflags.p, 1, 3 * n, main_st));
   u64 *wr_pl = dwritten.p + n, *wr_fri = dwritten.p + 2 * n;
+  // main: transcript (challenges) -> [fork] -> challenges fill -> range check;  side: [wait fork] -> plonk;  side2: [wait fork] -> FRI.
+  // Slices 3 and 2 need only the challenges, so they start behind the transcript pass, next to the fill (round 4; until then the plonk
+  // slice waited for the fill as well and FRI ran after it: at 64 proofs 2.9 + max(2.0, 1.5) ms of dependent kernels, now 2.3 + 1.6).
   {
     int rc = wcs.prepare(ctx, c, n, main_st);
     if (rc != GPV_OK) return rc;
-    Timed t(ctx, TK_WIT_CHALLENGES, main_st);
-    wcs.launch(main_st, dcd, dproofs, n, dtrace + w_rc, total, dch);
+  }
+  // FRI next to the fill only while the fill leaves room (below four waves per SIMD of fill lanes): 5.7 instead of 6.5 ms at 64 proofs, 6.5 / 7.4
+  // at 256, 9.3 / 9.5 at 1024 -- but 21.1 / 20.3 at 4096, where three store streams at once only get in each other's way
+  const bool fri_beside = (size_t)wcs.n_segments * n < (size_t)4 * 64 * gpvk_device_simds();
+  hipStream_t side2 = fri_beside ? ctx->side2 : main_st;
+  {
+    Timed t(ctx, TK_WIT_TRANSCRIPT, main_st);
+    wcs.launch(main_st, dcd, dproofs, n, dtrace + w_rc, total, dch, 1);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_st));
   HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
+  if (fri_beside) HIP_TRY(ctx, hipStreamWaitEvent(side2, ctx->ev_fork, 0));
   {
     Timed t(ctx, TK_WIT_PLONK, side);
-    gpvk_witness_plonk(side, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch, total, dtab.p, dws.p, wsw, dflags.p + n, wr_pl);
+    gpvk_witness_plonk(side, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch, total, dtab.p, (u32)tab[3 + 2 * (size_t)c->dc.n_gates], dws.p, wsw, dflags.p + n, wr_pl);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));
-  {
-    Timed t(ctx, TK_WIT_FRI, main_st);
-    gpvk_witness_fri(main_st, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch + w_pl, total, prefix, round, dflags.p + 2 * n, wr_fri);
+  auto launch_fri = [&]() {
+    Timed t(ctx, TK_WIT_FRI, side2);
+    gpvk_witness_fri(side2, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch + w_pl, total, prefix, round, dflags.p + 2 * n, wr_fri);
+  };
+  if (fri_beside) {
+    launch_fri();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_side2_done, side2));
   }
+  {
+    Timed t(ctx, TK_WIT_CHALLENGES, main_st);
+    wcs.launch(main_st, dcd, dproofs, n, dtrace + w_rc, total, dch, 2);
+  }
+  if (!fri_beside) launch_fri();
   {
     Timed t(ctx, TK_WIT_RANGE, main_st);
     gpvk_witness_range_check(main_st, dcd, dproofs, n, dtrace, total, dflags.p);
   }
+  if (fri_beside) HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_side2_done, 0));
   HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_side_done, 0));
   CHECK_LAUNCH(ctx);
   std::vector<u64> written((2 + nq) * n);

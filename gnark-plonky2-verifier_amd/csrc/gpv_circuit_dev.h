@@ -69,3 +69,5 @@ struct DevCircuit {
 // per-proof derived values produced by the transcript kernel and consumed by plonk / merkle / fri kernels
 // layout: [n_challenge_words challenges | 4 pi hash | 4 reduced openings (zeta batch, zeta*g batch)]
 #define GPV_DERIVED_EXTRA 8
+// unit table of the plonk witness slice (gpvi_witness_plonk_table, gpv_witness.cuh): this unit is a whole gate row, not a piece of a PoseidonGate
+#define GPV_WIT_WHOLE_GATE 255u

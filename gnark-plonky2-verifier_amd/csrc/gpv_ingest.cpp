@@ -921,7 +921,10 @@ FriWitSizes witness_fri_layout(const DevCircuit& c, std::vector<uint8_t>* kinds)
 }
 // ---- slice 3: plonk.PlonkChip.Verify (csrc/gpv_witness.cuh, third part), the same walk without the arithmetic
 struct PlonkWitLayout : FriWitLayout {
-  std::vector<uint64_t> tab;  // [off_sids | reduce_off | final_off | gate_off[n_gates] | gate_acc_off[n_gates]] (csrc/gpv_witness.cuh WPlonkTab)
+  // [off_sids | reduce_off | final_off | gate_off[n_gates] | gate_acc_off[n_gates] | n_units | units[n_units][4]] (csrc/gpv_witness.cuh WPlonkTab);
+  // a unit = {gate row, piece (GPV_WIT_WHOLE_GATE, or 0..8 of a PoseidonGate), first word, first word of its filter products}
+  std::vector<uint64_t> tab;
+  size_t piece_start[9] = {0};  // set by gate() for a PoseidonGate
   void add_ext() { ext2_mul_add(); }
   void sub_ext() { ext2_mul_add(); }
   void scalar_mul_ext() { ext2_mul_add(); }
@@ -999,17 +1002,21 @@ struct PlonkWitLayout : FriWitLayout {
         break;
       }
       case GPV_GATE_POSEIDON:
+        // piece_start[i]: where piece i of csrc/gpv_witness.cuh (dev_witness_plonk_poseidon_piece) starts -- wherever the gate replaces its
+        // state by wire values (poseidon_gate.go:120-126, :143-146, :160-166) the evaluation can be resumed from the wires alone
         sub_ext(); mul_ext();
         for (int i = 0; i < 4; i++) { sub_ext(); mul_ext(); sub_ext(); }
         for (int i = 0; i < 4; i++) { add_ext(); sub_ext(); }
         for (int r = 0; r < 4; r++) {
           constant_layer_ext();
           if (r != 0) for (int i = 0; i < 12; i++) sub_ext();
+          if (r != 0) piece_start[r] = words;  // pieces 1..3 start after the constraints of round r
           for (int i = 0; i < 12; i++) sbox_ext();
           mds_layer_ext();
         }
         for (int i = 0; i < 12; i++) add_ext();
         for (int i = 0; i < 11 * 11; i++) { mul_ext(); add_ext(); }
+        piece_start[4] = words;  // the 22 partial rounds + the second half's first constant layer and constraints
         for (int r = 0; r < 22; r++) {
           sub_ext(); sbox_ext();
           if (r != 21) add_ext();
@@ -1018,6 +1025,7 @@ struct PlonkWitLayout : FriWitLayout {
         for (int r = 0; r < 4; r++) {
           constant_layer_ext();
           for (int i = 0; i < 12; i++) sub_ext();
+          piece_start[5 + r] = words;
           for (int i = 0; i < 12; i++) sbox_ext();
           mds_layer_ext();
         }
@@ -1039,6 +1047,7 @@ PlonkWitLayout witness_plonk_layout(const DevCircuit& c, std::vector<uint8_t>* k
   L.kinds = kinds;
   L.tab.assign(3 + 2 * (size_t)c.n_gates, 0);
   for (uint32_t i = 0; i < c.degree_bits; i++) L.mul_ext();  // expPowerOf2Extension plonk.go:55-61
+  std::vector<uint64_t> units;
   for (uint32_t row = 0; row < c.n_gates; row++) {           // EvaluateGateConstraints evaluate_gates.go:77-105
     L.tab[3 + row] = L.words;
     const uint32_t sel = c.selector_index[row];
@@ -1046,10 +1055,24 @@ PlonkWitLayout witness_plonk_layout(const DevCircuit& c, std::vector<uint8_t>* k
       if (i != row) { L.sub_ext(); L.mul_ext(); }
     if (c.n_groups > 1) { L.sub_ext(); L.mul_ext(); }
     const uint32_t n = L.gate(c.gates[row]);
+    const size_t fm0 = L.words;  // the n products constraint x filter (evaluate_gates.go:68-74), one mul_ext each
     for (uint32_t i = 0; i < n; i++) L.mul_ext();
+    const size_t fm_words = n ? (L.words - fm0) / n : 0;
+    if (c.gates[row].kind == GPV_GATE_POSEIDON) {
+      // nine lanes instead of one (the gate is 42 % of the slice and was its long pole): constraints owned by piece 0..8
+      static const uint32_t first_k[10] = {0, 17, 29, 41, 41, 75, 87, 99, 111, 123};
+      L.piece_start[0] = L.tab[3 + row];
+      for (uint32_t pc = 0; pc < 9; pc++) {
+        units.push_back(row); units.push_back(pc); units.push_back(L.piece_start[pc]); units.push_back(fm0 + fm_words * first_k[pc]);
+      }
+    } else {
+      units.push_back(row); units.push_back(GPV_WIT_WHOLE_GATE); units.push_back(L.tab[3 + row]); units.push_back(fm0);
+    }
     L.tab[3 + c.n_gates + row] = L.words;
     for (uint32_t i = 0; i < n; i++) L.add_ext();
   }
+  L.tab.push_back(units.size() / 4);
+  L.tab.insert(L.tab.end(), units.begin(), units.end());
   L.tab[0] = L.words;
   for (uint32_t i = 0; i < c.num_routed; i++) L.scalar_mul_ext();  // evalVanishingPoly :121-207
   L.sub_ext(); L.scalar_mul_ext(); L.sub_ext(); L.div_ext();       // evalL0 :63-83

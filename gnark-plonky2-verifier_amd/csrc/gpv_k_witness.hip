@@ -43,9 +43,13 @@ __global__ __launch_bounds__(64) void k_witness_challenges_fill(const DevCircuit
                                                    trace + p * words_per_proof, seg_off[seg], seg, n_segments, staged ? wt_lds : nullptr);
   if (live && wrote != seg_len[seg]) atomicOr(bad, 2u);
 }
+// pass: 1 = the cooperative transcript (yields the challenges and the permutation log), 2 = the fill, 0 = both. The caller of the whole
+// trace runs the passes apart: the plonk and FRI slices need only the challenges, so they start after pass 1, next to the fill.
 void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, u64* challenges,
-                             u64* log, u32 n_segments, const u64* seg_off, const u64* seg_len, u32* bad) {
-  GPVK_LAUNCH(k_witness_challenges_log_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 64)), dim3(64), 0, st, dcd, proofs, n, log, n_segments, challenges, bad);
+                             u64* log, u32 n_segments, const u64* seg_off, const u64* seg_len, u32* bad, int pass) {
+  if (pass != 2)
+    GPVK_LAUNCH(k_witness_challenges_log_coop, dim3(gpvk_blocks_for(n * PGL_COOP_LANES, 64)), dim3(64), 0, st, dcd, proofs, n, log, n_segments, challenges, bad);
+  if (pass == 1) return;
   const bool staged = gpvk_witness_staged(n * n_segments, 2);
   GPVK_LAUNCH(k_witness_challenges_fill, dim3(gpvk_blocks_for(n * n_segments, 64)), dim3(64), staged ? GPV_WT_LDS_WORDS * 8 : 0, st, dcd, proofs, n, log, n_segments,
               seg_off, seg_len, trace, words_per_proof, bad, staged ? 1 : 0);
@@ -104,9 +108,9 @@ void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& h
 // with the layout); consistent[p] is cleared by the lane that sees the assertion of plonk.go:248 (or evalL0's, :75-80) fail.
 __global__ __launch_bounds__(64) void k_witness_plonk_units(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ challenges,
                                                             size_t n, u64* __restrict__ trace, size_t words_per_proof, const u64* __restrict__ tab,
-                                                            u64* __restrict__ ws, size_t ws_words, unsigned long long* __restrict__ written, int staged) {
+                                                            u32 n_units, u64* __restrict__ ws, size_t ws_words, unsigned long long* __restrict__ written, int staged) {
   extern __shared__ u64 wt_lds[];
-  const u32 units = dc->n_gates + 1;  // one lane per gate + the lane of what does not depend on the gates
+  const u32 units = n_units + 1;  // one lane per unit of the table (a gate row, or one of the nine pieces of a PoseidonGate) + the lane of what does not depend on the gates
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = item < n * units;
   if (!live) item = n * units - 1;  // stays for the wave's write-out; repeats the last item, reports nothing
@@ -116,8 +120,16 @@ __global__ __launch_bounds__(64) void k_witness_plonk_units(const DevCircuit* __
   const size_t p = item - (size_t)u * n;
   const u64* rec = proofs + p * (dc->proof_nbytes / 8);
   WPlonkTab t{tab, dc->n_gates};
-  const size_t wrote = u < dc->n_gates ? dev_witness_plonk_gate(dc, rec, u, trace + p * words_per_proof, t, ws + p * ws_words, staged ? wt_lds : nullptr)
-                                       : dev_witness_plonk_perm(dc, rec, challenges + p * dc->n_challenge_words, trace + p * words_per_proof, t, ws + p * ws_words, staged ? wt_lds : nullptr);
+  u64* const lds = staged ? wt_lds : nullptr;
+  size_t wrote;
+  if (u < n_units) {
+    const u64* e = t.unit(u);
+    const u32 row = (u32)e[0], piece = (u32)e[1];
+    wrote = piece == GPV_WIT_WHOLE_GATE ? dev_witness_plonk_gate(dc, rec, row, trace + p * words_per_proof, t, ws + p * ws_words, lds)
+                                        : dev_witness_plonk_poseidon_piece(dc, rec, row, piece, (size_t)e[2], (size_t)e[3], trace + p * words_per_proof, ws + p * ws_words, lds);
+  } else {
+    wrote = dev_witness_plonk_perm(dc, rec, challenges + p * dc->n_challenge_words, trace + p * words_per_proof, t, ws + p * ws_words, lds);
+  }
   if (live) atomicAdd(&written[p], (unsigned long long)wrote);
 }
 __global__ __launch_bounds__(64) void k_witness_plonk_acc(const DevCircuit* __restrict__ dc, size_t n, u64* __restrict__ trace, size_t words_per_proof,
@@ -155,11 +167,11 @@ __global__ __launch_bounds__(64) void k_witness_plonk_reduce(const DevCircuit* _
 }
 // consistent: preset to 1 by the caller; written: preset to 0
 void gpvk_witness_plonk(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
-                        size_t words_per_proof, const u64* tab, u64* ws, size_t ws_words, uint8_t* consistent, u64* written) {
+                        size_t words_per_proof, const u64* tab, u32 n_units, u64* ws, size_t ws_words, uint8_t* consistent, u64* written) {
   unsigned long long* wr = (unsigned long long*)written;
-  const bool staged = gpvk_witness_staged(n * (hc.n_gates + 1), 3);
-  GPVK_LAUNCH(k_witness_plonk_units, dim3(gpvk_blocks_for(n * (hc.n_gates + 1), 64)), dim3(64), staged ? GPV_WT_LDS_WORDS * 8 : 0, st, dcd, proofs, challenges, n, trace,
-              words_per_proof, tab, ws, ws_words, wr, staged ? 1 : 0);
+  const bool staged = gpvk_witness_staged(n * (n_units + 1), 3);
+  GPVK_LAUNCH(k_witness_plonk_units, dim3(gpvk_blocks_for(n * (n_units + 1), 64)), dim3(64), staged ? GPV_WT_LDS_WORDS * 8 : 0, st, dcd, proofs, challenges, n, trace,
+              words_per_proof, tab, n_units, ws, ws_words, wr, staged ? 1 : 0);
   GPVK_LAUNCH(k_witness_plonk_acc, dim3(gpvk_blocks_for(n * hc.num_gate_constraints, 64)), dim3(64), 0, st, dcd, n, trace, words_per_proof, tab, ws, ws_words, wr);
   GPVK_LAUNCH(k_witness_plonk_reduce, dim3(gpvk_blocks_for(n * hc.num_challenges, 64)), dim3(64), 0, st, dcd, proofs, challenges, n, trace, words_per_proof, tab,
               ws, ws_words, consistent, wr);

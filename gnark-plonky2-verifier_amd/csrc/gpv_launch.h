@@ -168,7 +168,7 @@ void gpvk_gather_pih(hipStream_t st, const u64* derived, u64* out, u32 ncw, size
 // *bad != 0 afterwards = the kernels' walk and the layout disagree
 #define GPV_WIT_LOG_WORDS 21
 void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, u64* challenges,
-                             u64* log, u32 n_segments, const u64* seg_off, const u64* seg_len, u32* bad);
+                             u64* log, u32 n_segments, const u64* seg_off, const u64* seg_len, u32* bad, int pass = 0);
 void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
                       size_t words_per_proof, size_t prefix_words, size_t round_words, uint8_t* consistent, u64* written);
 void gpvk_witness_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, uint8_t* ok);
@@ -179,9 +179,9 @@ static inline size_t gpv_wit_plonk_ws_words(const DevCircuit& c) {
   return 2 * ((size_t)c.n_gates * (c.num_gate_constraints + GPV_WIT_PLONK_TMP) + c.num_gate_constraints + 3 * (size_t)c.num_routed +
               (size_t)c.num_challenges * (c.num_pp + 2) + 1);
 }
-// tab: [3 + 2 n_gates] words from gpvi_witness_plonk_table (device copy); consistent preset to 1, written to 0
+// tab: gpvi_witness_plonk_table (device copy; n_units = its unit count); consistent preset to 1, written to 0
 void gpvk_witness_plonk(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
-                        size_t words_per_proof, const u64* tab, u64* ws, size_t ws_words, uint8_t* consistent, u64* written);
+                        size_t words_per_proof, const u64* tab, u32 n_units, u64* ws, size_t ws_words, uint8_t* consistent, u64* written);
 // gpv_k_plonk.hip
 void gpvk_gate_eval_unfiltered(hipStream_t st, DevGate g, const u64* weights, const u64* constants, u32 n_constants, const u64* wires,
                                u32 n_wires, const u64* pih, u64* out, u32 max_out, size_t n);

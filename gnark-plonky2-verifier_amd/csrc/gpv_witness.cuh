@@ -15,6 +15,7 @@
 // gl.Reduce = ReduceHint, SplitLimbs(remainder) (:246-281); gl.Add = MulAdd(a, 1, b) (:162-164).
 #pragma once
 #include "gpv_transcript.cuh"
+#include "gpv_plonk.cuh"  // the native extension-field Poseidon layers (piece 4 of a PoseidonGate resumes from a recomputed state)
 
 struct WBig {  // a lazy native-field value, < 2^256 (largest here: x * x^6 < 2^192; a 13-term row of 64 x 64-bit products < 2^132)
   u64 w[4];
@@ -1190,9 +1191,11 @@ GPV_DEV u32 wt_gate_unfiltered(WTrace& t, const DevGate& g, const u64* __restric
 //            quotient recombination with the assertion of plonk.go:248.
 // Offsets: WPlonkTab (host layout, csrc/gpv_ingest.cpp). Record sizes used for the interleaved places: an AddExtension / SubExtension /
 // ScalarMulExtension is two MulAdd records = 12 words, a MulExtension / MulAddExtension two Reduce records = 14 words.
-struct WPlonkTab {  // u64 table: [off_sids | reduce_off | final_off | gate_off[n_gates] | gate_acc_off[n_gates]]
+struct WPlonkTab {  // u64 table: [off_sids | reduce_off | final_off | gate_off[n_gates] | gate_acc_off[n_gates] | n_units | units[n_units][4]]
   const u64* t;
   u32 n_gates;
+  // unit u of phase 1: {gate row, piece (GPV_WIT_WHOLE_GATE or 0..8 of a PoseidonGate), first trace word, first word of its filter products}
+  GPV_DEV const u64* unit(u32 u) const { return t + 3 + 2 * (size_t)n_gates + 1 + 4 * (size_t)u; }
   GPV_DEV size_t off_sids() const { return t[0]; }
   GPV_DEV size_t reduce_off() const { return t[1]; }
   GPV_DEV size_t final_off() const { return t[2]; }
@@ -1246,6 +1249,123 @@ GPV_DEV size_t dev_witness_plonk_gate(const DevCircuit* __restrict__ dc, const u
   const size_t wrote_gate = wt_words_since(t, start);
   wt_drain(t);
   return wrote_gate;
+}
+// phase 1, piece `piece` of the PoseidonGate in row `row` (poseidon_gate.go:95-181). The gate is 42 % of the slice and one lane per gate made
+// it the long pole of the whole generator (round 3: 2.5 ms of the kernel's 2.5). But the gate CONSTRAINS its S-box inputs to wires and
+// continues from the wire values (:120-126 first half, :143-146 partial rounds, :160-166 second half), so wherever that happens the
+// literal evaluation can be resumed from the wires alone:
+//   0      filter, swap / delta constraints, round 0, constant layer of round 1 and its 12 constraints           constraints  0 .. 16
+//   1, 2   S-boxes + MDS of round r from the wires, constant layer of round r + 1 and its constraints             17 .. 28, 29 .. 40
+//   3      S-boxes + MDS of round 3, partialFirstConstantLayer, mdsPartialLayerInit                              (none)
+//   4      the 22 partial rounds (their other eleven state words are NOT wires: the state piece 3 ends in is recomputed natively,
+//          untraced) and the second half's first constant layer + constraints                                    41 .. 62, 63 .. 74
+//   5 - 7  S-boxes + MDS of second-half round r, next constant layer + constraints                               75 .. 110
+//   8      S-boxes + MDS of the last round, the 12 output constraints                                            111 .. 122
+// Every piece also writes the filter products (evaluate_gates.go:68-74) of ITS constraints, at their place behind the gate's body.
+GPV_DEV size_t dev_witness_plonk_poseidon_piece(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, u32 row, u32 piece, size_t start_off,
+                                                size_t fm_off, u64* __restrict__ trace, u64* __restrict__ wsp, u64* lds) {
+  WPlonkWs ws(dc, wsp);
+  u64* out = ws.filt + 2 * (size_t)row * dc->num_gate_constraints;
+  const u64* consts = rec + dc->off_constants;
+  const u64* wires = rec + dc->off_wires;
+  u64* const start = trace + start_off;
+  WTrace t = wt_open(lds, start);
+  const u32 sel = dc->selector_index[row];
+  const Ext sel_s = ws_ld(consts, sel), one = ext_make(1, 0);
+  Ext filter;
+  if (piece == 0) {  // computeFilter evaluate_gates.go:33-55, traced by the piece that owns the head of the row
+    filter = one;
+#pragma unroll 1
+    for (u32 i = dc->group_start[sel]; i < dc->group_end[sel]; i++) {
+      if (i == row) continue;
+      Ext d = wt_sub_ext(t, ext_make(i, 0), sel_s);
+      filter = wt_mul_ext(t, filter, d);
+    }
+    if (dc->n_groups > 1) {
+      Ext d = wt_sub_ext(t, ext_make(0xFFFFFFFFULL, 0), sel_s);
+      filter = wt_mul_ext(t, filter, d);
+    }
+  } else {
+    filter = gate_filter(dc, row, sel_s);  // the same field element, untraced
+    filter = ext_make(gl_canon(filter.a), gl_canon(filter.b));
+  }
+  const u32 start_full0 = 29, start_partial = 29 + 36, start_full1 = start_partial + 22;
+  Ext s[12];
+  u32 k = 0, k0 = 0;
+  if (piece == 0) {
+    const Ext swap = ws_ld(wires, 24);
+    Ext swap_m1 = wt_sub_ext(t, swap, one);
+    ws_st(out, k++, wt_mul_ext(t, swap, swap_m1));
+#pragma unroll 1
+    for (u32 i = 0; i < 4; i++) {
+      Ext diff = wt_sub_ext(t, ws_ld(wires, i + 4), ws_ld(wires, i));
+      Ext expected = wt_mul_ext(t, swap, diff);
+      ws_st(out, k++, wt_sub_ext(t, expected, ws_ld(wires, 25 + i)));
+    }
+#pragma unroll 1
+    for (u32 i = 0; i < 4; i++) {
+      s[i] = wt_add_ext(t, ws_ld(wires, i), ws_ld(wires, 25 + i));
+      s[i + 4] = wt_sub_ext(t, ws_ld(wires, i + 4), ws_ld(wires, 25 + i));
+    }
+#pragma unroll 1
+    for (u32 i = 8; i < 12; i++) s[i] = ws_ld(wires, i);
+    wt_constant_layer_ext(t, s, 0);
+  } else if (piece <= 3) {
+    k = k0 = 5 + 12 * piece;
+#pragma unroll 1
+    for (u32 i = 0; i < 12; i++) s[i] = ws_ld(wires, start_full0 + (piece - 1) * 12 + i);
+  } else if (piece == 4) {
+    k = k0 = 41;
+#pragma unroll 1
+    for (u32 i = 0; i < 12; i++) s[i] = pgl_sbox_ext(ws_ld(wires, start_full0 + 24 + i));  // what piece 3 writes out, natively
+    pgl_mds_ext(s);
+#pragma unroll 1
+    for (u32 i = 0; i < 12; i++) s[i].a = gl_add(gl_canon(s[i].a), PGL_FIRST[i]);
+    pgl_partial_init_ext(s);
+#pragma unroll 1
+    for (u32 i = 0; i < 12; i++) s[i] = ext_make(gl_canon(s[i].a), gl_canon(s[i].b));  // hint inputs are canonical field elements
+  } else {
+    k = k0 = 75 + 12 * (piece - 5);
+#pragma unroll 1
+    for (u32 i = 0; i < 12; i++) s[i] = ws_ld(wires, start_full1 + (piece - 5) * 12 + i);
+  }
+  if (piece == 4) {
+#pragma unroll 1
+    for (u32 r = 0; r < 22; r++) {
+      Ext sbox_in = ws_ld(wires, start_partial + r);
+      ws_st(out, k++, wt_sub_ext(t, s[0], sbox_in));
+      s[0] = wt_sbox_ext(t, sbox_in);
+      if (r != 21) s[0] = wt_add_ext(t, s[0], ext_make(PGL_PRC[r], 0));
+      wt_mds_partial_layer_fast_ext(t, s, (int)r);
+    }
+  } else {
+#pragma unroll 1
+    for (u32 i = 0; i < 12; i++) s[i] = wt_sbox_ext(t, s[i]);
+    wt_mds_layer_ext(t, s);
+  }
+  if (piece == 3) {
+#pragma unroll 1
+    for (u32 i = 0; i < 12; i++) s[i] = wt_add_ext(t, s[i], ext_make(PGL_FIRST[i], 0));  // :240-249
+    wt_mds_partial_layer_init_ext(t, s);
+  } else if (piece == 8) {
+#pragma unroll 1
+    for (u32 i = 0; i < 12; i++) ws_st(out, k++, wt_sub_ext(t, s[i], ws_ld(wires, 12 + i)));
+  } else {
+    // the constant layer of the NEXT round and its constraints against that round's S-box input wires
+    const u32 next_round = piece <= 2 ? piece + 1 : (piece == 4 ? 26 : 26 + (piece - 5) + 1);
+    const u32 next_wires = piece <= 2 ? start_full0 + piece * 12 : (piece == 4 ? start_full1 : start_full1 + (piece - 5 + 1) * 12);
+    wt_constant_layer_ext(t, s, (int)next_round);
+#pragma unroll 1
+    for (u32 i = 0; i < 12; i++) ws_st(out, k++, wt_sub_ext(t, s[i], ws_ld(wires, next_wires + i)));
+  }
+  size_t wrote = wt_words_since(t, start);
+  u64* const fm = trace + fm_off;
+  wt_seek(t, fm);
+#pragma unroll 1
+  for (u32 i = k0; i < k; i++) ws_st(out, i, wt_mul_ext(t, ws_ld(out, i), filter));
+  wrote += wt_words_since(t, fm);
+  wt_drain(t);
+  return wrote;
 }
 // phase 1, the lane of everything that does not depend on the gates
 GPV_DEV size_t dev_witness_plonk_perm(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch,
