@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--proofs-per-gpu", type=int, default=8192)
     ap.add_argument("--fixture", default="step", choices=["step", "decode_block"])
     ap.add_argument("--per-path-merkle", action="store_true", help="hash every step of every Merkle path, literally fri/fri.go:97-144 (GPV_OPT_MERKLE_SHARED_LEVELS = 0)")
+    ap.add_argument("--no-side-stream", action="store_true", help="GPV_OPT_SIDE_STREAM = 0: every kernel on one stream, one after the other (measurement: each kernel has the chip to itself)")
     ap.add_argument("--exchange", default="abi", choices=["abi", "torch"], help="who runs the accept all-gather for N > 1: libgpv's gpv_group (C ABI) or torch.distributed")
     ap.add_argument("--group-in-process", action="store_true", help="one process drives all N GPUs through gpv_group_create (do not launch under torchrun)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -289,6 +290,9 @@ def main():
     if args.per_path_merkle:
         for c in ctxs:
             c.set_option(2, 0)  # GPV_OPT_MERKLE_SHARED_LEVELS
+    if args.no_side_stream:
+        for c in ctxs:
+            c.set_option(6, 0)  # GPV_OPT_SIDE_STREAM
 
     # ---- circuit + synthetic batch, this process's blocks only
     wl = Workload(gpv, T, args.fixture, dev)
@@ -401,7 +405,7 @@ def main():
         "config": {"workload": "verifier.VerifierChip.Verify end-to-end (BASELINE config 4 shard)", "fixture": args.fixture,
                    "proofs_per_gpu": n_local, "global_batch": n_total, "queries_per_proof": ci.num_query_rounds,
                    "merkle_chains_per_proof": ci.num_query_rounds * (4 + len(ci.arity_bits)), "parallelism": "proof-sharded x%d" % n_ranks,
-                   "collective": collective,
+                   "collective": collective, "side_stream": "off (--no-side-stream): every kernel alone on one stream" if args.no_side_stream else "on (default)",
                    "merkle_shared_levels": "off: every path hashed on its own" if args.per_path_merkle else "on (default): the last 3 levels of each tree hashed once per distinct node, inputs compared "
                                            "word for word; accept bits identical to the per-path walk (GPV_OPT_MERKLE_SHARED_LEVELS)",
                    "bn254_fr_rows": "chosen per launch by occupancy (GPV_OPT_FR_EVALUATION = 0): waves per SIMD of full-length lanes (4 Merkle paths per query round) >= 4.5 "

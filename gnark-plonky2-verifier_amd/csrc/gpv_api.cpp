@@ -67,6 +67,7 @@ struct gpv_ctx {
   // shared upper Merkle levels (gpv_k_crown.hip)
   int merkle_shared = 1;  // GPV_OPT_MERKLE_SHARED_LEVELS: 0 off, 1 from GPV_MERKLE_SHARED_FROM proofs up, 2 always
   int fr_form = 0;        // GPV_OPT_FR_EVALUATION: 0 by launch size, 1 column scanning, 2 operand scanning (gpv_fr.cuh), 3 four lanes per permutation
+  int side_stream = 1;    // GPV_OPT_SIDE_STREAM: 1 transcript / plonk / FRI on the side stream under the leaf hashing, 0 everything on the main stream, one after the other
   void* crown = nullptr;
   size_t crown_bytes = 0;
   void* json_stage[2] = {nullptr, nullptr};  // pinned blocks of gpv_verify_json
@@ -306,6 +307,10 @@ extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
   }
   if (option == GPV_OPT_FR_EVALUATION && value >= 0 && value <= 3) {
     ctx->fr_form = value;
+    return GPV_OK;
+  }
+  if (option == GPV_OPT_SIDE_STREAM && value >= 0 && value <= 1) {
+    ctx->side_stream = value;
     return GPV_OK;
   }
   if (option == GPV_OPT_HOST_CHUNK_FIRST && value >= 1 && value <= (1 << 24)) {
@@ -571,6 +576,17 @@ static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* p
   rc = ensure_scratch(ctx, c, n);
   if (rc != GPV_OK) return rc;
   hipStream_t main_st = ctx->stream, side = ctx->side;
+  if (!ctx->side_stream) {  // GPV_OPT_SIDE_STREAM = 0 (measurement): the same launches on ONE stream, so that every kernel has the chip to itself
+    HIP_TRY(ctx, verdict_clear(ctx, n, main_st));
+    launch_transcript(ctx, main_st, dcd, proofs_dev, n);
+    launch_range_check(ctx, main_st, c, dcd, proofs_dev, n);
+    launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n);
+    launch_merkle_climb(ctx, main_st, c, dcd, proofs_dev, n, nullptr);
+    launch_plonk(ctx, main_st, c, dcd, proofs_dev, n);
+    launch_fri_query(ctx, main_st, c, dcd, proofs_dev, n);
+    CHECK_LAUNCH(ctx);
+    return GPV_OK;
+  }
   // The transcript goes first: its few waves (one lane per proof, a long dependent chain) must be resident before the leaf
   // hashing fills every wave slot of the chip, or they wait for the first Merkle waves to retire (milliseconds).
   HIP_TRY(ctx, verdict_clear(ctx, n, main_st));  // before the fork: the transcript reports into the visit counters
@@ -1596,6 +1612,7 @@ int gpvi_verify_host_batch(gpv_ctx* ctx, const gpv_circuit* c, const void* proof
     ctx->twin->merkle_shared = ctx->merkle_shared;
     ctx->twin->transcript_variant = ctx->transcript_variant;
     ctx->twin->fr_form = ctx->fr_form;
+    ctx->twin->side_stream = ctx->side_stream;
     ctx->twin->timing = ctx->timing;  // kernels of odd chunks are timed in the twin's accumulators; gpv_timing_get merges them
   }
   size_t done = 0, k = 0;

@@ -398,6 +398,25 @@ def test_verify_end_to_end(gpv, api, orc, name):  # verifier/verifier_test.go:13
     assert (ofail & 1).any()
 
 
+def test_side_stream_off_gives_the_same_verdicts(gpv, api, orc):
+    """GPV_OPT_SIDE_STREAM = 0 (the measurement form: every kernel alone on the context's stream) and the default pipeline agree with the
+    oracle on accept bits, masks and challenges."""
+    common, vo, circuit, proofs = _load(gpv, "step")
+    ci, packed, _ = T.load_fixture("step")
+    batch, tampered = T.synthetic_batch(ci, packed, 200, seed=21, tamper_every=3)
+    pb = gpv.variables.ProofBatch(circuit, batch)
+    chip = gpv.verifier.NewVerifierChip(api, common)
+    oacc, ofail, och = orc.verify(orc.circuit(ci), batch, n_threads=8)
+    try:
+        for mode in (0, 1):
+            api.set_option(gpv._lib.OPT_SIDE_STREAM, mode)
+            acc, mask, ch = chip.Verify(pb, vo, detail=True)
+            assert acc.tolist() == oacc.tolist() == (~tampered).astype(np.uint8).tolist(), mode
+            assert mask.tolist() == T.reported_mask(ofail).tolist() and (ch.flat == och).all(), mode
+    finally:
+        api.set_option(gpv._lib.OPT_SIDE_STREAM, 1)
+
+
 def test_verify_device_resident(gpv, api, orc):
     """gpv_verify_dev on torch-owned HBM buffers and torch's stream (the bench path)."""
     torch = pytest.importorskip("torch")

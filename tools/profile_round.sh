@@ -24,7 +24,14 @@ cd /tmp
 ( echo "# rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 1 <headline step only>   (MI355X, $TAG; KB)"
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o p -- $B --steps 1 --warmup 1 > /dev/null 2> $OUT/write.err
   summ $OUT/write --pmc ) > $OUT/pmc_write.txt
+# the same SQ pass with every kernel alone on one stream (GPV_OPT_SIDE_STREAM = 0): what k_merkle_leaves costs without the side stream underneath it
+( echo "# rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --no-side-stream --steps 1 --warmup 1 <headline step only>   (MI355X, $TAG)"
+  timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/sq1 -o p -- $B --no-side-stream --steps 1 --warmup 1 > /dev/null 2> $OUT/sq1.err
+  summ $OUT/sq1 --pmc ) > $OUT/pmc_sq_no_side_stream.txt
+( echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-side-stream --steps 5 --warmup 1 <headline step only>   (MI355X, $TAG)"
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats1 -o p -- $B --no-side-stream --steps 5 --warmup 1 > $OUT/bench_no_side_stream_under_rocprof.json 2> $OUT/stats1.err
+  summ $OUT/stats1 ) > $OUT/kernel_stats_no_side_stream.txt
 # HBM traffic of every kernel of the step, stamped with the build id of the library that was just profiled (bench.py checks it)
 python $ROOT/tools/make_traffic_json.py $OUT $TAG step 8192 > $OUT/traffic.json
-rm -rf $OUT/stats $OUT/sq $OUT/fetch $OUT/write
+rm -rf $OUT/stats $OUT/sq $OUT/fetch $OUT/write $OUT/sq1 $OUT/stats1
 for f in $OUT/*.err; do tail -n 2 $f; done
