@@ -519,6 +519,7 @@ def main():
             line["full_batch_65536"] = bench_full_batch(gpv, T, ctx, dev, args.fixture)
             line["single_proof"] = bench_single_proof(gpv, T, ctx, dev)
             line["witness_verify_1024"] = bench_witness(gpv, T, ctx, dev)
+            line["witness_verify_4096"] = bench_witness(gpv, T, ctx, dev, 4096)  # 44 GB of trace: the store-bound regime ("the trace cursor")
         if not args.no_poseidon_gl:
             line["poseidon_gl"] = bench_poseidon_gl(gpv, T, ctx, dev)
         if not args.no_heterogeneous and n_ranks == 1:

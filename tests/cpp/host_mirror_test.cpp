@@ -29,6 +29,14 @@ int main(int argc, char** argv) {
     circuit.pack_proof("{\"proof\": {}}");
     EXPECT(false);
   } catch (const gpv::Error& e) { EXPECT(e.code == GPV_ESHAPE); }
+  {  // the batch packer with a status per proof: the malformed text gets GPV_ESHAPE and an all-zero record, its neighbours are packed
+    std::string pj = slurp(dir + "/proof_with_public_inputs.json");
+    std::vector<int32_t> status;
+    std::vector<uint8_t> three = circuit.pack_proofs({pj, "{\"proof\": {}}", pj}, 2, &status);
+    EXPECT(status == (std::vector<int32_t>{GPV_OK, GPV_ESHAPE, GPV_OK}));
+    EXPECT(std::equal(proof.begin(), proof.end(), three.begin()) && std::equal(proof.begin(), proof.end(), three.begin() + 2 * proof.size()));
+    for (size_t i = 0; i < proof.size(); i++) EXPECT(three[proof.size() + i] == 0);
+  }
   // shard arithmetic is host-only: contiguous blocks, the extra proofs on the low ranks
   EXPECT(verifier::VerifierGroup::ShardBounds(65536, 7, 8) == std::make_pair((size_t)57344, (size_t)65536));
   EXPECT(verifier::VerifierGroup::ShardBounds(10, 1, 4) == std::make_pair((size_t)3, (size_t)6));
@@ -175,8 +183,16 @@ int main(int argc, char** argv) {
       EXPECT(vchip.Verify(two) == (std::vector<uint8_t>{1, 1}));
     }
     api.set_option(GPV_OPT_FR_EVALUATION, 0);
+    {  // JSON texts -> verdicts with a status per proof (gpv_verify_json_status); GPV_OPT_SIDE_STREAM = 0 gives the same verdicts
+      std::vector<int32_t> status;
+      std::vector<uint8_t> acc = vchip.VerifyJSON({pj, "[1, 2", pj}, 2, &status);
+      EXPECT(acc == (std::vector<uint8_t>{1, 0, 1}) && status == (std::vector<int32_t>{GPV_OK, GPV_ESHAPE, GPV_OK}));
+      api.set_option(GPV_OPT_SIDE_STREAM, 0);
+      EXPECT(vchip.Verify(two) == (std::vector<uint8_t>{1, 1}));
+      api.set_option(GPV_OPT_SIDE_STREAM, 1);
+    }
     api.synchronize();
-    EXPECT(api.timing_get(7).second == 4 && api.timing_get(7).first > 0);  // four launches of the leaf hashing
+    EXPECT(api.timing_get(7).second == 6 && api.timing_get(7).first > 0);  // six launches of the leaf hashing (four forms, the JSON batch, the one-stream run)
     api.timing_enable(false);
     plonk::PlonkChip pchip(api, circuit);
     std::vector<uint64_t> gc = pchip.EvaluateGateConstraints(proof);
