@@ -658,16 +658,18 @@ def bench_witness(gpv, T, ctx, dev, n=1024):
     gpv._lib.check(L.gpv_witness_verify_dev(*args), ctx.h)
     ctx.timing_enable(True)
     ctx.timing_reset()
-    reps = 3
-    t0 = time.perf_counter()
+    reps, times = 5, []
     for _ in range(reps):
+        t0 = time.perf_counter()
         gpv._lib.check(L.gpv_witness_verify_dev(*args), ctx.h)  # synchronises: the lanes' word counts are checked against the host layout
-    dt = (time.perf_counter() - t0) / reps
-    km = {nm: ctx.timing_get(k)[0] for nm, k in (("transcript_pass", 13), ("challenges_fill", 9), ("plonk", 10), ("fri", 11), ("range_check", 12))}
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[reps // 2]  # the median call: a 44 GB output buffer makes single calls noisy (first touches, clock ramps)
+    km = {nm: ctx.timing_get(k)[0] for nm, k in (("transcript_pass", 13), ("plonk_gate_units_beside_it", 14), ("challenges_fill", 9), ("plonk_rest", 10), ("fri", 11), ("range_check", 12))}
     ctx.timing_enable(False)
     if not ((status.cpu().numpy() == 0) == ~tam).all():
         raise SystemExit("witness_verify: status bytes do not match the tamper mask")
-    return {"entry_point": "gpv_witness_verify_dev", "proofs": n, "trace_words_per_proof": int(words), "ms_per_call": 1e3 * dt, "proofs_per_s": n / dt,
+    return {"entry_point": "gpv_witness_verify_dev", "proofs": n, "trace_words_per_proof": int(words), "ms_per_call": 1e3 * dt, "ms_per_call_all": [round(1e3 * x, 2) for x in times],
+            "proofs_per_s": n / dt,
             "trace_words_per_s": n * words / dt, "store_GBs": 8 * n * words / dt / 1e9, "store_frac_of_hbm_peak": 8 * n * words / dt / 1e9 / HBM_PEAK_GBS,
             "kernel_ms": km, "checked": "status == 0 exactly for the untampered proofs"}
 

@@ -28,7 +28,7 @@
 
 // ================================================================ context
 enum { TK_MERKLE = 0, TK_PGL = 1, TK_TRANSCRIPT = 2, TK_PLONK = 3, TK_FRI = 4, TK_RANGE = 5, TK_PBN = 6, TK_LEAVES = 7, TK_LOWER = 8, TK_WIT_CHALLENGES = 9,
-       TK_WIT_PLONK = 10, TK_WIT_FRI = 11, TK_WIT_RANGE = 12, TK_WIT_TRANSCRIPT = 13, TK_COUNT = 14 };
+       TK_WIT_PLONK = 10, TK_WIT_FRI = 11, TK_WIT_RANGE = 12, TK_WIT_TRANSCRIPT = 13, TK_WIT_PLONK_GATES = 14, TK_COUNT = 15 };
 
 struct TimingRec {
   int kind;
@@ -1239,9 +1239,11 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
   HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * (2 + nq) * n, main_st));
   HIP_TRY(ctx, hipMemsetAsync(dflags.p, 1, 3 * n, main_st));
   u64 *wr_pl = dwritten.p + n, *wr_fri = dwritten.p + 2 * n;
-  // main: transcript (challenges) -> [fork] -> challenges fill -> range check;  side: [wait fork] -> plonk;  side2: [wait fork] -> FRI.
-  // Slices 3 and 2 need only the challenges, so they start behind the transcript pass, next to the fill (round 4; until then the plonk
-  // slice waited for the fill as well and FRI ran after it: at 64 proofs 2.9 + max(2.0, 1.5) ms of dependent kernels, now 2.3 + 1.6).
+  // main: [C] -> transcript (challenges) -> [fork] -> challenges fill -> range check
+  // side: [wait C] -> plonk gate units -> [wait fork] -> rest of plonk;          side2: [wait fork] -> FRI (small batches; else on main behind the fill)
+  // The gate units of slice 3 (85 % of it) read no challenge: they run beside the transcript pass, which leaves most of the chip idle (16 lanes
+  // per proof, a dependent chain). Slice 2 and the rest of slice 3 need only the challenges, so they start behind the transcript pass, next to the fill
+  // (round 4; until then the plonk slice waited for the fill as well and FRI ran after it).
   {
     int rc = wcs.prepare(ctx, c, n, main_st);
     if (rc != GPV_OK) return rc;
@@ -1250,6 +1252,13 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
   // at 256, 9.3 / 9.5 at 1024 -- but 21.1 / 20.3 at 4096, where three store streams at once only get in each other's way
   const bool fri_beside = (size_t)wcs.n_segments * n < (size_t)4 * 64 * gpvk_device_simds();
   hipStream_t side2 = fri_beside ? ctx->side2 : main_st;
+  const u32 n_units = (u32)tab[3 + 2 * (size_t)c->dc.n_gates];
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_cleared, main_st));  // the counters and flags are cleared, the unit table is uploaded
+  HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_cleared, 0));
+  {
+    Timed t(ctx, TK_WIT_PLONK_GATES, side);
+    gpvk_witness_plonk(side, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch, total, dtab.p, n_units, dws.p, wsw, dflags.p + n, wr_pl, 1);
+  }
   {
     Timed t(ctx, TK_WIT_TRANSCRIPT, main_st);
     wcs.launch(main_st, dcd, dproofs, n, dtrace + w_rc, total, dch, 1);
@@ -1259,7 +1268,7 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
   if (fri_beside) HIP_TRY(ctx, hipStreamWaitEvent(side2, ctx->ev_fork, 0));
   {
     Timed t(ctx, TK_WIT_PLONK, side);
-    gpvk_witness_plonk(side, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch, total, dtab.p, (u32)tab[3 + 2 * (size_t)c->dc.n_gates], dws.p, wsw, dflags.p + n, wr_pl);
+    gpvk_witness_plonk(side, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch, total, dtab.p, n_units, dws.p, wsw, dflags.p + n, wr_pl, 2);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));
   auto launch_fri = [&]() {

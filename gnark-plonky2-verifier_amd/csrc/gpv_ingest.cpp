@@ -921,7 +921,8 @@ FriWitSizes witness_fri_layout(const DevCircuit& c, std::vector<uint8_t>* kinds)
 }
 // ---- slice 3: plonk.PlonkChip.Verify (csrc/gpv_witness.cuh, third part), the same walk without the arithmetic
 struct PlonkWitLayout : FriWitLayout {
-  // [off_sids | reduce_off | final_off | gate_off[n_gates] | gate_acc_off[n_gates] | n_units | units[n_units][4]] (csrc/gpv_witness.cuh WPlonkTab);
+  // [off_sids | reduce_off | final_off | gate_off[n_gates] | gate_acc_off[n_gates] | n_units | units[n_units][4] | first challenge block, words per block,
+  // words of its head, words per routed wire] (csrc/gpv_witness.cuh WPlonkTab);
   // a unit = {gate row, piece (GPV_WIT_WHOLE_GATE, or 0..8 of a PoseidonGate), first word, first word of its filter products}
   std::vector<uint64_t> tab;
   size_t piece_start[9] = {0};  // set by gate() for a PoseidonGate
@@ -1076,14 +1077,28 @@ PlonkWitLayout witness_plonk_layout(const DevCircuit& c, std::vector<uint8_t>* k
   L.tab[0] = L.words;
   for (uint32_t i = 0; i < c.num_routed; i++) L.scalar_mul_ext();  // evalVanishingPoly :121-207
   L.sub_ext(); L.scalar_mul_ext(); L.sub_ext(); L.div_ext();       // evalL0 :63-83
+  // per challenge: [z1 term | numerator / denominator of every routed wire | partial-product checks]; the blocks have one length, and inside a block the
+  // wires' records have one length: the device cuts them into units (csrc/gpv_witness.cuh dev_witness_plonk_perm_unit) from these three numbers
+  size_t blk0 = 0, blk_words = 0, wire_words = 0, head_words = 0;
   for (uint32_t i = 0; i < c.num_challenges; i++) {
+    const size_t b0 = L.words;
     L.sub_ext(); L.mul_ext();
-    for (uint32_t j = 0; j < c.num_routed; j++) { L.add_ext(); L.mul_ext(); L.add_ext(); L.mul_ext(); L.add_ext(); }
+    if (i == 0) { blk0 = b0; head_words = L.words - b0; }
+    for (uint32_t j = 0; j < c.num_routed; j++) {
+      const size_t w0 = L.words;
+      L.add_ext(); L.mul_ext(); L.add_ext(); L.mul_ext(); L.add_ext();
+      wire_words = L.words - w0;
+    }
     for (uint32_t k = 0; k <= c.num_pp; k++) {                     // checkPartialProducts :85-119
       for (uint32_t j = 1; j < c.qdf; j++) { L.mul_ext(); L.mul_ext(); }
       L.mul_ext(); L.mul_ext(); L.sub_ext();
     }
+    if (i == 0) blk_words = L.words - b0;
   }
+  L.tab.push_back(blk0);
+  L.tab.push_back(blk_words);
+  L.tab.push_back(head_words);
+  L.tab.push_back(wire_words);
   const size_t n_terms = (size_t)c.num_challenges * (c.num_pp + 2) + c.num_gate_constraints;
   L.tab[1] = L.words;
   for (size_t i = 0; i < n_terms * c.num_challenges; i++) { L.scalar_mul_ext(); L.add_ext(); }

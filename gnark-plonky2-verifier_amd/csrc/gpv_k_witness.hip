@@ -108,16 +108,20 @@ void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& h
 // with the layout); consistent[p] is cleared by the lane that sees the assertion of plonk.go:248 (or evalL0's, :75-80) fail.
 __global__ __launch_bounds__(64) void k_witness_plonk_units(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ challenges,
                                                             size_t n, u64* __restrict__ trace, size_t words_per_proof, const u64* __restrict__ tab,
-                                                            u32 n_units, u64* __restrict__ ws, size_t ws_words, unsigned long long* __restrict__ written, int staged) {
+                                                            u32 n_units, u32 unit_lo, u32 unit_hi, u64* __restrict__ ws, size_t ws_words,
+                                                            unsigned long long* __restrict__ written, int staged) {
   extern __shared__ u64 wt_lds[];
-  const u32 units = n_units + 1;  // one lane per unit of the table (a gate row, or one of the nine pieces of a PoseidonGate) + the lane of what does not depend on the gates
+  // units unit_lo .. unit_hi - 1 of: one lane per entry of the unit table (a gate row, or one of the nine pieces of a PoseidonGate), then (from unit
+  // n_units on) the units of what does not depend on the gates (dev_witness_plonk_perm_unit). The gate units read no challenge, so the caller of the
+  // whole trace launches them BEFORE the transcript pass has produced any (gpv_witness_verify) and the others behind it.
+  const u32 units = unit_hi - unit_lo;
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = item < n * units;
   if (!live) item = n * units - 1;  // stays for the wave's write-out; repeats the last item, reports nothing
   // unit-major: the 64 lanes of a wave work on the SAME unit of 64 proofs (proof-major order put 14 different gates in one wave, which
   // then executed every gate's code one after the other: 4.7 ms instead of 2.x for 256 proofs)
-  const u32 u = (u32)(item / n);
-  const size_t p = item - (size_t)u * n;
+  const u32 u = unit_lo + (u32)(item / n);
+  const size_t p = item - (size_t)(u - unit_lo) * n;
   const u64* rec = proofs + p * (dc->proof_nbytes / 8);
   WPlonkTab t{tab, dc->n_gates};
   u64* const lds = staged ? wt_lds : nullptr;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(64) void k_witness_plonk_units(const DevCircuit* __
     wrote = piece == GPV_WIT_WHOLE_GATE ? dev_witness_plonk_gate(dc, rec, row, trace + p * words_per_proof, t, ws + p * ws_words, lds)
                                         : dev_witness_plonk_poseidon_piece(dc, rec, row, piece, (size_t)e[2], (size_t)e[3], trace + p * words_per_proof, ws + p * ws_words, lds);
   } else {
-    wrote = dev_witness_plonk_perm(dc, rec, challenges + p * dc->n_challenge_words, trace + p * words_per_proof, t, ws + p * ws_words, lds);
+    wrote = dev_witness_plonk_perm_unit(dc, rec, challenges + p * dc->n_challenge_words, u - n_units, trace + p * words_per_proof, t, ws + p * ws_words, lds);
   }
   if (live) atomicAdd(&written[p], (unsigned long long)wrote);
 }
@@ -165,13 +169,17 @@ __global__ __launch_bounds__(64) void k_witness_plonk_reduce(const DevCircuit* _
   }
   if (!ok) consistent[p] = 0;
 }
-// consistent: preset to 1 by the caller; written: preset to 0
+// consistent: preset to 1 by the caller; written: preset to 0. part: 0 = the whole slice; 1 = the gate units only (they need no challenge);
+// 2 = the rest (the gate-independent lane, the per-constraint sums, the reduction) -- gpv_witness_verify runs part 1 beside the transcript.
 void gpvk_witness_plonk(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
-                        size_t words_per_proof, const u64* tab, u32 n_units, u64* ws, size_t ws_words, uint8_t* consistent, u64* written) {
+                        size_t words_per_proof, const u64* tab, u32 n_units, u64* ws, size_t ws_words, uint8_t* consistent, u64* written, int part) {
   unsigned long long* wr = (unsigned long long*)written;
-  const bool staged = gpvk_witness_staged(n * (n_units + 1), 3);
-  GPVK_LAUNCH(k_witness_plonk_units, dim3(gpvk_blocks_for(n * (n_units + 1), 64)), dim3(64), staged ? GPV_WT_LDS_WORDS * 8 : 0, st, dcd, proofs, challenges, n, trace,
-              words_per_proof, tab, n_units, ws, ws_words, wr, staged ? 1 : 0);
+  const u32 all = n_units + gpv_wit_perm_units(hc);
+  const u32 lo = part == 2 ? n_units : 0, hi = part == 1 ? n_units : all;
+  const bool staged = gpvk_witness_staged(n * (size_t)(hi - lo), 3);
+  GPVK_LAUNCH(k_witness_plonk_units, dim3(gpvk_blocks_for(n * (hi - lo), 64)), dim3(64), staged ? GPV_WT_LDS_WORDS * 8 : 0, st, dcd, proofs, challenges, n, trace,
+              words_per_proof, tab, n_units, lo, hi, ws, ws_words, wr, staged ? 1 : 0);
+  if (part == 1) return;
   GPVK_LAUNCH(k_witness_plonk_acc, dim3(gpvk_blocks_for(n * hc.num_gate_constraints, 64)), dim3(64), 0, st, dcd, n, trace, words_per_proof, tab, ws, ws_words, wr);
   GPVK_LAUNCH(k_witness_plonk_reduce, dim3(gpvk_blocks_for(n * hc.num_challenges, 64)), dim3(64), 0, st, dcd, proofs, challenges, n, trace, words_per_proof, tab,
               ws, ws_words, consistent, wr);

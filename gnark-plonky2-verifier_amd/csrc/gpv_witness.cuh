@@ -1196,6 +1196,9 @@ struct WPlonkTab {  // u64 table: [off_sids | reduce_off | final_off | gate_off[
   u32 n_gates;
   // unit u of phase 1: {gate row, piece (GPV_WIT_WHOLE_GATE or 0..8 of a PoseidonGate), first trace word, first word of its filter products}
   GPV_DEV const u64* unit(u32 u) const { return t + 3 + 2 * (size_t)n_gates + 1 + 4 * (size_t)u; }
+  GPV_DEV u32 n_units() const { return (u32)t[3 + 2 * (size_t)n_gates]; }
+  // the per-challenge blocks of the gate-independent part: [first block | words per block | words of a block's head | words per routed wire]
+  GPV_DEV const u64* blocks() const { return unit(n_units()); }
   GPV_DEV size_t off_sids() const { return t[0]; }
   GPV_DEV size_t reduce_off() const { return t[1]; }
   GPV_DEV size_t final_off() const { return t[2]; }
@@ -1422,6 +1425,106 @@ GPV_DEV size_t dev_witness_plonk_perm(const DevCircuit* __restrict__ dc, const u
     }
   }
   wrote += wt_words_since(t, start);
+  wt_drain(t);
+  return wrote;
+}
+// The same part cut into units (round 4): one lane per proof walked 21 000 words of dependent records -- after the PoseidonGate was cut up, the long pole
+// of the whole slice (6 ms at 4096 proofs, whatever the batch). Everything in it is a function of the challenges and the openings, and every record has a
+// fixed place, so:
+//   r = 0                          expPowerOf2Extension, the sIDs, evalL0 (what dev_witness_plonk_perm does before its loop over the challenges)
+//   r = 1 + i (chunks + 1) + c     challenge i: c < chunks: numerator / denominator of routed wires 8 c .. 8 c + 7; c = chunks: the z1 term and the partial-product
+//                                  checks. The sIDs, L_0 and the numerators / denominators a unit does not trace itself are recomputed natively (the same
+//                                  field elements, canonical).
+#define GPV_WIT_PERM_CHUNK 8u
+__host__ __device__ inline u32 gpv_wit_perm_units(const DevCircuit& c) { return 1 + c.num_challenges * ((c.num_routed + GPV_WIT_PERM_CHUNK - 1) / GPV_WIT_PERM_CHUNK + 1); }
+GPV_DEV Ext wit_canon(Ext x) { return ext_make(gl_canon(x.a), gl_canon(x.b)); }
+GPV_DEV size_t dev_witness_plonk_perm_unit(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch, u32 r,
+                                           u64* __restrict__ trace, const WPlonkTab& tab, u64* __restrict__ wsp, u64* lds) {
+  WPlonkWs ws(dc, wsp);
+  const u32 nc = dc->num_challenges, nr = dc->num_routed, qdf = dc->qdf, npp = dc->num_pp;
+  const Ext zeta = ext_make(ch[dc->ch_zeta], ch[dc->ch_zeta + 1]), one = ext_make(1, 0);
+  const u64* wires = rec + dc->off_wires;
+  const u64 degree = (u64)1 << dc->degree_bits;
+  WTrace t = wt_open(lds, trace);
+  if (r == 0) {
+    Ext zeta_pow_n = zeta;  // expPowerOf2Extension :55-61
+#pragma unroll 1
+    for (u32 i = 0; i < dc->degree_bits; i++) zeta_pow_n = wt_mul_ext(t, zeta_pow_n, zeta_pow_n);
+    ws_st(ws.zpn, 0, zeta_pow_n);
+    size_t wrote = wt_words_since(t, trace);
+    u64* const start = trace + tab.off_sids();
+    wt_seek(t, start);
+#pragma unroll 1
+    for (u32 i = 0; i < nr; i++) wt_scalar_mul_ext(t, zeta, dc->k_is[i]);  // evalVanishingPoly :121-207: the sIDs
+    Ext eval_zero_poly = wt_sub_ext(t, zeta_pow_n, one);                     // evalL0 :63-83
+    Ext scaled = wt_scalar_mul_ext(t, zeta, degree);
+    Ext denominator = wt_sub_ext(t, scaled, ext_make(degree, 0));
+    wt_div_ext(t, eval_zero_poly, denominator);
+    wrote += wt_words_since(t, start);
+    wt_drain(t);
+    return wrote;
+  }
+  const u32 chunks = (nr + GPV_WIT_PERM_CHUNK - 1) / GPV_WIT_PERM_CHUNK;
+  const u32 i = (r - 1) / (chunks + 1), c = (r - 1) - i * (chunks + 1);
+  const u64* blk = tab.blocks();
+  u64* const block = trace + blk[0] + (size_t)i * blk[1];
+  const Ext beta = ext_make(ch[dc->ch_betas + i], 0), gamma = ext_make(ch[dc->ch_gammas + i], 0);
+  if (c < chunks) {
+    const u32 j0 = c * GPV_WIT_PERM_CHUNK, j1 = j0 + GPV_WIT_PERM_CHUNK < nr ? j0 + GPV_WIT_PERM_CHUNK : nr;
+    u64* const start = block + blk[2] + (size_t)j0 * blk[3];
+    wt_seek(t, start);
+#pragma unroll 1
+    for (u32 j = j0; j < j1; j++) {
+      const Ext sid = wit_canon(ext_scalar_mul(zeta, dc->k_is[j]));
+      Ext wpg = wt_add_ext(t, ws_ld(wires, j), gamma);
+      Ext bs = wt_mul_ext(t, beta, sid);
+      wt_add_ext(t, bs, wpg);
+      Ext bg = wt_mul_ext(t, beta, ws_ld(rec + dc->off_sigmas, j));
+      wt_add_ext(t, bg, wpg);
+    }
+    const size_t wrote = wt_words_since(t, start);
+    wt_drain(t);
+    return wrote;
+  }
+  // the z1 term and checkPartialProducts :85-119 of challenge i
+  Ext zeta_pow_n = zeta;
+#pragma unroll 1
+  for (u32 k = 0; k < dc->degree_bits; k++) zeta_pow_n = ext_sqr(zeta_pow_n);
+  const Ext den0 = ext_sub(ext_scalar_mul(zeta, degree), ext_make(degree, 0));
+  const Ext l0 = wit_canon(ext_mul(ext_sub(zeta_pow_n, one), ext_inv(den0)));  // InverseExtension of 0 is 0 (base.go:316-336): the same value at zeta = 1
+  const u32 per = npp + 2;
+  wt_seek(t, block);
+  const Ext z = ws_ld(rec + dc->off_zs, i);
+  Ext zm1 = wt_sub_ext(t, z, one);
+  ws_st(ws.head, i * per, wt_mul_ext(t, l0, zm1));
+  size_t wrote = wt_words_since(t, block);
+  u64* const pp = block + blk[2] + (size_t)nr * blk[3];
+  wt_seek(t, pp);
+  Ext acc_k = z;
+#pragma unroll 1
+  for (u32 k = 0; k <= npp; k++) {
+    Ext np = one, dp = one;
+#pragma unroll 1
+    for (u32 j = 0; j < qdf; j++) {
+      const u32 w = k * qdf + j;
+      const Ext wpg = ext_add(ws_ld(wires, w), gamma);
+      const Ext num = wit_canon(ext_add(ext_mul(beta, ext_scalar_mul(zeta, dc->k_is[w])), wpg));
+      const Ext den = wit_canon(ext_add(ext_mul(beta, ws_ld(rec + dc->off_sigmas, w)), wpg));
+      if (j == 0) {
+        np = num;
+        dp = den;
+      } else {
+        np = wt_mul_ext(t, np, num);
+        dp = wt_mul_ext(t, dp, den);
+      }
+    }
+    const Ext acc_next = k < npp ? ws_ld(rec + dc->off_pp, i * npp + k) : ws_ld(rec + dc->off_zs_next, i);
+    Ext a = wt_mul_ext(t, acc_k, np);
+    Ext b = wt_mul_ext(t, acc_next, dp);
+    ws_st(ws.head, i * per + 1 + k, wt_sub_ext(t, a, b));
+    acc_k = acc_next;
+  }
+  wrote += wt_words_since(t, pp);
   wt_drain(t);
   return wrote;
 }

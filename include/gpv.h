@@ -422,8 +422,9 @@ int gpv_group_read_rank_accept(gpv_group* g, int local_index, uint8_t* accept, s
  * the stream each kernel was launched on. kind: 0 = the whole Merkle sibling walk (k_merkle_climb, or k_merkle_climb_lower +
  * k_crown_* with shared levels), 1 = poseidon_gl_permute, 2 = transcript, 3 = plonk, 4 = fri_query, 5 = range_check,
  * 6 = poseidon_bn254_permute, 7 = merkle leaf digests (k_merkle_leaves), 8 = k_merkle_climb_lower alone; the witness kernels of
- * gpv_witness_verify[_dev]: 9 = challenges (the fill pass), 10 = plonk, 11 = fri, 12 = range_check, 13 = the transcript pass of the challenges
- * slice (it yields the challenges; plonk and FRI start behind it).
+ * gpv_witness_verify[_dev]: 9 = challenges (the fill pass), 10 = plonk (in gpv_witness_verify: what needs the challenges), 11 = fri, 12 = range_check,
+ * 13 = the transcript pass of the challenges slice (it yields the challenges; FRI and the rest of plonk start behind it), 14 = the gate units of the
+ * plonk slice (they read no challenge and run beside the transcript pass).
  * Timing is off by default (no event overhead). */
 int gpv_timing_enable(gpv_ctx* ctx, int on);
 int gpv_timing_reset(gpv_ctx* ctx);

@@ -78,9 +78,9 @@ for name in ("step", "decode_block"):
         t = time.perf_counter()
         gpv._lib.check(L.gpv_witness_verify_dev(*args), ctx.h)
         dt = time.perf_counter() - t
-        km = [ctx.timing_get(k)[0] for k in (13, 9, 10, 11, 12)]
+        km = [ctx.timing_get(k)[0] for k in (13, 14, 9, 10, 11, 12)]
         ctx.timing_enable(False)
         assert int(dstatus.sum()) == 0
-        print("%-13s %5d proofs: %8.1f ms = %7.0f proofs/s = %.2f G trace words/s (%.1f GB of trace, %.2f TB/s); kernels: transcript %.1f, then challenges fill %.1f | plonk %.1f (side stream), fri %.1f, range check %.2f ms"
+        print("%-13s %5d proofs: %8.1f ms = %7.0f proofs/s = %.2f G trace words/s (%.1f GB of trace, %.2f TB/s); kernels: transcript %.1f beside plonk gate units %.1f (side stream), then challenges fill %.1f | rest of plonk %.1f (side stream), fri %.1f, range check %.2f ms"
               % (name, m, dt * 1e3, m / dt, m * words / dt / 1e9, 8e-9 * m * words, 8e-12 * m * words / dt, *km))
         del dtrace
