@@ -67,9 +67,12 @@ struct gpv_ctx {
   // shared upper Merkle levels (gpv_k_crown.hip)
   int merkle_shared = 1;  // GPV_OPT_MERKLE_SHARED_LEVELS: 0 off, 1 from GPV_MERKLE_SHARED_FROM proofs up, 2 always
   int fr_form = 0;        // GPV_OPT_FR_EVALUATION: 0 by launch size, 1 column scanning, 2 operand scanning (gpv_fr.cuh), 3 four lanes per permutation
+  int wit_staging = 0;    // GPV_OPT_WITNESS_STAGING: 0 the witness kernels stage their output through LDS when the launch is large enough, 1 always, 2 never
   int side_stream = 1;    // GPV_OPT_SIDE_STREAM: 1 transcript / plonk / FRI on the side stream under the leaf hashing, 0 everything on the main stream, one after the other
   void* crown = nullptr;
   size_t crown_bytes = 0;
+  void* wit = nullptr;  // grow-only scratch of gpv_witness_verify[_dev] (tables, counters, flags, the plonk workspace, the permutation log): a call
+  size_t wit_bytes = 0; // used to hipMalloc / hipFree seven buffers, and hipFree synchronises the device -- a millisecond of a 5 ms call
   void* json_stage[2] = {nullptr, nullptr};  // pinned blocks of gpv_verify_json
   size_t json_stage_bytes = 0;
   uint8_t* stage = nullptr;
@@ -276,6 +279,7 @@ extern "C" int gpv_ctx_destroy(gpv_ctx* ctx) {
   if (ctx->twin) gpv_ctx_destroy(ctx->twin);
   if (ctx->ev_twin_done) hipEventDestroy(ctx->ev_twin_done);
   if (ctx->crown) hipFree(ctx->crown);
+  if (ctx->wit) hipFree(ctx->wit);
   for (void* p : ctx->json_stage)
     if (p) hipHostFree(p);
   if (ctx->stage) hipFree(ctx->stage);
@@ -307,6 +311,10 @@ extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
   }
   if (option == GPV_OPT_FR_EVALUATION && value >= 0 && value <= 3) {
     ctx->fr_form = value;
+    return GPV_OK;
+  }
+  if (option == GPV_OPT_WITNESS_STAGING && value >= 0 && value <= 2) {
+    ctx->wit_staging = value;
     return GPV_OK;
   }
   if (option == GPV_OPT_SIDE_STREAM && value >= 0 && value <= 1) {
@@ -1048,16 +1056,29 @@ extern "C" int gpv_public_inputs_hash(gpv_ctx* ctx, const gpv_circuit* c, const 
 // Witness slice 1 (csrc/gpv_witness.cuh): the hint outputs of GetPublicInputsHash + GetChallenges in the reference's call order.
 // scratch of slice 1's two passes: the permutation log, the segment table on the device, the mismatch flag
 struct WitChallengesScratch {
-  DevBuf<u64> log, seg;
-  DevBuf<u32> bad;
+  DevBuf<uint8_t> own;  // when the caller brings no scratch
+  struct P { u64* p; };
+  P log{nullptr}, seg{nullptr};
+  struct Q { u32* p; } bad{nullptr};
   std::vector<uint64_t> off, len;  // host copies: must outlive the upload
   u32 n_segments = 0;
-  int prepare(gpv_ctx* ctx, const gpv_circuit* c, size_t n, hipStream_t st) {
+  static size_t up(size_t b) { return (b + 255) / 256 * 256; }
+  size_t bytes(const gpv_circuit* c, size_t n) {
     gpvi_witness_challenges_segments(c, &off, &len);
     n_segments = (u32)off.size();
-    HIP_TRY(ctx, log.alloc((size_t)n_segments * GPV_WIT_LOG_WORDS * n));
-    HIP_TRY(ctx, seg.alloc(2 * (size_t)n_segments));
-    HIP_TRY(ctx, bad.alloc(1));
+    return up(8 * (size_t)n_segments * GPV_WIT_LOG_WORDS * n) + up(16 * (size_t)n_segments) + 256;
+  }
+  // scratch: bytes(c, n) bytes of device memory, or null (allocated here)
+  int prepare(gpv_ctx* ctx, const gpv_circuit* c, size_t n, hipStream_t st, void* scratch = nullptr) {
+    const size_t need = bytes(c, n);
+    if (!scratch) {
+      HIP_TRY(ctx, own.alloc(need));
+      scratch = own.p;
+    }
+    uint8_t* b = (uint8_t*)scratch;
+    log.p = (u64*)b;
+    seg.p = (u64*)(b + up(8 * (size_t)n_segments * GPV_WIT_LOG_WORDS * n));
+    bad.p = (u32*)((uint8_t*)seg.p + up(16 * (size_t)n_segments));
     HIP_TRY(ctx, hipMemcpyAsync(seg.p, off.data(), 8 * (size_t)n_segments, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(seg.p + n_segments, len.data(), 8 * (size_t)n_segments, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(bad.p, 0, sizeof(u32), st));
@@ -1080,6 +1101,7 @@ struct WitChallengesScratch {
 extern "C" int gpv_witness_challenges(gpv_ctx* ctx, const gpv_circuit* c, const void* proofs, size_t n, uint64_t* trace, uint64_t* challenges) {
   REQUIRE(ctx, ctx && c && proofs && trace);
   ENTER(ctx);
+  gpvk_witness_staging(ctx->wit_staging);
   if (n == 0) return GPV_OK;
   const size_t words = gpv_witness_challenges_words(c), ncw = c->dc.n_challenge_words;
   HostBatch hb;
@@ -1107,6 +1129,7 @@ extern "C" int gpv_witness_fri(gpv_ctx* ctx, const gpv_circuit* c, const void* p
                                uint8_t* consistent) {
   REQUIRE(ctx, ctx && c && proofs && challenges && trace);
   ENTER(ctx);
+  gpvk_witness_staging(ctx->wit_staging);
   if (n == 0) return GPV_OK;
   for (u32 s = 0; s < c->dc.num_steps; s++) REQUIRE(ctx, c->dc.arity_bits[s] <= 5);
   size_t prefix = 0, round = 0;
@@ -1127,7 +1150,9 @@ extern "C" int gpv_witness_fri(gpv_ctx* ctx, const gpv_circuit* c, const void* p
   HIP_TRY(ctx, hipMemcpyAsync(dch.p, challenges, 8 * ncw * n, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * nq * n, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(dcons.p, 1, n, ctx->stream));
-  gpvk_witness_fri(ctx->stream, dcd, c->dc, (const u64*)hb.proofs.p, dch.p, n, dtrace.p, words, prefix, round, dcons.p, dwritten.p);
+  std::vector<uint64_t> piece_off;
+  gpvi_witness_fri_pieces(c, &piece_off);
+  gpvk_witness_fri(ctx->stream, dcd, c->dc, (const u64*)hb.proofs.p, dch.p, n, dtrace.p, words, prefix, round, piece_off.data(), dcons.p, dwritten.p);
   CHECK_LAUNCH(ctx);
   std::vector<u64> written(nq * n);
   HIP_TRY(ctx, hipMemcpyAsync(written.data(), dwritten.p, 8 * nq * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1148,6 +1173,7 @@ extern "C" int gpv_witness_plonk(gpv_ctx* ctx, const gpv_circuit* c, const void*
                                  uint8_t* consistent) {
   REQUIRE(ctx, ctx && c && proofs && challenges && trace);
   ENTER(ctx);
+  gpvk_witness_staging(ctx->wit_staging);
   if (n == 0) return GPV_OK;
   const size_t words = gpv_witness_plonk_words(c), ncw = c->dc.n_challenge_words, wsw = gpv_wit_plonk_ws_words(c->dc);
   HostBatch hb;
@@ -1221,19 +1247,32 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
   gpvi_witness_fri_sizes(c, &prefix, &round);
   const size_t nq = c->dc.num_queries, w_fri = prefix + nq * round, total = w_rc + w_ch + w_pl + w_fri, wsw = gpv_wit_plonk_ws_words(c->dc);
   for (u32 s = 0; s < c->dc.num_steps; s++) REQUIRE(ctx, c->dc.arity_bits[s] <= 5);
-  DevBuf<u64> dwritten, dws, dch_own, dtab;
-  DevBuf<uint8_t> dflags;  // [3][n]: range ok, plonk consistent, fri consistent
+  // every temporary of the call out of ONE grow-only allocation of the context
+  struct { u64* p; } dwritten, dws, dch_own, dtab;
+  struct { uint8_t* p; } dflags;  // [3][n]: range ok, plonk consistent, fri consistent
   WitChallengesScratch wcs;
   std::vector<uint64_t> tab;
   gpvi_witness_plonk_table(c, &tab);
-  HIP_TRY(ctx, dtab.alloc(tab.size()));
-  HIP_TRY(ctx, hipMemcpyAsync(dtab.p, tab.data(), 8 * tab.size(), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, dwritten.alloc((2 + nq) * n));
-  HIP_TRY(ctx, dws.alloc(wsw * n));
-  HIP_TRY(ctx, dflags.alloc(3 * n));
-  if (!dch) {
-    HIP_TRY(ctx, dch_own.alloc((size_t)c->dc.n_challenge_words * n));
-    dch = dch_own.p;
+  {
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_tab = up(8 * tab.size()), b_wr = up(8 * (2 + nq) * n), b_ws = up(8 * wsw * n), b_fl = up(3 * n),
+                 b_ch = dch ? 0 : up(8 * (size_t)c->dc.n_challenge_words * n), b_wcs = wcs.bytes(c, n);
+    const size_t need = b_tab + b_wr + b_ws + b_fl + b_ch + b_wcs;
+    if (need > ctx->wit_bytes) {
+      if (ctx->wit) { hipStreamSynchronize(ctx->stream); hipFree(ctx->wit); ctx->wit = nullptr; ctx->wit_bytes = 0; }
+      HIP_TRY(ctx, hipMalloc(&ctx->wit, need));
+      ctx->wit_bytes = need;
+    }
+    uint8_t* b = (uint8_t*)ctx->wit;
+    dtab.p = (u64*)b; b += b_tab;
+    dwritten.p = (u64*)b; b += b_wr;
+    dws.p = (u64*)b; b += b_ws;
+    dflags.p = b; b += b_fl;
+    dch_own.p = (u64*)b; b += b_ch;
+    if (!dch) dch = dch_own.p;
+    HIP_TRY(ctx, hipMemcpyAsync(dtab.p, tab.data(), 8 * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    int rc = wcs.prepare(ctx, c, n, ctx->stream, b);
+    if (rc != GPV_OK) return rc;
   }
   hipStream_t main_st = ctx->stream, side = ctx->side;
   HIP_TRY(ctx, hipMemsetAsync(dwritten.p, 0, 8 * (2 + nq) * n, main_st));
@@ -1244,10 +1283,6 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
   // The gate units of slice 3 (85 % of it) read no challenge: they run beside the transcript pass, which leaves most of the chip idle (16 lanes
   // per proof, a dependent chain). Slice 2 and the rest of slice 3 need only the challenges, so they start behind the transcript pass, next to the fill
   // (round 4; until then the plonk slice waited for the fill as well and FRI ran after it).
-  {
-    int rc = wcs.prepare(ctx, c, n, main_st);
-    if (rc != GPV_OK) return rc;
-  }
   // FRI next to the fill only while the fill leaves room (below four waves per SIMD of fill lanes): 5.7 instead of 6.5 ms at 64 proofs, 6.5 / 7.4
   // at 256, 9.3 / 9.5 at 1024 -- but 21.1 / 20.3 at 4096, where three store streams at once only get in each other's way
   const bool fri_beside = (size_t)wcs.n_segments * n < (size_t)4 * 64 * gpvk_device_simds();
@@ -1271,9 +1306,11 @@ static int witness_verify_core(gpv_ctx* ctx, const gpv_circuit* c, const DevCirc
     gpvk_witness_plonk(side, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch, total, dtab.p, n_units, dws.p, wsw, dflags.p + n, wr_pl, 2);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));
+  std::vector<uint64_t> fri_piece_off;
+  gpvi_witness_fri_pieces(c, &fri_piece_off);
   auto launch_fri = [&]() {
     Timed t(ctx, TK_WIT_FRI, side2);
-    gpvk_witness_fri(side2, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch + w_pl, total, prefix, round, dflags.p + 2 * n, wr_fri);
+    gpvk_witness_fri(side2, dcd, c->dc, dproofs, dch, n, dtrace + w_rc + w_ch + w_pl, total, prefix, round, fri_piece_off.data(), dflags.p + 2 * n, wr_fri);
   };
   if (fri_beside) {
     launch_fri();
@@ -1321,6 +1358,7 @@ extern "C" int gpv_witness_verify_dev(gpv_ctx* ctx, const gpv_circuit* c, const 
                                       uint64_t* challenges_dev, uint8_t* status_dev) {
   REQUIRE(ctx, ctx && c && proofs_dev && trace_dev);
   ENTER(ctx);
+  gpvk_witness_staging(ctx->wit_staging);
   if (n == 0) return GPV_OK;
   const DevCircuit* dcd;
   int rc = circuit_on_device(ctx, c, &dcd);
@@ -1331,6 +1369,7 @@ extern "C" int gpv_witness_verify(gpv_ctx* ctx, const gpv_circuit* c, const void
                                   uint8_t* status) {
   REQUIRE(ctx, ctx && c && proofs && trace);
   ENTER(ctx);
+  gpvk_witness_staging(ctx->wit_staging);
   if (n == 0) return GPV_OK;
   const size_t total = gpv_witness_verify_words(c), ncw = c->dc.n_challenge_words;
   HostBatch hb;

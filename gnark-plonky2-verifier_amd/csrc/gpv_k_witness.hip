@@ -8,7 +8,14 @@
 // (0.5 waves per SIMD), 6.1 / 4.0 at 1024, 17.2 / 10.0 at 4096; FRI (28 lanes per proof) 2.0 / 3.0 at 64, 3.0 / 3.3 at 256, 3.8 / 3.6 at 1024
 // (0.44), 12.7 / 6.7 at 4096; plonk units (15 lanes per proof, the long pole is ONE lane's Poseidon gate) 3.8 / 6.9 at 64, 6.1 / 8.2 at 1024,
 // 18.4 / 12.9 at 4096 (0.94). quarter_waves: the threshold in quarters of a wave per SIMD.
-static bool gpvk_witness_staged(size_t lanes, unsigned quarter_waves) { return 4 * lanes >= (size_t)quarter_waves * 64 * gpvk_device_simds(); }
+// GPV_OPT_WITNESS_STAGING of the context whose entry point is running on this host thread: 0 by occupancy, 1 always, 2 never (the parity
+// tests force both forms at sizes the oracle can follow).
+static thread_local int g_witness_staging = 0;
+void gpvk_witness_staging(int mode) { g_witness_staging = mode; }
+static bool gpvk_witness_staged(size_t lanes, unsigned quarter_waves) {
+  if (g_witness_staging) return g_witness_staging == 1;
+  return 4 * lanes >= (size_t)quarter_waves * 64 * gpvk_device_simds();
+}
 
 // Slice 1 in two passes (gpv_witness.cuh): the native (cooperative) transcript logs every permutation's input, then one lane per (proof, permutation)
 // writes that permutation's literal trace at its fixed offset. `bad` is set when a lane's word count (or the number of logged
@@ -77,31 +84,36 @@ void gpvk_witness_range_check(hipStream_t st, const DevCircuit* dcd, const u64* 
   GPVK_LAUNCH(k_witness_range_check, dim3(4096), dim3(256), 0, st, dcd, proofs, n, trace, words_per_proof, ok);
 }
 
-// Witness slice 2: one lane per (proof, query round); the lane of query 0 also emits what precedes the rounds. written[p * nq + q] =
-// words the lane wrote (checked on the host against the layout).
+// Witness slice 2 in units (gpv_witness.cuh dev_witness_fri_unit): the prefix, then per query round the combination and one unit per reduction step.
+// written[p * nq + q] += the words a unit wrote (the prefix counts for round 0; checked on the host against the layout).
 __global__ __launch_bounds__(64) void k_witness_fri(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, const u64* __restrict__ challenges,
                                                     size_t n, u64* __restrict__ trace, size_t words_per_proof, size_t prefix_words, size_t round_words,
-                                                    uint8_t* __restrict__ consistent, u64* __restrict__ written, int staged) {
+                                                    WFriPieces pieces, uint8_t* __restrict__ consistent, unsigned long long* __restrict__ written, int staged) {
   extern __shared__ u64 wt_lds[];
+  const u32 nq = dc->num_queries, units = 1 + nq * (1 + dc->num_steps);
   size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const u32 nq = dc->num_queries;
-  const bool live = item < n * nq;
-  if (!live) item = n * nq - 1;  // stays for the wave's write-out; repeats the last item, reports nothing
-  // round-major: a wave holds the same query round of 64 proofs (the lanes of round 0 all carry the prefix; no wave waits for one lane)
-  const u32 q = (u32)(item / n);
-  const size_t p = item - (size_t)q * n;
+  const bool live = item < n * units;
+  if (!live) item = n * units - 1;  // stays for the wave's write-out; repeats the last item, reports nothing
+  // unit-major: a wave holds the same unit of 64 proofs (lockstep; no wave waits for one lane's prefix)
+  const u32 u = (u32)(item / n);
+  const size_t p = item - (size_t)u * n;
   size_t wrote = 0;
-  const bool ok = dev_witness_fri(dc, proofs + p * (dc->proof_nbytes / 8), challenges + p * dc->n_challenge_words, q, trace + p * words_per_proof,
-                                  prefix_words, round_words, &wrote, staged ? wt_lds : nullptr);
+  u32 q = 0;
+  const bool ok = dev_witness_fri_unit(dc, proofs + p * (dc->proof_nbytes / 8), challenges + p * dc->n_challenge_words, u, trace + p * words_per_proof,
+                                       prefix_words, round_words, pieces, &q, &wrote, staged ? wt_lds : nullptr);
   if (!live) return;
-  written[p * nq + q] = wrote;
+  atomicAdd(&written[p * nq + q], (unsigned long long)wrote);
   if (!ok) consistent[p] = 0;
 }
+// piece_off: 1 + num_steps words (gpvi_witness_fri_pieces)
 void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
-                      size_t words_per_proof, size_t prefix_words, size_t round_words, uint8_t* consistent, u64* written) {
-  const bool staged = gpvk_witness_staged(n * hc.num_queries, 2);
-  GPVK_LAUNCH(k_witness_fri, dim3(gpvk_blocks_for(n * hc.num_queries, 64)), dim3(64), staged ? GPV_WT_LDS_WORDS * 8 : 0, st, dcd, proofs, challenges, n, trace,
-              words_per_proof, prefix_words, round_words, consistent, written, staged ? 1 : 0);
+                      size_t words_per_proof, size_t prefix_words, size_t round_words, const u64* piece_off, uint8_t* consistent, u64* written) {
+  WFriPieces pieces;
+  for (u32 i = 0; i < 1 + GPV_MAX_STEPS; i++) pieces.off[i] = i < 1 + hc.num_steps ? piece_off[i] : 0;
+  const size_t lanes = n * (1 + (size_t)hc.num_queries * (1 + hc.num_steps));
+  const bool staged = gpvk_witness_staged(lanes, 2);
+  GPVK_LAUNCH(k_witness_fri, dim3(gpvk_blocks_for(lanes, 64)), dim3(64), staged ? GPV_WT_LDS_WORDS * 8 : 0, st, dcd, proofs, challenges, n, trace,
+              words_per_proof, prefix_words, round_words, pieces, consistent, (unsigned long long*)written, staged ? 1 : 0);
 }
 
 // Witness slice 3: PlonkChip.Verify in three phases (gpv_witness.cuh). written[p] += every lane's word count (the host compares the sum

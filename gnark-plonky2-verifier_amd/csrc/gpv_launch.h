@@ -167,10 +167,11 @@ void gpvk_gather_pih(hipStream_t st, const u64* derived, u64* out, u32 ncw, size
 // slice 1: log [n][n_segments][GPV_WIT_LOG_WORDS] scratch; seg_off / seg_len [n_segments] from the host layout (gpvi_witness_challenges_segments);
 // *bad != 0 afterwards = the kernels' walk and the layout disagree
 #define GPV_WIT_LOG_WORDS 21
+void gpvk_witness_staging(int mode);  // for the witness launches of the calling host thread: 0 staged by occupancy, 1 always, 2 never
 void gpvk_witness_challenges(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, u64* challenges,
                              u64* log, u32 n_segments, const u64* seg_off, const u64* seg_len, u32* bad, int pass = 0);
 void gpvk_witness_fri(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* challenges, size_t n, u64* trace,
-                      size_t words_per_proof, size_t prefix_words, size_t round_words, uint8_t* consistent, u64* written);
+                      size_t words_per_proof, size_t prefix_words, size_t round_words, const u64* piece_off, uint8_t* consistent, u64* written);
 void gpvk_witness_range_check(hipStream_t st, const DevCircuit* dcd, const u64* proofs, size_t n, u64* trace, size_t words_per_proof, uint8_t* ok);
 // per-proof workspace of the plonk witness kernels in words (gpv_witness.cuh WPlonkWs): filtered constraints and tmp per gate + gate_terms +
 // sIDs + numerators + denominators + per challenge [z1 term | partial-product checks] + zeta^n, all extension elements

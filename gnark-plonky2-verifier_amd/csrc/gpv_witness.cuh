@@ -617,87 +617,135 @@ GPV_DEV Ext wt_reduce_with_powers_words(WTrace& t, const u64* __restrict__ lo, c
   for (const u64* w = hi; w > lo; w -= 2) acc = wt_mul_add_ext(t, wbe_from(acc), s, ext_make(w[-2], w[-1]));
   return acc;
 }
-// One (proof, query) lane. prefix_words: length of the part that precedes the query rounds (GetInstance + fromOpeningsAndAlpha), emitted
-// by the lane of query 0; round_words: length of one query round. Returns false when one of the reference's FRI consistency assertions
-// (:460-461, :496-497) fails -- the trace is what the solver would be handed either way.
-GPV_DEV bool dev_witness_fri(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch, u32 q,
-                             u64* __restrict__ trace, size_t prefix_words, size_t round_words, size_t* written, u64* lds) {
+// Slice 2 in units (round 4). One lane per (proof, query round) walked 17 000 words of dependent records, and the lane of round 0 the prefix before them:
+// with 28 lanes per proof the kernel was latency-bound at every batch size and sat on the critical chain transcript -> fill -> FRI. A round's values are a
+// function of the challenges and the proof alone, every record has a fixed place, and every assertion compares a piece's OWN result with proof data, so
+// the round is cut where a result is handed on, and the next piece recomputes what it is handed natively (the same field elements, canonical, untraced):
+//   unit 0                          the prefix: GetInstance + fromOpeningsAndAlpha (fri.go:46-50, :82-95)
+//   unit 1 + q (1 + steps) + 0      round q: x_index, calculateSubgroupX, friCombineInitial; asserts step 0's evaluation against its result (:460-461)
+//   unit 1 + q (1 + steps) + 1 + s  round q, reduction step s: computeEvaluation and the squarings of x; asserts step s + 1's evaluation -- the last step
+//                                   evaluates the final polynomial behind it and asserts that (:496-497)
+// piece_off: where the pieces of a round start (host layout, gpvi_witness_fri_pieces). Returns false when an assertion the unit owns fails.
+GPV_DEV Ext wit_canon(Ext x) { return ext_make(gl_canon(x.a), gl_canon(x.b)); }
+struct WFriPieces {
+  u64 off[1 + GPV_MAX_STEPS];
+};
+GPV_DEV bool dev_witness_fri_unit(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch, u32 unit,
+                                  u64* __restrict__ trace, size_t prefix_words, size_t round_words, const WFriPieces& pieces, u32* q_out,
+                                  size_t* written, u64* lds) {
   const Ext zeta = ext_make(ch[dc->ch_zeta], ch[dc->ch_zeta + 1]), alpha = ext_make(ch[dc->ch_fri_alpha], ch[dc->ch_fri_alpha + 1]);
   const OpeningRanges orr = opening_ranges(dc);
-  Ext points[2], precomputed[2];
-  size_t wrote = 0;
   WTrace t = wt_open(lds, trace);
-  if (q == 0) {  // GetInstance fri.go:46-50, then fromOpeningsAndAlpha :82-95: the zeta batch, then the zeta*g batch
-    points[1] = wt_mul_ext(t, ext_make(dc->root_degree, 0), zeta);
+  if (unit == 0) {  // GetInstance fri.go:46-50, then fromOpeningsAndAlpha :82-95: the zeta batch, then the zeta*g batch
+    wt_mul_ext(t, ext_make(dc->root_degree, 0), zeta);
     Ext acc = wt_reduce_with_powers_words(t, rec + orr.b0, rec + orr.b1, ext_make(0, 0), alpha);
-    precomputed[0] = wt_reduce_with_powers_words(t, rec + orr.a0, rec + orr.a1, acc, alpha);
-    precomputed[1] = wt_reduce_with_powers_words(t, rec + orr.c0, rec + orr.c1, ext_make(0, 0), alpha);
-    wrote = wt_words_since(t, trace);
-  } else {  // the same values without a trace
+    wt_reduce_with_powers_words(t, rec + orr.a0, rec + orr.a1, acc, alpha);
+    wt_reduce_with_powers_words(t, rec + orr.c0, rec + orr.c1, ext_make(0, 0), alpha);
+    *written = wt_words_since(t, trace);
+    *q_out = 0;
+    wt_drain(t);
+    return true;
+  }
+  const u32 per = 1 + dc->num_steps, q = (unit - 1) / per, piece = (unit - 1) - q * per;
+  *q_out = q;
+  const u64* qrec = rec + dc->off_queries + (size_t)q * dc->query_words;
+  const u32 nlog = dc->lde_bits;
+  u64* const start = trace + prefix_words + (size_t)q * round_words + pieces.off[piece];
+  wt_seek(t, start);
+  bool ok = true;
+  if (piece == 0) {
+    Ext points[2], precomputed[2];  // what the prefix traces, natively
+    points[0] = zeta;
     points[1] = ext_scalar_mul(zeta, dc->root_degree);
     Ext acc = ext_make(0, 0);
     for (u32 w = orr.b1; w > orr.b0; w -= 2) acc = ext_muladd(acc, alpha, ext_make(rec[w - 2], rec[w - 1]));
     for (u32 w = orr.a1; w > orr.a0; w -= 2) acc = ext_muladd(acc, alpha, ext_make(rec[w - 2], rec[w - 1]));
-    precomputed[0] = acc;
+    precomputed[0] = wit_canon(acc);
     acc = ext_make(0, 0);
     for (u32 w = orr.c1; w > orr.c0; w -= 2) acc = ext_muladd(acc, alpha, ext_make(rec[w - 2], rec[w - 1]));
-    precomputed[1] = acc;
-  }
-  points[0] = zeta;
-  u64* const round_start = trace + prefix_words + (size_t)q * round_words;
-  wt_seek(t, round_start);
-  bool ok = true;
-  const u64* qrec = rec + dc->off_queries + (size_t)q * dc->query_words;
-  const u32 nlog = dc->lde_bits;
-  WBig xi = wb_from(ch[dc->ch_queries + q]);
-  const u64 x_index = wt_reduce(t, xi);  // :400
-  u32 idx = (u32)(x_index & (((u64)1 << nlog) - 1));
-  // calculateSubgroupX :187-206: the reversed bit list pairs bit (nlog - 1 - i) with base^(2^i)
-  u64 x = wt_mul(t, 7, wt_exp_from_bits_const_base(t, dc->root_lde, __brev(idx) >> (32 - nlog), nlog));
-  // friCombineInitial :208-251
-  Ext total = ext_make(0, 0);
+    precomputed[1] = wit_canon(acc);
+    points[1] = wit_canon(points[1]);
+    WBig xi = wb_from(ch[dc->ch_queries + q]);
+    const u64 x_index = wt_reduce(t, xi);  // :400
+    const u32 idx = (u32)(x_index & (((u64)1 << nlog) - 1));
+    // calculateSubgroupX :187-206: the reversed bit list pairs bit (nlog - 1 - i) with base^(2^i)
+    const u64 x = wt_mul(t, 7, wt_exp_from_bits_const_base(t, dc->root_lde, __brev(idx) >> (32 - nlog), nlog));
+    Ext total = ext_make(0, 0);  // friCombineInitial :208-251
 #pragma unroll 1
-  for (int b = 0; b < 2; b++) {
-    Ext reduced = ext_make(0, 0);
-    u32 n_evals = 0;
-    if (b == 0) {
+    for (int b = 0; b < 2; b++) {
+      Ext reduced = ext_make(0, 0);
+      u32 n_evals = 0;
+      if (b == 0) {
 #pragma unroll 1
-      for (int o = 3; o >= 0; o--) {  // ReduceWithPowers runs from the last polynomial down: oracle 3 first
-        const u32 len = dc->leaf_len[o] - dc->leaf_salt[o];
-        n_evals += len;
+        for (int o = 3; o >= 0; o--) {  // ReduceWithPowers runs from the last polynomial down: oracle 3 first
+          const u32 len = dc->leaf_len[o] - dc->leaf_salt[o];
+          n_evals += len;
 #pragma unroll 1
-        for (u32 i = len; i-- > 0;) reduced = wt_mul_add_ext(t, wbe_from(reduced), alpha, ext_make(qrec[dc->leaf_off[o] + i], 0));
+          for (u32 i = len; i-- > 0;) reduced = wt_mul_add_ext(t, wbe_from(reduced), alpha, ext_make(qrec[dc->leaf_off[o] + i], 0));
+        }
+      } else {
+        n_evals = dc->num_challenges;
+#pragma unroll 1
+        for (u32 i = n_evals; i-- > 0;) reduced = wt_mul_add_ext(t, wbe_from(reduced), alpha, ext_make(qrec[dc->leaf_off[2] + i], 0));
       }
-    } else {
-      n_evals = dc->num_challenges;
-#pragma unroll 1
-      for (u32 i = n_evals; i-- > 0;) reduced = wt_mul_add_ext(t, wbe_from(reduced), alpha, ext_make(qrec[dc->leaf_off[2] + i], 0));
+      WBigExt numerator = wt_sub_ext_nr(wbe_from(reduced), precomputed[b]);
+      Ext denominator = wt_sub_ext(t, ext_make(x, 0), points[b]);
+      Ext e = wt_exp_ext(t, alpha, n_evals);
+      total = wt_mul_ext(t, e, total);
+      ok &= !ext_is_zero(denominator);  // fri.go:241-242 (InverseExtension's "operand != 0"); InverseHint of 0 is 0, the trace goes on
+      Ext inv = wt_inverse_ext(t, denominator);
+      total = wt_mul_add_ext(t, numerator, inv, total);
     }
-    WBigExt numerator = wt_sub_ext_nr(wbe_from(reduced), precomputed[b]);
-    Ext denominator = wt_sub_ext(t, ext_make(x, 0), points[b]);
-    Ext e = wt_exp_ext(t, alpha, n_evals);
-    total = wt_mul_ext(t, e, total);
-    ok &= !ext_is_zero(denominator);  // fri.go:241-242 (InverseExtension's "operand != 0"); InverseHint of 0 is 0, the trace goes on
-    Ext inv = wt_inverse_ext(t, denominator);
-    total = wt_mul_add_ext(t, numerator, inv, total);
-  }
-  Ext old_eval = total;
+    if (dc->num_steps) {
+      const u64* evals = qrec + dc->step_evals_off[0];
+      const u32 idx_in = idx & ((1u << dc->arity_bits[0]) - 1);
+      ok &= evals[2 * idx_in] == total.a && evals[2 * idx_in + 1] == total.b;  // :460-461 of step 0
+    } else {  // no reduction step: the final polynomial follows the combination directly
+      Ext fin = ext_make(0, 0);
 #pragma unroll 1
-  for (u32 s = 0; s < dc->num_steps; s++) {
+      for (u32 i = dc->final_len; i-- > 0;) fin = wt_mul_add_ext(t, wbe_from(fin), ext_make(x, 0), ext_make(rec[dc->off_final + 2 * i], rec[dc->off_final + 2 * i + 1]));
+      ok &= fin.a == total.a && fin.b == total.b;
+    }
+  } else {
+    const u32 s = piece - 1;
+    // the subgroup point and the index as step s finds them: x^(2^(bits folded so far)), idx >> that many bits (natively)
+    u32 idx = (u32)(gl_canon(ch[dc->ch_queries + q]) & (((u64)1 << nlog) - 1));
+    u64 x = 1, wp = dc->root_lde;
+    {
+      const u32 e = __brev(idx) >> (32 - nlog);
+#pragma unroll 1
+      for (u32 b = 0; b < nlog; b++) {
+        if ((e >> b) & 1) x = gl_mul(x, wp);
+        wp = gl_sqr(wp);
+      }
+      x = gl_mul(x, 7);
+    }
+#pragma unroll 1
+    for (u32 k = 0; k < s; k++) {
+#pragma unroll 1
+      for (u32 j = 0; j < dc->arity_bits[k]; j++) x = gl_sqr(x);
+      idx >>= dc->arity_bits[k];
+    }
+    x = gl_canon(x);
     const u64* evals = qrec + dc->step_evals_off[s];
     const u32 ab = dc->arity_bits[s];
     const u32 idx_in = idx & ((1u << ab) - 1);
-    ok &= evals[2 * idx_in] == old_eval.a && evals[2 * idx_in + 1] == old_eval.b;  // :460-461
-    old_eval = wt_compute_evaluation(t, x, idx_in, ab, evals, ext_make(ch[dc->ch_fri_betas + 2 * s], ch[dc->ch_fri_betas + 2 * s + 1]), &ok);
+    Ext result = wt_compute_evaluation(t, x, idx_in, ab, evals, ext_make(ch[dc->ch_fri_betas + 2 * s], ch[dc->ch_fri_betas + 2 * s + 1]), &ok);
 #pragma unroll 1
     for (u32 j = 0; j < ab; j++) x = wt_mul(t, x, x);  // :486-488
     idx >>= ab;
-  }
-  Ext fin = ext_make(0, 0);  // finalPolyEval :253-259
+    if (s + 1 < dc->num_steps) {
+      const u64* next = qrec + dc->step_evals_off[s + 1];
+      const u32 nin = idx & ((1u << dc->arity_bits[s + 1]) - 1);
+      ok &= next[2 * nin] == result.a && next[2 * nin + 1] == result.b;  // :460-461 of step s + 1
+    } else {
+      Ext fin = ext_make(0, 0);  // finalPolyEval :253-259
 #pragma unroll 1
-  for (u32 i = dc->final_len; i-- > 0;) fin = wt_mul_add_ext(t, wbe_from(fin), ext_make(x, 0), ext_make(rec[dc->off_final + 2 * i], rec[dc->off_final + 2 * i + 1]));
-  ok &= fin.a == old_eval.a && fin.b == old_eval.b;  // :496-497
-  *written = wrote + wt_words_since(t, round_start);
+      for (u32 i = dc->final_len; i-- > 0;) fin = wt_mul_add_ext(t, wbe_from(fin), ext_make(x, 0), ext_make(rec[dc->off_final + 2 * i], rec[dc->off_final + 2 * i + 1]));
+      ok &= fin.a == result.a && fin.b == result.b;  // :496-497
+    }
+  }
+  *written = wt_words_since(t, start);
   wt_drain(t);
   return ok;
 }
@@ -1437,7 +1485,6 @@ GPV_DEV size_t dev_witness_plonk_perm(const DevCircuit* __restrict__ dc, const u
 //                                  field elements, canonical).
 #define GPV_WIT_PERM_CHUNK 8u
 __host__ __device__ inline u32 gpv_wit_perm_units(const DevCircuit& c) { return 1 + c.num_challenges * ((c.num_routed + GPV_WIT_PERM_CHUNK - 1) / GPV_WIT_PERM_CHUNK + 1); }
-GPV_DEV Ext wit_canon(Ext x) { return ext_make(gl_canon(x.a), gl_canon(x.b)); }
 GPV_DEV size_t dev_witness_plonk_perm_unit(const DevCircuit* __restrict__ dc, const u64* __restrict__ rec, const u64* __restrict__ ch, u32 r,
                                            u64* __restrict__ trace, const WPlonkTab& tab, u64* __restrict__ wsp, u64* lds) {
   WPlonkWs ws(dc, wsp);

@@ -143,10 +143,13 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
  * GPV_OPT_SIDE_STREAM: 1 (default) = the transcript, the plonk check and the FRI field work run on a second stream underneath the Merkle leaf
  * hashing; 0 = every kernel of gpv_verify[_dev] on the context's stream, one after the other (a measurement aid: each kernel then has the
  * chip to itself; same verdicts).
+ * GPV_OPT_WITNESS_STAGING: how the witness generator's kernels (gpv_witness_*) write their traces: 0 (default) = staged through LDS and written
+ * out by the wave in whole 128-byte lines when the launch is large enough to hide the flushes, straight to memory otherwise; 1 = always staged,
+ * 2 = never. Identical traces.
  * GPV_OPT_HOST_CHUNK_FIRST / GPV_OPT_HOST_CHUNK_MAX: gpv_verify uploads a host batch in chunks of first, first, 2 first, 4 first, ...
  * proofs capped at max and verifies them as they arrive, two in flight (defaults 1024 / 8192; 1 .. 2^24). */
 enum { GPV_OPT_TRANSCRIPT_VARIANT = 1, GPV_OPT_MERKLE_SHARED_LEVELS = 2, GPV_OPT_FR_EVALUATION = 3, GPV_OPT_HOST_CHUNK_FIRST = 4,
-       GPV_OPT_HOST_CHUNK_MAX = 5, GPV_OPT_SIDE_STREAM = 6 };
+       GPV_OPT_HOST_CHUNK_MAX = 5, GPV_OPT_SIDE_STREAM = 6, GPV_OPT_WITNESS_STAGING = 7 };
 int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value);
 /* Copies the last error text of this context (or of context-free calls when ctx == NULL). */
 int gpv_last_error_message(gpv_ctx* ctx, char* buf, size_t buf_len);

@@ -1512,7 +1512,7 @@ def test_shared_merkle_levels_with_colliding_queries(gpv, api, orc, name):
 
 # ---------------------------------------------------------------- the "denominator != 0" assertions
 @pytest.mark.parametrize("name", ["decode_block", "step"])
-def test_denominator_assertions_on_their_poles(gpv, api, orc, name):
+def test_denominator_assertions_on_their_poles(gpv, api, orc, name, staging):
     """GPV_FAIL_PLONK_L0 (plonk.go:75-80), GPV_FAIL_FRI_DENOM (fri.go:241-242) and GPV_FAIL_FRI_INTERP (fri.go:280-286 via
     quadratic_extension.go:124-125) had code on both sides and were driven by no test: random corruption reaches them with probability
     2^-64. Supplied challenges reach them at will (T.pole_challenges: zeta = 1, zeta^n = 1, zeta / g zeta = the subgroup point of a query
@@ -1738,8 +1738,17 @@ def _group_rank_failure_does_not_strand_the_others(gpv):
 
 
 # ---------------------------------------------------------------- witness generator, protocol slice 1
+@pytest.fixture(params=[2, 1], ids=["direct-stores", "staged"])
+def staging(request, gpv, api):
+    """Every word-for-word comparison of the witness traces runs in BOTH write-out forms (GPV_OPT_WITNESS_STAGING): straight to memory, and staged
+    through the LDS ring with the wave writing whole lines. By occupancy (the default) these batch sizes would only ever take the first."""
+    api.set_option(gpv._lib.OPT_WITNESS_STAGING, request.param)
+    yield request.param
+    api.set_option(gpv._lib.OPT_WITNESS_STAGING, 0)
+
+
 @pytest.mark.parametrize("name", ["decode_block", "step"])
-def test_witness_challenges_trace(gpv, api, orc, name):
+def test_witness_challenges_trace(gpv, api, orc, name, staging):
     """gpv_witness_challenges: the ordered outputs of the reference's hints (MulAddHint / ReduceHint / SplitLimbsHint, base.go:223-359)
     while Verify runs GetPublicInputsHash + GetChallenges -- GPU (literal lazy evaluation, csrc/gpv_witness.cuh) == oracle
     (oracle/orc_witness.h) word for word on the fixture and on records with random openings / caps / public inputs / non-canonical
@@ -1786,7 +1795,7 @@ def test_witness_challenges_trace(gpv, api, orc, name):
 
 
 @pytest.mark.parametrize("name", ["decode_block", "step"])
-def test_witness_fri_trace(gpv, api, orc, name):
+def test_witness_fri_trace(gpv, api, orc, name, staging):
     """gpv_witness_fri: the ordered hint outputs of fri.Chip.GetInstance + VerifyFriProof (fri.go:40-61, :500-548) -- the GPU's literal
     evaluation (csrc/gpv_witness.cuh: n^2 barycentric weights, 66 extension inversions per query round) == the oracle's, word for word,
     on the fixture, on records with corrupted openings / leaves / step evaluations / final polynomial (the consistency flag must follow
@@ -1826,7 +1835,7 @@ def test_witness_fri_trace(gpv, api, orc, name):
 
 
 @pytest.mark.parametrize("name", ["decode_block", "step"])
-def test_witness_plonk_trace(gpv, api, orc, name):
+def test_witness_plonk_trace(gpv, api, orc, name, staging):
     """gpv_witness_plonk: the ordered hint outputs of plonk.PlonkChip.Verify (plonk.go:209-250) -- the GPU's literal evaluation
     (csrc/gpv_witness.cuh: every gate constraint materialised, filtered and summed per index; the Poseidon gate through the extension
     layers; algebra products as InnerProductExtension calls) == the oracle's, word for word, on the fixture, on records with corrupted
@@ -1872,7 +1881,7 @@ def test_witness_plonk_trace(gpv, api, orc, name):
 
 
 @pytest.mark.parametrize("name", ["decode_block", "step"])
-def test_witness_verify_is_the_four_slices_in_order(gpv, api, orc, name):
+def test_witness_verify_is_the_four_slices_in_order(gpv, api, orc, name, staging):
     """gpv_witness_verify: the hint trace of VerifierChip.Verify as a whole (verifier.go:143-178) == the oracle's rangeCheckProof trace,
     then its GetPublicInputsHash + GetChallenges trace, then its PlonkChip.Verify trace, then its GetInstance + VerifyFriProof trace (the
     latter two under the challenges the oracle derives itself), word for word and hint kind for hint kind; the status bits follow the
@@ -1918,7 +1927,7 @@ def test_witness_verify_is_the_four_slices_in_order(gpv, api, orc, name):
 
 
 @pytest.mark.parametrize("shape", BEYOND_SHAPES, ids=lambda s: "%s-%s-cap%d%s-%s" % (s[0], "".join(map(str, s[1])), s[2], "-salted" if s[3] else "", "gl" if s[4] else "bn"))
-def test_witness_on_shapes_beyond_the_reference(gpv, api, orc, shape):
+def test_witness_on_shapes_beyond_the_reference(gpv, api, orc, shape, staging):
     """The witness generator on the shapes of SURVEY 8f.2 / 8f.4 (other FRI arities incl. 32, other cap heights, salted leaves, Poseidon-
     Goldilocks hashes in the transcript): every slice == the oracle's literal restatement word for word -- the FRI and plonk slices under the
     synthetic record's supplied challenges (the valid record must come out consistent), the challenges slice and the concatenated trace

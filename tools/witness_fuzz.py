@@ -53,7 +53,12 @@ for name in ("decode_block", "step"):
     batch = words.reshape(-1).view(np.uint8)
     pb = gpv.variables.ProofBatch(circuit, batch)
     chip = gpv.verifier.NewVerifierChip(ctx, common)
+    ctx.set_option(gpv._lib.OPT_WITNESS_STAGING, 2)   # direct stores ...
     trace, kinds_gpu, ch, status = chip.WitnessVerify(pb)
+    ctx.set_option(gpv._lib.OPT_WITNESS_STAGING, 1)   # ... and staged through the LDS ring, the wave writing whole lines: the same trace
+    trace_s, _, ch_s, status_s = chip.WitnessVerify(pb)
+    ctx.set_option(gpv._lib.OPT_WITNESS_STAGING, 0)
+    assert (trace_s == trace).all() and (np.asarray(ch_s.flat) == np.asarray(ch.flat)).all() and status_s.tolist() == status.tolist(), name
     t = time.time()
     b2 = batch.reshape(n, -1)
     o_rc = orc.witness_range_check(oc, b2)
@@ -68,7 +73,7 @@ for name in ("decode_block", "step"):
     assert (np.asarray(ch.flat).reshape(n, -1) == och).all()
     want_status = [(0 if c_pl[i] else 2) | (0 if c_fri[i] else 4) for i in range(n)]
     assert status.tolist() == want_status, name
-    print("%-13s %4d records x %d words agree with the oracle word for word (by kind %s; %d with a failing plonk assertion, %d with a failing FRI one); oracle %.1f s"
+    print("%-13s %4d records x %d words, written directly and staged, agree with the oracle word for word (by kind %s; %d with a failing plonk assertion, %d with a failing FRI one); oracle %.1f s"
           % (name, n, trace.shape[1], np.bincount(kinds, minlength=len(KINDS)).tolist(), sum(1 for s in want_status if s & 2), sum(1 for s in want_status if s & 4), t_or),
           flush=True)
 print("kinds: " + "; ".join("%d %s" % (i, k) for i, k in enumerate(KINDS)))
