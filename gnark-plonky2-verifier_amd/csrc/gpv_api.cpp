@@ -1788,7 +1788,7 @@ extern "C" int gpv_verify_json(gpv_ctx* ctx, const gpv_circuit* c, const char* c
 }
 extern "C" int gpv_verify_json_status(gpv_ctx* ctx, const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
                                       int n_threads, uint8_t* accept, int32_t* status) {
-  REQUIRE(ctx, ctx && c && accept && status && (n == 0 || (proof_jsons && proof_lens)));
+  REQUIRE(ctx, ctx && c && (n == 0 || (accept && status && proof_jsons && proof_lens)));
   if (n == 0) return GPV_OK;
   return verify_json_core(ctx, c, proof_jsons, proof_lens, n, n_threads, accept, status);
 }

@@ -1536,7 +1536,8 @@ extern "C" int gpv_proof_pack_json_batch(const gpv_circuit* circ, const char* co
 }
 extern "C" int gpv_proof_pack_json_batch_status(const gpv_circuit* circ, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
                                                 void* out_packed, int n_threads, int32_t* status) {
-  if (!circ || !out_packed || !status || (n && (!proof_jsons || !proof_lens))) return GPV_EINVAL;
+  if (!circ || (n && (!out_packed || !status || !proof_jsons || !proof_lens))) return GPV_EINVAL;
+  if (n == 0) return GPV_OK;
   size_t bad = n;
   std::string msg;
   int rc = pack_json_batch_core(circ, proof_jsons, proof_lens, n, out_packed, n_threads, status, &bad, &msg);
