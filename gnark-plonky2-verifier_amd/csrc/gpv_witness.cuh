@@ -158,6 +158,12 @@ GPV_DEV void wt_flush_event(WTrace& t) { t = wt_flush_event_call(t); }
 // out of line, the wait for its own stores at the return) and for kernels whose long pole is one lane's latency.
 template <int K>
 GPV_DEV void wt_emit(WTrace& t, const u64 (&v)[K]) {
+#ifdef GPV_WT_DRY  // experiment build only (make wtdry -> tools/probe/libgpv_wtdry.so): every record is computed and dropped, nothing is stored
+#pragma unroll
+  for (int i = 0; i < K; i++) asm volatile("" ::"v"(v[i]));
+  t.p += K;
+  return;
+#endif
   if (t.lane & GPV_WT_STAGED) {  // (not "ring != null": the ring starts at LDS offset 0)
     if (__builtin_amdgcn_ballot_w64(t.nu + K > GPV_WT_SLOTS) != 0) wt_flush_event(t);
 #pragma unroll

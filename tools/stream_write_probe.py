@@ -15,7 +15,7 @@ TOTAL_WORDS = 4096 * 702670          # slice 1 of 4096 `step` proofs
 BASE_STREAMS, SPIN = 4096 * 139, 46  # one lane per (proof, permutation); SPIN multiply-adds per 16 bytes ~ the compute-only time of the real kernel
 
 
-def run(label, n_streams, lps, cw):
+def run(label, n_streams, lps, cw, SPIN=SPIN):
     words_per_stream = TOTAL_WORDS // n_streams
     steps = words_per_stream // (lps * cw)
     stride = (steps * lps * cw + 37 * 2 + 1) // 2 * 2   # streams back to back, a ragged gap between them (like the trace's slices)
@@ -37,3 +37,7 @@ run("64 lanes per stream, 16 B each (1 KB contiguous per store instruction)", BA
 run("64 lanes per stream, 128 B each (8 KB contiguous per step)", BASE_STREAMS // 64, 64, 16)
 run("one lane per stream, 16 B per step, 1/8 of the streams (8 x longer)", BASE_STREAMS // 8, 1, 2)
 run("one lane per stream, 16 B per step, 1/64 of the streams", BASE_STREAMS // 64, 1, 2)
+# the ceiling: the same volume with NO arithmetic between the stores (what the memory system takes when nothing else is in the way)
+run("no arithmetic: 64 lanes per stream, 16 B each (a plain streaming fill)", BASE_STREAMS // 64, 64, 2, SPIN=0)
+run("no arithmetic: 8 lanes per stream, 16 B each (the flush events' pattern)", BASE_STREAMS // 8, 8, 2, SPIN=0)
+run("no arithmetic: one lane per stream, 16 B per step", BASE_STREAMS, 1, 2, SPIN=0)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Throughput of the witness slices (gpv_witness_challenges / _plonk / _fri, host buffers in and out): python tools/witness_rate.py [n]"""
+"""Throughput of the witness slices (gpv_witness_challenges / _plonk / _fri, host buffers in and out): python tools/witness_rate.py [n]
+  --dry   load tools/probe/libgpv_wtdry.so (make -C gnark-plonky2-verifier_amd/csrc wtdry: the trace stores compiled out) and time only the
+          device-resident entry point: what the arithmetic alone costs. Nothing is compared in that mode -- no trace exists."""
 import importlib
 import sys
 import time
@@ -13,10 +15,26 @@ sys.path.insert(0, str(ROOT / "tests"))
 import gpv_testlib as T  # noqa: E402
 
 gpv = importlib.import_module("gnark-plonky2-verifier_amd")
+ONLY = None
+if "--only" in sys.argv:     # --only M: just the device-resident entry point on `step`, M proofs (the PMC passes of tools/witness_pmc.sh)
+    k = sys.argv.index("--only")
+    ONLY = int(sys.argv[k + 1])
+    del sys.argv[k:k + 2]
+STAGING = None
+if "--staging" in sys.argv:  # --staging 1 | 2: GPV_OPT_WITNESS_STAGING (always staged | never)
+    k = sys.argv.index("--staging")
+    STAGING = int(sys.argv[k + 1])
+    del sys.argv[k:k + 2]
+DRY = "--dry" in sys.argv
+if DRY:
+    sys.argv.remove("--dry")
+    gpv._lib.LIB_PATH = ROOT / "tools" / "probe" / "libgpv_wtdry.so"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ctx = gpv.default_context()
+if STAGING is not None:
+    ctx.set_option(7, STAGING)
 print("# gpv_witness_challenges / _plonk / _fri: hint traces of VerifierChip.Verify, %d proofs per call, host buffers in and out" % n)
-for name in ("step", "decode_block"):
+for name in (() if DRY or ONLY else ("step", "decode_block")):
     d = T.GOLDEN / name
     common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
     vo = gpv.variables.DeserializeVerifierOnlyCircuitData(gpv.types.ReadVerifierOnlyCircuitData(d / "verifier_only_circuit_data.json"))
@@ -58,15 +76,15 @@ import ctypes  # noqa: E402
 import torch  # noqa: E402
 
 L = gpv._lib.lib()
-print("# gpv_witness_verify_dev: range_check | challenges | plonk | fri, everything resident in HBM")
-for name in ("step", "decode_block"):
+print("# gpv_witness_verify_dev: range_check | challenges | plonk | fri, everything resident in HBM" + (" -- DRY build: trace stores compiled out, times only" if DRY else ""))
+for name in (("step",) if ONLY else ("step", "decode_block")):
     d = T.GOLDEN / name
     common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
     vo = gpv.variables.DeserializeVerifierOnlyCircuitData(gpv.types.ReadVerifierOnlyCircuitData(d / "verifier_only_circuit_data.json"))
     circuit = gpv.variables.circuit_for(common, vo)
     ci, packed, _ = T.load_fixture(name)
     words = L.gpv_witness_verify_words(ctypes.c_void_p(circuit.h))
-    for m in (64, 256, 1024, 4096):
+    for m in ((ONLY,) if ONLY else (64, 256, 1024, 4096)):
         batch, _ = T.synthetic_batch(ci, packed, m, seed=5, tamper_every=0)
         dproofs = torch.from_numpy(batch.view(np.uint8).reshape(-1).copy()).cuda()
         dtrace = torch.empty(m * words, dtype=torch.int64, device="cuda")
@@ -80,7 +98,7 @@ for name in ("step", "decode_block"):
         dt = time.perf_counter() - t
         km = [ctx.timing_get(k)[0] for k in (13, 14, 9, 10, 11, 12)]
         ctx.timing_enable(False)
-        assert int(dstatus.sum()) == 0
+        assert DRY or int(dstatus.sum()) == 0
         print("%-13s %5d proofs: %8.1f ms = %7.0f proofs/s = %.2f G trace words/s (%.1f GB of trace, %.2f TB/s); kernels: transcript %.1f beside plonk gate units %.1f (side stream), then challenges fill %.1f | rest of plonk %.1f (side stream), fri %.1f, range check %.2f ms"
               % (name, m, dt * 1e3, m / dt, m * words / dt / 1e9, 8e-9 * m * words, 8e-12 * m * words / dt, *km))
         del dtrace
