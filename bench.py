@@ -60,12 +60,13 @@ def executed_mads_per_perm(zero_head):
     csrc/gpv_fr.cuh is one pinned v_mad_u64_u32, and a column-scanning row of K products costs 81 K (+ 9 with an addend) + 81 for
     the Montgomery step (a squaring 45 + 81). Per permutation (csrc/gpv_poseidon.cuh): 88 S-boxes = 176 squarings + 88
     multiply-with-addend, 60 four-product rows (32 mix rows + 28 partial-round rows), 28 five-product rows, 84 two-product updates;
-    TwoToOne (zero_head) saves two S-boxes and turns four four-product rows into two-product ones. tools/isa_count.py counts the
-    same numbers in the shipped code object (profiles/r04_isa_counts.json)."""
+    TwoToOne (zero_head) saves two S-boxes, turns four four-product rows into two-product ones and evaluates one row of the last mix
+    instead of four (its caller keeps s[0] only). tools/isa_count.py counts the same numbers in the shipped code object
+    (profiles/r04_isa_counts.json)."""
     sqr, mul_add, dot4, dot5, dot2_add = 45 + 81, 81 + 9 + 81, 4 * 81 + 81, 5 * 81 + 81, 2 * 81 + 9 + 81
     total = 176 * sqr + 88 * mul_add + 60 * dot4 + 28 * dot5 + 84 * dot2_add
     if zero_head:
-        total += -2 * (2 * sqr + mul_add) - 4 * dot4 + 4 * dot2_add
+        total += -2 * (2 * sqr + mul_add) - 4 * dot4 + 4 * dot2_add - 3 * dot4
     return total
 
 

@@ -193,11 +193,13 @@ GPV_DEV Fr pbn_dot4(const u32* tab, int base, const Fr& a0, const Fr& a1, const 
 // mix (bn254.go:194-208): out_i = sum_j m[j][i] s_j; tab holds the transposed matrix, tab[4 i + j] = m[j][i].
 // HALF (TwoToOne's first round, wave-uniform): s_0 and s_1 are constants whose share of row i is the precomputed PBN_KK[i],
 // so a row is that addend + two products.
+// rows < 4 (wave-uniform; the last mix of a permutation whose caller keeps only s_0): only rows 0 .. rows - 1 are evaluated; rows == 1 leaves
+// row 0 in s_0 and the rest of the state undefined.
 template <bool HALF_POSSIBLE, class FA>
-GPV_DEV void pbn_mix(PbnState& st, const u32* tab, bool half = false) {
+GPV_DEV void pbn_mix(PbnState& st, const u32* tab, bool half = false, int rows = 4) {
   Fr r0 = fr_zero(), r1 = fr_zero(), r2 = fr_zero(), r3 = fr_zero();
 #pragma unroll 1
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < rows; i++) {
     Fr acc;
     if (HALF_POSSIBLE && half)
       acc = FA::dot2_add(st.s2, pbn_load(tab, 4 * i + 2), st.s3, pbn_load(tab, 4 * i + 3), pbn_load(PBN_KK, i));
@@ -208,7 +210,7 @@ GPV_DEV void pbn_mix(PbnState& st, const u32* tab, bool half = false) {
     r2 = r3;
     r3 = acc;
   }
-  st.s0 = r0;
+  st.s0 = rows == 4 ? r0 : r3;  // after `rows` trips of the rotation row 0 sits in r[4 - rows]; only rows = 1 and 4 are used
   st.s1 = r1;
   st.s2 = r2;
   st.s3 = r3;
@@ -217,7 +219,9 @@ GPV_DEV void pbn_mix(PbnState& st, const u32* tab, bool half = false) {
 // ZERO_HEAD: the caller guarantees s[0] = s[1] = 0 (TwoToOne, bn254.go:96-104). Then the first S-box layer of those two
 // elements and their share of the first mix are constants (PBN_KK, tools/gen_constants.py): the first round costs two
 // S-boxes and four two-product rows instead of four and four four-product rows -- exact, 1.6 % fewer multiply-adds.
-template <bool ZERO_HEAD = false, class FA = FrChain>
+// ONLY_S0: the caller keeps s[0] alone (TwoToOne; the sponge's output is state[0], bn254.go:75-76,103): the last mix evaluates one row instead
+// of four -- 3 four-product rows, 1.3 % of the permutation's multiply-adds; s[1..3] are undefined afterwards.
+template <bool ZERO_HEAD = false, class FA = FrChain, bool ONLY_S0 = false>
 GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
   PbnState st;
   // ark(0): lazy limb-wise sums (< 2^30 per limb) feed the first squaring directly
@@ -242,7 +246,7 @@ GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
       const bool head = ZERO_HEAD && half == 0 && i == 0;
       const int it = half == 0 ? (i + 1) * 4 : (i < 3 ? 20 + 56 + 4 * i : -1);
       pbn_sbox_ark<FA>(st, it, head ? 2 : 4);
-      pbn_mix<ZERO_HEAD, FA>(st, (half == 0 && i == 3) ? PBN_PT : PBN_MT, head);
+      pbn_mix<ZERO_HEAD, FA>(st, (half == 0 && i == 3) ? PBN_PT : PBN_MT, head, (ONLY_S0 && half == 1 && i == 3) ? 1 : 4);
     }
     if (half == 1) break;
     // 56 partial rounds (bn254.go:152-169), evaluated two at a time. The reference updates s_k += t * S[7i+3+k] every round
@@ -274,7 +278,7 @@ GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
 template <class FA = FrChain>
 GPV_DEV Fr poseidon_bn254_two_to_one(const Fr& l, const Fr& r) {
   Fr s[4] = {fr_zero(), fr_zero(), l, r};
-  poseidon_bn254_permute<true, FA>(s);
+  poseidon_bn254_permute<true, FA, true>(s);
   return s[0];
 }
 // HashOrNoop / HashNoPad over a leaf of Goldilocks words (bn254.go:47-94); `leaf` may be strided.

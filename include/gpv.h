@@ -196,7 +196,8 @@ int gpv_proof_pack_json_batch(const gpv_circuit* c, const char* const* proof_jso
 /* The same with a status PER PROOF, for batches fed by untrusted provers: every text is converted, status[i] = GPV_OK or the error
  * gpv_proof_pack_json gives for text i (GPV_ESHAPE where types/deserialize.go:92-108 / fri/fri_utils.go:167-228 panic; GPV_EINVAL for a
  * NULL text), and a failed text leaves an all-zero record. The reference's panic is per proof because its API is per proof; a batch call
- * that gave up at the first malformed text would let one prover void everybody's batch. Returns GPV_OK unless an argument is bad. */
+ * that gave up at the first malformed text would let one prover void everybody's batch. Returns GPV_OK unless an argument is bad (n = 0
+ * needs no buffers). */
 int gpv_proof_pack_json_batch_status(const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
                                      void* out_packed, int n_threads, int32_t* status);
 
