@@ -22,6 +22,9 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> out(gpv_proof_nbytes(ci));
   std::mt19937_64 rng(12345);
   long ok = 0, shape = 0, other = 0;
+  std::vector<std::string> batch_texts;
+  std::vector<int> batch_rc;
+  std::vector<std::vector<uint8_t>> batch_rec;
   const char junk[] = "{}[],:\"\\0123456789-eE.tfn \n\x00\xff";
   for (int it = 0; it < iters; it++) {
     std::string m = p;
@@ -43,10 +46,39 @@ int main(int argc, char** argv) {
     }
     int rc = gpv_proof_pack_json(ci, m.data(), m.size(), out.data());
     if (rc == 0) ok++; else if (rc == GPV_ESHAPE) shape++; else other++;
+    if (batch_texts.size() < 96) {  // kept for the batched leg below, with what the single call said
+      batch_texts.push_back(m);
+      batch_rc.push_back(rc);
+      batch_rec.push_back(rc == 0 ? out : std::vector<uint8_t>(out.size(), 0));
+    }
     // the streaming route (tried first by gpv_proof_pack_json) and the tree route alone must agree on the verdict and on every byte
     std::vector<uint8_t> out2(out.size(), 0xAB);
     int rc2 = gpvi_proof_pack_json_tree(ci, m.data(), m.size(), out2.data());
     if (rc2 != rc || (rc == 0 && memcmp(out.data(), out2.data(), out.size()))) other++;
+  }
+  // The batched entry point with a status per text (untrusted provers in one batch): the same texts, valid ones and a NULL mixed in, on 1 and 5
+  // threads -- status[i] and record i must be what the single call gave (a failed text leaves zeros), whatever its neighbours are.
+  {
+    for (int k = 0; k < 8; k++) { batch_texts.push_back(p); batch_rc.push_back(0); std::vector<uint8_t> r(out.size()); gpv_proof_pack_json(ci, p.data(), p.size(), r.data()); batch_rec.push_back(r); }
+    const size_t nb = batch_texts.size() + 1, rec = out.size();
+    std::vector<const char*> ptrs(nb);
+    std::vector<size_t> lens(nb);
+    for (size_t i = 0; i + 1 < nb; i++) { ptrs[i] = batch_texts[i].data(); lens[i] = batch_texts[i].size(); }
+    ptrs[nb - 1] = nullptr; lens[nb - 1] = 0;
+    for (int threads : {1, 5}) {
+      std::vector<uint8_t> recs(nb * rec, 0xCD);
+      std::vector<int32_t> st(nb, 12345);
+      if (gpv_proof_pack_json_batch_status(ci, ptrs.data(), lens.data(), nb, recs.data(), threads, st.data()) != GPV_OK) other++;
+      for (size_t i = 0; i + 1 < nb; i++)
+        if (st[i] != batch_rc[i] || memcmp(recs.data() + i * rec, batch_rec[i].data(), rec)) other++;
+      if (st[nb - 1] != GPV_EINVAL) other++;
+      for (size_t b = 0; b < rec; b++) if (recs[(nb - 1) * rec + b]) { other++; break; }
+      // the plain batch form gives up at the lowest failing index
+      int want = 0;
+      for (size_t i = 0; i + 1 < nb && !want; i++) want = batch_rc[i];
+      if (!want) want = GPV_EINVAL;
+      if (gpv_proof_pack_json_batch(ci, ptrs.data(), lens.data(), nb, recs.data(), threads) != want) other++;
+    }
   }
   // the circuit parsers too
   long cok = 0, cerr = 0;
