@@ -1782,7 +1782,7 @@ static int verify_json_core(gpv_ctx* ctx, const gpv_circuit* c, const char* cons
 }
 extern "C" int gpv_verify_json(gpv_ctx* ctx, const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n, int n_threads,
                                uint8_t* accept) {
-  REQUIRE(ctx, ctx && c && accept && (n == 0 || (proof_jsons && proof_lens)));
+  REQUIRE(ctx, ctx && c && (n == 0 || (accept && proof_jsons && proof_lens)));
   if (n == 0) return GPV_OK;
   return verify_json_core(ctx, c, proof_jsons, proof_lens, n, n_threads, accept, nullptr);
 }

@@ -1522,7 +1522,8 @@ static int pack_json_batch_core(const gpv_circuit* circ, const char* const* proo
 }
 extern "C" int gpv_proof_pack_json_batch(const gpv_circuit* circ, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
                                          void* out_packed, int n_threads) {
-  if (!circ || !out_packed || (n && (!proof_jsons || !proof_lens))) return GPV_EINVAL;
+  if (!circ || (n && (!out_packed || !proof_jsons || !proof_lens))) return GPV_EINVAL;
+  if (n == 0) return GPV_OK;
   std::vector<int32_t> status(n, GPV_OK);
   size_t bad = n;
   std::string msg;

@@ -544,7 +544,8 @@ def test_batch_ingest_reports_a_status_per_proof(gpv):
     assert L.gpv_proof_pack_json_batch_status(ctypes.c_void_p(circuit.h), texts, lens, 1, gpv._lib.ptr(out), 1, None) == gpv._lib.GPV_EINVAL
     st = np.zeros(1, dtype=np.int32)
     assert L.gpv_proof_pack_json_batch_status(ctypes.c_void_p(circuit.h), texts, lens, 0, gpv._lib.ptr(out), 1, gpv._lib.ptr(st)) == gpv._lib.GPV_OK
-    assert L.gpv_proof_pack_json_batch_status(ctypes.c_void_p(circuit.h), None, None, 0, None, 1, None) == gpv._lib.GPV_OK   # an empty batch needs no buffers
+    assert L.gpv_proof_pack_json_batch_status(ctypes.c_void_p(circuit.h), None, None, 0, None, 1, None) == gpv._lib.GPV_OK
+    assert L.gpv_proof_pack_json_batch(ctypes.c_void_p(circuit.h), None, None, 0, None, 1) == gpv._lib.GPV_OK  # and the plain form   # an empty batch needs no buffers
     nulls = (ctypes.c_char_p * 1)(None)
     assert L.gpv_proof_pack_json_batch_status(ctypes.c_void_p(circuit.h), nulls, lens, 1, gpv._lib.ptr(out), 1, gpv._lib.ptr(st)) == gpv._lib.GPV_OK
     assert st[0] == gpv._lib.GPV_EINVAL and not out.any()
