@@ -12,6 +12,9 @@ ctx = gpv.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 dev = torch.device("cuda:0")
 KINDS = (("merkle_walk", 0), ("transcript", 2), ("plonk", 3), ("fri_query", 4), ("range_check", 5), ("merkle_leaves", 7), ("merkle_climb_lower", 8))
+SIZES = (1, 16, 256)
+if "--sizes" in sys.argv:  # --sizes 1024,2048: the stage times at other batch sizes (then nothing else)
+    SIZES = tuple(int(x) for x in sys.argv[sys.argv.index("--sizes") + 1].split(","))
 if "--one" in sys.argv:  # a single proof, 30 calls per fixture and nothing else: the run to put under rocprofv3 --kernel-trace --stats
     for name in ("step", "decode_block"):
         d = T.GOLDEN / name
@@ -34,7 +37,7 @@ for name in ("step", "decode_block"):
     ci, packed, _ = T.load_fixture(name)
     chip = gpv.verifier.NewVerifierChip(ctx, common)
     rec = torch.from_numpy(np.frombuffer(packed, dtype=np.int64).copy()).to(dev)
-    for n in (1, 16, 256):
+    for n in SIZES:
         batch = rec.repeat(n, 1).contiguous()
         acc = torch.zeros(n, dtype=torch.uint8, device=dev)
         for _ in range(3): chip.VerifyDevice(circuit, batch.data_ptr(), n, acc.data_ptr())
@@ -52,6 +55,8 @@ for name in ("step", "decode_block"):
         assert int(acc.sum().item()) == n
         print("%-13s n=%4d  %.2f ms per call;  kernel ms: %s" % (name, n, dt * 1e3, "  ".join("%s %.2f" % (k, v) for k, v in st.items())), flush=True)
 
+if "--sizes" in sys.argv:
+    sys.exit(0)
 print("# n  ms per call with GPV_OPT_FR_EVALUATION = 2 (one lane per permutation, operand scanning) / 3 (four lanes per permutation) / 0 (by size); step fixture")
 d = T.GOLDEN / "step"
 common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
