@@ -22,7 +22,12 @@ orc = T.oracle()
 P = T.GL_P
 KINDS = ["one bit anywhere", "one bit in the hash section", "a hash replaced by its neighbour", "a query-section word", "two corruptions",
          "a hash replaced by random 256 bits", "one bit of a supplied challenge",
-         "a supplied challenge on a pole (zeta = 1 / zeta or g zeta = a query's subgroup point / beta_s = a coset point of a query's step; often combined with a corrupted word)"]
+         "a supplied challenge on a pole (zeta = 1 / zeta or g zeta = a query's subgroup point / beta_s = a coset point of a query's step; often combined with a corrupted word)",
+         "a Goldilocks word set to a boundary value (0, 1, p - 1, p, p + 1, 2^32 - 1, 2^32, 2^63, 2^64 - 1)",
+         "a hash set to a boundary value (0, 1, r - 1, r, r + 1, 2^254, 2^256 - 1: gnark takes witnesses mod r)"]
+GL_EDGES = [0, 1, P - 1, P, P + 1, 2**32 - 1, 2**32, 2**63, 2**64 - 1]
+FR_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+FR_EDGES = [0, 1, FR_R - 1, FR_R, FR_R + 1, 2**254, 2**256 - 1]
 
 
 def mutate(ci, packed, ch0, rng, gl_hashes):
@@ -33,7 +38,7 @@ def mutate(ci, packed, ch0, rng, gl_hashes):
     kinds = np.zeros(n, dtype=int)
     poles = T.pole_challenges(ci, ch0)[1] if chs is not None else None
     for i in range(1, n):
-        k = int(rng.integers(0, 8 if chs is not None else 6))
+        k = int(rng.choice([0, 1, 2, 3, 4, 5, 8, 9] + ([6, 7] if chs is not None else [])))
         kinds[i] = k
         if k == 0:
             words[i, int(rng.integers(0, nw))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 64)))
@@ -50,6 +55,12 @@ def mutate(ci, packed, ch0, rng, gl_hashes):
         elif k == 5:
             w = n_gl + 4 * int(rng.integers(0, (nw - n_gl) // 4))
             words[i, w:w + 4] = rng.integers(0, 2**63, 4, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 4, dtype=np.uint64)
+        elif k == 8:
+            words[i, int(rng.integers(0, n_gl))] = np.uint64(GL_EDGES[int(rng.integers(0, len(GL_EDGES)))])
+        elif k == 9:
+            w = n_gl + 4 * int(rng.integers(0, (nw - n_gl) // 4))
+            v = FR_EDGES[int(rng.integers(0, len(FR_EDGES)))]
+            words[i, w:w + 4] = [np.uint64((v >> (64 * j)) & (2**64 - 1)) for j in range(4)]
         elif k == 6:
             chs[i, int(rng.integers(0, chs.shape[1]))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 40)))
         else:  # the "denominator != 0" assertions (plonk.go:75-80, fri.go:241-242, :280-286): reachable only through the challenges
@@ -94,7 +105,7 @@ def run(label, circuit, common, ci, packed, ch0, gl_hashes, vo=None):
         assert bad.size == 0, (label, mode, "mask", bad[:5], kinds[bad[:5]])
     ctx.set_option(2, 1)
     print("%-58s %5d records (%4d accepted; by kind %s) agree with the oracle, shared levels on and off; oracle %.1f s"
-          % (label, n, int(oacc.sum()), np.bincount(kinds, minlength=8).tolist(), t_or), flush=True)
+          % (label, n, int(oacc.sum()), np.bincount(kinds, minlength=10).tolist(), t_or), flush=True)
 
 
 for name in ("decode_block", "step"):
