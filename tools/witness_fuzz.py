@@ -20,7 +20,7 @@ ctx = gpv.default_context()
 orc = T.oracle()
 P = T.GL_P
 KINDS = ["untouched", "one low bit of an opening", "a random opening word", "a query-section word", "a final-polynomial / PoW word", "a public input", "a cap / sibling hash bit",
-         "every opening random"]
+         "every opening random", "a proof word set to 0, 1 or p - 1 (zero operands, zero quotients, InverseHint of 0)", "a public input set to 0, p - 1, p or 2^64 - 1"]
 for name in ("decode_block", "step"):
     d = T.GOLDEN / name
     common = gpv.types.ReadCommonCircuitData(d / "common_circuit_data.json")
@@ -50,6 +50,10 @@ for name in ("decode_block", "step"):
             words[i, int(rng.integers(n_gl, words.shape[1]))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 60)))
         elif k == 7:
             words[i, :n_open] = rng.integers(0, P, n_open, dtype=np.uint64)
+        elif k == 8:
+            words[i, int(rng.integers(0, n_gl - ci.num_public_inputs))] = np.uint64([0, 1, P - 1][int(rng.integers(0, 3))])
+        elif k == 9 and ci.num_public_inputs:
+            words[i, n_gl - 1 - int(rng.integers(0, ci.num_public_inputs))] = np.uint64([0, P - 1, P, 2**64 - 1][int(rng.integers(0, 4))])
     batch = words.reshape(-1).view(np.uint8)
     pb = gpv.variables.ProofBatch(circuit, batch)
     chip = gpv.verifier.NewVerifierChip(ctx, common)
