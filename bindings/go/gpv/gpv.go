@@ -419,12 +419,12 @@ func NewGroup(deviceIDs []int) *Group {
 // GroupUniqueID / NewGroupRank: one process per GPU; rank 0 creates the id, the caller hands it to the other ranks.
 func GroupUniqueID() [128]byte {
 	var id [128]byte
-	groupCheck(C.gpv_group_unique_id(ptr(id)), nil)
+	groupCheck(C.gpv_group_unique_id(ptr(id[:])), nil)
 	return id
 }
 func NewGroupRank(device, rank, world int, id [128]byte) *Group {
 	var h *C.gpv_group
-	groupCheck(C.gpv_group_create_rank(&h, C.int(device), C.int(rank), C.int(world), ptr(id)), nil)
+	groupCheck(C.gpv_group_create_rank(&h, C.int(device), C.int(rank), C.int(world), ptr(id[:])), nil)
 	return &Group{h}
 }
 func (g *Group) Close()     { C.gpv_group_destroy(g.h) }
@@ -550,6 +550,31 @@ func (g *Group) ReadRankAccept(local, nTotal int) []bool {
 		out[i] = acc[i] == 1
 	}
 	return out
+}
+
+// CommInfo is what RCCL itself reports about a rank's communicator and which RCCL image libgpv bound (gpv_group_comm_info): the evidence
+// that a multi-GPU run really ran as N RCCL ranks.
+type CommInfo struct {
+	CommReady        bool
+	NcclCommCount    int64 // ncclCommCount; -1 before the communicator exists
+	NcclUserRank     int64 // ncclCommUserRank
+	NcclVersion      int64 // ncclGetVersion; -1 when no RCCL image is bound
+	Exchange         int64 // 0 none, 1 ncclAllGather, 2 peer copies (the last verify call)
+	LibraryPreloaded int64 // 1 already mapped when bound, 0 loaded by libgpv, -1 none
+	AllGatherCalls   int64
+	World            int64
+	Library          string // path of the bound RCCL image
+}
+
+func (g *Group) CommInfo(local int) CommInfo {
+	info := make([]int64, 8)
+	lib := make([]byte, 512)
+	groupCheck(C.gpv_group_comm_info(g.h, C.int(local), (*C.int64_t)(ptr(info)), (*C.char)(ptr(lib)), C.size_t(len(lib))), g.h)
+	n := 0
+	for n < len(lib) && lib[n] != 0 {
+		n++
+	}
+	return CommInfo{info[0] != 0, info[1], info[2], info[3], info[4], info[5], info[6], info[7], string(lib[:n])}
 }
 
 // WitnessRangeCheck / WitnessChallenges: the hint outputs of Verify's first three statements (verifier/verifier.go:148-150) in call order

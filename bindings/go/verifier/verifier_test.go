@@ -10,11 +10,15 @@ import (
 	"github.com/succinctlabs/gnark-plonky2-verifier/bindings/go/variables"
 )
 
-func TestBlockVerifier(t *testing.T) {
+// TestStepVerifier is the reference's test of that name on the fixture it uses (verifier/verifier_test.go:13-41: "step", :17);
+// TestBlockVerifier runs the same sequence on the other fixture under testdata/ (the one fri_test.go / plonk_test.go also use).
+func TestStepVerifier(t *testing.T)  { runVerifier(t, "step") }
+func TestBlockVerifier(t *testing.T) { runVerifier(t, "decode_block") }
+
+func runVerifier(t *testing.T, plonky2Circuit string) {
 	ctx := gpv.NewContext(0)
 	defer ctx.Close()
 
-	plonky2Circuit := "decode_block"
 	commonCircuitData := types.ReadCommonCircuitData("../../../tests/golden/" + plonky2Circuit + "/common_circuit_data.json")
 	verifierOnlyCircuitData := variables.DeserializeVerifierOnlyCircuitData(types.ReadVerifierOnlyCircuitData("../../../tests/golden/" + plonky2Circuit + "/verifier_only_circuit_data.json"))
 	circuit := variables.CircuitFor(commonCircuitData, verifierOnlyCircuitData)

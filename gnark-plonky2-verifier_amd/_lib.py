@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "gpv_verify_given_challenges", "gpv_verify_given_challenges_dev",
     "gpv_shard_bounds", "gpv_accept_slot_bytes", "gpv_group_create", "gpv_group_unique_id", "gpv_group_create_rank", "gpv_group_destroy",
     "gpv_group_world", "gpv_group_local", "gpv_group_rank", "gpv_group_set_option", "gpv_group_last_error_message",
-    "gpv_group_verify", "gpv_group_verify_dev", "gpv_group_read_rank_accept",
+    "gpv_group_verify", "gpv_group_verify_dev", "gpv_group_read_rank_accept", "gpv_group_comm_info",
 ]
 # declared with a non-int/size_t return type (not matched by the header scan of the tests)
 ABI_SYMBOLS_OTHER = ["gpv_group_ctx"]
@@ -201,6 +201,7 @@ def _load(path):
         L.gpv_group_verify.argtypes = [vp, vp, vp, sz, vp]
         L.gpv_group_verify_dev.argtypes = [vp, vp, ctypes.POINTER(vp), sz, ctypes.POINTER(vp)]
         L.gpv_group_read_rank_accept.argtypes = [vp, i32, vp, sz]
+        L.gpv_group_comm_info.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, sz]
     return L
 
 
@@ -362,6 +363,16 @@ class Group:
         out = np.empty(n_total, dtype=np.uint8)
         self._check(lib().gpv_group_read_rank_accept(ctypes.c_void_p(self.h), local_index, ptr(out), n_total))
         return out
+
+    def comm_info(self, local_index=0):
+        """gpv_group_comm_info: what RCCL itself reports about this rank's communicator and which RCCL image libgpv bound."""
+        info = (ctypes.c_int64 * 8)()
+        buf = ctypes.create_string_buffer(512)
+        self._check(lib().gpv_group_comm_info(ctypes.c_void_p(self.h), local_index, info, buf, 512))
+        return {"comm_ready": bool(info[0]), "nccl_comm_count": int(info[1]), "nccl_user_rank": int(info[2]), "nccl_version": int(info[3]),
+                "exchange": {0: "none", 1: "ncclAllGather", 2: "peer copies"}.get(int(info[4]), str(int(info[4]))),
+                "library_preloaded": {1: True, 0: False}.get(int(info[5])), "allgather_calls": int(info[6]), "world": int(info[7]),
+                "library": buf.value.decode("utf-8", "replace")}
 
 
 _default_ctx = None

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -28,7 +29,8 @@
 
 // ================================================================ context
 enum { TK_MERKLE = 0, TK_PGL = 1, TK_TRANSCRIPT = 2, TK_PLONK = 3, TK_FRI = 4, TK_RANGE = 5, TK_PBN = 6, TK_LEAVES = 7, TK_LOWER = 8, TK_WIT_CHALLENGES = 9,
-       TK_WIT_PLONK = 10, TK_WIT_FRI = 11, TK_WIT_RANGE = 12, TK_WIT_TRANSCRIPT = 13, TK_WIT_PLONK_GATES = 14, TK_COUNT = 15 };
+       TK_WIT_PLONK = 10, TK_WIT_FRI = 11, TK_WIT_RANGE = 12, TK_WIT_TRANSCRIPT = 13, TK_WIT_PLONK_GATES = 14, TK_EXCHANGE = 15 /* gpv_group's exchange step */, TK_COUNT = 16 };
+static_assert(TK_EXCHANGE == GPVI_TK_EXCHANGE, "gpv_internal.h");
 
 struct TimingRec {
   int kind;
@@ -1801,4 +1803,22 @@ const char* gpvi_ctx_get_error(const gpv_ctx* ctx) { return ctx->err.c_str(); }
 int gpvi_take_launch_error(gpv_ctx* ctx) {
   CHECK_LAUNCH(ctx);
   return GPV_OK;
+}
+void* gpvi_timed_begin(gpv_ctx* ctx, int kind) {
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  if (!ctx->timing || kind < 0 || kind >= TK_COUNT) return nullptr;
+  TimingRec* r = new (std::nothrow) TimingRec();
+  if (!r) return nullptr;
+  r->kind = kind;
+  if (hipEventCreate(&r->start) != hipSuccess) { delete r; return nullptr; }
+  if (hipEventCreate(&r->stop) != hipSuccess) { hipEventDestroy(r->start); delete r; return nullptr; }
+  hipEventRecord(r->start, ctx->stream);
+  return r;
+}
+void gpvi_timed_end(gpv_ctx* ctx, void* h) {
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  TimingRec* r = (TimingRec*)h;
+  hipEventRecord(r->stop, ctx->stream);
+  ctx->recs.push_back(*r);
+  delete r;
 }

@@ -10,8 +10,11 @@
 //   gpv_group_create       one process drives n devices: a worker thread + gpv_ctx per device, ncclCommInitAll clique
 //   gpv_group_create_rank  one process per GPU (torch.distributed.run, MPI, a Go supervisor): ncclCommInitRank with a unique
 //                          id the caller distributes
-// RCCL is loaded with dlopen at the first use that needs it ("librccl.so.1": the copy already mapped by PyTorch when there is
-// one, else the ROCm one), so libgpv.so has no link-time dependency on it and single-GPU hosts never touch it.
+// RCCL is bound with dlopen at the first use that needs it, so libgpv.so has no link-time dependency on it and single-GPU hosts never
+// touch it. An image that is ALREADY mapped into the process wins (RTLD_NOLOAD first: under PyTorch that is torch's bundled copy, whose
+// soname is librccl.so.1 too -- two RCCL images in one process would each keep their own bootstrap state); only then is one loaded by
+// name (a Go / C++ caller gets the ROCm copy). Which image was bound, and what RCCL itself says about the communicator (ncclCommCount,
+// ncclCommUserRank, ncclGetVersion), is reported by gpv_group_comm_info -- the evidence a scaling record needs.
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only; every function is resolved with dlsym
 #include <stdarg.h>
@@ -60,6 +63,12 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  // diagnostics (gpv_group_comm_info); a build of RCCL without one of them reports -1 there
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  bool preloaded = false;  // bound to an image that was already mapped (RTLD_NOLOAD) rather than loaded by this library
+  std::string path;        // dladdr of ncclAllGather: the file the code actually comes from
 };
 std::mutex g_rccl_mu;
 Rccl g_rccl;
@@ -69,16 +78,24 @@ const Rccl* rccl(std::string* why) {
   if (g_rccl.handle) return &g_rccl;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
-  for (const char* nm : names) {
-    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-    if (h) break;
+  bool preloaded = false;
+  for (const char* nm : names) {  // an image the process already holds (PyTorch's, or one the host application linked)
+    h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+    if (h) { preloaded = true; break; }
   }
+  if (!h)
+    for (const char* nm : names) {
+      h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
   if (!h) {
-    *why = std::string("RCCL not loadable: ") + (dlerror() ? dlerror() : "dlopen failed");
+    const char* de = dlerror();
+    *why = std::string("RCCL not loadable: ") + (de ? de : "dlopen failed");
     return nullptr;
   }
   Rccl r;
   r.handle = h;
+  r.preloaded = preloaded;
 #define SYM(field, name)                                                         \
   *(void**)(&r.field) = dlsym(h, name);                                          \
   if (!r.field) { *why = std::string("RCCL symbol missing: ") + name; dlclose(h); return nullptr; }
@@ -91,6 +108,11 @@ const Rccl* rccl(std::string* why) {
   SYM(GroupEnd, "ncclGroupEnd");
   SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+  *(void**)(&r.CommCount) = dlsym(h, "ncclCommCount");
+  *(void**)(&r.CommUserRank) = dlsym(h, "ncclCommUserRank");
+  *(void**)(&r.GetVersion) = dlsym(h, "ncclGetVersion");
+  Dl_info di;
+  if (dladdr((void*)r.AllGather, &di) && di.dli_fname) r.path = di.dli_fname;
   g_rccl = r;
   return &g_rccl;
 }
@@ -105,6 +127,8 @@ struct Worker {
   size_t accept_all_cap = 0;
   uint8_t* peer_status = nullptr;  // [world] pinned host: the status bytes of every rank's slot after the exchange
   int status = 0;                  // this rank's own status for the current call (0 = block verified)
+  uint64_t n_allgather = 0;        // ncclAllGather calls this rank has enqueued (gpv_group_comm_info)
+  int last_exchange = 0;           // exchange of the last call: 0 none, 1 ncclAllGather, 2 peer copies
   int rc = GPV_OK;
   std::string err;
 };
@@ -322,6 +346,36 @@ extern "C" int gpv_group_last_error_message(gpv_group* g, char* buf, size_t buf_
   return GPV_OK;
 }
 
+// What RCCL itself says about a rank's communicator and which RCCL image was bound (include/gpv.h). Never forms a communicator.
+extern "C" int gpv_group_comm_info(gpv_group* g, int local_index, int64_t* info, char* library, size_t library_len) {
+  if (!g || !info || local_index < 0 || (size_t)local_index >= g->w.size()) return GPV_EINVAL;
+  std::lock_guard<std::mutex> lk(g->call_mu);
+  Worker& w = g->w[local_index];
+  bool bound;
+  {
+    std::lock_guard<std::mutex> lk2(g_rccl_mu);
+    bound = g_rccl.handle != nullptr;
+  }
+  for (int i = 0; i < 8; i++) info[i] = -1;
+  info[0] = g->comm_ready && w.comm ? 1 : 0;
+  if (info[0]) {
+    int v = -1;
+    if (g_rccl.CommCount && g_rccl.CommCount(w.comm, &v) == ncclSuccess) info[1] = v;
+    v = -1;
+    if (g_rccl.CommUserRank && g_rccl.CommUserRank(w.comm, &v) == ncclSuccess) info[2] = v;
+  }
+  if (bound) {
+    int v = -1;
+    if (g_rccl.GetVersion && g_rccl.GetVersion(&v) == ncclSuccess) info[3] = v;
+    info[5] = g_rccl.preloaded ? 1 : 0;
+  }
+  info[4] = w.last_exchange;
+  info[6] = (int64_t)w.n_allgather;
+  info[7] = g->world;
+  if (library && library_len) snprintf(library, library_len, "%s", bound ? g_rccl.path.c_str() : "");
+  return GPV_OK;
+}
+
 static bool peer_copies(const gpv_group* g) { return g->collective == 2; }
 static bool wants_collective(const gpv_group* g) { return !peer_copies(g) && (g->world > 1 || g->collective == 1); }
 
@@ -399,6 +453,9 @@ static void exchange(gpv_group* g, Worker& w, const uint8_t* accept_local_dev, s
   const size_t slot = gpv_accept_slot_bytes(n_total, g->world);
   hipStream_t st = gpvi_ctx_stream(w.ctx);
   uint8_t* mine = w.bits + (size_t)w.rank * slot;
+  w.last_exchange = peer_copies(g) ? 2 : wants_collective(g) ? 1 : 0;
+  // timing kind 15 (gpv_timing_get): pack + all-gather + unpack + status fetch as the stream sees them; with peer copies the second phase only
+  GpviTimed timed(peer_copies(g) ? nullptr : w.ctx, GPVI_TK_EXCHANGE);
   if (w.status == 0) {
     gpvk_pack_accept_bits(st, accept_local_dev, hi - lo, mine, slot);  // writes the whole slot: bits, zero padding, zero trailer
     if (gpvi_take_launch_error(w.ctx) != GPV_OK) rank_failed(w, GPV_EDEVICE, "pack_accept_bits");
@@ -414,6 +471,7 @@ static void exchange(gpv_group* g, Worker& w, const uint8_t* accept_local_dev, s
   if (wants_collective(g)) {
     ncclResult_t e = g_rccl.AllGather(mine, w.bits, slot, ncclUint8, w.comm, st);
     if (e != ncclSuccess) { worker_fail(w, GPV_EDEVICE, "ncclAllGather: %s", g_rccl.GetErrorString(e)); return; }
+    w.n_allgather++;
   }
   exchange_finish(g, w, n_total, accept_all_dev);
 }
@@ -423,6 +481,7 @@ static void gather_by_peer_copies(gpv_group* g, Worker& w, size_t n_total, uint8
   const size_t slot = gpv_accept_slot_bytes(n_total, g->world);
   hipStream_t st = gpvi_ctx_stream(w.ctx);
   W_HIP(w, hipSetDevice(w.device));
+  GpviTimed timed(w.ctx, GPVI_TK_EXCHANGE);
   for (auto& o : g->w) {
     if (o.rank == w.rank) continue;
     const uint8_t* src = o.bits + (size_t)o.rank * slot;
@@ -453,13 +512,16 @@ static void join_as_failed(gpv_group* g, size_t n_total) {
   uint8_t* mine = w.bits + (size_t)w.rank * slot;
   hipMemsetAsync(mine, 0, slot, st);
   hipMemsetAsync(mine + slot - GPV_SLOT_TRAILER, 1, 1, st);
-  if (g_rccl.AllGather(mine, w.bits, slot, ncclUint8, w.comm, st) == ncclSuccess) hipStreamSynchronize(st);
+  if (g_rccl.AllGather(mine, w.bits, slot, ncclUint8, w.comm, st) == ncclSuccess) { w.n_allgather++; hipStreamSynchronize(st); }
 }
 
 extern "C" int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const void* const* shard_dev, size_t n_total,
                                     uint8_t* const* accept_all_dev) {
-  if (!g || !c || !shard_dev || !accept_all_dev) return GPV_EINVAL;
+  if (!g) return GPV_EINVAL;
   std::lock_guard<std::mutex> lk(g->call_mu);
+  // a bad argument in ONE process of a multi-process job: the others are on their way into the all-gather, so this one joins it with its flag
+  // raised (a no-op for in-process groups and before the communicator exists)
+  if (!c || !shard_dev || !accept_all_dev) { group_error(g, "NULL argument"); if (n_total) join_as_failed(g, n_total); return GPV_EINVAL; }
   if (n_total == 0) return GPV_OK;
   if (wants_collective(g)) {
     int rc = ensure_comm(g);
@@ -503,8 +565,9 @@ extern "C" int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const vo
 }
 
 extern "C" int gpv_group_verify(gpv_group* g, const gpv_circuit* c, const void* proofs, size_t n_total, uint8_t* accept) {
-  if (!g || !c || !accept) return GPV_EINVAL;  // `proofs` may be NULL when none of this process's blocks holds a proof (n_total < world)
+  if (!g) return GPV_EINVAL;  // `proofs` may be NULL when none of this process's blocks holds a proof (n_total < world)
   std::lock_guard<std::mutex> lk(g->call_mu);
+  if (!c || !accept) { group_error(g, "NULL argument"); if (n_total) join_as_failed(g, n_total); return GPV_EINVAL; }
   if (n_total == 0) return GPV_OK;
   if (wants_collective(g)) {
     int rc = ensure_comm(g);

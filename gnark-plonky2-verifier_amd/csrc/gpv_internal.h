@@ -11,3 +11,14 @@ int gpvi_ctx_device(const gpv_ctx* ctx);
 void gpvi_ctx_set_error(gpv_ctx* ctx, const char* msg);
 const char* gpvi_ctx_get_error(const gpv_ctx* ctx);
 int gpvi_take_launch_error(gpv_ctx* ctx);  // GPV_EDEVICE if a kernel launch of this thread failed since the last check
+// A HIP-event bracket on the context's stream, accumulated under timing kind `kind` (gpv_timing_get) when timing is enabled; a null context
+// times nothing. Used by the group's exchange step (kind 15).
+enum { GPVI_TK_EXCHANGE = 15 };
+void* gpvi_timed_begin(gpv_ctx* ctx, int kind);
+void gpvi_timed_end(gpv_ctx* ctx, void* h);
+struct GpviTimed {
+  gpv_ctx* ctx;
+  void* h;
+  GpviTimed(gpv_ctx* c, int kind) : ctx(c), h(c ? gpvi_timed_begin(c, kind) : nullptr) {}
+  ~GpviTimed() { if (h) gpvi_timed_end(ctx, h); }
+};

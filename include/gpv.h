@@ -420,6 +420,20 @@ int gpv_group_verify_dev(gpv_group* g, const gpv_circuit* c, const void* const* 
                          uint8_t* const* accept_all_dev);
 /* Diagnostics: the gathered verdict as local rank `local_index` holds it on its own device after gpv_group_verify. */
 int gpv_group_read_rank_accept(gpv_group* g, int local_index, uint8_t* accept, size_t n_total);
+/* Diagnostics: what RCCL ITSELF reports about local rank `local_index`'s communicator, and which RCCL image libgpv bound -- the evidence
+ * that a multi-GPU run really ran as N RCCL ranks (a scaling record quotes it). Never forms a communicator: before the first call that
+ * needs one (gpv_group_verify* with world > 1 or GPV_GROUP_OPT_COLLECTIVE = 1), info[0] = 0 and info[1..2] = -1.
+ *   info[0]  1 once the rank's communicator exists, else 0
+ *   info[1]  ncclCommCount(comm)      -- ranks RCCL sees in the communicator (must equal gpv_group_world)
+ *   info[2]  ncclCommUserRank(comm)   -- this rank as RCCL numbers it (must equal gpv_group_rank)
+ *   info[3]  ncclGetVersion           -- e.g. 22105; -1 when no RCCL image is bound
+ *   info[4]  exchange of the last verify call of this rank: 0 none (a group of one), 1 ncclAllGather, 2 peer copies
+ *   info[5]  1 = the RCCL image was ALREADY mapped into the process when libgpv bound it (dlopen RTLD_NOLOAD: under PyTorch its bundled
+ *            copy, so that one process never holds two RCCL images), 0 = libgpv loaded it by name, -1 = none bound
+ *   info[6]  ncclAllGather calls this rank has enqueued so far
+ *   info[7]  gpv_group_world
+ * library [library_len] (may be NULL) receives the path of the bound RCCL image (dladdr of ncclAllGather), "" when none is bound. */
+int gpv_group_comm_info(gpv_group* g, int local_index, int64_t* info /* [8] */, char* library, size_t library_len);
 
 /* ------------------------------------------------------------------ measurement helpers */
 /* Average duration (ms) of the named kernel class over the launches since the last reset, measured with HIP events on
@@ -428,7 +442,8 @@ int gpv_group_read_rank_accept(gpv_group* g, int local_index, uint8_t* accept, s
  * 6 = poseidon_bn254_permute, 7 = merkle leaf digests (k_merkle_leaves), 8 = k_merkle_climb_lower alone; the witness kernels of
  * gpv_witness_verify[_dev]: 9 = challenges (the fill pass), 10 = plonk (in gpv_witness_verify: what needs the challenges), 11 = fri, 12 = range_check,
  * 13 = the transcript pass of the challenges slice (it yields the challenges; FRI and the rest of plonk start behind it), 14 = the gate units of the
- * plonk slice (they read no challenge and run beside the transcript pass).
+ * plonk slice (they read no challenge and run beside the transcript pass); 15 = the exchange step of a gpv_group on this rank's context
+ * (gpv_group_ctx): packing the accept bits, the all-gather (ncclAllGather or peer copies), unpacking, the status fetch -- as the stream sees them.
  * Timing is off by default (no event overhead). */
 int gpv_timing_enable(gpv_ctx* ctx, int on);
 int gpv_timing_reset(gpv_ctx* ctx);

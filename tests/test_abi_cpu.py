@@ -78,6 +78,38 @@ def test_go_shim_covers_the_header():
     assert declared - py == set(), sorted(declared - py)
 
 
+def test_go_shim_call_sites_match_the_header(tmp_path):
+    """The Go shim cannot be compiled here, so tools/check_go_shim.py derives the cgo type of every argument of every C.gpv_* call site and
+    compares it with the prototype in include/gpv.h (count and exact type: `*C.uint64_t`, `unsafe.Pointer`, `**C.char`, `C.size_t` ...).
+    The checker itself is checked on seeded defects: the round-4 regression (the generic ptr() handed an ARRAY -- ADVICE r4), a dropped
+    argument, a pointer of the wrong element type, a size passed as C.int, and a call of a function the header does not declare."""
+    import shutil
+    sys.path.insert(0, str(T.ROOT / "tools"))
+    import check_go_shim as G
+    problems, stats = G.check()
+    assert problems == [], "\n".join(problems)
+    assert stats["call_sites"] >= stats["header_functions"] >= 89 and stats["arguments_checked"] > 350
+    src = (T.ROOT / "bindings" / "go" / "gpv" / "gpv.go").read_text()
+    seeded = [
+        ("C.gpv_group_unique_id(ptr(id[:]))", "C.gpv_group_unique_id(ptr(id))", "needs a slice"),
+        ("C.gpv_gl2_exp(ctx.h, u64p(a), C.uint64_t(exponent), u64p(out), C.size_t(len(a)/2))", "C.gpv_gl2_exp(ctx.h, u64p(a), u64p(out), C.size_t(len(a)/2))", "called with 4 arguments, the header declares 5"),
+        ("C.gpv_gl2_exp(ctx.h, u64p(a), C.uint64_t(exponent), u64p(out), C.size_t(len(a)/2))", "C.gpv_gl2_exp(ctx.h, u64p(a), C.uint64_t(exponent), (*C.uint32_t)(ptr(out)), C.size_t(len(a)/2))", "is *C.uint32_t, the header wants *C.uint64_t"),
+        ("C.gpv_gl2_exp(ctx.h, u64p(a), C.uint64_t(exponent), u64p(out), C.size_t(len(a)/2))", "C.gpv_gl2_exp(ctx.h, u64p(a), C.uint64_t(exponent), u64p(out), C.int(len(a)/2))", "is C.int, the header wants C.size_t"),
+        ("C.gpv_gl2_exp(ctx.h,", "C.gpv_gl2_expo(ctx.h,", "is not declared in include/gpv.h"),
+        ("C.gpv_gl2_exp(ctx.h, u64p(a)", "C.gpv_gl2_exp(c.h, u64p(a)", "the header wants *C.gpv_ctx"),
+    ]
+    for k, (old, new, expect) in enumerate(seeded):
+        assert src.count(old) >= 1, old
+        d = tmp_path / ("seed%d" % k)
+        shutil.copytree(T.ROOT / "bindings" / "go", d)
+        mutated = src.replace(old, new, 1)
+        if "c.h" in new and "c.h" not in old:  # give the mutated function a circuit to pass in place of the context
+            mutated = mutated.replace("func (ctx *Context) Gl2Exp(a []uint64, exponent uint64) []uint64 {", "func (ctx *Context) Gl2Exp(c *Circuit, a []uint64, exponent uint64) []uint64 {", 1)
+        (d / "gpv" / "gpv.go").write_text(mutated)
+        problems, _ = G.check(go_dir=d)
+        assert any(expect in p for p in problems), (new, problems)
+
+
 def test_no_cpu_fallback(gpv):
     with pytest.raises(gpv.DeviceError):
         gpv.Context(0)

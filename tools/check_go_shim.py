@@ -1,0 +1,352 @@
+"""Mechanical check of the UNCOMPILED Go shim against the C header (`ptr(id)` on an array).
+
+No Go toolchain exists in this image, so `go vet` / `go build` cannot run. This tool does the part of their job that decides whether the
+cgo calls can compile at all: for every `C.gpv_*( ... )` call site under bindings/go it derives the cgo type of each argument expression
+with a small type inference over the Go source (conversions `C.T(x)`, pointer casts `(*C.T)(x)`, the helpers' declared return types,
+`var` declarations, struct fields, function parameters, `make([]T, n)` slices, multi-value assignments from helper functions) and compares
+it with the type cgo assigns to that parameter of the prototype in include/gpv.h (`const T*` -> `*C.T`, `void*` -> `unsafe.Pointer`,
+`const void* const*` -> `*unsafe.Pointer`, `size_t` -> `C.size_t`, ...). It also checks the generic helper `ptr[T any](s []T)` is only
+ever handed a slice (the round-4 regression), and that every header function is called somewhere.
+
+    python tools/check_go_shim.py            # prints a summary, exit status 1 on any mismatch
+
+tests/test_abi_cpu.py::test_go_shim_call_sites_match_the_header runs it.
+"""
+import re
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+GO_DIR = ROOT / "bindings" / "go"
+NIL = "<nil>"
+UNTYPED = "<untyped integer constant>"
+INT_TYPES = {"C.int", "C.uint", "C.size_t", "C.int32_t", "C.uint32_t", "C.int64_t", "C.uint64_t", "C.uint8_t", "C.long", "C.ulong"}
+
+
+# ---------------------------------------------------------------- header side
+def header_prototypes(text=None):
+    """{name: (return cgo type, [param cgo types], [param names])} for every function include/gpv.h declares."""
+    if text is None:
+        text = (ROOT / "include" / "gpv.h").read_text()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    protos = {}
+    for m in re.finditer(r"(?m)^\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*(?:\s*\*)*)\s*(gpv_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+        plist = [p.strip() for p in params.replace("\n", " ").split(",")] if params.strip() and params.strip() != "void" else []
+        types, names = [], []
+        for p in plist:
+            t, nm = split_param(p)
+            types.append(c_to_cgo(t))
+            names.append(nm)
+        protos[name] = (c_to_cgo(ret), types, names)
+    return protos
+
+
+def split_param(p):
+    p = re.sub(r"\[[^\]]*\]", "", p).strip()  # `uint64_t out[4]` does not occur, but be safe
+    m = re.match(r"^(.*?)([A-Za-z_][A-Za-z0-9_]*)$", p)
+    if m and m.group(1).strip() and not m.group(1).strip().endswith(("const", "struct")):
+        return m.group(1).strip(), m.group(2)
+    return p, ""
+
+
+def c_to_cgo(t):
+    """The Go type cgo gives a C parameter type: const is dropped, `void*` is unsafe.Pointer, every other `T*` is `*C.T`."""
+    t = re.sub(r"\bconst\b", " ", t)
+    stars = t.count("*")
+    base = " ".join(t.replace("*", " ").split())
+    base = {"unsigned char": "uchar", "unsigned int": "uint", "unsigned": "uint", "unsigned long": "ulong", "long long": "longlong"}.get(base, base)
+    if base == "void":
+        if stars == 0:
+            return "void"
+        return "*" * (stars - 1) + "unsafe.Pointer"
+    return "*" * stars + "C." + base
+
+
+# ---------------------------------------------------------------- Go side
+def strip_go_comments(src):
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c == '"':
+            j = i + 1
+            while j < n and src[j] != '"':
+                j += 2 if src[j] == "\\" else 1
+            out.append('""')
+            i = j + 1
+        elif c == "`":
+            j = src.index("`", i + 1)
+            out.append('""')
+            i = j + 1
+        elif src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            seg = src[i:j + 2]
+            out.append("\n" * seg.count("\n"))
+            i = j + 2
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def split_args(s):
+    args, depth, cur = [], 0, []
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            args.append("".join(cur).strip())
+            cur = []
+        else:
+            cur.append(ch)
+    last = "".join(cur).strip()
+    if last:
+        args.append(last)
+    return args
+
+
+def matching_paren(src, i):
+    """index of the `)` that closes the `(` at src[i]"""
+    depth = 0
+    for j in range(i, len(src)):
+        if src[j] == "(":
+            depth += 1
+        elif src[j] == ")":
+            depth -= 1
+            if depth == 0:
+                return j
+    raise ValueError("unbalanced parentheses")
+
+
+GO_TYPE = r"(?:\*|\[\d*\])*(?:C\.\w+|unsafe\.Pointer|\w+(?:\.\w+)?)"
+
+
+class GoFile:
+    def __init__(self, path):
+        self.path = path
+        self.src = strip_go_comments(path.read_text())
+        # top-level functions: name -> (params text, results text)
+        self.funcs = {}
+        self.func_spans = []  # (start, end, header text)
+        for m in re.finditer(r"(?m)^func\s*(\([^)]*\))?\s*(\w+)(?:\[[^\]]*\])?\s*\(", self.src):
+            open_i = m.end() - 1
+            close_i = matching_paren(self.src, open_i)
+            rest = self.src[close_i + 1:]
+            rm = re.match(r"\s*(\([^)]*\)|[^{\n]*?)\s*\{", rest)
+            results = rm.group(1).strip() if rm else ""
+            self.funcs[m.group(2)] = (self.src[open_i + 1:close_i], results)
+            self.func_spans.append((m.start(), m.group(1) or "", self.src[open_i + 1:close_i]))
+        self.structs = {}
+        for m in re.finditer(r"(?m)^type\s+(\w+)\s+struct\s*\{([^}]*)\}", self.src):
+            fields = {}
+            for line in m.group(2).replace(";", "\n").split("\n"):
+                fm = re.match(r"\s*([\w, ]+?)\s+(" + GO_TYPE + r")\s*$", line)
+                if fm:
+                    for nm in fm.group(1).split(","):
+                        fields[nm.strip()] = fm.group(2)
+            self.structs[m.group(1)] = fields
+
+    def enclosing(self, pos):
+        """(receiver text, params text, body text up to pos) of the top-level function around pos"""
+        best = None
+        for start, recv, params in self.func_spans:
+            if start <= pos:
+                best = (start, recv, params)
+        start, recv, params = best
+        return recv, params, self.src[start:pos]
+
+
+def result_types(results):
+    results = results.strip()
+    if not results:
+        return []
+    if results.startswith("("):
+        return [r.strip().split()[-1] for r in split_args(results[1:-1])]
+    return [results]
+
+
+def param_types(params_text):
+    """{name: type} for a Go parameter list `a, b []uint64, n int`"""
+    out, pending = {}, []
+    for p in split_args(params_text):
+        parts = p.split()
+        if len(parts) == 1:
+            pending.append(parts[0])
+        else:
+            t = " ".join(parts[1:])
+            for nm in pending + [parts[0]]:
+                out[nm] = t
+            pending = []
+    return out
+
+
+class Inference:
+    def __init__(self, files):
+        self.files = files
+        self.funcs, self.structs = {}, {}
+        for f in files:
+            self.funcs.update(f.funcs)
+            self.structs.update(f.structs)
+
+    def var_type(self, name, gf, pos):
+        recv, params, body = gf.enclosing(pos)
+        # declared: var name T   /   var name T = ...
+        m = None
+        for m in re.finditer(r"\bvar\s+((?:\w+\s*,\s*)*\w+)\s+(" + GO_TYPE + r")", body):
+            if name in [x.strip() for x in m.group(1).split(",")]:
+                found = m.group(2)
+                return found
+        m = None
+        # name := make([]T, ...)
+        for m in re.finditer(r"\b" + re.escape(name) + r"\s*:?=\s*make\((\[\]" + GO_TYPE + r")\s*,", body):
+            pass
+        if m:
+            return m.group(1)
+        # closure: name := func(...) RET {
+        m = re.search(r"\b" + re.escape(name) + r"\s*:=\s*func\s*\(([^)]*)\)\s*(" + GO_TYPE + r")\s*\{", body)
+        if m:
+            return "func:" + m.group(2)
+        # a, b, c := helper(...)
+        for m in re.finditer(r"(?m)^\s*([\w, ]+?)\s*:?=\s*(\w+)\(", body):
+            names = [x.strip() for x in m.group(1).split(",")]
+            if name in names and m.group(2) in self.funcs:
+                rts = result_types(self.funcs[m.group(2)][1])
+                if len(rts) == len(names):
+                    return rts[names.index(name)]
+        # name := C.T(...) / (*C.T)(...)
+        m = re.search(r"\b" + re.escape(name) + r"\s*:=\s*([^\n]+)", body)
+        if m:
+            t = self.expr_type(m.group(1).strip(), gf, pos, depth=1)
+            if t:
+                return t
+        # a parameter of the innermost closure around pos, then of the function
+        for m in reversed(list(re.finditer(r"\bfunc\s*\(([^)]*)\)", body))):
+            if body.count("{", m.end()) > body.count("}", m.end()):  # still inside that closure's body
+                cp = param_types(m.group(1))
+                if name in cp:
+                    return cp[name]
+        pt = param_types(params)
+        if name in pt:
+            return pt[name]
+        rm = re.match(r"\(\s*(\w+)\s+(" + GO_TYPE + r")\s*\)", recv or "")
+        if rm and rm.group(1) == name:
+            return rm.group(2)
+        return None
+
+    def expr_type(self, e, gf, pos, depth=0):
+        e = e.strip()
+        if depth > 4:
+            return None
+        if e == "nil":
+            return NIL
+        if re.match(r"^(0x[0-9a-fA-F]+|\d+)$", e) or re.match(r"^C\.[A-Z][A-Z0-9_]*$", e):
+            return UNTYPED  # integer literal, or a C enum / macro constant (cgo emits those as untyped Go constants)
+        m = re.match(r"^C\.(\w+)\(", e)
+        if m and matching_paren(e, m.end() - 1) == len(e) - 1:
+            return "C." + m.group(1)
+        m = re.match(r"^\((\*+)(C\.\w+|unsafe\.Pointer)\)\(", e)
+        if m and matching_paren(e, m.end() - 1) == len(e) - 1:
+            return m.group(1) + m.group(2)
+        m = re.match(r"^(ptr|unsafe\.Pointer)\(", e)
+        if m and matching_paren(e, m.end() - 1) == len(e) - 1:
+            return "unsafe.Pointer"
+        m = re.match(r"^&(\w+)\[0\]$", e)
+        if m:
+            t = self.var_type(m.group(1), gf, pos)
+            return "*" + t[2:] if t and t.startswith("[]") else None
+        m = re.match(r"^&(\w+)$", e)
+        if m:
+            t = self.var_type(m.group(1), gf, pos)
+            return "*" + t if t else None
+        m = re.match(r"^(\w+)\.(\w+)$", e)
+        if m:
+            t = self.var_type(m.group(1), gf, pos)
+            if t:
+                fields = self.structs.get(t.lstrip("*"), {})
+                return fields.get(m.group(2))
+            return None
+        m = re.match(r"^(\w+)\(", e)
+        if m and matching_paren(e, m.end() - 1) == len(e) - 1:
+            name = m.group(1)
+            t = self.var_type(name, gf, pos)
+            if t and t.startswith("func:"):
+                return t[5:]
+            if name in self.funcs:
+                rts = result_types(self.funcs[name][1])
+                return rts[0] if len(rts) == 1 else None
+            return None
+        if re.match(r"^\w+$", e):
+            return self.var_type(e, gf, pos)
+        return None
+
+
+def compatible(want, got):
+    if got == NIL:
+        return want.startswith("*") or want == "unsafe.Pointer"
+    if got == UNTYPED:
+        return want in INT_TYPES
+    return want == got
+
+
+def check(verbose=False, go_dir=None):
+    go_dir = Path(go_dir) if go_dir else GO_DIR
+    protos = header_prototypes()
+    files = [GoFile(p) for p in sorted(go_dir.rglob("*.go"))]
+    inf = Inference(files)
+    problems, called, n_sites, n_args = [], set(), 0, 0
+    for gf in files:
+        rel = gf.path.relative_to(go_dir.parent.parent) if go_dir == GO_DIR else gf.path.relative_to(go_dir)
+        for m in re.finditer(r"\bC\.(gpv_[a-z0-9_]+)\(", gf.src):
+            name = m.group(1)
+            line = gf.src.count("\n", 0, m.start()) + 1
+            close = matching_paren(gf.src, m.end() - 1)
+            args = split_args(gf.src[m.end():close])
+            n_sites += 1
+            if name not in protos:
+                problems.append("%s:%d: C.%s is not declared in include/gpv.h" % (rel, line, name))
+                continue
+            called.add(name)
+            ret, want, pnames = protos[name]
+            if len(args) != len(want):
+                problems.append("%s:%d: C.%s called with %d arguments, the header declares %d" % (rel, line, name, len(args), len(want)))
+                continue
+            for k, (a, w) in enumerate(zip(args, want)):
+                n_args += 1
+                got = inf.expr_type(a, gf, m.start())
+                if got is None:
+                    problems.append("%s:%d: C.%s argument %d (%s): cannot derive the type of `%s` (header wants %s)" % (rel, line, name, k + 1, pnames[k], a, w))
+                elif not compatible(w, got):
+                    problems.append("%s:%d: C.%s argument %d (%s): `%s` is %s, the header wants %s" % (rel, line, name, k + 1, pnames[k], a, got, w))
+                elif verbose:
+                    print("  ok %s:%d %s arg %d %s : %s" % (rel, line, name, k + 1, a, got))
+        # the generic helper ptr[T any](s []T) infers T from a SLICE; an array argument does not compile
+        for m in re.finditer(r"\bptr\((\w+)\)", gf.src):
+            t = inf.var_type(m.group(1), gf, m.start())
+            line = gf.src.count("\n", 0, m.start()) + 1
+            if t is None:
+                problems.append("%s:%d: ptr(%s): cannot derive the type of `%s`" % (rel, line, m.group(1), m.group(1)))
+            elif not t.startswith("[]"):
+                problems.append("%s:%d: ptr(%s): `%s` is %s, ptr[T any](s []T) needs a slice (use %s[:])" % (rel, line, m.group(1), m.group(1), t, m.group(1)))
+    for name in protos:
+        if name not in called:
+            problems.append("include/gpv.h declares %s, no cgo call site under bindings/go" % name)
+    return problems, {"header_functions": len(protos), "call_sites": n_sites, "arguments_checked": n_args}
+
+
+def main():
+    problems, stats = check(verbose="-v" in sys.argv)
+    for p in problems:
+        print(p)
+    print("check_go_shim: %(header_functions)d header functions, %(call_sites)d cgo call sites, %(arguments_checked)d arguments checked" % stats,
+          "-- %d problem(s)" % len(problems))
+    return 1 if problems else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
