@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--no-clock-sample", action="store_true", help="do not run the one-wave shader-clock sampler beside the timed steps")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the BASELINE config 3 / config 5 legs (fri_verify_4096, merkle_only_4096)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the accept all-gather even at world size 1 (test hook)")
+    ap.add_argument("--strict-exchange", action="store_true", help="exit non-zero instead of falling back to the torch.distributed exchange when the C-ABI group cannot be formed on every rank "
+                    "(the JSON line is still printed, with exchange_fallback = true)")
+    ap.add_argument("--no-exchange-probe", action="store_true", help="N = 1 only: skip the world-1 group leg that runs the RCCL all-gather of the accept bits once per step and reports its cost")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -355,6 +358,7 @@ def main():
     lower_ms, _ = ctx.timing_get(8)
     stage_ms = {nm: ctx.timing_get(k)[0] for nm, k in (("merkle_walk", 0), ("merkle_climb_lower", 8), ("merkle_leaves", 7), ("transcript", 2), ("plonk", 3),
                                                         ("fri_query", 4), ("range_check", 5))}
+    exchange_ms, exchange_launches = ctx.timing_get(15) if group is not None else (None, 0)  # pack + all-gather + unpack on rank 0's stream (HIP events)
     ctx.timing_enable(False)
     # Shader clock under THIS load, sampled OUTSIDE the timed region: a one-wave sampler (tools/probe: s_memtime against the 100 MHz
     # s_memrealtime) spins beside three more, untimed steps of the same workload. (Run beside the timed steps it cost 1.5 % of the
@@ -412,7 +416,31 @@ def main():
                    "bn254_fr_rows": "chosen per launch by occupancy (GPV_OPT_FR_EVALUATION = 0): waves per SIMD of full-length lanes (4 Merkle paths per query round) >= 4.5 "
                                     "column scanning (this workload from ~2600 proofs per GPU up), <= 0.5 four lanes per permutation (about 290 proofs), operand scanning in between; identical results"},
     }
+    # ---- what RCCL itself observed: rank count, version and the image libgpv bound, from gpv_group_comm_info of the
+    # group that ran the timed steps; a fallback to the torch exchange is a top-level key, and fatal under --strict-exchange
+    exchange_fallback = bool(use_collective and args.exchange == "abi" and exchange != "abi")
+    line["exchange_fallback"] = exchange_fallback
+    if exchange_fallback:
+        line["exchange_fallback_reason"] = exchange_note.strip(" ()")
+    if group is not None:
+        info = group.comm_info(0)
+        line["rccl"] = {"ranks": info["nccl_comm_count"] if info["comm_ready"] else None, "user_rank": info["nccl_user_rank"] if info["comm_ready"] else None,
+                        "version": info["nccl_version"] if info["nccl_version"] >= 0 else None, "library": info["library"] or None,
+                        "library_preloaded": info["library_preloaded"], "allgather_calls": info["allgather_calls"], "exchange": info["exchange"],
+                        "exchange_ms": exchange_ms, "exchange_launches": exchange_launches, "group_world": info["world"],
+                        "source": "gpv_group_comm_info (ncclCommCount / ncclCommUserRank / ncclGetVersion / dladdr of ncclAllGather) after the timed steps; "
+                                  "exchange_ms = HIP events around pack + ncclAllGather + unpack + status fetch on rank 0's stream (gpv_timing_get kind 15)"}
+        if use_collective and (not info["comm_ready"] or info["nccl_comm_count"] != n_ranks):
+            raise SystemExit("RCCL reports %s ranks in the communicator, the job has %d" % (info["nccl_comm_count"], n_ranks))
+    elif exchange == "torch":
+        line["rccl"] = {"ranks": dist.get_world_size(), "user_rank": dist.get_rank(), "version": "%d.%d.%d" % tuple(torch.cuda.nccl.version()[:3]),
+                        "library": None, "exchange": "torch.distributed all_gather_into_tensor", "source": "torch.distributed (the C-ABI group was not used)"}
     if rank == 0:
+        if not use_collective and not args.no_exchange_probe and group is None:
+            try:
+                line["rccl"] = bench_exchange_probe(gpv, wl, batch, n_local, expect, local_rank, max(2, min(args.steps, 3)))
+            except Exception as e:  # noqa: BLE001 -- a measurement leg: say what failed, keep the line
+                line["rccl"] = {"error": str(e)[:300]}
         leaf_perms, climb_perms = perms_per_proof(ci)
         n_chains = ci.num_query_rounds * (4 + len(ci.arity_bits))
         # Two kernels of nearly equal length carry the step: k_merkle_leaves (leaf digests) and k_merkle_climb_lower (the sibling
@@ -542,8 +570,45 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
+    if exchange_fallback and args.strict_exchange:
+        sys.stdout.flush()
+        os._exit(3)  # every rank leaves non-zero: a scaling driver must not record a fallback run as the C-ABI path
     if hard_exit:
         os._exit(0)
+
+
+def bench_exchange_probe(gpv, wl, batch, n_local, expect, device, steps):
+    """N = 1: the exchange step of the multi-GPU path on every default line. A gpv_group of ONE rank (gpv_group_create_rank, the form
+    torch.distributed.run uses) with the RCCL all-gather forced on (GPV_GROUP_OPT_COLLECTIVE = 1) verifies the bench's own shard; the cost of
+    pack + ncclAllGather + unpack + status fetch is measured with HIP events on the rank's stream, and RCCL's own view of the communicator is
+    reported. The transport at world 1 is a device-local copy inside RCCL: this prices the launch sequence, not xGMI."""
+    import torch
+    grp = gpv.Group(rank=0, world=1, unique_id=gpv.Group.unique_id(), device_id=device)
+    try:
+        grp.set_option(gpv._lib.GROUP_OPT_COLLECTIVE, 1)
+        c = grp.context(0)
+        acc = torch.zeros(n_local, dtype=torch.uint8, device=batch.device)
+        torch.cuda.synchronize()
+        grp.verify_dev(wl.circuit, [batch.data_ptr()], n_local, [acc.data_ptr()])  # forms the communicator
+        c.timing_enable(True)
+        c.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            grp.verify_dev(wl.circuit, [batch.data_ptr()], n_local, [acc.data_ptr()])
+        with_ms = 1e3 * (time.perf_counter() - t0) / steps
+        ex_ms, ex_n = c.timing_get(15)
+        c.timing_enable(False)
+        if not (acc.cpu().numpy() == expect).all():
+            raise RuntimeError("accept vector mismatch through the world-1 group")
+        info = grp.comm_info(0)
+        return {"ranks": info["nccl_comm_count"], "user_rank": info["nccl_user_rank"], "version": info["nccl_version"], "library": info["library"],
+                "library_preloaded": info["library_preloaded"], "allgather_calls": info["allgather_calls"], "exchange": info["exchange"],
+                "exchange_ms": ex_ms, "exchange_launches": ex_n, "group_world": info["world"], "ms_per_step_through_the_group": with_ms,
+                "slot_bytes": int(gpv._lib.lib().gpv_accept_slot_bytes(n_local, 1)),
+                "source": "world-1 probe leg (the timed steps above ran on a plain context): gpv_group_create_rank + GPV_GROUP_OPT_COLLECTIVE = 1 on this "
+                          "run's shard; gpv_group_comm_info; exchange_ms = HIP events around pack + ncclAllGather + unpack + status fetch (gpv_timing_get kind 15)"}
+    finally:
+        grp.close()
 
 
 def bench_poseidon_gl(gpv, T, ctx, dev):

@@ -563,18 +563,19 @@ type CommInfo struct {
 	LibraryPreloaded int64 // 1 already mapped when bound, 0 loaded by libgpv, -1 none
 	AllGatherCalls   int64
 	World            int64
+	LastStatus       int64 // this rank's part of the last group call: 0, its own error, or -6 (GPV_EPEER)
 	Library          string // path of the bound RCCL image
 }
 
 func (g *Group) CommInfo(local int) CommInfo {
-	info := make([]int64, 8)
+	info := make([]int64, 10)
 	lib := make([]byte, 512)
 	groupCheck(C.gpv_group_comm_info(g.h, C.int(local), (*C.int64_t)(ptr(info)), (*C.char)(ptr(lib)), C.size_t(len(lib))), g.h)
 	n := 0
 	for n < len(lib) && lib[n] != 0 {
 		n++
 	}
-	return CommInfo{info[0] != 0, info[1], info[2], info[3], info[4], info[5], info[6], info[7], string(lib[:n])}
+	return CommInfo{info[0] != 0, info[1], info[2], info[3], info[4], info[5], info[6], info[7], info[8], string(lib[:n])}
 }
 
 // WitnessRangeCheck / WitnessChallenges: the hint outputs of Verify's first three statements (verifier/verifier.go:148-150) in call order

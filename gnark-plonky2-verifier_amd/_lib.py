@@ -366,12 +366,12 @@ class Group:
 
     def comm_info(self, local_index=0):
         """gpv_group_comm_info: what RCCL itself reports about this rank's communicator and which RCCL image libgpv bound."""
-        info = (ctypes.c_int64 * 8)()
+        info = (ctypes.c_int64 * 10)()
         buf = ctypes.create_string_buffer(512)
         self._check(lib().gpv_group_comm_info(ctypes.c_void_p(self.h), local_index, info, buf, 512))
         return {"comm_ready": bool(info[0]), "nccl_comm_count": int(info[1]), "nccl_user_rank": int(info[2]), "nccl_version": int(info[3]),
                 "exchange": {0: "none", 1: "ncclAllGather", 2: "peer copies"}.get(int(info[4]), str(int(info[4]))),
-                "library_preloaded": {1: True, 0: False}.get(int(info[5])), "allgather_calls": int(info[6]), "world": int(info[7]),
+                "library_preloaded": {1: True, 0: False}.get(int(info[5])), "allgather_calls": int(info[6]), "world": int(info[7]), "last_status": int(info[8]),
                 "library": buf.value.decode("utf-8", "replace")}
 
 

@@ -356,7 +356,7 @@ extern "C" int gpv_group_comm_info(gpv_group* g, int local_index, int64_t* info,
     std::lock_guard<std::mutex> lk2(g_rccl_mu);
     bound = g_rccl.handle != nullptr;
   }
-  for (int i = 0; i < 8; i++) info[i] = -1;
+  for (int i = 0; i < 10; i++) info[i] = -1;
   info[0] = g->comm_ready && w.comm ? 1 : 0;
   if (info[0]) {
     int v = -1;
@@ -372,6 +372,8 @@ extern "C" int gpv_group_comm_info(gpv_group* g, int local_index, int64_t* info,
   info[4] = w.last_exchange;
   info[6] = (int64_t)w.n_allgather;
   info[7] = g->world;
+  info[8] = w.rc;  // this rank's part of the last group call: GPV_OK, its own error, or GPV_EPEER when another rank failed
+  info[9] = 0;
   if (library && library_len) snprintf(library, library_len, "%s", bound ? g_rccl.path.c_str() : "");
   return GPV_OK;
 }

@@ -603,14 +603,14 @@ class VerifierGroup {
   }
   struct CommInfo {  // gpv_group_comm_info: what RCCL itself reports, and which RCCL image the library bound
     bool comm_ready;
-    int64_t nccl_comm_count, nccl_user_rank, nccl_version, exchange, library_preloaded, allgather_calls, world;
+    int64_t nccl_comm_count, nccl_user_rank, nccl_version, exchange, library_preloaded, allgather_calls, world, last_status;
     std::string library;
   };
   CommInfo GetCommInfo(int local_index = 0) {
-    int64_t v[8];
+    int64_t v[10];
     char lib[512];
     check(gpv_group_comm_info(g_, local_index, v, lib, sizeof lib));
-    return CommInfo{v[0] != 0, v[1], v[2], v[3], v[4], v[5], v[6], v[7], lib};
+    return CommInfo{v[0] != 0, v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], lib};
   }
   static std::pair<size_t, size_t> ShardBounds(size_t n, int rank, int world) {
     size_t lo = 0, hi = 0;

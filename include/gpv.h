@@ -432,8 +432,10 @@ int gpv_group_read_rank_accept(gpv_group* g, int local_index, uint8_t* accept, s
  *            copy, so that one process never holds two RCCL images), 0 = libgpv loaded it by name, -1 = none bound
  *   info[6]  ncclAllGather calls this rank has enqueued so far
  *   info[7]  gpv_group_world
+ *   info[8]  status of THIS rank's part of the last group call: GPV_OK, the rank's own error, or GPV_EPEER when another rank failed
+ *   info[9]  reserved (0)
  * library [library_len] (may be NULL) receives the path of the bound RCCL image (dladdr of ncclAllGather), "" when none is bound. */
-int gpv_group_comm_info(gpv_group* g, int local_index, int64_t* info /* [8] */, char* library, size_t library_len);
+int gpv_group_comm_info(gpv_group* g, int local_index, int64_t* info /* [10] */, char* library, size_t library_len);
 
 /* ------------------------------------------------------------------ measurement helpers */
 /* Average duration (ms) of the named kernel class over the launches since the last reset, measured with HIP events on

@@ -1027,6 +1027,12 @@ def test_group_world1_with_rccl_collective(gpv, orc, mode):
             out = torch.full((n,), 7, dtype=torch.uint8, device="cuda:0")
             grp.verify_dev(circuit, [t.data_ptr()], n, [out.data_ptr()])
             assert out.cpu().numpy().tolist() == acc.tolist()
+        # what RCCL itself says about the communicator, and which image was bound (gpv_group_comm_info): the evidence a scaling record quotes
+        info = grp.comm_info(0)
+        assert info["comm_ready"] and info["nccl_comm_count"] == 1 and info["nccl_user_rank"] == 0 and info["world"] == 1, info
+        assert info["nccl_version"] > 20000 and "rccl" in info["library"] and info["exchange"] == "ncclAllGather", info
+        assert info["allgather_calls"] == 8 and info["last_status"] == 0, info   # four sizes x (host batch + device-resident)
+        assert info["library_preloaded"] is True, info                            # torch is imported: its bundled RCCL image is the one bound
         # per-context options reach the rank's context through the group; its context is usable for primitives
         grp.set_option(2, 0)  # GPV_OPT_MERKLE_SHARED_LEVELS off
         batch, tampered = T.synthetic_batch(ci, packed, 1100, seed=9, tamper_every=5)
@@ -1072,6 +1078,85 @@ def test_group_several_ranks_on_one_gpu_peer_copy_exchange(gpv, orc, monkeypatch
     monkeypatch.delenv("GPV_GROUP_ALLOW_DUPLICATE_DEVICES")
     with pytest.raises(gpv.GpvError):
         gpv.Group(device_ids=[0, 0])
+
+
+def _config4_batch_on_device(torch, ci, packed, n):
+    """BASELINE config 4's synthetic batch: n copies of the packed `step` record, proof i tampered iff splitmix64(1 + i) % 16 == 0."""
+    dev = torch.device("cuda:0")
+    rec = torch.from_numpy(np.frombuffer(packed, dtype=np.int64).copy()).to(dev)
+    batch = rec.repeat(n, 1).contiguous()
+    q0, qwords, f0, qfr, n_gl = T.query_section_layout(ci)
+    tampered = np.array([T.splitmix64(1 + i) % 16 == 0 for i in range(n)])
+    rows = torch.tensor(np.nonzero(tampered)[0], device=dev)
+    cols = torch.tensor([q0 + T.splitmix64(2 + int(i)) % (ci.num_query_rounds * qwords) for i in np.nonzero(tampered)[0]], device=dev)
+    batch[rows, cols] = batch[rows, cols] ^ 1
+    torch.cuda.synchronize()
+    return batch, tampered
+
+
+def _eight_ranks_config4(gpv, torch, circuit, fail_rank=None, set_fault=None):
+    ci, packed, _ = T.load_fixture("step")
+    world, n = 8, 65536
+    batch, tampered = _config4_batch_on_device(torch, ci, packed, n)
+    expect = (~tampered).astype(np.uint8)
+    rec = circuit.proof_nbytes
+    grp = gpv.Group(device_ids=[0] * world)
+    try:
+        assert (grp.world, grp.local, grp.ranks) == (world, world, list(range(world)))
+        grp.set_option(gpv._lib.GROUP_OPT_COLLECTIVE, 2)
+        bounds = [gpv.shard_bounds(n, r, world) for r in range(world)]
+        assert all(hi - lo == 8192 for lo, hi in bounds)
+        outs = [torch.full((n,), 9, dtype=torch.uint8, device="cuda:0") for _ in range(world)]
+        shard_ptrs = [batch.data_ptr() + lo * rec for lo, hi in bounds]
+        for c in (grp.context(r) for r in range(world)):
+            c.timing_enable(True)
+        grp.verify_dev(circuit, shard_ptrs, n, [o.data_ptr() for o in outs])
+        for r, o in enumerate(outs):  # every rank holds the WHOLE verdict
+            assert (o.cpu().numpy() == expect).all(), r
+            info = grp.comm_info(r)
+            assert (info["world"], info["exchange"], info["last_status"], info["comm_ready"]) == (world, "peer copies", 0, False), info
+            ms, cnt = grp.context(r).timing_get(15)   # the exchange step was bracketed on this rank's stream
+            assert cnt == 1 and 0 < ms < 50, (r, ms, cnt)
+        if fail_rank is not None:
+            for o in outs:
+                o.fill_(9)
+            set_fault(100, fail_rank)
+            try:
+                with pytest.raises(gpv.GpvError):
+                    grp.verify_dev(circuit, shard_ptrs, n, [o.data_ptr() for o in outs])
+            finally:
+                set_fault(0)
+            # the failing rank reports its own error, the other seven GPV_EPEER -- nobody was left waiting, nobody reports a verdict
+            status = [grp.comm_info(r)["last_status"] for r in range(world)]
+            assert status == [gpv._lib.GPV_EDEVICE if r == fail_rank else gpv._lib.GPV_EPEER for r in range(world)], status
+            grp.verify_dev(circuit, shard_ptrs, n, [o.data_ptr() for o in outs])  # and the group is usable afterwards
+            for r, o in enumerate(outs):
+                assert (o.cpu().numpy() == expect).all(), r
+    finally:
+        grp.close()
+        del batch
+        torch.cuda.empty_cache()
+
+
+def test_group_eight_ranks_at_config4_shape_on_one_gpu(gpv, monkeypatch):
+    """BASELINE config 4 at its real shape -- 65 536 `step` proofs as 8 ranks x 8192 -- through gpv_group_verify_dev with all eight ranks
+    (eight worker threads, eight contexts, one shared circuit) on the ONE GPU of this box and the peer-copy exchange (an RCCL clique cannot
+    hold two ranks of one device): what an 8-GPU node runs except for the transport of the 8 x 1 KiB of packed accept bits. Every rank's
+    device buffer must hold the verdict of the whole batch == the tamper mask."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("GPV_GROUP_ALLOW_DUPLICATE_DEVICES", "1")
+    common, vo, circuit, proofs = _load(gpv, "step")
+    _eight_ranks_config4(gpv, torch, circuit)
+
+
+def test_group_eight_ranks_one_fails_at_config4_shape(gpv, monkeypatch):
+    """The same eight ranks with rank 5 reporting a failed verification (fault hook, libgpv_test.so): the call fails on every rank --
+    GPV_EDEVICE on rank 5, GPV_EPEER on the other seven (gpv_group_comm_info's per-rank status) -- and the next call is clean."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("GPV_GROUP_ALLOW_DUPLICATE_DEVICES", "1")
+    with gpv._lib.test_library():
+        common, vo, circuit = _load_uncached(gpv, "step")
+        _eight_ranks_config4(gpv, torch, circuit, fail_rank=5, set_fault=lambda *a: _set_fault(gpv, *a))
 
 
 def test_group_multi_device_if_present(gpv, orc):
