@@ -470,6 +470,7 @@ def main():
         # (FETCH_SIZE x2 on gfx950, WRITE_SIZE), recorded in profiles/traffic.json, and is only reported when that file was
         # measured on this exact configuration.
         traffic, traffic_source = None, None
+        valu_per_perm, valu_source = None, "profiles/traffic.json has no SQ_INSTS_VALU entry for this kernel, fixture, batch and library build"
         lib_id = library_build_id(gpv)
         try:
             tfile = json.loads((ROOT / "profiles" / "traffic.json").read_text())
@@ -482,12 +483,21 @@ def main():
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_source = "profiles/traffic.json (build %s = the loaded library): separate rocprofv3 --pmc passes (%s), not measured in this run" % (
                     str(lib_id)[:12], tj.get("source", "see file"))
+                if tj.get("valu_wave_insts_per_launch"):  # VALU wave-instructions per launch / (permutations per launch / 64 lanes)
+                    valu_per_perm = tj["valu_wave_insts_per_launch"] * 64.0 / (dom_perms * n_local)
+                    valu_source = "%s (build %s = the loaded library) / (%d permutations per launch / 64 lanes)" % (tj.get("valu_source"), str(lib_id)[:12], dom_perms * n_local)
         except Exception:
             traffic = None
         line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "launch_ms": dom_ms,
                             "launches": merkle_launches,
                             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_proof": alg_bytes_per_proof,
+                            # SURVEY 8d's own figures beside the per-kernel one: the whole packed record charged to the dominant kernel, and the whole step
+                            # (proofs/s x record bytes / peak) -- both tiny by construction (about 2 000 multiply-adds per input byte)
+                            "record_bytes_per_proof_8d": circuit.proof_nbytes,
+                            "frac_8d_record_over_dominant_kernel": (circuit.proof_nbytes * n_local / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_ms > 0 else 0.0,
+                            "frac_8d_whole_step": proofs_per_s / n_ranks * circuit.proof_nbytes / 1e9 / HBM_PEAK_GBS,
+                            "frac_8d_whole_step_vs_measured_copy_ceiling": proofs_per_s / n_ranks * circuit.proof_nbytes / 1e9 / 6290.0,
                             "other_kernels_ms": {k: v[0] for k, v in cand.items() if k != dom},
                             "note": "integer-VALU bound workload; see valu_roofline"}
         # VALU roofline, two numerators and two denominators, every one recomputable from this line + profiles/:
@@ -503,20 +513,17 @@ def main():
                          "k_merkle_climb_lower": executed_mads_per_perm(True)}
         rate = lambda perms, ms, per_perm: float(perms) * per_perm * n_local / (ms * 1e-3) if ms > 0 else 0.0  # noqa: E731
         peak_meas = MAD_LANES_PER_CLK * clock_ghz * 1e9 if clock_ghz else None
-        isa = {}
-        try:
-            isa = json.loads((ROOT / "profiles" / "r03_isa_counts.json").read_text())
-        except Exception:
-            pass
         a_alg, a_exec = rate(dom_perms, dom_ms, per_perm_alg), rate(dom_perms, dom_ms, per_perm_exec[dom])
         line["valu_roofline"] = {
             "bound": "valu_int32_mad", "kernel": dom, "unit": "T v_mad_u64_u32 lane-ops/s",
             "achieved": a_exec / 1e12, "peak": MAD_PEAK_MODEL / 1e12, "frac": a_exec / MAD_PEAK_MODEL,
             "numerator": "executed multiply-adds (frac_algorithmic counts SURVEY 8d's 784 x 136 per permutation instead)",
-            "peak_definition": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (model: max clock)",
+            "peak_definition": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (model: max clock, one wave64 v_mad_u64_u32 per SIMD every 4.0 cycles; the clock-resolved "
+                               "microbenchmark measures 4.30 cycles per instruction -- profiles/r03p_microbench.txt -- so this peak is 7 % above what the pipe sustains and every "
+                               "fraction quoted against it is understated by that much)",
             "executed_mads_per_perm": per_perm_exec[dom], "algorithmic_mads_per_perm": per_perm_alg,
             "executed_mads_source": "exact by construction of the Fr rows (bench.py executed_mads_per_perm); static count of the shipped code object: profiles/r04_isa_counts.json (tools/isa_count.py)",
-            "executed_valu_per_perm": isa.get("pmc_valu_per_perm"), "executed_valu_source": isa.get("pmc_source"),
+            "executed_valu_per_perm": valu_per_perm, "executed_valu_source": valu_source,
             "achieved_algorithmic": a_alg / 1e12, "frac_algorithmic": a_alg / MAD_PEAK_MODEL,
             "achieved_executed": a_exec / 1e12, "frac_executed": a_exec / MAD_PEAK_MODEL,
             "shader_clock_ghz_under_load": clock_ghz, "shader_clock_source": "tools/probe one-wave sampler (s_memtime / s_memrealtime) beside 3 untimed steps of the same workload",

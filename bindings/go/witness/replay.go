@@ -50,7 +50,8 @@ type Replay struct {
 	trace      []uint64 // gpv.WitnessVerify: [WitnessVerifyWords] of this proof
 	kinds      []uint8  // Circuit.WitnessVerifyLayout: one GPV_HINT_* id per hint call, program order
 	offset     []int    // word offset of record k (program order)
-	execToProg []int    // j-th executed hint call -> its number in program order (nil until Bind: identity is assumed)
+	execToProg []int    // j-th executed hint call -> its number in program order (nil until Bind / BindFrom / UseProgramOrder)
+	bound      bool     // an order has been chosen: Options() refuses to serve before that
 	next       int      // hint calls served so far
 	Mismatches int      // popped records that did not fit the call's inputs (recomputed the reference's way)
 }
@@ -71,19 +72,23 @@ func NewReplay(trace []uint64, kinds []uint8) *Replay {
 // instructions of a level in ascending index (constraint.System.Levels). Call it once per compiled circuit; the map can be shared by
 // every Replay of that circuit (BindFrom). Only the reference's four hints are counted: gnark's own hints (api.ToBinary inside
 // BN254Chip.ToVec, the index decompositions) are not in the trace and keep their own functions.
-func (r *Replay) Bind(cs constraint.ConstraintSystem) error {
+//
+// HintSystem is what Bind needs from the compiled circuit. No gnark type implements it as is (ADVICE r4): FromSystem
+// (adapter_gnark_v0_9.go) wraps gnark v0.9.1's *constraint.System -- r.Bind(witness.FromSystem(&ccs.(*cs_bn254.R1CS).System)).
+type HintSystem interface {
+	GetNbInstructions() int
+	GetInstruction(int) constraint.Instruction
+	GetHintIDOf(constraint.Instruction) (solver.HintID, bool) // the instruction's hint id when it is a hint call
+	GetLevels() [][]int
+}
+
+func (r *Replay) Bind(sys HintSystem) error {
 	ours := map[solver.HintID]bool{
 		solver.GetHintID(gl.MulAddHint): true, solver.GetHintID(gl.ReduceHint): true,
 		solver.GetHintID(gl.InverseHint): true, solver.GetHintID(gl.SplitLimbsHint): true,
 	}
-	sys, ok := cs.(interface {
-		GetNbInstructions() int
-		GetInstruction(int) constraint.Instruction
-		GetHintIDOf(constraint.Instruction) (solver.HintID, bool) // thin helper over the hint blueprint's DecompressHint; see INTEGRATION.md section 3
-		GetLevels() [][]uint32
-	})
-	if !ok {
-		return fmt.Errorf("witness: constraint system does not expose instructions / levels")
+	if sys == nil {
+		return fmt.Errorf("witness: nil system")
 	}
 	progNumber := make(map[int]int) // instruction index -> hint number in program order
 	n := 0
@@ -105,14 +110,25 @@ func (r *Replay) Bind(cs constraint.ConstraintSystem) error {
 		}
 	}
 	r.execToProg = order
+	r.bound = true
 	return nil
 }
 
 // BindFrom shares the order map computed by another Replay of the same compiled circuit.
-func (r *Replay) BindFrom(bound *Replay) { r.execToProg = bound.execToProg }
+func (r *Replay) BindFrom(other *Replay) { r.execToProg, r.bound = other.execToProg, other.bound }
+
+// UseProgramOrder declares that the solver reaches the hint calls in program order (a solver that does not schedule by levels). With
+// gnark's level-scheduled solver this is WRONG for all but the first level: nearly every record would be rejected by the cross-check and
+// recomputed the reference's way -- correct, and slower than no replay at all (ADVICE r4). It exists for such solvers and for tests; it is
+// never assumed silently.
+func (r *Replay) UseProgramOrder() { r.execToProg, r.bound = nil, true }
 
 // Options: the solver options to prove with -- groth16.Prove(ccs, pk, w, backend.WithSolverOptions(replay.Options()...)).
 func (r *Replay) Options() []solver.Option {
+	if !r.bound {
+		// Before round 5 an unbound Replay silently fell back to program order (see UseProgramOrder for what that costs).
+		panic("witness: Options() before a successful Bind / BindFrom (or an explicit UseProgramOrder): the replay does not know the solver's hint order")
+	}
 	return []solver.Option{
 		solver.WithNbTasks(1), // the cursor below is an ORDER: see the package comment
 		solver.OverrideHint(solver.GetHintID(gl.MulAddHint), r.serve(kindMulAdd, gl.MulAddHint)),

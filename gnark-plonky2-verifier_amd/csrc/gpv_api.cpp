@@ -1744,14 +1744,19 @@ static int verify_json_core(gpv_ctx* ctx, const gpv_circuit* c, const char* cons
   auto pack = [&](size_t k, PackResult* r) {  // block k into buf[k & 1]; runs on the packing thread: thread-local error text is copied out
     const size_t lo = k * block, m = n - lo < block ? n - lo : block;
     r->rc = gpv_proof_pack_json_batch_status(c, proof_jsons + lo, proof_lens + lo, m, buf[k & 1], n_threads, status + lo);
-    if (r->rc != GPV_OK) { r->err = gpv_get_global_error(); return; }
-    if (abort_on_bad)
-      for (size_t i = 0; i < m; i++)
-        if (status[lo + i] != GPV_OK) {
-          r->rc = status[lo + i];
-          r->err = gpv_get_global_error();  // "proof <i in block>: ..."
-          return;
-        }
+    // the copies of the error text may throw; on the packing thread an escaping exception is std::terminate: keep the code, drop the text
+    try {
+      if (r->rc != GPV_OK) { r->err = gpv_get_global_error(); return; }
+      if (abort_on_bad)
+        for (size_t i = 0; i < m; i++)
+          if (status[lo + i] != GPV_OK) {
+            r->rc = status[lo + i];
+            r->err = gpv_get_global_error();  // "proof <i in block>: ..."
+            return;
+          }
+    } catch (...) {
+      if (r->rc == GPV_OK) r->rc = GPV_ENOMEM;
+    }
   };
   const size_t blocks = (n + block - 1) / block;
   PackResult cur;
@@ -1786,13 +1791,23 @@ extern "C" int gpv_verify_json(gpv_ctx* ctx, const gpv_circuit* c, const char* c
                                uint8_t* accept) {
   REQUIRE(ctx, ctx && c && (n == 0 || (accept && proof_jsons && proof_lens)));
   if (n == 0) return GPV_OK;
-  return verify_json_core(ctx, c, proof_jsons, proof_lens, n, n_threads, accept, nullptr);
+  try {  // the status vector, the error strings: nothing may cross the C boundary, and the context's lock is released by the unwinding
+    return verify_json_core(ctx, c, proof_jsons, proof_lens, n, n_threads, accept, nullptr);
+  } catch (...) {
+    gpv_set_global_error("gpv_verify_json: out of host memory");
+    return GPV_ENOMEM;
+  }
 }
 extern "C" int gpv_verify_json_status(gpv_ctx* ctx, const gpv_circuit* c, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
                                       int n_threads, uint8_t* accept, int32_t* status) {
   REQUIRE(ctx, ctx && c && (n == 0 || (accept && status && proof_jsons && proof_lens)));
   if (n == 0) return GPV_OK;
-  return verify_json_core(ctx, c, proof_jsons, proof_lens, n, n_threads, accept, status);
+  try {
+    return verify_json_core(ctx, c, proof_jsons, proof_lens, n, n_threads, accept, status);
+  } catch (...) {
+    gpv_set_global_error("gpv_verify_json_status: out of host memory");
+    return GPV_ENOMEM;
+  }
 }
 
 // ---- internal accessors for gpv_group.cpp (one worker per context)

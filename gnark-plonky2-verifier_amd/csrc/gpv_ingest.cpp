@@ -1402,8 +1402,14 @@ bool fast_pack_proof(const DevCircuit& c, const char* json, size_t len, uint64_t
 extern "C" int gpv_proof_pack_json(const gpv_circuit* circ, const char* proof_json, size_t proof_len, void* out_packed) {
   if (!circ || !proof_json || !out_packed) return GPV_EINVAL;
   memset(out_packed, 0, circ->dc.proof_nbytes);
-  if (fast_pack_proof(circ->dc, proof_json, proof_len, (uint64_t*)out_packed)) return GPV_OK;
-  return gpvi_proof_pack_json_tree(circ, proof_json, proof_len, out_packed);
+  try {  // the tree route allocates (arena, error strings): nothing may cross the C boundary
+    if (fast_pack_proof(circ->dc, proof_json, proof_len, (uint64_t*)out_packed)) return GPV_OK;
+    return gpvi_proof_pack_json_tree(circ, proof_json, proof_len, out_packed);
+  } catch (...) {
+    memset(out_packed, 0, circ->dc.proof_nbytes);
+    gpv_set_global_error("out of host memory while reading a proof");
+    return GPV_ENOMEM;
+  }
 }
 // The tree (DOM) route alone: every proof the streaming pass gives up on, and every error (tests/cpp/ingest_fuzz.cpp compares the two).
 int gpvi_proof_pack_json_tree(const gpv_circuit* circ, const char* proof_json, size_t proof_len, void* out_packed) {
@@ -1501,7 +1507,12 @@ static int pack_json_batch_core(const gpv_circuit* circ, const char* const* proo
       std::lock_guard<std::mutex> lk(msg_mu);
       if (i < lowest.load()) {
         lowest = i;
-        if (first_msg) *first_msg = proof_jsons[i] ? gpv_get_global_error() : "null text";  // thread-local text of this worker
+        // thread-local text of this worker; the copy may throw on a worker thread, where an escaping exception is std::terminate:
+        // the status keeps the code, only the text is lost
+        try {
+          if (first_msg) *first_msg = proof_jsons[i] ? gpv_get_global_error() : "null text";
+        } catch (...) {
+        }
       }
     }
   };
@@ -1524,16 +1535,21 @@ extern "C" int gpv_proof_pack_json_batch(const gpv_circuit* circ, const char* co
                                          void* out_packed, int n_threads) {
   if (!circ || (n && (!out_packed || !proof_jsons || !proof_lens))) return GPV_EINVAL;
   if (n == 0) return GPV_OK;
-  std::vector<int32_t> status(n, GPV_OK);
-  size_t bad = n;
-  std::string msg;
-  int rc = pack_json_batch_core(circ, proof_jsons, proof_lens, n, out_packed, n_threads, status.data(), &bad, &msg);
-  if (rc != GPV_OK) return rc;
-  if (bad < n) {
-    gpv_set_global_error("proof %zu: %s", bad, msg.c_str());
-    return status[bad];
+  try {
+    std::vector<int32_t> status(n, GPV_OK);
+    size_t bad = n;
+    std::string msg;
+    int rc = pack_json_batch_core(circ, proof_jsons, proof_lens, n, out_packed, n_threads, status.data(), &bad, &msg);
+    if (rc != GPV_OK) return rc;
+    if (bad < n) {
+      gpv_set_global_error("proof %zu: %s", bad, msg.c_str());
+      return status[bad];
+    }
+    return GPV_OK;
+  } catch (...) {  // the status vector of a huge batch
+    gpv_set_global_error("out of host memory");
+    return GPV_ENOMEM;
   }
-  return GPV_OK;
 }
 extern "C" int gpv_proof_pack_json_batch_status(const gpv_circuit* circ, const char* const* proof_jsons, const size_t* proof_lens, size_t n,
                                                 void* out_packed, int n_threads, int32_t* status) {

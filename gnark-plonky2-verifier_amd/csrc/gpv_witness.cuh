@@ -132,7 +132,10 @@ GPV_DEV void wt_flush_event_body(WTrace& t) {
   for (u32 k = 0; k < 8; k++) {
     const u32 j = 8 * k + (lane >> 3);
     const wt_glb_u64* src = (const wt_glb_u64*)(size_t)(e[k] & ~(u64)7) + 2 * c;
-    const u32 at = wt_index(src, j);  // an even row (16-byte aligned word pair), and row + 1 has the same column; a stream without a line: some valid ring address
+    // an even row (16-byte aligned word pair), and row + 1 has the same column. A stream WITHOUT a complete line is read too (its value is dropped below) and
+    // its f may be unaligned -- an odd row, 31 in the worst case, whose "row + 1" would lie past the ring: clearing the row's low bit keeps both reads inside
+    // the wave's GPV_WT_LDS_WORDS words for every lane (a no-op for the streams that are stored)
+    const u32 at = wt_index(src, j) & ~64u;
     v0[k] = t.ring[at];
     v1[k] = t.ring[at + 64];
   }

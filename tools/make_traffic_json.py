@@ -50,9 +50,23 @@ def per_dispatch(path, counter):
     return out
 
 
+def counter_sums(path, counter):
+    """{kernel: sum over all rows} of one counter in a pmc summary (SQ counters come as one row per shader engine and dispatch)"""
+    out = {}
+    try:
+        for line in Path(path).read_text().splitlines():
+            f = line.split()
+            if len(f) >= 6 and f[1] == counter:
+                out[f[0]] = float(f[3])
+    except OSError:
+        pass
+    return out
+
+
 def main():
     d, tag, fixture, n = Path(sys.argv[1]), sys.argv[2], sys.argv[3], int(sys.argv[4])
     fetch, write = per_dispatch(d / "pmc_fetch.txt", "FETCH_SIZE"), per_dispatch(d / "pmc_write.txt", "WRITE_SIZE")
+    valu, gui = counter_sums(d / "pmc_sq.txt", "SQ_INSTS_VALU"), counter_sums(d / "pmc_sq.txt", "GRBM_GUI_ACTIVE")
     out = {"_comment": "HBM bytes per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh): FETCH_SIZE[KB] x 1024 x 2 (gfx950 "
                        "half-count correction) + WRITE_SIZE[KB] x 1024. bench.py quotes an entry only for the matching fixture / batch AND the "
                        "library build it was measured on.",
@@ -63,6 +77,9 @@ def main():
         out[k] = {"fixture": fixture, "proofs_per_gpu": n, "dispatches_per_step": fetch[k][0] // 2, "fetch_size_kb_raw": fetch[k][1],
                   "write_size_kb": write[k][1], "traffic_bytes_per_launch": int(fetch[k][1] * 1024 * 2 + write[k][1] * 1024),
                   "source": "profiles/%s_pmc_fetch.txt + profiles/%s_pmc_write.txt" % (tag, tag)}
+        if k in valu:  # VALU wave-instructions per launch: the SQ pass ran the same number of launches as the FETCH pass (fetch[k][0])
+            out[k]["valu_wave_insts_per_launch"] = valu[k] / fetch[k][0]
+            out[k]["valu_source"] = "profiles/%s_pmc_sq.txt: sum of SQ_INSTS_VALU / %d launches" % (tag, fetch[k][0])
     json.dump(out, sys.stdout, indent=1)
     print()
 

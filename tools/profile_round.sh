@@ -14,7 +14,7 @@ summ() { db=$(find $1 -name '*_results.db' | head -1); [ -n "$db" ] && python $R
 cd /tmp
 ( echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 <headline step only>   (MI355X, $TAG)"
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o p -- $B --steps 5 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-  summ $OUT/stats ) > $OUT/kernel_stats.txt
+  summ $OUT/stats "--skip-first 1" ) > $OUT/kernel_stats.txt
 ( echo "# rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_SALU --kernel-trace -- python bench.py --steps 1 --warmup 1 <headline step only>   (MI355X, $TAG; 2 pipeline passes)"
   timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_SALU --kernel-trace -d $OUT/sq -o p -- $B --steps 1 --warmup 1 > /dev/null 2> $OUT/sq.err
   summ $OUT/sq --pmc ) > $OUT/pmc_sq.txt
@@ -30,7 +30,7 @@ cd /tmp
   summ $OUT/sq1 --pmc ) > $OUT/pmc_sq_no_side_stream.txt
 ( echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-side-stream --steps 5 --warmup 1 <headline step only>   (MI355X, $TAG)"
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats1 -o p -- $B --no-side-stream --steps 5 --warmup 1 > $OUT/bench_no_side_stream_under_rocprof.json 2> $OUT/stats1.err
-  summ $OUT/stats1 ) > $OUT/kernel_stats_no_side_stream.txt
+  summ $OUT/stats1 "--skip-first 1" ) > $OUT/kernel_stats_no_side_stream.txt
 # HBM traffic of every kernel of the step, stamped with the build id of the library that was just profiled (bench.py checks it)
 python $ROOT/tools/make_traffic_json.py $OUT $TAG step 8192 > $OUT/traffic.json
 rm -rf $OUT/stats $OUT/sq $OUT/fetch $OUT/write $OUT/sq1 $OUT/stats1

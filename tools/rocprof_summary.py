@@ -3,6 +3,9 @@
 
   python tools/rocprof_summary.py gpurun_out/prof_r1/stats/r1_results.db            # kernel-trace --stats summary
   python tools/rocprof_summary.py gpurun_out/prof_r1/pmc_fetch/r1_results.db --pmc  # per-kernel PMC counters
+  python tools/rocprof_summary.py <db> --skip-first 1     # adds avg_us_timed: the average WITHOUT each kernel's first N dispatches -- the
+                                                          # bench's warm-up step(s), which bench.py's own launch_ms (HIP events over the timed
+                                                          # region) does not contain either; the two then measure the same launches
 
 The outputs committed under profiles/ are produced with this script from the databases the GPU runs leave in
 gpurun_out/ (scratch).
@@ -14,12 +17,20 @@ import sys
 def main():
     db = sqlite3.connect(sys.argv[1])
     pmc = "--pmc" in sys.argv
+    skip = int(sys.argv[sys.argv.index("--skip-first") + 1]) if "--skip-first" in sys.argv else 0
     if not pmc:
         rows = db.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc").fetchall()
-        print("%-72s %6s %14s %14s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+        timed = {}
+        if skip:
+            per = {}
+            for name, start, end in db.execute("select name, start, end from kernels order by start").fetchall():
+                per.setdefault(name, []).append((end - start) / 1000.0)
+            timed = {k: (sum(v[skip:]) / len(v[skip:]) if len(v) > skip else None) for k, v in per.items()}
+        print("%-72s %6s %14s %14s %7s%s" % ("kernel", "calls", "total_us", "avg_us", "pct", ("   avg_us_timed (without the first %d)" % skip) if skip else ""))
         for name, calls, total, avg, pct in rows:
             short = name.split("(")[0][-72:]
-            print("%-72s %6d %14.3f %14.3f %7.2f" % (short, calls, total, avg, pct))
+            t = timed.get(name)
+            print("%-72s %6d %14.3f %14.3f %7.2f%s" % (short, calls, total, avg, pct, ("   %14.3f" % t) if t is not None else ""))
         regs = db.execute("select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
                           "max(grid_x), max(grid_y), max(workgroup_x) from kernels group by name").fetchall()
         print()
