@@ -71,6 +71,7 @@ struct gpv_ctx {
   int fr_form = 0;        // GPV_OPT_FR_EVALUATION: 0 by launch size, 1 column scanning, 2 operand scanning (gpv_fr.cuh), 3 four lanes per permutation
   int wit_staging = 0;    // GPV_OPT_WITNESS_STAGING: 0 the witness kernels stage their output through LDS when the launch is large enough, 1 always, 2 never
   int side_stream = 1;    // GPV_OPT_SIDE_STREAM: 1 transcript / plonk / FRI on the side stream under the leaf hashing, 0 everything on the main stream, one after the other
+  int merkle_longest_alone = 0;  // GPV_OPT_MERKLE_LONGEST_ALONE: 0 by batch size, 1 never, 2 whenever the operand-scanning kernels run -- the longest tree class hashed by waves that take a SIMD each
   void* crown = nullptr;
   size_t crown_bytes = 0;
   void* wit = nullptr;  // grow-only scratch of gpv_witness_verify[_dev] (tables, counters, flags, the plonk workspace, the permutation log): a call
@@ -323,6 +324,10 @@ extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
     ctx->side_stream = value;
     return GPV_OK;
   }
+  if (option == GPV_OPT_MERKLE_LONGEST_ALONE && value >= 0 && value <= 2) {
+    ctx->merkle_longest_alone = value;
+    return GPV_OK;
+  }
   if (option == GPV_OPT_HOST_CHUNK_FIRST && value >= 1 && value <= (1 << 24)) {
     ctx->host_chunk_first = (size_t)value;
     if (ctx->host_chunk_max < ctx->host_chunk_first) ctx->host_chunk_max = ctx->host_chunk_first;
@@ -529,29 +534,68 @@ static void launch_plonk(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, con
   Timed t(ctx, TK_PLONK, st);
   gpvk_plonk(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, verdict_of(ctx));
 }
-static void launch_merkle_leaves(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n) {
+// tree_mask: the trees this launch covers (all of them, or one group of the class-pipelined pipeline)
+static void launch_merkle_leaves(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, u32 tree_mask = ~0u,
+                                 bool solo = false) {
   Timed t(ctx, TK_LEAVES, st);
-  gpvk_merkle_leaves(st, dcd, c->dc, (const u64*)proofs, n, ctx->digests, verdict_of(ctx), ctx->fr_form);
+  gpvk_merkle_leaves(st, dcd, c->dc, (const u64*)proofs, n, ctx->digests, verdict_of(ctx), ctx->fr_form, tree_mask, solo);
+}
+// The sibling walks of the trees of tree_mask: up to GPV_CROWN_LEVELS below the cap when the upper levels are shared (launch_merkle_crown then
+// hashes every distinct upper node once), else the whole walk and the comparison with the cap entry.
+static void launch_merkle_walk(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, uint8_t* ok_dev,
+                               u32 tree_mask = ~0u) {
+  if (!ok_dev && merkle_shared_for(ctx, c, n)) {
+    CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown, ctx->crown_bytes);
+    Timed tl(ctx, TK_LOWER, st);
+    gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS, verdict_of(ctx), ctx->fr_form,
+                            tree_mask);
+    return;
+  }
+  gpvk_merkle_climb(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, verdict_of(ctx), ok_dev, ctx->fr_form, tree_mask);
+}
+static void launch_merkle_crown(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, uint8_t* ok_dev) {
+  if (ok_dev || !merkle_shared_for(ctx, c, n)) return;
+  CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown, ctx->crown_bytes);
+  if (++ctx->crown_gen >= (1u << 30)) {  // generations are 30-bit stamps: start over on a clean scratch
+    gpvk_note_launch(hipMemsetAsync(ctx->crown, 0, ctx->crown_bytes, st), "memset(crown scratch)");
+    ctx->crown_gen = 1;
+  }
+  gpvk_crown(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, b, verdict_of(ctx), ctx->crown_gen, ctx->fr_form);
 }
 static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n,
                                 uint8_t* ok_dev) {
   Timed t(ctx, TK_MERKLE, st);
-  if (!ok_dev && merkle_shared_for(ctx, c, n)) {
-    // per-path hashing up to GPV_CROWN_LEVELS below the cap, then every distinct upper node once
-    CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown, ctx->crown_bytes);
-    {
-      Timed tl(ctx, TK_LOWER, st);
-      gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS, verdict_of(ctx),
-                              ctx->fr_form);
-    }
-    if (++ctx->crown_gen >= (1u << 30)) {  // generations are 30-bit stamps: start over on a clean scratch
-      gpvk_note_launch(hipMemsetAsync(ctx->crown, 0, ctx->crown_bytes, st), "memset(crown scratch)");
-      ctx->crown_gen = 1;
-    }
-    gpvk_crown(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, b, verdict_of(ctx), ctx->crown_gen, ctx->fr_form);
-    return;
+  launch_merkle_walk(ctx, st, c, dcd, proofs, n, ok_dev);
+  launch_merkle_crown(ctx, st, c, dcd, proofs, n, ok_dev);
+}
+// ---- the longest tree class on SIMDs of its own (round 5; GPV_OPT_MERKLE_LONGEST_ALONE). The leaf phase of a mid-size batch is bound by its longest
+// chains -- the 16 dependent permutations of a `step` wires leaf -- and inside the common launch each of those waves shares its SIMD with a stream of
+// short waves (the dispatcher refills the slot beside it as long as waves are pending), running at half its speed while SIMDs elsewhere run dry:
+// 1024 proofs hash their leaves in 6.0 ms where the work is 4.2 ms. With the longest class in a kernel whose waves take a whole SIMD each
+// (k_merkle_leaves_wide_solo) and the other classes beside it as a second launch on a second stream, the long chains run at a lone wave's speed from
+// start to end and everything else fills the other SIMDs. Pays while the class has no more waves than the device has SIMDs (a lone wave reaches 82 % of
+// a SIMD's issue rate, so beyond that the shared launch is the better use of the chip). Same lanes, same kernels' code, same results.
+// Which trees: the longest leaf class, and the second longest with it while both fit -- a SIMD that holds two 10-permutation waves is the next pole
+// (20 permutations' worth of issue slots against an average of 18). "Fit" leaves the SIMDs the other classes need: the budget is GPV_ALONE_MAX_SIMDS_X16 / 16
+// of the device's SIMDs (measured on both fixtures, profiles/r05_longest_alone.txt).
+#define GPV_ALONE_MAX_SIMDS_X16 11
+static u32 merkle_longest_alone(const gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
+  const DevCircuit& d = c->dc;
+  if (ctx->merkle_longest_alone == 1 || !ctx->side_stream || d.n_trees < 2 || !gpvk_merkle_leaves_wide(d, n, ctx->fr_form)) return 0;
+  u32 best = 0, second = 0, best_t = 0, second_t = 0, third = 0;
+  for (u32 t = 0; t < d.n_trees; t++) {
+    const u32 p = gpvk_merkle_leaf_perms(d, t);
+    if (p > best) { third = second; second = best; second_t = best_t; best = p; best_t = t; }
+    else if (p > second) { third = second; second = p; second_t = t; }
+    else if (p > third) third = p;
   }
-  gpvk_merkle_climb(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, verdict_of(ctx), ok_dev, ctx->fr_form);
+  if (best < 6 || 4 * best < 5 * second) return 0;  // nothing stands out: the common launch balances such classes by itself
+  const size_t waves = (n * d.num_queries + 63) / 64, budget = (size_t)gpvk_device_simds() * GPV_ALONE_MAX_SIMDS_X16 / 16;
+  if (ctx->merkle_longest_alone == 2) return 1u << best_t;
+  if (waves > budget) return 0;
+  u32 mask = 1u << best_t;
+  if (d.n_trees >= 3 && second >= 6 && 4 * second >= 5 * third && 2 * waves <= budget) mask |= 1u << second_t;
+  return mask;
 }
 // both Merkle phases back to back on one stream (entry points with caller-supplied challenges)
 static void launch_merkle(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, uint8_t* ok_dev) {
@@ -606,7 +650,17 @@ static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* p
   HIP_TRY(ctx, hipEventRecord(ctx->ev_transcript, side));
   launch_range_check(ctx, main_st, c, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_cleared, main_st));
-  launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n);
+  const u32 alone = merkle_longest_alone(ctx, c, n);
+  if (alone) {  // the longest class on SIMDs of its own (main stream), the others beside it (second side stream); the walks wait for both
+    launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n, alone, true);
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));  // the visit counters are cleared
+    gpvk_head_start(ctx->side2, 20);  // the main stream's waves are placed first: they need EMPTY SIMDs (10 us suffice; without it the long class ends at 6.9 ms instead of 4.3)
+    gpvk_merkle_leaves(ctx->side2, dcd, c->dc, (const u64*)proofs_dev, n, ctx->digests, verdict_of(ctx), ctx->fr_form, ~alone, false);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_side2_done, ctx->side2));
+    HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_side2_done, 0));
+  } else {
+    launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n);
+  }
   HIP_TRY(ctx, hipStreamWaitEvent(side, ctx->ev_cleared, 0));  // plonk and the FRI queries OR into the fail masks
   launch_plonk(ctx, side, c, dcd, proofs_dev, n);
   launch_fri_query(ctx, side, c, dcd, proofs_dev, n);

@@ -181,6 +181,18 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_leaves_wide(const D
                                                                     size_t n, MerkleOrder order, u32* __restrict__ digests, Verdict v) {
   merkle_leaves_body<HashBNWide>(dc, proofs, n, order, digests, v);
 }
+// The same kernel with a SIMD to itself (round 5). A wave of this kernel is allocated 424 of a SIMD's 512 registers (the accumulator register touched
+// below): no second wave of a hashing kernel can be resident beside it, nor one of k_plonk / k_fri_query (128 each) -- only the cooperative transcript's
+// (80: latency-bound waves that issue little). For the LONGEST tree
+// class of a mid-size batch: its waves are the critical chain of the leaf phase (16 dependent permutations for a `step` wires leaf), and as part of the
+// common launch each of them shares its SIMD with a stream of short waves for its whole life, at half its speed (two resident waves: 495 us per permutation
+// each, against 246 us alone; tools/lone_wave_probe.py). Alone it runs at 82 % of the SIMD's issue rate -- so this pays only while there are SIMDs to spare
+// (gpvk_merkle_leaves: the class has no more waves than the device has SIMDs); the other classes then run beside it as a second launch on a second stream.
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_leaves_wide_solo(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                    size_t n, MerkleOrder order, u32* __restrict__ digests, Verdict v) {
+  asm volatile("v_accvgpr_write_b32 a175, 0" ::: "a175");
+  merkle_leaves_body<HashBNWide>(dc, proofs, n, order, digests, v);
+}
 __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                                    const u64* __restrict__ derived, size_t n, MerkleOrder order,
                                                                    const u32* __restrict__ digests, Verdict v,
@@ -283,21 +295,30 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK_GL) void k_merkle_climb_lower_gl(c
                                                                                u32 crown_levels, Verdict v) {
   merkle_climb_lower_body<HashGL>(dc, proofs, derived, n, order, digests, mid, crown_levels, v);
 }
-static MerkleOrder merkle_order(const DevCircuit& c, bool leaves) {
+// permutations of a tree's leaf digest / hashes of its sibling walk (one lane's chain in the two phases)
+u32 gpvk_merkle_leaf_perms(const DevCircuit& c, u32 t) {
+  const u32 len = t < 4 ? c.leaf_len[t] : (2u << c.arity_bits[t - 4]);
+  return c.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS ? (len <= 4 ? 0 : (len + 7) / 8) : (len <= 3 ? 0 : (len + 8) / 9);
+}
+u32 gpvk_merkle_siblings(const DevCircuit& c, u32 t) { return t < 4 ? c.init_siblings : c.step_siblings[t - 4]; }
+// The trees of `tree_mask` (bit t = tree t; the class-pipelined launches of gpv_api.cpp run a subset per stream), most expensive first;
+// *count = how many.
+static MerkleOrder merkle_order(const DevCircuit& c, bool leaves, u32 tree_mask, u32* count) {
   // cost of a phase-1 chain = ceil(leaf_len / 9) permutations, of a phase-2 chain = number of siblings;
   // classes are launched most expensive first so that the short ones fill the tail
   MerkleOrder o;
   u32 cost[4 + GPV_MAX_STEPS];
+  u32 k = 0;
   for (u32 t = 0; t < c.n_trees; t++) {
-    u32 len = t < 4 ? c.leaf_len[t] : (2u << c.arity_bits[t - 4]);
-    u32 sib = t < 4 ? c.init_siblings : c.step_siblings[t - 4];
     // (the lower-levels mode subtracts the same constant from every class)
-    cost[t] = !leaves ? sib : c.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS ? (len <= 4 ? 0 : (len + 7) / 8) : (len <= 3 ? 0 : (len + 8) / 9);
-    o.cls[t] = t;
+    cost[t] = leaves ? gpvk_merkle_leaf_perms(c, t) : gpvk_merkle_siblings(c, t);
+    if (tree_mask >> t & 1) o.cls[k++] = t;
   }
-  for (u32 i = 0; i < c.n_trees; i++)
-    for (u32 j = i + 1; j < c.n_trees; j++)
+  for (u32 i = k; i < 4 + GPV_MAX_STEPS; i++) o.cls[i] = 0;
+  for (u32 i = 0; i < k; i++)
+    for (u32 j = i + 1; j < k; j++)
       if (cost[o.cls[j]] > cost[o.cls[i]]) { u32 t = o.cls[i]; o.cls[i] = o.cls[j]; o.cls[j] = t; }
+  *count = k;
   return o;
 }
 
@@ -335,51 +356,79 @@ void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n
   GPVK_LAUNCH(k_poseidon_bn254_to_vec, dim3(gpvk_blocks_for(n, 256)), dim3(256), 0, st, h, out, n);
 }
 size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n) { return n * hc.num_queries * hc.n_trees * FR_LIMBS; }
-void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, Verdict v, int form) {
+void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, Verdict v, int form,
+                        u32 tree_mask, bool solo) {
   size_t items = n * hc.num_queries;
+  u32 nt = 0;
+  const MerkleOrder ord = merkle_order(hc, true, tree_mask, &nt);
+  if (!nt) return;
   if (hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && gpvk_fr_quad_pays(gpvk_full_paths(hc, items), form)) {
-    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_quad, dim3(gpvk_blocks_for(4 * items, GPV_QUAD_BLOCK), hc.n_trees), dim3(GPV_QUAD_BLOCK), 0, st, dcd, proofs, n,
-                merkle_order(hc, true), digests, v);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_quad, dim3(gpvk_blocks_for(4 * items, GPV_QUAD_BLOCK), nt), dim3(GPV_QUAD_BLOCK), 0, st, dcd, proofs, n,
+                ord, digests, v);
     return;
   }
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
-    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs, n,
-                merkle_order(hc, true), digests, v);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), nt), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs, n,
+                ord, digests, v);
   else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form))
-    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
-                merkle_order(hc, true), digests, v);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
+                ord, digests, v);
+  else if (solo)
+    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_wide_solo, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
+                ord, digests, v);
   else
-    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
-                merkle_order(hc, true), digests, v);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
+                ord, digests, v);
+}
+// One wave that does nothing for `ticks` of the 100 MHz constant clock (s_memrealtime): a head start for a kernel launched on ANOTHER stream just before.
+// Two launches on two queues are dispatched interleaved; the longest class's waves need SIMDs that are EMPTY, and the other launch's waves (which fit
+// anywhere) would take them first -- measured: the long class then ends at 6.9 ms instead of 5.5 (gpv_api.cpp, merkle_longest_alone). Not a
+// synchronisation: the results do not depend on it, only the placement of the waves does.
+__global__ void k_head_start(u32 ticks) {
+  const u64 t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+void gpvk_head_start(hipStream_t st, u32 microseconds) { GPVK_LAUNCH(k_head_start, dim3(1), dim3(64), 0, st, 100u * microseconds); }
+// Which launch of the leaf phase takes the operand-scanning one-lane kernels (neither four lanes per permutation nor column scanning): only then does
+// the question of giving the longest class SIMDs of its own arise (gpv_api.cpp)
+bool gpvk_merkle_leaves_wide(const DevCircuit& hc, size_t n, int form) {
+  const size_t full = gpvk_full_paths(hc, n * hc.num_queries);
+  return hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && !gpvk_fr_quad_pays(full, form) && !gpvk_fr_chain_pays(full, form);
 }
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                       const u32* digests, Verdict v, uint8_t* ok_out, int form) {
+                       const u32* digests, Verdict v, uint8_t* ok_out, int form, u32 tree_mask) {
   size_t items = n * hc.num_queries;
+  u32 nt_all = 0;
+  const MerkleOrder ord_all = merkle_order(hc, false, tree_mask, &nt_all);
+  if (!nt_all) return;
   if (hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && gpvk_fr_quad_pays(gpvk_full_paths(hc, items), form)) {
-    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_quad, dim3(gpvk_blocks_for(4 * items, GPV_QUAD_BLOCK), hc.n_trees), dim3(GPV_QUAD_BLOCK), 0, st, dcd, proofs,
-                derived, n, merkle_order(hc, false), digests, v, ok_out);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_quad, dim3(gpvk_blocks_for(4 * items, GPV_QUAD_BLOCK), nt_all), dim3(GPV_QUAD_BLOCK), 0, st, dcd, proofs,
+                derived, n, ord_all, digests, v, ok_out);
     return;
   }
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
-    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs,
-                derived, n, merkle_order(hc, false), digests, v, ok_out);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), nt_all), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs,
+                derived, n, ord_all, digests, v, ok_out);
   else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form))
-    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
-                merkle_order(hc, false), digests, v, ok_out);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt_all), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
+                ord_all, digests, v, ok_out);
   else
-    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
-                merkle_order(hc, false), digests, v, ok_out);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt_all), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
+                ord_all, digests, v, ok_out);
 }
 void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                             const u32* digests, u64* mid, u32 crown_levels, Verdict v, int form) {
+                             const u32* digests, u64* mid, u32 crown_levels, Verdict v, int form, u32 tree_mask) {
   size_t items = n * hc.num_queries;
+  u32 nt = 0;
+  const MerkleOrder ord = merkle_order(hc, false, tree_mask, &nt);
+  if (!nt) return;
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
-    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), hc.n_trees), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd,
-                proofs, derived, n, merkle_order(hc, false), digests, mid, crown_levels, v);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), nt), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd,
+                proofs, derived, n, ord, digests, mid, crown_levels, v);
   else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form))
-    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
-                derived, n, merkle_order(hc, false), digests, mid, crown_levels, v);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
+                derived, n, ord, digests, mid, crown_levels, v);
   else
-    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), hc.n_trees), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
-                derived, n, merkle_order(hc, false), digests, mid, crown_levels, v);
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower_wide, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
+                derived, n, ord, digests, mid, crown_levels, v);
 }

@@ -146,10 +146,14 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
  * GPV_OPT_WITNESS_STAGING: how the witness generator's kernels (gpv_witness_*) write their traces: 0 (default) = staged through LDS and written
  * out by the wave in whole 128-byte lines when the launch is large enough to hide the flushes, straight to memory otherwise; 1 = always staged,
  * 2 = never. Identical traces.
+ * GPV_OPT_MERKLE_LONGEST_ALONE: the leaf digests of the tree with the longest leaves (the wires oracle: 16 dependent permutations per leaf for the fixtures) by
+ * waves that take a SIMD each, beside the other trees' launch on a second stream, instead of one launch for all trees -- mid-size batches are bound by those
+ * chains. 0 (default) = when the operand-scanning kernels run and that tree has no more waves than the device has SIMDs (about 290 .. 2 300 `step` proofs on an
+ * MI355X), 1 = never, 2 = whenever the operand-scanning kernels run. Identical verdicts.
  * GPV_OPT_HOST_CHUNK_FIRST / GPV_OPT_HOST_CHUNK_MAX: gpv_verify uploads a host batch in chunks of first, first, 2 first, 4 first, ...
  * proofs capped at max and verifies them as they arrive, two in flight (defaults 1024 / 8192; 1 .. 2^24). */
 enum { GPV_OPT_TRANSCRIPT_VARIANT = 1, GPV_OPT_MERKLE_SHARED_LEVELS = 2, GPV_OPT_FR_EVALUATION = 3, GPV_OPT_HOST_CHUNK_FIRST = 4,
-       GPV_OPT_HOST_CHUNK_MAX = 5, GPV_OPT_SIDE_STREAM = 6, GPV_OPT_WITNESS_STAGING = 7 };
+       GPV_OPT_HOST_CHUNK_MAX = 5, GPV_OPT_SIDE_STREAM = 6, GPV_OPT_WITNESS_STAGING = 7, GPV_OPT_MERKLE_LONGEST_ALONE = 8 };
 int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value);
 /* Copies the last error text of this context (or of context-free calls when ctx == NULL). */
 int gpv_last_error_message(gpv_ctx* ctx, char* buf, size_t buf_len);

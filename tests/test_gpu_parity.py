@@ -234,6 +234,58 @@ def test_fr_evaluation_orders_are_identical(gpv, api, orc, form):
         api.set_option(3, 0)
 
 
+@pytest.mark.parametrize("name", ["step", "decode_block"])
+def test_longest_leaf_class_alone_is_identical(gpv, api, orc, name):
+    """GPV_OPT_MERKLE_LONGEST_ALONE (round 5): the leaf digests of the tree(s) with the longest leaves by waves that take a SIMD each
+    (k_merkle_leaves_wide_solo, main stream) beside the other trees' launch on a second stream -- same lanes, same code, another launch shape.
+    Forced on (2, with the operand-scanning kernels forced too: the automatic choice would take four lanes per permutation at these sizes) and by
+    size (0, at a batch where the rule picks the two longest classes), against one launch for all trees (1) and the oracle: accept bits, failure
+    masks and challenges, on valid records, records with a corrupted word in a leaf of EVERY tree, and random records; ragged batch sizes."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
+    oc = orc.circuit(ci)
+    rng = np.random.default_rng(77)
+    vchip = gpv.verifier.NewVerifierChip(api, common)
+    q0, qwords, f0, qfr, n_gl = T.query_section_layout(ci)
+    n = 70
+    recs = _random_records(ci, len(packed), n, rng)
+    recs[:40] = np.frombuffer(packed, dtype=np.uint64)
+    for i in range(8, 40):   # one flipped bit somewhere in the query section (leaves of every tree, step evaluations)
+        recs[i, q0 + int(rng.integers(0, ci.num_query_rounds * qwords))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 64)))
+    pb = gpv.variables.ProofBatch(circuit, recs.tobytes())
+    oacc, ofail, och = orc.verify(oc, recs.tobytes(), n_threads=8)
+    assert oacc[:8].all() and not oacc[8:40].any()
+    api.set_option(gpv._lib.OPT_FR_EVALUATION, 2)
+    try:
+        got = {}
+        for mode in (1, 2):
+            api.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, mode)
+            for shared in (2, 0):
+                api.set_option(2, shared)
+                accept, mask, ch = vchip.Verify(pb, vo, detail=True)
+                assert (ch.flat == och).all() and accept.tolist() == oacc.tolist() and mask.tolist() == T.reported_mask(ofail).tolist(), (mode, shared)
+                got[(mode, shared)] = (accept.copy(), mask.copy())
+        assert all((got[(2, s)][1] == got[(1, s)][1]).all() for s in (2, 0))
+    finally:
+        api.set_option(gpv._lib.OPT_FR_EVALUATION, 0)
+        api.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 0)
+        api.set_option(2, 1)
+    # by size: 700 proofs -> the operand-scanning kernels, the two longest classes alone (350 + 350 waves beside the other four classes)
+    n = 700
+    batch, tampered = T.synthetic_batch(ci, packed, n, seed=31, tamper_every=5)
+    pbn = gpv.variables.ProofBatch(circuit, batch)
+    acc0, mask0, ch0 = vchip.Verify(pbn, vo, detail=True)
+    api.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 1)
+    try:
+        acc1, mask1, ch1 = vchip.Verify(pbn, vo, detail=True)
+    finally:
+        api.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 0)
+    assert acc0.tolist() == (~tampered).astype(np.uint8).tolist() == acc1.tolist() and (mask0 == mask1).all() and (np.asarray(ch0.flat) == np.asarray(ch1.flat)).all()
+    sample = slice(0, 48)
+    oacc, ofail, _ = orc.verify(oc, batch[sample], n_threads=8)
+    assert acc0[sample].tolist() == oacc.tolist() and mask0[sample].tolist() == T.reported_mask(ofail).tolist()
+
+
 # ---------------------------------------------------------------- gates (plonk/gates/gates_test.go:712-768)
 def test_gate_kats(gpv, api, orc):
     kat = json.loads((T.GOLDEN / "gates_kat.json").read_text())
@@ -1738,6 +1790,34 @@ def _verdict_is_fail_closed(gpv, api, orc, shared):
                 assert 0.3 * n <= hit.sum() <= 0.7 * n, (name, int(hit.sum()))           # half a grid, about half of the proofs
             acc, mask, _ch = chip.Verify(pb, vo, detail=True)                            # and the next run is clean again
             assert acc.tolist() == [1] * n and not mask.any(), name
+        # the leaf phase as two launches (the longest class alone on the main stream, the others on a second one; forced, with the operand-scanning
+        # kernels): half of BOTH grids, and both launches skipped, must reject exactly the proofs concerned
+        api.set_option(gpv._lib.OPT_FR_EVALUATION, 2)
+        api.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 2)
+        try:
+            acc, mask, _ch = chip.Verify(pb, vo, detail=True)
+            assert acc.tolist() == [1] * n and not mask.any()
+            for num, den in ((1, 2), (0, 1)):
+                _set_fault(gpv, 5, -1, num, den)
+                try:
+                    acc, mask, _ch = chip.Verify(pb, vo, detail=True)
+                finally:
+                    _set_fault(gpv, 0)
+                hit = (mask & T.FAIL_INCOMPLETE) != 0
+                assert (acc == 0)[hit].all() and (acc == 1)[~hit].all() and not mask[~hit].any()
+                assert hit.all() if num == 0 else 0.3 * n <= hit.sum() <= 0.7 * n, (num, int(hit.sum()))
+            for nth in (0, 1):  # ONE of the two launches skipped: every proof misses the digests of that launch's trees
+                _set_fault(gpv, 5, nth, 0, 1)
+                try:
+                    acc, mask, _ch = chip.Verify(pb, vo, detail=True)
+                finally:
+                    _set_fault(gpv, 0)
+                assert not acc.any() and ((mask & T.FAIL_INCOMPLETE) != 0).all(), nth
+            acc, mask, _ch = chip.Verify(pb, vo, detail=True)
+            assert acc.tolist() == [1] * n and not mask.any()
+        finally:
+            api.set_option(gpv._lib.OPT_FR_EVALUATION, 0)
+            api.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 0)
         if shared == 2:
             # the crown scratch is reused across batch sizes. A larger batch leaves slots / items / digests all over it; the
             # smaller batch that follows, with a whole level launch skipped, must not find anything that reads as a current stamp.
