@@ -434,9 +434,10 @@ static int circuit_on_device(gpv_ctx* ctx, const gpv_circuit* c, const DevCircui
 // ================================================================ primitive kernels
 // ================================================================ protocol kernels
 // ================================================================ launch helpers (device pointers)
-// The shared upper levels pay from ~1000 proofs up (profiles/r01k_batch_sweep.txt): below that the level kernels are too
-// small to fill the GPU and the extra launches cost more than the saved hashes.
-#define GPV_MERKLE_SHARED_FROM 1024
+// The shared upper levels pay from ~500 proofs up: below that the level kernels are too small to fill the GPU and the extra launches cost more than
+// the saved hashes (round 1 measured ~1000, profiles/r01k_batch_sweep.txt; re-measured with the round-5 leaf launch: +1.7 .. 3.5 % at 512 - 896,
+// -2.7 % at 384, profiles/r05_shared_levels_sweep.txt).
+#define GPV_MERKLE_SHARED_FROM 512
 static bool merkle_shared_for(const gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
   if (ctx->merkle_shared == 0 || !gpvk_crown_supported(c->dc, n)) return false;
   return ctx->merkle_shared == 2 || n >= GPV_MERKLE_SHARED_FROM;
@@ -577,8 +578,11 @@ static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit*
 // a SIMD's issue rate, so beyond that the shared launch is the better use of the chip). Same lanes, same kernels' code, same results.
 // Which trees: the longest leaf class, and the second longest with it while both fit -- a SIMD that holds two 10-permutation waves is the next pole
 // (20 permutations' worth of issue slots against an average of 18). "Fit" leaves the SIMDs the other classes need: the budget is GPV_ALONE_MAX_SIMDS_X16 / 16
-// of the device's SIMDs (measured on both fixtures, profiles/r05_longest_alone.txt).
+// of the device's SIMDs for the longest class alone (beyond it the SIMDs left over are too few for the other five classes: +2 % at 1536 `step` proofs,
+// -3 % at 2048), 15 / 16 for the two longest together -- they finish at different times, and the rest moves onto the SIMDs the shorter one vacates
+// (profiles/r05_longest_alone.txt).
 #define GPV_ALONE_MAX_SIMDS_X16 11
+#define GPV_ALONE_MAX_SIMDS_2_X16 15
 static u32 merkle_longest_alone(const gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
   const DevCircuit& d = c->dc;
   if (ctx->merkle_longest_alone == 1 || !ctx->side_stream || d.n_trees < 2 || !gpvk_merkle_leaves_wide(d, n, ctx->fr_form)) return 0;
@@ -594,7 +598,7 @@ static u32 merkle_longest_alone(const gpv_ctx* ctx, const gpv_circuit* c, size_t
   if (ctx->merkle_longest_alone == 2) return 1u << best_t;
   if (waves > budget) return 0;
   u32 mask = 1u << best_t;
-  if (d.n_trees >= 3 && second >= 6 && 4 * second >= 5 * third && 2 * waves <= budget) mask |= 1u << second_t;
+  if (d.n_trees >= 3 && second >= 6 && 4 * second >= 5 * third && 2 * waves <= (size_t)gpvk_device_simds() * GPV_ALONE_MAX_SIMDS_2_X16 / 16) mask |= 1u << second_t;
   return mask;
 }
 // both Merkle phases back to back on one stream (entry points with caller-supplied challenges)

@@ -227,7 +227,6 @@ struct FrSqrStep<2 * FR_LIMBS> {
 // Operands: normalised or lazy sums of two normalised values, any value < 2^261; a product row returns < sum a_t b_t / R + r.
 // `one` (0 or 1, wave-uniform) multiplies the addend.
 struct FrChain {
-  static constexpr bool tape = false;
   GPV_DEV static u32 one() { return frr_one(); }
   GPV_DEV static Fr mul(const Fr& a, const Fr& b) { return fr_row<1, false>(&a, &b, a, 0u); }
   GPV_DEV static Fr sqr(const Fr& a) {
@@ -255,7 +254,6 @@ struct FrChain {
   }
 };
 struct FrWide {
-  static constexpr bool tape = true;  // the partial rounds read their constants from PBN_TAPE, one entry ahead (gpv_poseidon.cuh)
   GPV_DEV static u32 one() { return 1u; }
   GPV_DEV static Fr mul(const Fr& a, const Fr& b) {
     FrCols c;
@@ -306,50 +304,6 @@ struct FrWide {
     return frc_reduce(c);
   }
 };
-// ---------------------------------------------------------------- constants read ahead of their use (round 5)
-// A table entry is nine SGPRs, loaded with s_load right where a row needs it; the scalar cache (16 KB) does not hold the 18 KB of Poseidon-BN254
-// tables that every wave cycles through, so each of those loads is an L2 round trip (~240 cycles) that the compiler places a dozen instructions
-// before the first use: nothing when four waves share a SIMD, 14 % of a permutation for a wave that has the SIMD to itself (tools/lone_wave_probe.py:
-// 246 us against 212 us with every read redirected to one hot entry). KTape reads a table that is laid out in consumption order (PBN_TAPE) one entry
-// AHEAD: issue the load of entry k + 1, run the products of entry k, wait -- by then the load has landed. Written with inline asm because nothing else
-// pins a scalar load that early (the scheduler sinks it to its use to save SGPRs); __builtin_amdgcn_sched_barrier keeps the products between issue and
-// wait. The loaded registers are named as outputs of the ISSUE statement although they are only valid after the WAIT statement -- so between the two
-// nothing may read, copy or spill them: issue and wait of an entry always sit in ONE basic block with only multiply-adds between them, every use goes
-// through the wait statement's outputs, and tools/isa_lint.py checks the shipped code object for exactly this property (run by tests/test_abi_cpu.py).
-typedef u32 u32x8 __attribute__((ext_vector_type(8)));
-struct KBuf {
-  u32x8 lo;  // limbs 0 .. 7
-  u32 hi;    // limb 8
-};
-GPV_DEV void k_issue(KBuf& k, const u32* p) {  // p: wave-uniform, dword-aligned (entries are 36 bytes apart)
-  asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20" : "=&s"(k.lo), "=&s"(k.hi) : "s"(p));
-  __builtin_amdgcn_sched_barrier(0);
-}
-GPV_DEV void k_wait(KBuf& k) {
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(k.lo), "+s"(k.hi));
-}
-GPV_DEV u32 k_limb(const KBuf& k, int j) { return j < 8 ? k.lo[j] : k.hi; }
-// The 18 column sums as they stand: an empty statement the optimiser cannot see through, so the multiply-adds of one step stay in that step (without it
-// the re-association pass collects the products of several steps behind their waits -- a column is one long sum to it -- and the reads ahead cover nothing).
-GPV_DEV void frc_pin(FrCols& c) {
-  asm volatile("" : "+v"(c.t[0]), "+v"(c.t[1]), "+v"(c.t[2]), "+v"(c.t[3]), "+v"(c.t[4]), "+v"(c.t[5]), "+v"(c.t[6]), "+v"(c.t[7]), "+v"(c.t[8]), "+v"(c.t[9]),
-               "+v"(c.t[10]), "+v"(c.t[11]), "+v"(c.t[12]), "+v"(c.t[13]), "+v"(c.t[14]), "+v"(c.t[15]), "+v"(c.t[16]), "+v"(c.t[17]));
-}
-// c += a * k / start from k * R (the operand-scanning rows of FrCols with a tape entry as the constant operand)
-GPV_DEV void frc_mac_k(FrCols& c, const Fr& a, const KBuf& k) {
-#pragma unroll
-  for (int i = 0; i < FR_LIMBS; i++)
-#pragma unroll
-    for (int j = 0; j < FR_LIMBS; j++) c.t[i + j] += (u64)a.l[i] * k_limb(k, j);
-}
-GPV_DEV void frc_init_addend_k(FrCols& c, const KBuf& k) {
-#pragma unroll
-  for (int i = 0; i < FR_LIMBS; i++) {
-    c.t[i] = 0;
-    c.t[FR_LIMBS + i] = k_limb(k, i);
-  }
-}
 // conversions and one-off products (not on a hot path): the compact form
 GPV_DEV Fr fr_mul(const Fr& a, const Fr& b) { return FrChain::mul(a, b); }
 // ---------------------------------------------------------------- conversions

@@ -219,62 +219,6 @@ GPV_DEV void pbn_mix(PbnState& st, const u32* tab, bool half = false, int rows =
   st.s2 = r2;
   st.s3 = r3;
 }
-// The 56 partial rounds in the operand-scanning form with the constants read from PBN_TAPE one entry ahead (gpv_fr.cuh, KTape): the same windows,
-// the same rows in the same order, the same values as the loop in poseidon_bn254_permute -- only where a constant comes from differs. A step
-// "uses entry X, prefetches the next one into Y": issue(Y); products with X; wait(Y). 17 entries per window, so the buffers swap roles once per
-// window: nine s_mov put the next window's first entry back into A.
-#define PBN_STEP(cur, nxt, body) \
-  do {                           \
-    k_issue(nxt, tp);            \
-    tp += FR_LIMBS;              \
-    body;                        \
-    frc_pin(c);                  \
-    k_wait(nxt);                 \
-  } while (0)
-GPV_DEV void pbn_partial_rounds_tape(PbnState& st) {
-  const u32* tp = PBN_TAPE;
-  KBuf A, B;
-  k_issue(A, tp);
-  tp += FR_LIMBS;
-  k_wait(A);
-#pragma unroll 1
-  for (int w = 0; w < 28; w++) {
-    FrCols c;
-    Fr x2 = FrWide::sqr(st.s0), x4 = FrWide::sqr(x2);
-    PBN_STEP(A, B, { frc_init_addend_k(c, A); frc_mac(c, x4, st.s0); });  // t_A = s_0^5 + C[20 + A]
-    const Fr ta = frc_reduce(c);
-    frc_zero(c);
-    PBN_STEP(B, A, frc_mac_k(c, ta, B));       // round A's new s_0 = S[7A] t_A + sum_k S[7A + k] s_k
-    PBN_STEP(A, B, frc_mac_k(c, st.s1, A));
-    PBN_STEP(B, A, frc_mac_k(c, st.s2, B));
-    PBN_STEP(A, B, frc_mac_k(c, st.s3, A));
-    const Fr s0a = frc_reduce(c);
-    x2 = FrWide::sqr(s0a);
-    x4 = FrWide::sqr(x2);
-    PBN_STEP(B, A, { frc_init_addend_k(c, B); frc_mac(c, x4, s0a); });    // t_B
-    const Fr tb = frc_reduce(c);
-    frc_zero(c);
-    PBN_STEP(A, B, frc_mac_k(c, tb, A));       // round B's new s_0 over the window's base values, cross constant X_w last
-    PBN_STEP(B, A, frc_mac_k(c, st.s1, B));
-    PBN_STEP(A, B, frc_mac_k(c, st.s2, A));
-    PBN_STEP(B, A, frc_mac_k(c, st.s3, B));
-    PBN_STEP(A, B, frc_mac_k(c, ta, A));
-    st.s0 = frc_reduce(c);
-    frc_init_addend(c, st.s1);                 // s_k += t_A S[7A + 3 + k] + t_B S[7B + 3 + k], one reduction each
-    PBN_STEP(B, A, frc_mac_k(c, ta, B));
-    PBN_STEP(A, B, frc_mac_k(c, tb, A));
-    st.s1 = frc_reduce(c);
-    frc_init_addend(c, st.s2);
-    PBN_STEP(B, A, frc_mac_k(c, ta, B));
-    PBN_STEP(A, B, frc_mac_k(c, tb, A));
-    st.s2 = frc_reduce(c);
-    frc_init_addend(c, st.s3);
-    PBN_STEP(B, A, frc_mac_k(c, ta, B));
-    PBN_STEP(A, B, frc_mac_k(c, tb, A));       // prefetches the next window's C[20 + A'] into B ...
-    st.s3 = frc_reduce(c);
-    A = B;                                     // ... which the next trip expects in A (valid registers by now: plain copies)
-  }
-}
 // bn254.go:39-45, state in Montgomery form (each element normalised, < 2.2 r on entry)
 // ZERO_HEAD: the caller guarantees s[0] = s[1] = 0 (TwoToOne, bn254.go:96-104). Then the first S-box layer of those two
 // elements and their share of the first mix are constants (PBN_KK, tools/gen_constants.py): the first round costs two
@@ -316,10 +260,6 @@ GPV_DEV void poseidon_bn254_permute(Fr s[4]) {
     // Bounds: s_1..s_3 are never reduced below their running bound -- each round adds < 1.02 r, so after 56 rounds they are
     // < 60 r < 2^260 (R = 2^261 = 168.9 r); limbs are normalised by every reduction; the 5-product row stays below
     // (2 * 2.2 + 3 * 60) r^2 / R + r < 2.1 r and its columns below 45 * 2^58 + 9 * 2^58 < 2^63.8.
-    if (FA::tape) {  // the operand-scanning kernels: the same windows with their constants read ahead (pbn_partial_rounds_tape)
-      pbn_partial_rounds_tape(st);
-      continue;
-    }
 #pragma unroll 1
     for (int w = 0; w < 28; w++) {
       const int a = 2 * w, b = 2 * w + 1;

@@ -128,7 +128,7 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
 /* Tuning knobs. GPV_OPT_TRANSCRIPT_VARIANT: 0 = automatic (by batch size), 1 = one lane per proof (least total work; its
  * latency hides under the Merkle leaf hashing for batches >= ~4000 proofs), 2 = cooperative, 16 lanes per proof (about
  * 5x lower latency, 3x the work). Both produce identical challenges.
- * GPV_OPT_MERKLE_SHARED_LEVELS: 1 (default) = for batches of 1024 proofs or more (2 = for every batch) the last three levels of every Merkle tree are hashed once per distinct
+ * GPV_OPT_MERKLE_SHARED_LEVELS: 1 (default) = for batches of 512 proofs or more (2 = for every batch) the last three levels of every Merkle tree are hashed once per distinct
  * node instead of once per query path (the paths of a proof's queries meet near the cap; inputs are compared word for
  * word and a proof whose paths disagree is re-hashed path by path, so accept bits are identical); 0 = every path on its
  * own, literally fri/fri.go:97-144.

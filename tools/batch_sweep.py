@@ -16,7 +16,10 @@ chip = gpv.verifier.NewVerifierChip(ctx, common)
 dev = torch.device("cuda:0")
 rec = torch.from_numpy(np.frombuffer(packed, dtype=np.int64).copy()).to(dev)
 print("# n  shared_levels  ms_per_step  proofs_per_s")
-for n in (1, 16, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
+SIZES = (1, 16, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384)
+if "--sizes" in sys.argv:
+    SIZES = tuple(int(x) for x in sys.argv[sys.argv.index("--sizes") + 1].split(","))
+for n in SIZES:
     batch = rec.repeat(n, 1).contiguous()
     acc = torch.zeros(n, dtype=torch.uint8, device=dev)
     for mode in (1, 2, 0):
