@@ -554,8 +554,9 @@ def main():
             line["merkle_only_4096"] = bench_merkle_only(gpv, T, ctx, dev, max(2, min(args.steps, 5)))
             line["full_batch_65536"] = bench_full_batch(gpv, T, ctx, dev, args.fixture)
             line["single_proof"] = bench_single_proof(gpv, T, ctx, dev)
+            line["mid_size_batches"] = bench_mid_size(gpv, T, ctx, wl, dev)
             line["witness_verify_1024"] = bench_witness(gpv, T, ctx, dev)
-            line["witness_verify_4096"] = bench_witness(gpv, T, ctx, dev, 4096)  # 44 GB of trace: the store-bound regime ("the trace cursor")
+            line["witness_verify_4096"] = bench_witness(gpv, T, ctx, dev, 4096)  # 44 GB of trace: the store-bound regime (docs/DESIGN_HISTORY.md section 3, "the trace cursor")
         if not args.no_poseidon_gl:
             line["poseidon_gl"] = bench_poseidon_gl(gpv, T, ctx, dev)
         if not args.no_heterogeneous and n_ranks == 1:
@@ -711,6 +712,39 @@ def bench_single_proof(gpv, T, ctx, dev):
                 raise SystemExit("single_proof: %s %s proof: accept = %d" % (name, label, int(acc.item())))
         out[name] = res
     out["entry_point"] = "gpv_verify_dev, n = 1, record resident in HBM; accept checked (valid: 1, tampered: 0)"
+    return out
+
+
+def bench_mid_size(gpv, T, ctx, wl, dev, sizes=(512, 1024, 2048, 4096)):
+    """The operating point of a service rather than of a benchmark: gpv_verify_dev on batches of a few hundred to a few thousand proofs of the
+    line's fixture (1 in 16 tampered, accept vector checked), every call synchronised before the next. Below ~1 600 proofs the longest tree class is
+    hashed by waves that take a SIMD each (GPV_OPT_MERKLE_LONGEST_ALONE); `one_launch` is the same batch with that switched off."""
+    chip = gpv.verifier.NewVerifierChip(ctx, wl.common)
+    out = {}
+    for n in sizes:
+        batch, tam = wl.cloned_batch(0, n, n)
+        expect = (~tam).astype(np.uint8)
+        acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        row = {}
+        for label, mode in (("default", 0), ("one_launch", 1)):
+            ctx.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, mode)
+            for _ in range(3):
+                chip.VerifyDevice(wl.circuit, batch.data_ptr(), n, acc.data_ptr())
+            ctx.synchronize()
+            reps = 12
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                chip.VerifyDevice(wl.circuit, batch.data_ptr(), n, acc.data_ptr())
+                ctx.synchronize()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            if not (acc.cpu().numpy() == expect).all():
+                raise SystemExit("mid_size: accept vector mismatch at n = %d (%s)" % (n, label))
+            row[label + "_ms"] = ms
+            row[label + "_proofs_per_s"] = n / ms * 1e3
+        ctx.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 0)
+        out[str(n)] = row
+    out["entry_point"] = "gpv_verify_dev, records resident in HBM, every call synchronised; accept == tamper mask"
     return out
 
 

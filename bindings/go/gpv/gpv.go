@@ -469,7 +469,7 @@ func NewCircuitBeyondReference(commonJSON, verifierOnlyJSON []byte) *Circuit {
 
 func (c *Circuit) NumGateConstraints() int { return int(C.gpv_num_gate_constraints(c.h)) }
 
-// Describe returns the flat circuit description (gpv_circuit_describe; layout in DESIGN.md).
+// Describe returns the flat circuit description (gpv_circuit_describe; layout in include/gpv.h).
 func (c *Circuit) Describe() []uint64 {
 	n := int(C.gpv_circuit_describe(c.h, nil, 0))
 	blob := make([]uint64, n)

@@ -12,6 +12,9 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libgpv.so"
 # the same objects + the fault-injection hook of csrc/gpv_testhooks.h (csrc/Makefile); loaded by the fail-closed tests only
 TEST_LIB_PATH = PKG_DIR / "libgpv_test.so"
+# False: do not import torch before loading the library (the system ROCm runtime is used then) -- the sanitizer runs of tools/asan/ set it:
+# the ASan runtime's HSA interceptors do not get along with the HIP runtime bundled in the torch wheel
+SHARE_TORCH_RUNTIME = True
 
 GPV_OK, GPV_ESHAPE, GPV_ECONFIG, GPV_EDEVICE, GPV_EINVAL, GPV_ENOMEM, GPV_EPEER = 0, -1, -2, -3, -4, -5, -6
 
@@ -96,10 +99,11 @@ def _load(path):
         # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if libgpv pulled in the system copy first,
         # torch would later fail with "No HIP GPUs are available". Loading torch first makes both share torch's runtime.
         # (C/C++/Go hosts without torch simply use the system ROCm runtime.)
-        try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
+        if SHARE_TORCH_RUNTIME:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = ctypes.CDLL(str(path))
         vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
         L.gpv_ctx_create.argtypes = [ctypes.POINTER(vp), i32]

@@ -246,6 +246,11 @@ __global__ __launch_bounds__(GPV_QUAD_BLOCK) void k_merkle_leaves_quad(const Dev
   Fr d = poseidon_bn254_hash_or_noop_quad(leaf, leaf_len, lds, lane4);
   if (lane4 == 0) HashBN::store_digest(digests + ((size_t)tree * items + item) * FR_LIMBS, d);
 }
+// (Sanitizer build only, make asan: this one kernel stays uninstrumented. AddressSanitizer guards every per-lane load with a branch to its report call; in
+// this kernel the compiler then runs part of the quad exchange inside such a lane-divergent region, a DPP read from a masked-off lane returns 0
+// (bound_ctrl), and a VALID batch is rejected -- on the instrumented build only: -O2 and xnack+ builds without the sanitizer agree with the oracle,
+// tools/asan/probe_modes.py. Its addressing is dev_merkle_path, the same code the instrumented k_merkle_climb[_wide] run.)
+__attribute__((no_sanitize("address")))
 __global__ __launch_bounds__(GPV_QUAD_BLOCK) void k_merkle_climb_quad(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                                       const u64* __restrict__ derived, size_t n, MerkleOrder order,
                                                                       const u32* __restrict__ digests, Verdict v, uint8_t* __restrict__ ok_out) {

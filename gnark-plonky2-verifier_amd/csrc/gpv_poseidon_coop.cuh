@@ -4,7 +4,7 @@
 //
 //   replaces poseidon/goldilocks.go:30-37 (same permutation as poseidon_gl_permute in gpv_poseidon.cuh)
 //
-// Trade-off (measured): a round costs ~170 instructions per lane instead of 690-1750, so the LATENCY
+// Trade-off (measured, docs/DESIGN_HISTORY.md section 3): a round costs ~170 instructions per lane instead of 690-1750, so the LATENCY
 // of a permutation drops ~5x -- which is what the strictly sequential Fiat-Shamir transcript needs -- but a wave carries
 // 4 states instead of 64, so total work per state is ~3x higher: for THROUGHPUT (2^20 independent states) one lane per
 // state wins and stays the default of gpv_poseidon_gl_permute. Cross-lane traffic: 24 ds_bpermute_b32 per round.

@@ -16,7 +16,19 @@
 struct PglState {
   u64 s[12];
 };
+// (Sanitizer build, make asan: inlined instead. On this toolchain an AddressSanitizer-instrumented kernel that CALLS a device function faults on a wild
+// address at the call -- k_transcript and k_derive_extra both, on valid input, while the same kernels of the product build run under HSA_XNACK=1 and
+// without; tools/asan/probe_transcript.py. Inlined, the instrumented code is the same arithmetic.)
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define GPV_PGL_CALL_INLINED 1
+#endif
+#endif
+#ifdef GPV_PGL_CALL_INLINED
+__device__ __forceinline__ PglState poseidon_gl_permute_call(PglState st) {
+#else
 __device__ __noinline__ PglState poseidon_gl_permute_call(PglState st) {
+#endif
   poseidon_gl_permute<GlLatency>(st.s);  // one wave per SIMD here: ILP beats issue-slot count
   return st;
 }

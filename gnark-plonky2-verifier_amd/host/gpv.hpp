@@ -85,7 +85,7 @@ class Circuit {
   size_t num_challenge_words() const { return gpv_num_challenge_words(h_); }
   size_t num_gate_constraints() const { return gpv_num_gate_constraints(h_); }
   size_t hash_kind() const { return gpv_circuit_hash_kind(h_); }  // GPV_HASH_KIND_*
-  std::vector<uint64_t> describe() const {                          // the flat circuit description ("blob")
+  std::vector<uint64_t> describe() const {                          // the flat circuit description ("blob": the words gpv_circuit_describe returns, include/gpv.h)
     std::vector<uint64_t> blob(gpv_circuit_describe(h_, nullptr, 0));
     gpv_circuit_describe(h_, blob.data(), blob.size());
     return blob;

@@ -186,7 +186,7 @@ size_t gpv_num_merkle_trees(const gpv_circuit* c);     /* per query: 4 initial +
  * reference has no such path, see DESIGN.md "parity unpinned"). Either way a hash is 4 x u64 in the packed record. */
 enum { GPV_HASH_KIND_POSEIDON_BN254 = 0, GPV_HASH_KIND_POSEIDON_GOLDILOCKS = 1 };
 size_t gpv_circuit_hash_kind(const gpv_circuit* c);
-/* Flat description ("circuit blob", layout in DESIGN.md) -- lets a caller inspect what was parsed.
+/* Flat description ("circuit blob") -- lets a caller inspect what was parsed.
  * Returns the number of words needed; writes at most cap words. */
 size_t gpv_circuit_describe(const gpv_circuit* c, uint64_t* blob, size_t cap);
 /* types.ReadProofWithPublicInputs + variables.DeserializeProofWithPublicInputs

@@ -9,8 +9,19 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 sys.path.insert(0, str(ROOT))
 
 
+def pytest_addoption(parser):
+    parser.addoption("--libgpv", default=None, help="run the tests on another build of the library (e.g. tools/asan/libgpv_asan.so: the sanitizer build, "
+                     "with the ASan runtime preloaded -- tools/asan/run_asan_fuzz.sh); torch's bundled HIP runtime is not loaded first then")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    alt = config.getoption("--libgpv")
+    if alt:
+        import importlib
+        gpv = importlib.import_module("gnark-plonky2-verifier_amd")
+        gpv._lib.LIB_PATH = Path(alt).resolve()
+        gpv._lib.SHARE_TORCH_RUNTIME = False
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -448,7 +448,7 @@ def test_witness_challenges_layout_and_oracle_trace(gpv, name):
     body = rec[:n_gl - ci.num_public_inputs]
     assert rc.shape == (1, 2 * body.size) and (rc[0, 0::2] == body >> np.uint64(32)).all() and (rc[0, 1::2] == (body & np.uint64(0xFFFFFFFF))).all()
     assert L.gpv_witness_range_check_words(ctypes.c_void_p(circuit.h)) == rc.shape[1] == {"decode_block": 19078, "step": 19202}[name]
-    # per permutation: 130 MulAdd + 630 Reduce + 890 SplitLimbs = 5190 words
+    # per permutation: 130 MulAdd + 630 Reduce + 890 SplitLimbs = 5190 words (docs/DESIGN_HISTORY.md, "Witness generator")
     assert int((ok == 0).sum()) * 2 + int((ok == 1).sum()) * 5 + int((ok == 3).sum()) * 2 == len(words)
 
 

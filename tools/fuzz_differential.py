@@ -1,7 +1,8 @@
 """Long differential run: corrupted copies of valid records through libgpv (shared Merkle levels on and off) against the CPU
 oracle -- accept bits and failure masks must agree on every record. Covers the two reference fixtures (full Verify, own
 transcript), the same fixtures with supplied challenges, the Poseidon-Goldilocks configuration and a set of shapes beyond the
-reference (the latter three through gpv_verify_given_challenges).   python tools/fuzz_differential.py [n_per_case] [seed]
+reference (the latter three through gpv_verify_given_challenges).   python tools/fuzz_differential.py [n_per_case] [seed] [form]
+(form: GPV_OPT_FR_EVALUATION forced -- 1 column scanning, 2 operand scanning, 3 four lanes per permutation; default 0 = by launch size)
 (Test infrastructure, like tests/: it is the only reason this script touches oracle/.)"""
 import importlib
 import json
@@ -18,6 +19,9 @@ gpv = importlib.import_module("gnark-plonky2-verifier_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = gpv.default_context()
+if len(sys.argv) > 3:
+    ctx.set_option(gpv._lib.OPT_FR_EVALUATION, int(sys.argv[3]))
+    print("# GPV_OPT_FR_EVALUATION = %d" % int(sys.argv[3]))
 orc = T.oracle()
 P = T.GL_P
 KINDS = ["one bit anywhere", "one bit in the hash section", "a hash replaced by its neighbour", "a query-section word", "two corruptions",

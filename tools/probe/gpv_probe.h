@@ -24,7 +24,7 @@ int gpvp_row_mix_rate(int device, int chains, int waves, double* lane_mads_per_s
  * shader cycles / wall time of the sampling window. */
 int gpvp_clock_sample_begin(int device, unsigned microseconds);
 int gpvp_clock_sample_end(double* ghz);
-/* MFMA feasibility probe (DESIGN.md "measured and not adopted", profiles/r02d_mfma_probe.txt): one mix row sum_j C_j * X_j computed
+/* MFMA feasibility probe (EXPERIMENTS.md section B, profiles/r02d_mfma_probe.txt): one mix row sum_j C_j * X_j computed
  * `iters` times per lane the product's way (which = 0: 4 x 81 v_mad_u64_u32) or as a byte-plane Toeplitz GEMM on
  * v_mfma_i32_32x32x32_i8 (which = 1); 2 = both kernels concurrently on two streams; 3 / 4 = the MFMA path's two halves alone;
  * 5 / 6 / 7 = 1 / 3 / 2 with the A operands read from precomputed Toeplitz register images. x [n][4][9] radix-2^29 limbs, c_limbs

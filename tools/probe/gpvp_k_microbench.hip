@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 }
 // The same row mix with TWO independent chains per lane issued in lock step (what interleaving two Fr rows would look like to the
 // scheduler: a dependent v_mad_u64_u32 is always separated from its predecessor by an independent one). WAVES = waves per SIMD the
-// kernel is compiled for: compares chain-level against wave-level parallelism.
+// kernel is compiled for: compares chain-level against wave-level parallelism (EXPERIMENTS.md section B).
 template <int CHAINS, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_microbench_row_mix_n(u64* out, int iters) {
   u32 a[9], m[CHAINS];
