@@ -49,7 +49,7 @@ struct gpv_ctx {
   hipEvent_t ev_fork = nullptr, ev_cleared = nullptr, ev_transcript = nullptr, ev_side_done = nullptr;
   // a second side stream: the FRI slice of the witness generator runs next to the challenges fill and the plonk slice (gpv_witness_verify)
   hipStream_t side2 = nullptr;
-  hipEvent_t ev_side2_done = nullptr;
+  hipEvent_t ev_side2_done = nullptr, ev_walk_fork = nullptr;
   u32* digests = nullptr;
   size_t digest_words = 0;
   int transcript_variant = 0;  // GPV_OPT_TRANSCRIPT_VARIANT
@@ -257,6 +257,7 @@ extern "C" int gpv_ctx_create(gpv_ctx** out, int device_id) {
       hipEventCreateWithFlags(&ctx->ev_side_done, hipEventDisableTiming) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_side2_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_walk_fork, hipEventDisableTiming) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->upload, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) {
     gpv_set_global_error("side stream / event creation failed on device %d", device_id);
@@ -537,22 +538,22 @@ static void launch_plonk(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, con
 }
 // tree_mask: the trees this launch covers (all of them, or one group of the class-pipelined pipeline)
 static void launch_merkle_leaves(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, u32 tree_mask = ~0u,
-                                 bool solo = false) {
+                                 int solo = GPV_SOLO_NONE) {
   Timed t(ctx, TK_LEAVES, st);
   gpvk_merkle_leaves(st, dcd, c->dc, (const u64*)proofs, n, ctx->digests, verdict_of(ctx), ctx->fr_form, tree_mask, solo);
 }
 // The sibling walks of the trees of tree_mask: up to GPV_CROWN_LEVELS below the cap when the upper levels are shared (launch_merkle_crown then
 // hashes every distinct upper node once), else the whole walk and the comparison with the cap entry.
 static void launch_merkle_walk(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, uint8_t* ok_dev,
-                               u32 tree_mask = ~0u) {
+                               u32 tree_mask = ~0u, bool solo = false) {
   if (!ok_dev && merkle_shared_for(ctx, c, n)) {
     CrownBufs b = gpvk_crown_carve(c->dc, n, ctx->crown, ctx->crown_bytes);
     Timed tl(ctx, TK_LOWER, st);
     gpvk_merkle_climb_lower(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, b.mid, GPV_CROWN_LEVELS, verdict_of(ctx), ctx->fr_form,
-                            tree_mask);
+                            tree_mask, solo);
     return;
   }
-  gpvk_merkle_climb(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, verdict_of(ctx), ok_dev, ctx->fr_form, tree_mask);
+  gpvk_merkle_climb(st, dcd, c->dc, (const u64*)proofs, (const u64*)ctx->derived, n, ctx->digests, verdict_of(ctx), ok_dev, ctx->fr_form, tree_mask, solo);
 }
 static void launch_merkle_crown(gpv_ctx* ctx, hipStream_t st, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, uint8_t* ok_dev) {
   if (ok_dev || !merkle_shared_for(ctx, c, n)) return;
@@ -581,11 +582,26 @@ static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit*
 // of the device's SIMDs for the longest class alone (beyond it the SIMDs left over are too few for the other five classes: +2 % at 1536 `step` proofs,
 // -3 % at 2048), 15 / 16 for the two longest together -- they finish at different times, and the rest moves onto the SIMDs the shorter one vacates
 // (profiles/r05_longest_alone.txt).
+// Below about 550 proofs the same reasoning goes one step further: the longest class is hashed FOUR lanes per permutation, still one wave per SIMD
+// (k_merkle_leaves_quad_solo: 147 instead of 261 us per permutation for a wave that is alone), while its quads -- 4 x the waves -- still fit in
+// GPV_ALONE_MAX_SIMDS_QUAD_X16 / 16 of the SIMDs; and the full-length sibling walks (the four initial trees') run one wave per SIMD too while all of them
+// fit (merkle_walk_alone), the step trees' shorter walks beside them.
 #define GPV_ALONE_MAX_SIMDS_X16 11
 #define GPV_ALONE_MAX_SIMDS_2_X16 15
-static u32 merkle_longest_alone(const gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
+#define GPV_ALONE_MAX_SIMDS_QUAD_X16 15
+#define GPV_ALONE_MAX_SIMDS_WALK_X16 15
+struct MerkleAlone {
+  u32 leaf_mask;  // trees whose leaf digests run one wave per SIMD on the main stream (0: one launch for all trees)
+  int leaf_shape; // GPV_SOLO_WIDE / GPV_SOLO_QUAD
+  u32 walk_mask;  // trees whose sibling walks run one wave per SIMD (0: one launch)
+};
+static int xenv(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }  // EXPERIMENT
+static MerkleAlone merkle_alone(const gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
   const DevCircuit& d = c->dc;
-  if (ctx->merkle_longest_alone == 1 || !ctx->side_stream || d.n_trees < 2 || !gpvk_merkle_leaves_wide(d, n, ctx->fr_form)) return 0;
+  MerkleAlone r = {0, GPV_SOLO_NONE, 0};
+  if (ctx->merkle_longest_alone == 1 || !ctx->side_stream || d.n_trees < 2 || !gpvk_merkle_leaves_wide(d, n, ctx->fr_form)) return r;
+  const size_t waves = (n * d.num_queries + 63) / 64, simds = gpvk_device_simds();
+  // ---- leaf digests
   u32 best = 0, second = 0, best_t = 0, second_t = 0, third = 0;
   for (u32 t = 0; t < d.n_trees; t++) {
     const u32 p = gpvk_merkle_leaf_perms(d, t);
@@ -593,13 +609,28 @@ static u32 merkle_longest_alone(const gpv_ctx* ctx, const gpv_circuit* c, size_t
     else if (p > second) { third = second; second = p; second_t = t; }
     else if (p > third) third = p;
   }
-  if (best < 6 || 4 * best < 5 * second) return 0;  // nothing stands out: the common launch balances such classes by itself
-  const size_t waves = (n * d.num_queries + 63) / 64, budget = (size_t)gpvk_device_simds() * GPV_ALONE_MAX_SIMDS_X16 / 16;
-  if (ctx->merkle_longest_alone == 2) return 1u << best_t;
-  if (waves > budget) return 0;
-  u32 mask = 1u << best_t;
-  if (d.n_trees >= 3 && second >= 6 && 4 * second >= 5 * third && 2 * waves <= (size_t)gpvk_device_simds() * GPV_ALONE_MAX_SIMDS_2_X16 / 16) mask |= 1u << second_t;
-  return mask;
+  if (best >= 6 && 4 * best >= 5 * second) {  // else nothing stands out: the common launch balances such classes by itself
+    if (ctx->merkle_longest_alone == 2) {
+      r.leaf_mask = 1u << best_t;
+      r.leaf_shape = GPV_SOLO_WIDE;
+    } else if (4 * waves <= simds * xenv("GPV_X_QUAD_X16", GPV_ALONE_MAX_SIMDS_QUAD_X16) / 16) {
+      r.leaf_mask = 1u << best_t;
+      r.leaf_shape = GPV_SOLO_QUAD;
+    } else if (waves <= simds * GPV_ALONE_MAX_SIMDS_X16 / 16) {
+      r.leaf_mask = 1u << best_t;
+      r.leaf_shape = GPV_SOLO_WIDE;
+      if (d.n_trees >= 3 && second >= 6 && 4 * second >= 5 * third && 2 * waves <= simds * GPV_ALONE_MAX_SIMDS_2_X16 / 16) r.leaf_mask |= 1u << second_t;
+    }
+  }
+  // ---- sibling walks: every tree whose walk has the full length, while all of them get a SIMD each
+  if (ctx->merkle_longest_alone == 0 && xenv("GPV_X_WALK", 1)) {
+    u32 longest = 0, k = 0, mask = 0;
+    for (u32 t = 0; t < d.n_trees; t++) longest = gpvk_merkle_siblings(d, t) > longest ? gpvk_merkle_siblings(d, t) : longest;
+    for (u32 t = 0; t < d.n_trees; t++)
+      if (gpvk_merkle_siblings(d, t) == longest) { mask |= 1u << t; k++; }
+    if (longest >= 4 && k < d.n_trees && k * waves <= simds * xenv("GPV_X_WALK_X16", GPV_ALONE_MAX_SIMDS_WALK_X16) / 16) r.walk_mask = mask;
+  }
+  return r;
 }
 // both Merkle phases back to back on one stream (entry points with caller-supplied challenges)
 static void launch_merkle(gpv_ctx* ctx, const gpv_circuit* c, const DevCircuit* dcd, const void* proofs, size_t n, uint8_t* ok_dev) {
@@ -654,12 +685,12 @@ static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* p
   HIP_TRY(ctx, hipEventRecord(ctx->ev_transcript, side));
   launch_range_check(ctx, main_st, c, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_cleared, main_st));
-  const u32 alone = merkle_longest_alone(ctx, c, n);
-  if (alone) {  // the longest class on SIMDs of its own (main stream), the others beside it (second side stream); the walks wait for both
-    launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n, alone, true);
+  const MerkleAlone alone = merkle_alone(ctx, c, n);
+  if (alone.leaf_mask) {  // the longest class on SIMDs of its own (main stream), the others beside it (second side stream); the walks wait for both
+    launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n, alone.leaf_mask, alone.leaf_shape);
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));  // the visit counters are cleared
     gpvk_head_start(ctx->side2, 20);  // the main stream's waves are placed first: they need EMPTY SIMDs (10 us suffice; without it the long class ends at 6.9 ms instead of 4.3)
-    gpvk_merkle_leaves(ctx->side2, dcd, c->dc, (const u64*)proofs_dev, n, ctx->digests, verdict_of(ctx), ctx->fr_form, ~alone, false);
+    gpvk_merkle_leaves(ctx->side2, dcd, c->dc, (const u64*)proofs_dev, n, ctx->digests, verdict_of(ctx), ctx->fr_form, ~alone.leaf_mask, GPV_SOLO_NONE);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_side2_done, ctx->side2));
     HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_side2_done, 0));
   } else {
@@ -670,7 +701,25 @@ static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* p
   launch_fri_query(ctx, side, c, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_side_done, side));
   HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_transcript, 0));
-  launch_merkle_climb(ctx, main_st, c, dcd, proofs_dev, n, nullptr);
+  if (alone.walk_mask) {  // the full-length walks one wave per SIMD (main stream), the step trees' shorter ones beside them; the shared levels wait for both
+    Timed t(ctx, TK_MERKLE, main_st);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_walk_fork, main_st));  // the transcript has finished AND the digests of every tree are there
+    launch_merkle_walk(ctx, main_st, c, dcd, proofs_dev, n, nullptr, alone.walk_mask, true);
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->side2, ctx->ev_walk_fork, 0));
+    gpvk_head_start(ctx->side2, 20);
+    {
+      // (untimed: the timing records of a context are drained on its main stream)
+      const bool timing = ctx->timing;
+      ctx->timing = false;
+      launch_merkle_walk(ctx, ctx->side2, c, dcd, proofs_dev, n, nullptr, ~alone.walk_mask, false);
+      ctx->timing = timing;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_side2_done, ctx->side2));
+    HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_side2_done, 0));
+    launch_merkle_crown(ctx, main_st, c, dcd, proofs_dev, n, nullptr);
+  } else {
+    launch_merkle_climb(ctx, main_st, c, dcd, proofs_dev, n, nullptr);
+  }
   HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_side_done, 0));
   CHECK_LAUNCH(ctx);
   return GPV_OK;

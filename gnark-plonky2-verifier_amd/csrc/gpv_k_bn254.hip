@@ -217,11 +217,42 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_lower_wide(co
                                                                          u32 crown_levels, Verdict v) {
   merkle_climb_lower_body<HashBNWide>(dc, proofs, derived, n, order, digests, mid, crown_levels, v);
 }
+// The walks with a SIMD per wave, like k_merkle_leaves_wide_solo: for a batch whose full-length walks (the four initial trees') have no more waves than
+// the device has SIMDs, so that none of them shares a SIMD with another (gpv_api.cpp, merkle_walk_alone).
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_wide_solo(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                   const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                                   const u32* __restrict__ digests, Verdict v,
+                                                                   uint8_t* __restrict__ ok_out) {
+  asm volatile("v_accvgpr_write_b32 a239, 0" ::: "a239");  // 184 + 240 = 424 of 512 registers
+  merkle_climb_body<HashBNWide>(dc, proofs, derived, n, order, digests, v, ok_out);
+}
+__global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_climb_lower_wide_solo(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+                                                                         const u64* __restrict__ derived, size_t n, MerkleOrder order,
+                                                                         const u32* __restrict__ digests, u64* __restrict__ mid,
+                                                                         u32 crown_levels, Verdict v) {
+  asm volatile("v_accvgpr_write_b32 a247, 0" ::: "a247");  // 176 + 248 = 424
+  merkle_climb_lower_body<HashBNWide>(dc, proofs, derived, n, order, digests, mid, crown_levels, v);
+}
 // Four lanes per (proof, query, tree): the same two phases with the quad permutation, for launches that leave most of the chip idle
 // (the digests travel in the same scratch; the walk is the per-path one, up to the cap -- sharing upper levels saves work, not latency).
+GPV_DEV void merkle_leaves_quad_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n, const MerkleOrder& order,
+                                     u32* __restrict__ digests, const Verdict& v, u32* lds);
 __global__ __launch_bounds__(GPV_QUAD_BLOCK) void k_merkle_leaves_quad(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
                                                                        MerkleOrder order, u32* __restrict__ digests, Verdict v) {
   __shared__ u32 lds[PBQ_WORDS];
+  merkle_leaves_quad_body(dc, proofs, n, order, digests, v, lds);
+}
+// ... and with a SIMD per wave (round 5): the longest leaf class of a batch of a few hundred proofs -- four lanes per permutation halve a lone wave's time per
+// permutation once more (147 us against 261), and with 416 of the 512 registers allocated no second hashing wave slows it; the other classes run beside it
+// in the operand-scanning form (gpv_api.cpp, merkle_longest_alone).
+__global__ __launch_bounds__(GPV_QUAD_BLOCK) void k_merkle_leaves_quad_solo(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+                                                                            MerkleOrder order, u32* __restrict__ digests, Verdict v) {
+  __shared__ u32 lds[PBQ_WORDS];
+  asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");  // 160 + 256 = 416
+  merkle_leaves_quad_body(dc, proofs, n, order, digests, v, lds);
+}
+GPV_DEV void merkle_leaves_quad_body(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n, const MerkleOrder& order,
+                                     u32* __restrict__ digests, const Verdict& v, u32* lds) {
   pbq_stage_tables(lds);
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, item = t >> 2;
   const u32 lane4 = (u32)t & 3;
@@ -362,11 +393,16 @@ void gpvk_poseidon_bn254_to_vec(hipStream_t st, const u64* h, u64* out, size_t n
 }
 size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n) { return n * hc.num_queries * hc.n_trees * FR_LIMBS; }
 void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, Verdict v, int form,
-                        u32 tree_mask, bool solo) {
+                        u32 tree_mask, int solo) {
   size_t items = n * hc.num_queries;
   u32 nt = 0;
   const MerkleOrder ord = merkle_order(hc, true, tree_mask, &nt);
   if (!nt) return;
+  if (solo == GPV_SOLO_QUAD) {  // the caller has checked gpvk_merkle_leaves_wide(): BN254, neither the four-lane nor the column-scanning regime
+    GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_quad_solo, dim3(gpvk_blocks_for(4 * items, GPV_QUAD_BLOCK), nt), dim3(GPV_QUAD_BLOCK), 0, st, dcd, proofs, n,
+                ord, digests, v);
+    return;
+  }
   if (hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && gpvk_fr_quad_pays(gpvk_full_paths(hc, items), form)) {
     GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_quad, dim3(gpvk_blocks_for(4 * items, GPV_QUAD_BLOCK), nt), dim3(GPV_QUAD_BLOCK), 0, st, dcd, proofs, n,
                 ord, digests, v);
@@ -401,11 +437,16 @@ bool gpvk_merkle_leaves_wide(const DevCircuit& hc, size_t n, int form) {
   return hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && !gpvk_fr_quad_pays(full, form) && !gpvk_fr_chain_pays(full, form);
 }
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                       const u32* digests, Verdict v, uint8_t* ok_out, int form, u32 tree_mask) {
+                       const u32* digests, Verdict v, uint8_t* ok_out, int form, u32 tree_mask, bool solo) {
   size_t items = n * hc.num_queries;
   u32 nt_all = 0;
   const MerkleOrder ord_all = merkle_order(hc, false, tree_mask, &nt_all);
   if (!nt_all) return;
+  if (solo) {
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_wide_solo, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt_all), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
+                ord_all, digests, v, ok_out);
+    return;
+  }
   if (hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && gpvk_fr_quad_pays(gpvk_full_paths(hc, items), form)) {
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_quad, dim3(gpvk_blocks_for(4 * items, GPV_QUAD_BLOCK), nt_all), dim3(GPV_QUAD_BLOCK), 0, st, dcd, proofs,
                 derived, n, ord_all, digests, v, ok_out);
@@ -422,11 +463,16 @@ void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& 
                 ord_all, digests, v, ok_out);
 }
 void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                             const u32* digests, u64* mid, u32 crown_levels, Verdict v, int form, u32 tree_mask) {
+                             const u32* digests, u64* mid, u32 crown_levels, Verdict v, int form, u32 tree_mask, bool solo) {
   size_t items = n * hc.num_queries;
   u32 nt = 0;
   const MerkleOrder ord = merkle_order(hc, false, tree_mask, &nt);
   if (!nt) return;
+  if (solo) {
+    GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower_wide_solo, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
+                derived, n, ord, digests, mid, crown_levels, v);
+    return;
+  }
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), nt), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd,
                 proofs, derived, n, ord, digests, mid, crown_levels, v);

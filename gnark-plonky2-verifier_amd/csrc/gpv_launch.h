@@ -121,7 +121,8 @@ size_t gpvk_merkle_digest_words(const DevCircuit& hc, size_t n);  // u32 words o
 // tree_mask: bit t = tree t takes part; solo: the operand-scanning kernel whose waves take a SIMD each (k_merkle_leaves_wide_solo; only when
 // gpvk_merkle_leaves_wide() holds) -- gpv_api.cpp launches the longest class of a mid-size batch that way, beside the other classes on a second stream
 void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, u32* digests, Verdict v, int form,
-                        u32 tree_mask = ~0u, bool solo = false);
+                        u32 tree_mask = ~0u, int solo = 0);
+enum { GPV_SOLO_NONE = 0, GPV_SOLO_WIDE = 1, GPV_SOLO_QUAD = 2 };  // a SIMD per wave: the operand-scanning kernel / four lanes per permutation
 bool gpvk_merkle_leaves_wide(const DevCircuit& hc, size_t n, int form);
 void gpvk_head_start(hipStream_t st, u32 microseconds);  // an idle wave for that long: whatever follows on `st` starts behind a launch made on another stream just before
 u32 gpvk_merkle_leaf_perms(const DevCircuit& hc, u32 tree);  // permutations of one leaf digest of that tree
@@ -151,11 +152,11 @@ bool gpvk_crown_supported(const DevCircuit& hc, size_t n);
 // alloc_bytes: size of the allocation at `base` (>= gpvk_crown_bytes(hc, n)); it alone fixes where the generation stamps live
 CrownBufs gpvk_crown_carve(const DevCircuit& hc, size_t n, void* base, size_t alloc_bytes);
 void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                             const u32* digests, u64* mid, u32 crown_levels, Verdict v, int form, u32 tree_mask = ~0u);
+                             const u32* digests, u64* mid, u32 crown_levels, Verdict v, int form, u32 tree_mask = ~0u, bool solo = false);
 void gpvk_crown(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n, CrownBufs b,
                 Verdict v, u32 gen, int form);
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
-                       const u32* digests, Verdict v, uint8_t* ok_out, int form, u32 tree_mask = ~0u);
+                       const u32* digests, Verdict v, uint8_t* ok_out, int form, u32 tree_mask = ~0u, bool solo = false);
 // gpv_k_transcript.hip
 void gpvk_range_check(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, size_t n, Verdict v);
 u32 gpvk_range_words(const DevCircuit& hc);  // words per record whose canonical form is checked

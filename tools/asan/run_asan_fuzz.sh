@@ -6,7 +6,8 @@
 # 2. tools/fuzz_differential.py on the instrumented library: corrupted records, poles, boundary values, both fixtures, shapes beyond the reference;
 # 3. a selection of the GPU parity tests on the instrumented library (pytest --libgpv).
 # Exit status 1 of a fuzz run whose 12 configurations all agree: the ASan runtime objects to a delete inside libhsa-runtime64's exit handlers
-# (__cxa_finalize -> libamdhip64 -> libhsa-runtime64 -> operator delete), after all the work is done -- the stock ROCm runtime is not ASan-clean at exit.
+# (__cxa_finalize -> libamdhip64 -> libhsa-runtime64 -> operator delete), after all the work is done -- the stock ROCm runtime is not ASan-clean at exit
+# ("CHECK failed: sanitizer_allocator_device.h:125 !dev_runtime_unloaded_").
 set -u
 N=${1:-64}; SEED=${2:-1}
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
@@ -32,5 +33,5 @@ done
 #  on this toolchain; the poles themselves are corruption kind 7 of the fuzz above)
 echo "== the colliding-query, shared-level, random-record, beyond-the-reference and leaf-launch GPU tests on libgpv_asan.so"
 LD_PRELOAD="$PRE" timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider --libgpv tools/asan/libgpv_asan.so \
-  -k "colliding or shared_merkle_levels_are_exact or merkle_and_fri or random_records_differential or shapes_beyond_the_reference or longest_leaf" -v 2>&1 | grep -E "PASSED|FAILED|ERROR|passed|failed|Fatal|Hostcall|fault|SUMMARY|ERROR: AddressSanitizer" | cut -c1-200 | tail -60
+  -k "(colliding or shared_merkle_levels_are_exact or merkle_and_fri or random_records_differential or shapes_beyond_the_reference or longest_leaf) and not witness" -v 2>&1 | grep -E "PASSED|FAILED|ERROR|passed|failed|Fatal|Hostcall|fault|SUMMARY|ERROR: AddressSanitizer" | cut -c1-200 | tail -60
 echo "   exit status ${PIPESTATUS[0]}"

@@ -47,7 +47,7 @@ def work(tid):
     try:
         while time.time() < stop_at and not errors:
             label, circuit, common, ci, packed, ch = cases[int(rng.integers(0, len(cases)))]
-            n = int(rng.choice([1, 7, 64, 257, 1024, 1500, 4096, 6000]))
+            n = int(rng.choice([1, 7, 64, 257, 600, 900, 1024, 1500, 4096, 6000]))
             batch, tampered = T.synthetic_batch(ci, packed, n, seed=int(rng.integers(0, 1 << 30)), tamper_every=int(rng.choice([2, 5, 16])))
             expect = (~tampered).astype(np.uint8)
             t = torch.from_numpy(batch.copy()).to(dev)
@@ -57,6 +57,7 @@ def work(tid):
             opt_shared, opt_form = int(rng.choice([0, 1, 2])), int(rng.choice([0, 1, 2, 3]))
             ctx.set_option(2, opt_shared)
             ctx.set_option(3, opt_form)  # GPV_OPT_FR_EVALUATION: by size / column scanning / operand scanning / four lanes per permutation
+            ctx.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, int(rng.choice([0, 0, 1, 2])))  # round 5: the leaf phase as one launch or two (the longest class alone)
             reps = int(rng.integers(2, 6))
             host_path = ch is None and rng.random() < 0.3  # gpv_verify on a host buffer: chunked upload, even / odd chunks on twin contexts
             pb = gpv.variables.ProofBatch(circuit, batch) if host_path else None
