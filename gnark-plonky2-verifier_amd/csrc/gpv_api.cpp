@@ -582,20 +582,27 @@ static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit*
 // of the device's SIMDs for the longest class alone (beyond it the SIMDs left over are too few for the other five classes: +2 % at 1536 `step` proofs,
 // -3 % at 2048), 15 / 16 for the two longest together -- they finish at different times, and the rest moves onto the SIMDs the shorter one vacates
 // (profiles/r05_longest_alone.txt).
-// Below about 550 proofs the same reasoning goes one step further: the longest class is hashed FOUR lanes per permutation, still one wave per SIMD
-// (k_merkle_leaves_quad_solo: 147 instead of 261 us per permutation for a wave that is alone), while its quads -- 4 x the waves -- still fit in
-// GPV_ALONE_MAX_SIMDS_QUAD_X16 / 16 of the SIMDs; and the full-length sibling walks (the four initial trees') run one wave per SIMD too while all of them
-// fit (merkle_walk_alone), the step trees' shorter walks beside them.
+// Below about 550 proofs the same reasoning goes further. The full-length sibling walks (the four initial trees') run one wave per SIMD too while all of them
+// fit in GPV_ALONE_MAX_SIMDS_WALK_X16 / 16 of the SIMDs, the step trees' shorter walks beside them. And while the longest class's QUADS -- 4 x the waves --
+// fit in GPV_ALONE_MAX_SIMDS_QUAD_X16 / 16 (about 150 .. 400 `step` proofs), it is hashed FOUR lanes per permutation, still one wave per SIMD
+// (k_merkle_leaves_quad_solo: 147 instead of 261 us per permutation for a wave that is alone), and every other class one wave per SIMD in the operand-scanning
+// form: 6.4 ms per call from 160 to 400 proofs (8.0 ms before; four lanes for EVERY path, the form of the smallest batches, takes 7.5 ms at 256 and wins
+// only below about 150: merkle_mixed_pays).
 #define GPV_ALONE_MAX_SIMDS_X16 11
 #define GPV_ALONE_MAX_SIMDS_2_X16 15
-#define GPV_ALONE_MAX_SIMDS_QUAD_X16 15
-#define GPV_ALONE_MAX_SIMDS_WALK_X16 15
+#define GPV_ALONE_MAX_SIMDS_QUAD_X16 11
+#define GPV_ALONE_MAX_SIMDS_WALK_X16 14
+// full-length lanes between 0.25 and 0.5 waves per SIMD, nothing forced, the second side stream available
+static bool merkle_mixed_pays(const gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
+  if (ctx->fr_form != 0 || ctx->merkle_longest_alone != 0 || !ctx->side_stream || c->dc.n_trees < 2 || c->dc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS) return false;
+  const size_t full = gpvk_full_paths(c->dc, n * c->dc.num_queries);
+  return gpvk_fr_quad_pays(full, 0) && 4 * full > (size_t)64 * gpvk_device_simds();
+}
 struct MerkleAlone {
   u32 leaf_mask;  // trees whose leaf digests run one wave per SIMD on the main stream (0: one launch for all trees)
   int leaf_shape; // GPV_SOLO_WIDE / GPV_SOLO_QUAD
   u32 walk_mask;  // trees whose sibling walks run one wave per SIMD (0: one launch)
 };
-static int xenv(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }  // EXPERIMENT
 static MerkleAlone merkle_alone(const gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
   const DevCircuit& d = c->dc;
   MerkleAlone r = {0, GPV_SOLO_NONE, 0};
@@ -613,7 +620,7 @@ static MerkleAlone merkle_alone(const gpv_ctx* ctx, const gpv_circuit* c, size_t
     if (ctx->merkle_longest_alone == 2) {
       r.leaf_mask = 1u << best_t;
       r.leaf_shape = GPV_SOLO_WIDE;
-    } else if (4 * waves <= simds * xenv("GPV_X_QUAD_X16", GPV_ALONE_MAX_SIMDS_QUAD_X16) / 16) {
+    } else if (4 * waves <= simds * GPV_ALONE_MAX_SIMDS_QUAD_X16 / 16) {
       r.leaf_mask = 1u << best_t;
       r.leaf_shape = GPV_SOLO_QUAD;
     } else if (waves <= simds * GPV_ALONE_MAX_SIMDS_X16 / 16) {
@@ -623,12 +630,12 @@ static MerkleAlone merkle_alone(const gpv_ctx* ctx, const gpv_circuit* c, size_t
     }
   }
   // ---- sibling walks: every tree whose walk has the full length, while all of them get a SIMD each
-  if (ctx->merkle_longest_alone == 0 && xenv("GPV_X_WALK", 1)) {
+  if (ctx->merkle_longest_alone == 0) {
     u32 longest = 0, k = 0, mask = 0;
     for (u32 t = 0; t < d.n_trees; t++) longest = gpvk_merkle_siblings(d, t) > longest ? gpvk_merkle_siblings(d, t) : longest;
     for (u32 t = 0; t < d.n_trees; t++)
       if (gpvk_merkle_siblings(d, t) == longest) { mask |= 1u << t; k++; }
-    if (longest >= 4 && k < d.n_trees && k * waves <= simds * xenv("GPV_X_WALK_X16", GPV_ALONE_MAX_SIMDS_WALK_X16) / 16) r.walk_mask = mask;
+    if (longest >= 4 && k < d.n_trees && k * waves <= simds * GPV_ALONE_MAX_SIMDS_WALK_X16 / 16) r.walk_mask = mask;
   }
   return r;
 }
@@ -685,12 +692,21 @@ static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* p
   HIP_TRY(ctx, hipEventRecord(ctx->ev_transcript, side));
   launch_range_check(ctx, main_st, c, dcd, proofs_dev, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_cleared, main_st));
+  // 150 .. 290 proofs: by its size the batch would take four lanes per permutation for every path; the mixed shapes of merkle_alone are faster there
+  // (6.3 ms flat against 6.4 .. 7.5), and they live in the operand-scanning regime
+  struct FormGuard {
+    gpv_ctx* c;
+    int saved;
+    ~FormGuard() { c->fr_form = saved; }
+  } form_guard{ctx, ctx->fr_form};
+  if (merkle_mixed_pays(ctx, c, n)) ctx->fr_form = 2;
   const MerkleAlone alone = merkle_alone(ctx, c, n);
   if (alone.leaf_mask) {  // the longest class on SIMDs of its own (main stream), the others beside it (second side stream); the walks wait for both
     launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n, alone.leaf_mask, alone.leaf_shape);
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));  // the visit counters are cleared
     gpvk_head_start(ctx->side2, 20);  // the main stream's waves are placed first: they need EMPTY SIMDs (10 us suffice; without it the long class ends at 6.9 ms instead of 4.3)
-    gpvk_merkle_leaves(ctx->side2, dcd, c->dc, (const u64*)proofs_dev, n, ctx->digests, verdict_of(ctx), ctx->fr_form, ~alone.leaf_mask, GPV_SOLO_NONE);
+    gpvk_merkle_leaves(ctx->side2, dcd, c->dc, (const u64*)proofs_dev, n, ctx->digests, verdict_of(ctx), ctx->fr_form, ~alone.leaf_mask,
+                       alone.leaf_shape == GPV_SOLO_QUAD ? GPV_SOLO_WIDE : GPV_SOLO_NONE);  // so few waves that every one of them gets a SIMD: two 10-permutation waves on one SIMD would be the pole
     HIP_TRY(ctx, hipEventRecord(ctx->ev_side2_done, ctx->side2));
     HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->ev_side2_done, 0));
   } else {

@@ -270,20 +270,27 @@ def test_longest_leaf_class_alone_is_identical(gpv, api, orc, name):
         api.set_option(gpv._lib.OPT_FR_EVALUATION, 0)
         api.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 0)
         api.set_option(2, 1)
-    # by size: 700 proofs -> the operand-scanning kernels, the two longest classes alone (350 + 350 waves beside the other four classes)
-    n = 700
-    batch, tampered = T.synthetic_batch(ci, packed, n, seed=31, tamper_every=5)
-    pbn = gpv.variables.ProofBatch(circuit, batch)
-    acc0, mask0, ch0 = vchip.Verify(pbn, vo, detail=True)
-    api.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 1)
-    try:
-        acc1, mask1, ch1 = vchip.Verify(pbn, vo, detail=True)
-    finally:
-        api.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 0)
-    assert acc0.tolist() == (~tampered).astype(np.uint8).tolist() == acc1.tolist() and (mask0 == mask1).all() and (np.asarray(ch0.flat) == np.asarray(ch1.flat)).all()
-    sample = slice(0, 48)
-    oacc, ofail, _ = orc.verify(oc, batch[sample], n_threads=8)
-    assert acc0[sample].tolist() == oacc.tolist() and mask0[sample].tolist() == T.reported_mask(ofail).tolist()
+    # by size (csrc/gpv_api.cpp merkle_alone / merkle_mixed_pays):
+    #   200 proofs: the longest class four lanes per permutation and one wave per SIMD, every other class and the full-length walks one wave per SIMD
+    #   450: the two longest classes one wave per SIMD (operand scanning), the full-length walks too
+    #   700: the two longest classes one wave per SIMD, one launch for the walks (shared upper levels from 512 proofs)
+    for n in (200, 450, 700):
+        batch, tampered = T.synthetic_batch(ci, packed, n, seed=31 + n, tamper_every=5)
+        words = batch.view(np.uint64).reshape(n, -1)
+        for i in range(0, n, 7):   # besides the tampered query words: a flipped bit in one sibling hash of every seventh record (the walks must catch it)
+            words[i, n_gl + 4 * f0 + int(rng.integers(0, 4 * ci.num_query_rounds * qfr))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 60)))
+        pbn = gpv.variables.ProofBatch(circuit, batch)
+        acc0, mask0, ch0 = vchip.Verify(pbn, vo, detail=True)
+        api.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 1)
+        try:
+            acc1, mask1, ch1 = vchip.Verify(pbn, vo, detail=True)
+        finally:
+            api.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 0)
+        assert acc0.tolist() == acc1.tolist() and (mask0 == mask1).all() and (np.asarray(ch0.flat) == np.asarray(ch1.flat)).all(), n
+        assert not acc0[tampered].any() and not acc0[::7].any() and acc0.sum() > n // 2, n
+        sample = slice(0, 56)
+        oacc, ofail, _ = orc.verify(oc, batch[sample], n_threads=8)
+        assert acc0[sample].tolist() == oacc.tolist() and mask0[sample].tolist() == T.reported_mask(ofail).tolist(), n
 
 
 # ---------------------------------------------------------------- gates (plonk/gates/gates_test.go:712-768)
@@ -1790,6 +1797,18 @@ def _verdict_is_fail_closed(gpv, api, orc, shared):
                 assert 0.3 * n <= hit.sum() <= 0.7 * n, (name, int(hit.sum()))           # half a grid, about half of the proofs
             acc, mask, _ch = chip.Verify(pb, vo, detail=True)                            # and the next run is clean again
             assert acc.tolist() == [1] * n and not mask.any(), name
+        # at this batch size both Merkle phases run as TWO launches each by default (csrc/gpv_api.cpp merkle_alone): one of the two skipped -- every
+        # proof misses that launch's trees
+        for stage in (5, 6):
+            for nth in (0, 1):
+                _set_fault(gpv, stage, nth, 0, 1)
+                try:
+                    acc, mask, _ch = chip.Verify(pb, vo, detail=True)
+                finally:
+                    _set_fault(gpv, 0)
+                assert not acc.any() and ((mask & T.FAIL_INCOMPLETE) != 0).all(), (stage, nth)
+        acc, mask, _ch = chip.Verify(pb, vo, detail=True)
+        assert acc.tolist() == [1] * n and not mask.any()
         # the leaf phase as two launches (the longest class alone on the main stream, the others on a second one; forced, with the operand-scanning
         # kernels): half of BOTH grids, and both launches skipped, must reject exactly the proofs concerned
         api.set_option(gpv._lib.OPT_FR_EVALUATION, 2)
