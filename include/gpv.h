@@ -146,10 +146,12 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
  * GPV_OPT_WITNESS_STAGING: how the witness generator's kernels (gpv_witness_*) write their traces: 0 (default) = staged through LDS and written
  * out by the wave in whole 128-byte lines when the launch is large enough to hide the flushes, straight to memory otherwise; 1 = always staged,
  * 2 = never. Identical traces.
- * GPV_OPT_MERKLE_LONGEST_ALONE: the leaf digests of the tree with the longest leaves (the wires oracle: 16 dependent permutations per leaf for the fixtures) by
- * waves that take a SIMD each, beside the other trees' launch on a second stream, instead of one launch for all trees -- mid-size batches are bound by those
- * chains. 0 (default) = when the operand-scanning kernels run and that tree has no more waves than the device has SIMDs (about 290 .. 2 300 `step` proofs on an
- * MI355X), 1 = never, 2 = whenever the operand-scanning kernels run. Identical verdicts.
+ * GPV_OPT_MERKLE_LONGEST_ALONE: the launch shapes of the Merkle phases for batches that do not fill the chip. Such a batch waits for its longest dependent
+ * chains (the 16 permutations of a wires leaf, then the sibling walk), and inside one launch for all trees those waves share their SIMD with a stream of
+ * short ones at half their speed. 0 (default) = by size: the tree with the longest leaves (and the second longest while both fit) is hashed by waves that
+ * take a SIMD each beside the other trees' launch on a second stream (about 150 .. 1 600 `step` proofs on an MI355X; below about 400 four lanes per
+ * permutation for that tree and a SIMD per wave for every tree), and up to 512 proofs the full-length sibling walks likewise; 1 = never (one launch per
+ * phase); 2 = the longest tree alone whenever the operand-scanning kernels run. Identical verdicts.
  * GPV_OPT_HOST_CHUNK_FIRST / GPV_OPT_HOST_CHUNK_MAX: gpv_verify uploads a host batch in chunks of first, first, 2 first, 4 first, ...
  * proofs capped at max and verifies them as they arrive, two in flight (defaults 1024 / 8192; 1 .. 2^24). */
 enum { GPV_OPT_TRANSCRIPT_VARIANT = 1, GPV_OPT_MERKLE_SHARED_LEVELS = 2, GPV_OPT_FR_EVALUATION = 3, GPV_OPT_HOST_CHUNK_FIRST = 4,
