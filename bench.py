@@ -414,7 +414,10 @@ def main():
                    "merkle_shared_levels": "off: every path hashed on its own" if args.per_path_merkle else "on (default): the last 3 levels of each tree hashed once per distinct node, inputs compared "
                                            "word for word; accept bits identical to the per-path walk (GPV_OPT_MERKLE_SHARED_LEVELS)",
                    "bn254_fr_rows": "chosen per launch by occupancy (GPV_OPT_FR_EVALUATION = 0): waves per SIMD of full-length lanes (4 Merkle paths per query round) >= 4.5 "
-                                    "column scanning (this workload from ~2600 proofs per GPU up), <= 0.5 four lanes per permutation (about 290 proofs), operand scanning in between; identical results"},
+                                    "column scanning (this workload from ~2600 proofs per GPU up), <= 0.5 four lanes per permutation (about 290 proofs), operand scanning in between; identical results",
+                   "merkle_launch_shapes": "one launch per phase at this batch size; below ~1600 proofs per GPU the longest tree class (below ~512 also the full-length sibling walks) run as waves "
+                                           "that take a SIMD each beside the other trees' launch on a second stream (GPV_OPT_MERKLE_LONGEST_ALONE = 0, DESIGN.md section 3; the "
+                                           "mid_size_batches leg measures it against one launch per phase)"},
     }
     # ---- what RCCL itself observed: rank count, version and the image libgpv bound, from gpv_group_comm_info of the
     # group that ran the timed steps; a fallback to the torch exchange is a top-level key, and fatal under --strict-exchange

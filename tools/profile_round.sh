@@ -9,7 +9,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="python $ROOT/bench.py --no-cpu-baseline --no-heterogeneous --no-poseidon-gl-config --no-poseidon-gl --no-config-legs --no-clock-sample"
+B="python $ROOT/bench.py --no-cpu-baseline --no-heterogeneous --no-poseidon-gl-config --no-poseidon-gl --no-config-legs --no-clock-sample --no-exchange-probe"
 summ() { db=$(find $1 -name '*_results.db' | head -1); [ -n "$db" ] && python $ROOT/tools/rocprof_summary.py $db ${2:-}; }
 cd /tmp
 ( echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 <headline step only>   (MI355X, $TAG)"
