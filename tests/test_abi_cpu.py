@@ -110,6 +110,32 @@ def test_go_shim_call_sites_match_the_header(tmp_path):
         assert any(expect in p for p in problems), (new, problems)
 
 
+def test_solo_kernels_take_a_simd_each():
+    """The launch shapes of mid-size batches rest on a property of the COMPILED kernels, not of the source: a wave of a `_solo` kernel must be
+    allocated so many registers that no hashing wave (>= 140) and no k_plonk / k_fri_query / k_transcript wave (128) fits beside it on a SIMD of 512, while the
+    cooperative transcript's (80) still does. Read from the code object of the built library's translation unit; a toolchain that allocates differently fails here
+    instead of silently running the long chains at half speed."""
+    import subprocess
+    csrc = T.ROOT / "gnark-plonky2-verifier_amd" / "csrc"
+
+    def vgprs(obj):
+        out = subprocess.run(["bash", str(T.ROOT / "tools" / "kernel_info.sh"), str(csrc / obj)], capture_output=True, text=True, check=True).stdout
+        d = {}
+        for line in out.splitlines():
+            f = line.split()
+            d[f[0]] = int(f[1].split("=")[1])
+        return d
+
+    bn, tr = vgprs("gpv_k_bn254.o"), vgprs("gpv_k_transcript.o")
+    solo = {k: v for k, v in bn.items() if "_solo" in k}
+    assert len(solo) == 4, sorted(solo)   # leaves wide / quad, climb wide, climb lower wide
+    others = [v for k, v in bn.items() if "k_merkle" in k and "_solo" not in k and "_gl" not in k]
+    coop = next(v for k, v in tr.items() if "k_transcript_coop" in k)
+    for k, v in solo.items():
+        assert v + 128 > 512 and v + min(others) > 512, (k, v)     # nothing that hashes, nothing of the side stream's big kernels
+        assert v + coop <= 512, (k, v, coop)                        # the cooperative transcript rides along
+
+
 def test_no_cpu_fallback(gpv):
     with pytest.raises(gpv.DeviceError):
         gpv.Context(0)
