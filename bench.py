@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the accept all-gather even at world size 1 (test hook)")
     ap.add_argument("--strict-exchange", action="store_true", help="exit non-zero instead of falling back to the torch.distributed exchange when the C-ABI group cannot be formed on every rank "
                     "(the JSON line is still printed, with exchange_fallback = true)")
+    ap.add_argument("--lib", default=None, help="measurement only: load this build of libgpv (an experiment build under tools/probe/) instead of the package's; the line says so")
     ap.add_argument("--no-exchange-probe", action="store_true", help="N = 1 only: skip the world-1 group leg that runs the RCCL all-gather of the accept bits once per step and reports its cost")
     args = ap.parse_args()
 
@@ -219,6 +220,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     import gpv_testlib as T
     gpv = importlib.import_module("gnark-plonky2-verifier_amd")
+    if args.lib:
+        gpv._lib.LIB_PATH = Path(args.lib).resolve()
     D = importlib.import_module("gnark-plonky2-verifier_amd.distributed")
 
     # ---- contexts: a plain context (single GPU / torch exchange) or the ranks of a gpv_group (C-ABI exchange)
@@ -406,6 +409,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u32-limb integer (BN254 Fr Montgomery, Goldilocks u64)",
+        **({"library_override": str(args.lib)} if args.lib else {}),
         "data": "synthetic: %d packed copies of testdata/%s per GPU, 1 in 16 tampered (splitmix64), resident in HBM" % (n_local, args.fixture),
         "config": {"workload": "verifier.VerifierChip.Verify end-to-end (BASELINE config 4 shard)", "fixture": args.fixture,
                    "proofs_per_gpu": n_local, "global_batch": n_total, "queries_per_proof": ci.num_query_rounds,
@@ -413,8 +417,8 @@ def main():
                    "collective": collective, "side_stream": "off (--no-side-stream): every kernel alone on one stream" if args.no_side_stream else "on (default)",
                    "merkle_shared_levels": "off: every path hashed on its own" if args.per_path_merkle else "on (default): the last 3 levels of each tree hashed once per distinct node, inputs compared "
                                            "word for word; accept bits identical to the per-path walk (GPV_OPT_MERKLE_SHARED_LEVELS)",
-                   "bn254_fr_rows": "chosen per launch by occupancy (GPV_OPT_FR_EVALUATION = 0): waves per SIMD of full-length lanes (4 Merkle paths per query round) >= 4.5 "
-                                    "column scanning (this workload from ~2600 proofs per GPU up), <= 0.5 four lanes per permutation (about 290 proofs), operand scanning in between; identical results",
+                   "bn254_fr_rows": "chosen per launch by occupancy (GPV_OPT_FR_EVALUATION = 0): waves per SIMD of full-length lanes (4 Merkle paths per query round) >= 7 "
+                                    "column scanning (this workload from 4096 proofs per GPU up), <= 0.5 four lanes per permutation (about 290 proofs), operand scanning in between; identical results",
                    "merkle_launch_shapes": "one launch per phase at this batch size; below ~1600 proofs per GPU the longest tree class (below ~512 also the full-length sibling walks) run as waves "
                                            "that take a SIMD each beside the other trees' launch on a second stream (GPV_OPT_MERKLE_LONGEST_ALONE = 0, DESIGN.md section 3; the "
                                            "mid_size_batches leg measures it against one launch per phase)"},

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(GPV_MERKLE_BLOCK) void k_merkle_leaves_wide(const D
   merkle_leaves_body<HashBNWide>(dc, proofs, n, order, digests, v);
 }
 // The same kernel with a SIMD to itself (round 5). A wave of this kernel is allocated 424 of a SIMD's 512 registers (the accumulator register touched
-// below): no second wave of a hashing kernel can be resident beside it, nor one of k_plonk / k_fri_query (128 each) -- only the cooperative transcript's
+// below): no second wave of a hashing kernel can be resident beside it, nor one of k_plonk / k_fri_query (128 / 271) -- only the cooperative transcript's
 // (80: latency-bound waves that issue little). For the LONGEST tree
 // class of a mid-size batch: its waves are the critical chain of the leaf phase (16 dependent permutations for a `step` wires leaf), and as part of the
 // common launch each of them shares its SIMD with a stream of short waves for its whole life, at half its speed (two resident waves: 495 us per permutation
@@ -411,7 +411,7 @@ void gpvk_merkle_leaves(hipStream_t st, const DevCircuit* dcd, const DevCircuit&
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), nt), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs, n,
                 ord, digests, v);
-  else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form))
+  else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form, GPV_FR_CHAIN_MIN_WAVES_X2_MERKLE))
     GPVK_LAUNCH_STAGE(GPV_STAGE_LEAVES, k_merkle_leaves, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, n,
                 ord, digests, v);
   else if (solo)
@@ -434,7 +434,7 @@ void gpvk_head_start(hipStream_t st, u32 microseconds) { GPVK_LAUNCH(k_head_star
 // the question of giving the longest class SIMDs of its own arise (gpv_api.cpp)
 bool gpvk_merkle_leaves_wide(const DevCircuit& hc, size_t n, int form) {
   const size_t full = gpvk_full_paths(hc, n * hc.num_queries);
-  return hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && !gpvk_fr_quad_pays(full, form) && !gpvk_fr_chain_pays(full, form);
+  return hc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS && !gpvk_fr_quad_pays(full, form) && !gpvk_fr_chain_pays(full, form, GPV_FR_CHAIN_MIN_WAVES_X2_MERKLE);
 }
 void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& hc, const u64* proofs, const u64* derived, size_t n,
                        const u32* digests, Verdict v, uint8_t* ok_out, int form, u32 tree_mask, bool solo) {
@@ -455,7 +455,7 @@ void gpvk_merkle_climb(hipStream_t st, const DevCircuit* dcd, const DevCircuit& 
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), nt_all), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd, proofs,
                 derived, n, ord_all, digests, v, ok_out);
-  else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form))
+  else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form, GPV_FR_CHAIN_MIN_WAVES_X2_MERKLE))
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt_all), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs, derived, n,
                 ord_all, digests, v, ok_out);
   else
@@ -476,7 +476,7 @@ void gpvk_merkle_climb_lower(hipStream_t st, const DevCircuit* dcd, const DevCir
   if (hc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS)
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower_gl, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK_GL), nt), dim3(GPV_MERKLE_BLOCK_GL), 0, st, dcd,
                 proofs, derived, n, ord, digests, mid, crown_levels, v);
-  else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form))
+  else if (gpvk_fr_chain_pays(gpvk_full_paths(hc, items), form, GPV_FR_CHAIN_MIN_WAVES_X2_MERKLE))
     GPVK_LAUNCH_STAGE(GPV_STAGE_CLIMB, k_merkle_climb_lower, dim3(gpvk_blocks_for(items, GPV_MERKLE_BLOCK), nt), dim3(GPV_MERKLE_BLOCK), 0, st, dcd, proofs,
                 derived, n, ord, digests, mid, crown_levels, v);
   else

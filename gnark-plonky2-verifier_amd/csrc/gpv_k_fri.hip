@@ -20,12 +20,12 @@ GPV_DEV void fri_query_body(const DevCircuit* __restrict__ dc, const u64* __rest
   if (f) atomicOr(&v.fail[p], f);
   atomicAdd(&v.done[p * GPV_DONE_STRIDE + GPV_DONE_FRI], 1u);
 }
-__global__ __launch_bounds__(64) GPVK_SIDE_STREAM_KERNEL void k_fri_query(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+__global__ __launch_bounds__(64) void k_fri_query(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                   const u64* __restrict__ derived, size_t n, Verdict v) {
   fri_query_body<false>(dc, proofs, derived, n, v);
 }
 // circuits with an arity-32 reduction step (beyond the reference)
-__global__ __launch_bounds__(64) GPVK_SIDE_STREAM_KERNEL void k_fri_query_a32(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+__global__ __launch_bounds__(64) GPVK_SIDE_STREAM_128 void k_fri_query_a32(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                       const u64* __restrict__ derived, size_t n, Verdict v) {
   fri_query_body<true>(dc, proofs, derived, n, v);
 }

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(GPV_PLONK_BLOCK) void k_gate_eval_unfiltered(DevGat
   gate_eval_unfiltered(g, v, weights, lds + threadIdx.x, GPV_PLONK_BLOCK, sink);
 }
 
-__global__ __launch_bounds__(GPV_PLONK_BLOCK) GPVK_SIDE_STREAM_KERNEL void k_plonk(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
+__global__ __launch_bounds__(GPV_PLONK_BLOCK) GPVK_SIDE_STREAM_128 void k_plonk(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs,
                                                            const u64* __restrict__ derived, size_t n, Verdict v) {
   extern __shared__ u64 lds[];  // GPV_PLONK_BLOCK x plonk_lds_words_per_lane(circuit) words
   gpvk_side_stream_priority();

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(GPV_RANGE_BLOCK) void k_range_check(const DevCircui
     if (any_bad) atomicOr(&v.fail[p], (u32)GPV_FAIL_RANGE);
   }
 }
-__global__ __launch_bounds__(64) GPVK_SIDE_STREAM_KERNEL void k_transcript(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
+__global__ __launch_bounds__(64) void k_transcript(const DevCircuit* __restrict__ dc, const u64* __restrict__ proofs, size_t n,
                                                    u64* __restrict__ derived, Verdict v) {
   gpvk_side_stream_priority();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -65,7 +65,16 @@ unsigned gpvk_fault_blocks(int stage, unsigned blocks);
 // Merkle kernels next to them on the same SIMDs issue a VALU instruction in every slot. Raising the wave's issue priority
 // lets the side-stream wave take a slot whenever its next instruction is ready, so its latency-bound critical path stays
 // hidden under the hashing instead of being stretched by the round-robin share (s_setprio: 0 = default .. 3 = highest).
-#define GPVK_SIDE_STREAM_KERNEL __attribute__((amdgpu_waves_per_eu(4, 4)))
+// GPVK_SIDE_STREAM_128: a 128-register allocation, so that a wave fits beside three column-scanning hashing waves (126 each). Round 5: only k_plonk
+// (and the arity-32 FRI kernel) keep it. k_transcript (152 registers, no spills) and k_fri_query (271) are compiled without: a capped one-lane-per-proof
+// transcript wave shares its SIMD with THREE hashing waves for ~10 ms at raised priority and makes them the stragglers of the leaf phase (4096 proofs:
+// 38.6 -> 36.0 ms without the cap); uncapped waves take the room of two, and the FRI waves wait for SIMDs that drain -- the phase's idle tail
+// (-1 % from 2048 to 8192 proofs; profiles/r05_side_uncapped.txt). `make sideuncapped` builds all of them without the cap.
+#ifdef GPV_X_SIDE_UNCAPPED
+#define GPVK_SIDE_STREAM_128
+#else
+#define GPVK_SIDE_STREAM_128 __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 #if defined(__HIPCC__)
 __device__ __forceinline__ void gpvk_side_stream_priority() { __builtin_amdgcn_s_setprio(3); }
 #endif
@@ -80,12 +89,16 @@ __device__ __forceinline__ void gpvk_side_stream_priority() { __builtin_amdgcn_s
 // (profiles/r04_form_crossover.txt, first table; the second table is this rule).
 //   four lanes per permutation   w <= 0.5   (the quads then put two waves on a SIMD; `step`, `decode_block` and the 12-tree geometry all
 //                                            cross over between 256 and 320 proofs = 0.44 .. 0.55)
-//   column scanning (FrChain)    w >= 4.5   (it needs four resident waves per SIMD to hide its serial chain; measured crossovers 2048 .. 3072
-//                                            proofs on both geometries = 3.5 .. 5.25; round 3 switched at 8.0, i.e. 4681 `step` proofs,
-//                                            which left 0.7 - 1.6 % at 3072 - 4096 proofs)
+//   column scanning (FrChain)    w >= 7.0 for the Merkle launches, 4.5 for the primitives (equal lanes)  (it needs four resident waves per SIMD to hide its serial chain, and below ~7 waves of full-length
+//                                            lanes per SIMD the classes no longer fill the slots in homogeneous generations: the long waves end
+//                                            up with one or two partners, where this form is at 62 - 80 % of its rate. Round 5, both fixtures
+//                                            (profiles/r05_form_crossover_whole.txt): operand scanning is 12 % faster at 2816 proofs, 3 - 5 % at
+//                                            3072 - 3328, 2 % at 3840, equal at 3584, 0.6 % slower at 4096 = 7.0. Round 4 switched at 4.5, measured
+//                                            on the Merkle phases alone; round 3 at 8.0)
 //   operand scanning (FrWide)    in between.
 // The shared-level kernels (one hash per lane over a compacted node list) keep the threshold measured for them in round 2: 12 waves per SIMD.
-#define GPV_FR_CHAIN_MIN_WAVES_X2 9         // 4.5 waves per SIMD, in halves
+#define GPV_FR_CHAIN_MIN_WAVES_X2 9         // primitives (equal lanes): 4.5 waves per SIMD, in halves
+#define GPV_FR_CHAIN_MIN_WAVES_X2_MERKLE 14  // Merkle launches (classes of different chain lengths): 7.0
 #define GPV_FR_QUAD_MAX_WAVES_X2 1          // 0.5
 #define GPV_FR_CHAIN_MIN_WAVES_X2_NODES 24  // k_crown_level: 12
 unsigned gpvk_device_simds();  // SIMDs of the CURRENT device (gpv_api.cpp; cached per device ordinal)

@@ -7,6 +7,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import gpv_testlib as T
 gpv = importlib.import_module("gnark-plonky2-verifier_amd")
+if "--lib" in sys.argv:  # an experiment build (tools/probe/libgpv_*.so)
+    gpv._lib.LIB_PATH = Path(sys.argv.pop(sys.argv.index("--lib") + 1)).resolve(); sys.argv.remove("--lib")
 n = int(sys.argv[1]); mode = int(sys.argv[2])
 ctx = gpv.Context(0)
 if len(sys.argv) > 3: ctx.set_stream(torch.cuda.current_stream().cuda_stream)
