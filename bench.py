@@ -562,6 +562,7 @@ def main():
             line["full_batch_65536"] = bench_full_batch(gpv, T, ctx, dev, args.fixture)
             line["single_proof"] = bench_single_proof(gpv, T, ctx, dev)
             line["mid_size_batches"] = bench_mid_size(gpv, T, ctx, wl, dev)
+            line["batches_in_flight"] = bench_in_flight(gpv, T, wl, dev)
             line["witness_verify_1024"] = bench_witness(gpv, T, ctx, dev)
             line["witness_verify_4096"] = bench_witness(gpv, T, ctx, dev, 4096)  # 44 GB of trace: the store-bound regime (docs/DESIGN_HISTORY.md section 3, "the trace cursor")
         if not args.no_poseidon_gl:
@@ -752,6 +753,46 @@ def bench_mid_size(gpv, T, ctx, wl, dev, sizes=(512, 1024, 2048, 4096)):
         ctx.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 0)
         out[str(n)] = row
     out["entry_point"] = "gpv_verify_dev, records resident in HBM, every call synchronised; accept == tamper mask"
+    return out
+
+
+def bench_in_flight(gpv, T, wl, dev, sizes=(512, 1024, 2048, 4096), ks=(1, 2, 3)):
+    """A STREAM of mid-size batches: k of them in flight, each on a context of its own (gpv.verifier.VerifierChipsInFlight), against one at a time --
+    the idle SIMDs of one batch's dependent hand-offs (leaves -> walk -> three shared levels) are filled by the next batch's kernels. Proofs/s over
+    24 batches of the line's fixture (1 in 16 tampered); every batch's accept vector is checked."""
+    out = {}
+    kmax = max(ks)
+    for n in sizes:
+        total = n * kmax
+        batch, tam = wl.cloned_batch(0, total, total)
+        expect = (~tam).astype(np.uint8)
+        acc = torch.zeros(total, dtype=torch.uint8, device=dev)
+        rec = wl.circuit.proof_nbytes
+        row = {}
+        for k in ks:
+            flight = gpv.verifier.VerifierChipsInFlight(wl.common, k=k, device_id=dev.index or 0)
+            try:
+                def sweep(rounds):
+                    for _ in range(rounds):
+                        for j in range(k):
+                            flight.VerifyDevice(wl.circuit, batch.data_ptr() + j * n * rec, n, acc.data_ptr() + j * n)
+                    flight.wait()
+                acc.zero_()
+                torch.cuda.synchronize()
+                sweep(2)
+                rounds = 24 // k
+                t0 = time.perf_counter()
+                sweep(rounds)
+                dt = time.perf_counter() - t0
+                if not (acc[:k * n].cpu().numpy() == expect[:k * n]).all():
+                    raise SystemExit("batches_in_flight: accept vector mismatch at n = %d, k = %d" % (n, k))
+                row["k%d_proofs_per_s" % k] = rounds * k * n / dt
+            finally:
+                flight.close()
+        out[str(n)] = row
+    out["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")
+    out["entry_point"] = ("gpv_verify_dev on k contexts round-robin (VerifierChipsInFlight), records resident in HBM, a context is synchronised only before it is reused; "
+                          "accept == tamper mask for every batch. Not the bench `value` (one 8192-proof batch at a time)")
     return out
 
 

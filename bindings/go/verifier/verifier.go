@@ -101,5 +101,63 @@ func (c *VerifierChip) VerifyWithChallengesDevice(circuit *gpv.Circuit, proofsDe
 	c.ctx.VerifyWithChallengesDev(circuit, proofsDev, challengesDev, n, acceptDev)
 }
 
+// VerifierChipsInFlight: a stream of device-resident batches with up to k of them in flight, each on a VerifierChip / context (= three streams)
+// of its own, so that the idle SIMDs of one batch's dependent hand-offs (leaf digests -> sibling walk -> three shared levels) are filled by the
+// next batch's kernels: batches of 1024 `step` proofs run at 87 000 proofs/s one at a time, 100 000 with two in flight (profiles/r05_in_flight.txt).
+// No counterpart in the reference; the verdicts are VerifyDevice's. With more than two in flight export GPU_MAX_HW_QUEUES=8 before the process
+// first touches HIP. Same type as the Python and C++ mirrors' (verifier.py, host/gpv.hpp).
+type VerifierChipsInFlight struct {
+	contexts []*gpv.Context
+	chips    []*VerifierChip
+	busy     []bool
+	next     int
+}
+
+func NewVerifierChipsInFlight(commonCircuitData types.CommonCircuitData, k int, device int) *VerifierChipsInFlight {
+	if k < 1 {
+		panic("VerifierChipsInFlight: k must be at least 1")
+	}
+	f := &VerifierChipsInFlight{busy: make([]bool, k)}
+	for j := 0; j < k; j++ {
+		ctx := gpv.NewContext(device)
+		f.contexts = append(f.contexts, ctx)
+		f.chips = append(f.chips, NewVerifierChip(ctx, commonCircuitData))
+	}
+	return f
+}
+
+// VerifyDevice enqueues one batch on the least recently used context (after that context's previous batch, so at most k are in flight) and
+// returns its ticket for Wait. The buffers must stay untouched until then.
+func (f *VerifierChipsInFlight) VerifyDevice(circuit *gpv.Circuit, proofsDev unsafe.Pointer, n int, acceptDev unsafe.Pointer) int {
+	j := f.next
+	if f.busy[j] {
+		f.contexts[j].Synchronize()
+	}
+	f.chips[j].VerifyDevice(circuit, proofsDev, n, acceptDev)
+	f.busy[j] = true
+	f.next = (j + 1) % len(f.chips)
+	return j
+}
+
+// Wait returns when the batch with this ticket has its accept vector in place; WaitAll, when every batch has.
+func (f *VerifierChipsInFlight) Wait(ticket int) {
+	if f.busy[ticket] {
+		f.contexts[ticket].Synchronize()
+		f.busy[ticket] = false
+	}
+}
+func (f *VerifierChipsInFlight) WaitAll() {
+	for j := range f.chips {
+		f.Wait(j)
+	}
+}
+func (f *VerifierChipsInFlight) Close() {
+	f.WaitAll()
+	for _, ctx := range f.contexts {
+		ctx.Close()
+	}
+	f.contexts, f.chips = nil, nil
+}
+
 // VerifyGroup: the batch sharded over the GPUs of a gpv.Group (contiguous blocks, one RCCL all-gather of the packed accept bits).
 func VerifyGroup(g *gpv.Group, proof variables.Proof) []bool { return g.Verify(proof.Circuit, proof.Packed, proof.N) }

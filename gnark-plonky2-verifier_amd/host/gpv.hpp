@@ -556,6 +556,38 @@ class VerifierChip {
   gpv::Api& api_;
   const gpv::Circuit& c_;
 };
+// A stream of device-resident batches with up to k of them in flight, each on a context (= three streams) of its own: the idle SIMDs of one
+// batch's dependent hand-offs (leaf digests -> sibling walk -> three shared levels) are filled by the next batch's kernels -- batches of 1024
+// `step` proofs: 87 000 proofs/s one at a time, 100 000 with two in flight (profiles/r05_in_flight.txt). No counterpart in the reference; the
+// verdicts are VerifierChip::VerifyDevice's. With more than two in flight export GPU_MAX_HW_QUEUES=8 before the process first touches HIP
+// (streams that share a hardware queue run in order; the runtime's default is 4 queues).
+class VerifierChipsInFlight {
+ public:
+  VerifierChipsInFlight(const gpv::Circuit& c, size_t k = 3, int device = 0) : c_(c), busy_(k, false) {
+    if (k == 0) throw gpv::Error(GPV_EINVAL, "VerifierChipsInFlight: k must be at least 1");
+    apis_.reserve(k);
+    for (size_t j = 0; j < k; j++) apis_.emplace_back(device);
+  }
+  // enqueue one batch on the least recently used context (after that context's previous batch); returns its ticket
+  size_t VerifyDevice(const void* proofs_dev, size_t n, uint8_t* accept_dev) {
+    const size_t j = next_;
+    if (busy_[j]) apis_[j].synchronize();
+    gpv::check(gpv_verify_dev(apis_[j].h(), c_.h(), proofs_dev, n, accept_dev), apis_[j].h());
+    busy_[j] = true;
+    next_ = (j + 1) % apis_.size();
+    return j;
+  }
+  void Wait(size_t ticket) {
+    if (ticket < busy_.size() && busy_[ticket]) { apis_[ticket].synchronize(); busy_[ticket] = false; }
+  }
+  void WaitAll() { for (size_t j = 0; j < busy_.size(); j++) Wait(j); }
+  size_t size() const { return apis_.size(); }
+ private:
+  const gpv::Circuit& c_;
+  std::vector<gpv::Api> apis_;
+  std::vector<bool> busy_;
+  size_t next_ = 0;
+};
 }  // namespace verifier
 
 // Multi-GPU: a proof batch sharded over the GPUs of one node (include/gpv.h gpv_group_*). The reference has no

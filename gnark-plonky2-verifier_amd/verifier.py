@@ -132,5 +132,47 @@ class VerifierChip:
         _lib.check(_lib.lib().gpv_verify_dev(self.ctx.h, circuit.h, _lib.ptr(proofs_dev_ptr), n, _lib.ptr(accept_dev_ptr)), self.ctx.h)
 
 
+class VerifierChipsInFlight:
+    """A stream of device-resident batches with up to `k` of them in flight, each on a VerifierChip / context (= three streams) of its own.
+    One batch is a chain of dependent launches -- leaf digests, sibling walk, three shared levels -- and each hand-off leaves SIMDs idle while
+    its last waves finish; the next batch's kernels fill them. One MI355X, `step` proofs, batches of 1024: 87 000 proofs/s one at a time,
+    100 000 with two in flight, 102 600 with three (2048: 102 500 / 110 500 / 112 800; profiles/r05_in_flight.txt). The reference has no
+    counterpart (it verifies one proof inside one circuit); same verdicts as VerifierChip.VerifyDevice, batch for batch.
+    The HIP runtime spreads streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and streams on one queue run in order: with more
+    than two batches in flight export GPU_MAX_HW_QUEUES=8 before the process first touches HIP."""
+
+    def __init__(self, commonCircuitData, k=3, device_id=0):
+        if k < 1:
+            raise ValueError("k must be at least 1")
+        self.contexts = [_lib.Context(device_id) for _ in range(k)]
+        self.chips = [VerifierChip(c, commonCircuitData) for c in self.contexts]
+        self._busy = [False] * k
+        self._next = 0
+
+    def VerifyDevice(self, circuit, proofs_dev_ptr, n, accept_dev_ptr):
+        """Enqueue one batch on the least recently used context (waiting for that context's previous batch first, so at most k are in
+        flight) and return its ticket for wait(). The buffers must stay untouched until then."""
+        j = self._next
+        if self._busy[j]:
+            self.contexts[j].synchronize()
+        self.chips[j].VerifyDevice(circuit, proofs_dev_ptr, n, accept_dev_ptr)
+        self._busy[j] = True
+        self._next = (j + 1) % len(self.chips)
+        return j
+
+    def wait(self, ticket=None):
+        """Until the batch with this ticket (every batch when None) has its accept vector in place."""
+        for j in (range(len(self.chips)) if ticket is None else (ticket,)):
+            if self._busy[j]:
+                self.contexts[j].synchronize()
+                self._busy[j] = False
+
+    def close(self):
+        self.wait()
+        for c in self.contexts:
+            c.close()
+        self.contexts, self.chips = [], []
+
+
 def NewVerifierChip(api=None, commonCircuitData=None):  # verifier.go:24
     return VerifierChip(api, commonCircuitData)

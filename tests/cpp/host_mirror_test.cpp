@@ -8,6 +8,13 @@
 
 #include "../../gnark-plonky2-verifier_amd/host/gpv.hpp"
 
+// device buffers for the device-resident entry points (the HIP runtime's C entry points; this file is compiled by g++ without HIP headers)
+extern "C" {
+int hipMalloc(void** p, size_t bytes);
+int hipFree(void* p);
+int hipMemcpy(void* dst, const void* src, size_t bytes, int kind);  // 1 = host to device, 2 = device to host
+}
+
 static std::string slurp(const std::string& p) {
   std::ifstream f(p);
   if (!f) { fprintf(stderr, "cannot open %s\n", p.c_str()); exit(2); }
@@ -208,6 +215,33 @@ int main(int argc, char** argv) {
     goldilocks::Vars one_alg = {1, 0, 0, 0}, x_alg = {3, 5, 7, 11};
     EXPECT(gl.MulExtensionAlgebra(one_alg, x_alg) == x_alg && gl.SubExtensionAlgebra(gl.AddExtensionAlgebra(x_alg, one_alg), one_alg) == x_alg);
     EXPECT(gl.ScalarMulExtensionAlgebra({1, 0}, x_alg) == x_alg);
+  }
+  {  // batches in flight on contexts of their own (VerifierChipsInFlight): seven batches of 1..4 proofs through three contexts, the proof
+     // (b + i) % 3 == 0 of batch b tampered -- every batch gets its own verdict whichever finishes first
+    verifier::VerifierChipsInFlight flight(circuit, 3, 0);
+    const size_t nb = 7, rec = proof.size();
+    std::vector<void*> dproofs(nb);
+    std::vector<uint8_t*> daccept(nb);
+    std::vector<size_t> count(nb);
+    for (size_t b = 0; b < nb; b++) {
+      count[b] = 1 + b % 4;
+      std::vector<uint8_t> host;
+      for (size_t i = 0; i < count[b]; i++) {
+        host.insert(host.end(), proof.begin(), proof.end());
+        if ((b + i) % 3 == 0) host[i * rec + 8 * (700 + b)] ^= 1;
+      }
+      EXPECT(hipMalloc(&dproofs[b], host.size()) == 0 && hipMalloc((void**)&daccept[b], count[b]) == 0);
+      EXPECT(hipMemcpy(dproofs[b], host.data(), host.size(), 1) == 0);
+    }
+    for (size_t b = 0; b < nb; b++) EXPECT(flight.VerifyDevice(dproofs[b], count[b], daccept[b]) == b % 3);
+    flight.WaitAll();
+    for (size_t b = 0; b < nb; b++) {
+      std::vector<uint8_t> got(count[b]);
+      EXPECT(hipMemcpy(got.data(), daccept[b], count[b], 2) == 0);
+      for (size_t i = 0; i < count[b]; i++) EXPECT(got[i] == ((b + i) % 3 == 0 ? 0 : 1));
+      hipFree(dproofs[b]);
+      hipFree(daccept[b]);
+    }
   }
   printf("host mirror ok\n");
   return 0;

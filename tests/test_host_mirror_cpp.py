@@ -11,7 +11,8 @@ LIBDIR = T.ROOT / "gnark-plonky2-verifier_amd"
 
 def _build():
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", str(EXE), str(T.ROOT / "tests/cpp/host_mirror_test.cpp"),
-                           "-L" + str(LIBDIR), "-lgpv", "-Wl,-rpath," + str(LIBDIR)])
+                           "-L" + str(LIBDIR), "-lgpv", "-Wl,-rpath," + str(LIBDIR),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])  # hipMalloc / hipMemcpy for the device-resident entry points
 
 
 def _has_gpu():
