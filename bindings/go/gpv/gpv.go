@@ -219,7 +219,8 @@ func cTexts(docs [][]byte) ([]*C.char, []C.size_t, func()) {
 }
 
 // SetOption: GPV_OPT_TRANSCRIPT_VARIANT (1) / GPV_OPT_MERKLE_SHARED_LEVELS (2) / GPV_OPT_FR_EVALUATION (3) / GPV_OPT_HOST_CHUNK_FIRST (4) /
-// GPV_OPT_HOST_CHUNK_MAX (5) / GPV_OPT_SIDE_STREAM (6) / GPV_OPT_WITNESS_STAGING (7) / GPV_OPT_MERKLE_LONGEST_ALONE (8).
+// GPV_OPT_HOST_CHUNK_MAX (5) / GPV_OPT_SIDE_STREAM (6) / GPV_OPT_WITNESS_STAGING (7) / GPV_OPT_MERKLE_LONGEST_ALONE (8) /
+// GPV_OPT_BATCHES_IN_FLIGHT (9).
 func (ctx *Context) SetOption(option, value int) { check(C.gpv_ctx_set_option(ctx.h, C.int(option), C.int(value)), ctx.h) }
 
 // GlHints = the hint functions of goldilocks.Chip (base.go:223-359): hint 0 MulAdd (3 -> 2 words per item), 1 Reduce (4 -> 5),

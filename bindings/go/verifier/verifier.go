@@ -103,7 +103,7 @@ func (c *VerifierChip) VerifyWithChallengesDevice(circuit *gpv.Circuit, proofsDe
 
 // VerifierChipsInFlight: a stream of device-resident batches with up to k of them in flight, each on a VerifierChip / context (= three streams)
 // of its own, so that the idle SIMDs of one batch's dependent hand-offs (leaf digests -> sibling walk -> three shared levels) are filled by the
-// next batch's kernels: batches of 1024 `step` proofs run at 87 000 proofs/s one at a time, 100 000 with two in flight (profiles/r05_in_flight.txt).
+// next batch's kernels: batches of 1024 `step` proofs run at 87 000 proofs/s one at a time, 102 400 with two in flight, 112 300 with three (profiles/r05_in_flight.txt).
 // No counterpart in the reference; the verdicts are VerifyDevice's. With more than two in flight export GPU_MAX_HW_QUEUES=8 before the process
 // first touches HIP. Same type as the Python and C++ mirrors' (verifier.py, host/gpv.hpp).
 type VerifierChipsInFlight struct {
@@ -120,6 +120,7 @@ func NewVerifierChipsInFlight(commonCircuitData types.CommonCircuitData, k int, 
 	f := &VerifierChipsInFlight{busy: make([]bool, k)}
 	for j := 0; j < k; j++ {
 		ctx := gpv.NewContext(device)
+		ctx.SetOption(9, k) // GPV_OPT_BATCHES_IN_FLIGHT: launch shapes for a shared device (include/gpv.h)
 		f.contexts = append(f.contexts, ctx)
 		f.chips = append(f.chips, NewVerifierChip(ctx, commonCircuitData))
 	}

@@ -299,6 +299,7 @@ class _BorrowedContext(Context):
 
 
 OPT_TRANSCRIPT_VARIANT, OPT_MERKLE_SHARED_LEVELS, OPT_FR_EVALUATION, OPT_HOST_CHUNK_FIRST, OPT_HOST_CHUNK_MAX, OPT_SIDE_STREAM, OPT_WITNESS_STAGING, OPT_MERKLE_LONGEST_ALONE = 1, 2, 3, 4, 5, 6, 7, 8  # gpv_ctx_set_option / gpv_group_set_option
+OPT_BATCHES_IN_FLIGHT = 9
 GROUP_OPT_COLLECTIVE = 100
 
 

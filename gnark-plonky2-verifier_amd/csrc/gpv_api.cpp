@@ -71,6 +71,7 @@ struct gpv_ctx {
   int fr_form = 0;        // GPV_OPT_FR_EVALUATION: 0 by launch size, 1 column scanning, 2 operand scanning (gpv_fr.cuh), 3 four lanes per permutation
   int wit_staging = 0;    // GPV_OPT_WITNESS_STAGING: 0 the witness kernels stage their output through LDS when the launch is large enough, 1 always, 2 never
   int side_stream = 1;    // GPV_OPT_SIDE_STREAM: 1 transcript / plonk / FRI on the side stream under the leaf hashing, 0 everything on the main stream, one after the other
+  int in_flight = 1;             // GPV_OPT_BATCHES_IN_FLIGHT: how many similar batches the caller keeps in flight on this device (contexts of their own)
   int merkle_longest_alone = 0;  // GPV_OPT_MERKLE_LONGEST_ALONE: 0 by batch size, 1 never, 2 whenever the operand-scanning kernels run -- the longest tree class hashed by waves that take a SIMD each
   void* crown = nullptr;
   size_t crown_bytes = 0;
@@ -327,6 +328,10 @@ extern "C" int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value) {
   }
   if (option == GPV_OPT_MERKLE_LONGEST_ALONE && value >= 0 && value <= 2) {
     ctx->merkle_longest_alone = value;
+    return GPV_OK;
+  }
+  if (option == GPV_OPT_BATCHES_IN_FLIGHT && value >= 1 && value <= 64) {
+    ctx->in_flight = value;
     return GPV_OK;
   }
   if (option == GPV_OPT_HOST_CHUNK_FIRST && value >= 1 && value <= (1 << 24)) {
@@ -594,7 +599,7 @@ static void launch_merkle_climb(gpv_ctx* ctx, hipStream_t st, const gpv_circuit*
 #define GPV_ALONE_MAX_SIMDS_WALK_X16 14
 // full-length lanes between 0.25 and 0.5 waves per SIMD, nothing forced, the second side stream available
 static bool merkle_mixed_pays(const gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
-  if (ctx->fr_form != 0 || ctx->merkle_longest_alone != 0 || !ctx->side_stream || c->dc.n_trees < 2 || c->dc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS) return false;
+  if (ctx->fr_form != 0 || ctx->merkle_longest_alone != 0 || ctx->in_flight > 1 || !ctx->side_stream || c->dc.n_trees < 2 || c->dc.hash_kind == GPV_HASH_POSEIDON_GOLDILOCKS) return false;
   const size_t full = gpvk_full_paths(c->dc, n * c->dc.num_queries);
   return gpvk_fr_quad_pays(full, 0) && 4 * full > (size_t)64 * gpvk_device_simds();
 }
@@ -606,7 +611,11 @@ struct MerkleAlone {
 static MerkleAlone merkle_alone(const gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
   const DevCircuit& d = c->dc;
   MerkleAlone r = {0, GPV_SOLO_NONE, 0};
-  if (ctx->merkle_longest_alone == 1 || !ctx->side_stream || d.n_trees < 2 || !gpvk_merkle_leaves_wide(d, n, ctx->fr_form)) return r;
+  // (the shapes give the critical chains SIMDs that are EMPTY: with other batches in flight on the device there are none, and the plain launches
+  // overlap better -- 1024-proof batches, three in flight: 107 600 proofs/s against 100 200 with the shapes; profiles/r05_in_flight.txt)
+  if (ctx->merkle_longest_alone == 1 || (ctx->in_flight > 1 && ctx->merkle_longest_alone == 0) || !ctx->side_stream || d.n_trees < 2 ||
+      !gpvk_merkle_leaves_wide(d, n, ctx->fr_form))
+    return r;
   const size_t waves = (n * d.num_queries + 63) / 64, simds = gpvk_device_simds();
   // ---- leaf digests
   u32 best = 0, second = 0, best_t = 0, second_t = 0, third = 0;
@@ -700,6 +709,13 @@ static int verify_pipeline_dev(gpv_ctx* ctx, const gpv_circuit* c, const void* p
     ~FormGuard() { c->fr_form = saved; }
   } form_guard{ctx, ctx->fr_form};
   if (merkle_mixed_pays(ctx, c, n)) ctx->fr_form = 2;
+  // GPV_OPT_BATCHES_IN_FLIGHT = k: the device holds k such batches, so four lanes per permutation (the form of a launch that leaves most of the chip
+  // idle) is chosen by k x the batch's lanes; the batch's own size still decides between operand and column scanning (four 1024-proof batches in
+  // flight: 110 200 proofs/s operand scanning, 102 800 column scanning)
+  if (ctx->in_flight > 1 && ctx->fr_form == 0 && c->dc.hash_kind != GPV_HASH_POSEIDON_GOLDILOCKS) {
+    const size_t full = gpvk_full_paths(c->dc, n * c->dc.num_queries);
+    if (gpvk_fr_quad_pays(full, 0) && !gpvk_fr_quad_pays(full * (size_t)ctx->in_flight, 0)) ctx->fr_form = 2;
+  }
   const MerkleAlone alone = merkle_alone(ctx, c, n);
   if (alone.leaf_mask) {  // the longest class on SIMDs of its own (main stream), the others beside it (second side stream); the walks wait for both
     launch_merkle_leaves(ctx, main_st, c, dcd, proofs_dev, n, alone.leaf_mask, alone.leaf_shape);
@@ -1786,6 +1802,8 @@ int gpvi_verify_host_batch(gpv_ctx* ctx, const gpv_circuit* c, const void* proof
     ctx->twin->transcript_variant = ctx->transcript_variant;
     ctx->twin->fr_form = ctx->fr_form;
     ctx->twin->side_stream = ctx->side_stream;
+    ctx->twin->merkle_longest_alone = ctx->merkle_longest_alone;
+    ctx->twin->in_flight = ctx->in_flight;
     ctx->twin->timing = ctx->timing;  // kernels of odd chunks are timed in the twin's accumulators; gpv_timing_get merges them
   }
   size_t done = 0, k = 0;

@@ -558,7 +558,7 @@ class VerifierChip {
 };
 // A stream of device-resident batches with up to k of them in flight, each on a context (= three streams) of its own: the idle SIMDs of one
 // batch's dependent hand-offs (leaf digests -> sibling walk -> three shared levels) are filled by the next batch's kernels -- batches of 1024
-// `step` proofs: 87 000 proofs/s one at a time, 100 000 with two in flight (profiles/r05_in_flight.txt). No counterpart in the reference; the
+// `step` proofs: 87 000 proofs/s one at a time, 102 400 with two in flight, 112 300 with three (profiles/r05_in_flight.txt). No counterpart in the reference; the
 // verdicts are VerifierChip::VerifyDevice's. With more than two in flight export GPU_MAX_HW_QUEUES=8 before the process first touches HIP
 // (streams that share a hardware queue run in order; the runtime's default is 4 queues).
 class VerifierChipsInFlight {
@@ -566,7 +566,10 @@ class VerifierChipsInFlight {
   VerifierChipsInFlight(const gpv::Circuit& c, size_t k = 3, int device = 0) : c_(c), busy_(k, false) {
     if (k == 0) throw gpv::Error(GPV_EINVAL, "VerifierChipsInFlight: k must be at least 1");
     apis_.reserve(k);
-    for (size_t j = 0; j < k; j++) apis_.emplace_back(device);
+    for (size_t j = 0; j < k; j++) {
+      apis_.emplace_back(device);
+      apis_.back().set_option(GPV_OPT_BATCHES_IN_FLIGHT, (int)k);  // launch shapes for a shared device (include/gpv.h)
+    }
   }
   // enqueue one batch on the least recently used context (after that context's previous batch); returns its ticket
   size_t VerifyDevice(const void* proofs_dev, size_t n, uint8_t* accept_dev) {

@@ -137,7 +137,7 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
  * permutation (half that latency again; for launches that leave most of the chip idle: up to about 290 proofs of the reference's
  * circuits -- a single proof verifies in 4.0 ms instead of 8.7). 0 (default) = chosen per launch by the occupancy it gives the device it runs
  * on (waves per SIMD of full-length lanes = 4 Merkle paths per query round / (64 x 4 x its compute units): four lanes per permutation up to
- * 0.5, column scanning from 4.5; profiles/r04_form_crossover.txt),
+ * 0.5, column scanning from 7 for the Merkle launches and 4.5 for the primitives; profiles/r04_form_crossover.txt, r05_form_crossover_whole.txt),
  * 1 = always column scanning, 2 = always operand scanning, 3 = always four lanes per permutation (Poseidon-BN254 kernels and
  * per-path Merkle walks; the shared upper levels keep form 2).
  * GPV_OPT_SIDE_STREAM: 1 (default) = the transcript, the plonk check and the FRI field work run on a second stream underneath the Merkle leaf
@@ -152,10 +152,17 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
  * take a SIMD each beside the other trees' launch on a second stream (about 150 .. 1 600 `step` proofs on an MI355X; below about 400 four lanes per
  * permutation for that tree and a SIMD per wave for every tree), and up to 512 proofs the full-length sibling walks likewise; 1 = never (one launch per
  * phase); 2 = the longest tree alone whenever the operand-scanning kernels run. Identical verdicts.
+ * GPV_OPT_BATCHES_IN_FLIGHT (default 1; 1 .. 64): how many similar batches the caller keeps in flight on this device, each on a context of its own
+ * (a service that receives mid-size batches: the next batch's kernels fill the SIMDs one batch's dependent hand-offs leave idle -- batches of 1024
+ * `step` proofs: 87 000 proofs/s one at a time, 112 300 with three in flight). The launch shapes then assume a shared device: no SIMD-per-wave shapes
+ * (GPV_OPT_MERKLE_LONGEST_ALONE = 0 behaves as 1), and four lanes per permutation only while k batches together leave most of the chip idle.
+ * Identical verdicts. The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and streams on one queue run
+ * in order: with more than two batches in flight export GPU_MAX_HW_QUEUES=8 before the process first touches HIP.
  * GPV_OPT_HOST_CHUNK_FIRST / GPV_OPT_HOST_CHUNK_MAX: gpv_verify uploads a host batch in chunks of first, first, 2 first, 4 first, ...
  * proofs capped at max and verifies them as they arrive, two in flight (defaults 1024 / 8192; 1 .. 2^24). */
 enum { GPV_OPT_TRANSCRIPT_VARIANT = 1, GPV_OPT_MERKLE_SHARED_LEVELS = 2, GPV_OPT_FR_EVALUATION = 3, GPV_OPT_HOST_CHUNK_FIRST = 4,
-       GPV_OPT_HOST_CHUNK_MAX = 5, GPV_OPT_SIDE_STREAM = 6, GPV_OPT_WITNESS_STAGING = 7, GPV_OPT_MERKLE_LONGEST_ALONE = 8 };
+       GPV_OPT_HOST_CHUNK_MAX = 5, GPV_OPT_SIDE_STREAM = 6, GPV_OPT_WITNESS_STAGING = 7, GPV_OPT_MERKLE_LONGEST_ALONE = 8,
+       GPV_OPT_BATCHES_IN_FLIGHT = 9 };
 int gpv_ctx_set_option(gpv_ctx* ctx, int option, int value);
 /* Copies the last error text of this context (or of context-free calls when ctx == NULL). */
 int gpv_last_error_message(gpv_ctx* ctx, char* buf, size_t buf_len);

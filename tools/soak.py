@@ -57,6 +57,7 @@ def work(tid):
             opt_shared, opt_form = int(rng.choice([0, 1, 2])), int(rng.choice([0, 1, 2, 3]))
             ctx.set_option(2, opt_shared)
             ctx.set_option(3, opt_form)  # GPV_OPT_FR_EVALUATION: by size / column scanning / operand scanning / four lanes per permutation
+            ctx.set_option(gpv._lib.OPT_BATCHES_IN_FLIGHT, int(rng.choice([1, 1, 2, 4])))  # the launch shapes of a shared device
             ctx.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, int(rng.choice([0, 0, 1, 2])))  # round 5: the leaf phase as one launch or two (the longest class alone)
             reps = int(rng.integers(2, 6))
             host_path = ch is None and rng.random() < 0.3  # gpv_verify on a host buffer: chunked upload, even / odd chunks on twin contexts
