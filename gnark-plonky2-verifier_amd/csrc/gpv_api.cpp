@@ -1803,9 +1803,15 @@ int gpvi_verify_host_batch(gpv_ctx* ctx, const gpv_circuit* c, const void* proof
     ctx->twin->fr_form = ctx->fr_form;
     ctx->twin->side_stream = ctx->side_stream;
     ctx->twin->merkle_longest_alone = ctx->merkle_longest_alone;
-    ctx->twin->in_flight = ctx->in_flight;
+    ctx->twin->in_flight = ctx->in_flight < 2 ? 2 : ctx->in_flight;  // two chunks share the device (4096 host-resident proofs: 93 800 -> 97 200 proofs/s)
     ctx->twin->timing = ctx->timing;  // kernels of odd chunks are timed in the twin's accumulators; gpv_timing_get merges them
   }
+  struct InFlightGuard {  // this context's chunks too, for the duration of the call
+    gpv_ctx* c;
+    int saved;
+    ~InFlightGuard() { c->in_flight = saved; }
+  } in_flight_guard{ctx, ctx->in_flight};
+  if (two && ctx->in_flight < 2) ctx->in_flight = 2;
   size_t done = 0, k = 0;
   while (done < n) {
     const size_t chunk = sched[k < (size_t)n_sched ? k : (size_t)n_sched - 1];
