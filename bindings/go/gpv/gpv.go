@@ -454,6 +454,10 @@ const (
 	OptFrEvaluation       = int(C.GPV_OPT_FR_EVALUATION)
 	OptHostChunkFirst     = int(C.GPV_OPT_HOST_CHUNK_FIRST)
 	OptHostChunkMax       = int(C.GPV_OPT_HOST_CHUNK_MAX)
+	OptSideStream         = int(C.GPV_OPT_SIDE_STREAM)
+	OptWitnessStaging     = int(C.GPV_OPT_WITNESS_STAGING)
+	OptMerkleLongestAlone = int(C.GPV_OPT_MERKLE_LONGEST_ALONE)
+	OptBatchesInFlight    = int(C.GPV_OPT_BATCHES_IN_FLIGHT)
 	GroupOptCollective    = int(C.GPV_GROUP_OPT_COLLECTIVE)
 	FailIncomplete        = uint32(C.GPV_FAIL_INCOMPLETE) // a stage did not visit the proof: rejected (fail-closed verdict)
 	FailRange             = uint32(C.GPV_FAIL_RANGE)

@@ -120,7 +120,7 @@ func NewVerifierChipsInFlight(commonCircuitData types.CommonCircuitData, k int, 
 	f := &VerifierChipsInFlight{busy: make([]bool, k)}
 	for j := 0; j < k; j++ {
 		ctx := gpv.NewContext(device)
-		ctx.SetOption(9, k) // GPV_OPT_BATCHES_IN_FLIGHT: launch shapes for a shared device (include/gpv.h)
+		ctx.SetOption(gpv.OptBatchesInFlight, k) // launch shapes for a shared device (include/gpv.h)
 		f.contexts = append(f.contexts, ctx)
 		f.chips = append(f.chips, NewVerifierChip(ctx, commonCircuitData))
 	}

@@ -110,6 +110,23 @@ def test_go_shim_call_sites_match_the_header(tmp_path):
         assert any(expect in p for p in problems), (new, problems)
 
 
+def test_option_ids_agree_across_the_mirrors():
+    """The GPV_OPT_* enum of include/gpv.h, the Python mirror's constants and the Go shim's (which take them from the header through cgo): one id each,
+    every header option present in the Python mirror under the same name."""
+    header = (T.ROOT / "include" / "gpv.h").read_text()
+    enum = re.search(r"enum \{ (GPV_OPT_TRANSCRIPT_VARIANT = 1.*?) \};", header, re.S).group(1)
+    ids = {m.group(1): int(m.group(2)) for m in re.finditer(r"GPV_OPT_(\w+) = (\d+)", enum)}
+    assert sorted(ids.values()) == list(range(1, len(ids) + 1)) and len(ids) == 9
+    lib_py = (T.ROOT / "gnark-plonky2-verifier_amd" / "_lib.py").read_text()
+    ns = {}
+    for line in lib_py.splitlines():
+        if line.startswith("OPT_"):
+            exec(line.split("#")[0], ns)
+    assert {k[4:]: v for k, v in ns.items() if k.startswith("OPT_")} == ids
+    go = (T.ROOT / "bindings" / "go" / "gpv" / "gpv.go").read_text()
+    assert set(re.findall(r"int\(C\.GPV_OPT_(\w+)\)", go)) == set(ids)
+
+
 def test_solo_kernels_take_a_simd_each():
     """The launch shapes of mid-size batches rest on a property of the COMPILED kernels, not of the source: a wave of a `_solo` kernel must be
     allocated so many registers that no hashing wave (>= 140) and no k_plonk / k_fri_query / k_transcript wave (128) fits beside it on a SIMD of 512, while the

@@ -31,7 +31,7 @@ for FORM in 0 1 2 3; do
 done
 # (the pole tests are not in the list: they also call the witness generator, whose kernels CALL device functions -- which an instrumented kernel cannot do
 #  on this toolchain; the poles themselves are corruption kind 7 of the fuzz above)
-echo "== the colliding-query, shared-level, random-record, beyond-the-reference and leaf-launch GPU tests on libgpv_asan.so"
+echo "== the colliding-query, shared-level, random-record, beyond-the-reference, leaf-launch and batches-in-flight GPU tests on libgpv_asan.so"
 LD_PRELOAD="$PRE" timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider --libgpv tools/asan/libgpv_asan.so \
-  -k "(colliding or shared_merkle_levels_are_exact or merkle_and_fri or random_records_differential or shapes_beyond_the_reference or longest_leaf) and not witness" -v 2>&1 | grep -E "PASSED|FAILED|ERROR|passed|failed|Fatal|Hostcall|fault|SUMMARY|ERROR: AddressSanitizer" | cut -c1-200 | tail -60
+  -k "(colliding or shared_merkle_levels_are_exact or merkle_and_fri or random_records_differential or shapes_beyond_the_reference or longest_leaf or batches_in_flight) and not witness" -v 2>&1 | grep -E "PASSED|FAILED|ERROR|passed|failed|Fatal|Hostcall|fault|SUMMARY|ERROR: AddressSanitizer" | cut -c1-200 | tail -60
 echo "   exit status ${PIPESTATUS[0]}"
