@@ -1722,3 +1722,72 @@ def witness_plonk_exact(ci, packed, challenges, pih):
         prod = w.mul_ext(zh, w.reduce_with_powers(quots[i * qdf:(i + 1) * qdf], zeta_pow_n))
         ok &= prod == reduced[i]
     return w.words, w.kinds, ok and not w.zero_inverse                            # evalL0's division by n (zeta - 1) = 0, plonk.go:75-80
+
+
+class DeviceBuffers:
+    """hipMalloc / hipMemcpy through the HIP runtime the process has already loaded (libgpv's), without torch: the device-AddressSanitizer runs
+    (tools/asan/) preload ROCm's runtime, and torch's bundled one cannot initialise beside it. Create it after the first gpv.Context."""
+
+    def __init__(self):
+        import ctypes
+        import os
+        self._ct = ctypes
+        self.hip = None
+        for name in ("libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so"):
+            try:
+                self.hip = ctypes.CDLL(name, mode=os.RTLD_NOLOAD | os.RTLD_NOW)
+                break
+            except OSError:
+                continue
+        if self.hip is None:
+            self.hip = ctypes.CDLL("libamdhip64.so")
+        self.ptrs = []
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed with HIP error %d" % (what, rc))
+
+    def alloc(self, nbytes, fill=0):
+        p = self._ct.c_void_p()
+        self._check(self.hip.hipMalloc(self._ct.byref(p), self._ct.c_size_t(max(1, nbytes))), "hipMalloc")
+        self._check(self.hip.hipMemset(p, self._ct.c_int(fill), self._ct.c_size_t(nbytes)), "hipMemset")
+        self._check(self.hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
+        self.ptrs.append(p)
+        return p.value
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        ptr = self.alloc(a.nbytes)
+        self._check(self.hip.hipMemcpy(self._ct.c_void_p(ptr), a.ctypes.data_as(self._ct.c_void_p), self._ct.c_size_t(a.nbytes), self._ct.c_int(1)), "hipMemcpy H2D")
+        return ptr
+
+    def download(self, ptr, nbytes):
+        out = np.empty(nbytes, dtype=np.uint8)
+        self._check(self.hip.hipMemcpy(out.ctypes.data_as(self._ct.c_void_p), self._ct.c_void_p(ptr), self._ct.c_size_t(nbytes), self._ct.c_int(2)), "hipMemcpy D2H")
+        return out
+
+    def fill(self, ptr, nbytes, value):
+        self._check(self.hip.hipMemset(self._ct.c_void_p(ptr), self._ct.c_int(value), self._ct.c_size_t(nbytes)), "hipMemset")
+        self._check(self.hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
+
+    def free_all(self):
+        for p in self.ptrs:
+            self.hip.hipFree(p)
+        self.ptrs = []
+
+
+def raise_hip_stack_limit():
+    """hipDeviceSetLimit(hipLimitStackSize, $GPV_ASAN_STACK_BYTES) on the HIP runtime the process has loaded; nothing when the variable is unset. For the
+    sanitizer build only: its instrumented kernels call the ASan runtime's device functions and so use a DYNAMIC stack, whose default per-lane limit k_plonk
+    overflows from 33 workgroups on (2049 proofs: "memory aperture violation" whatever the records hold; with 16 KB every stage passes --
+    tools/asan/probe_stages.py). Scratch is reserved per resident wave, so the limit is raised only for the few runs that need it
+    (tools/asan/probe_in_flight_cases.sh), never for a whole test session. The shipped kernels have a fixed private segment
+    (tests/test_abi_cpu.py::test_no_kernel_uses_a_dynamic_stack)."""
+    import ctypes
+    import os
+    if "GPV_ASAN_STACK_BYTES" not in os.environ:
+        return
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    rc = hip.hipDeviceSetLimit(ctypes.c_int(0), ctypes.c_size_t(int(os.environ["GPV_ASAN_STACK_BYTES"])))  # hipLimitStackSize = 0
+    if rc != 0:
+        raise RuntimeError("hipDeviceSetLimit(hipLimitStackSize) failed with HIP error %d" % rc)

@@ -129,7 +129,7 @@ def test_option_ids_agree_across_the_mirrors():
 
 def test_solo_kernels_take_a_simd_each():
     """The launch shapes of mid-size batches rest on a property of the COMPILED kernels, not of the source: a wave of a `_solo` kernel must be
-    allocated so many registers that no hashing wave (>= 140) and no k_plonk / k_fri_query / k_transcript wave (128) fits beside it on a SIMD of 512, while the
+    allocated so many registers that no hashing wave (>= 140) and no k_plonk / k_fri_query / k_transcript wave (>= 128) fits beside it on a SIMD of 512, while the
     cooperative transcript's (80) still does. Read from the code object of the built library's translation unit; a toolchain that allocates differently fails here
     instead of silently running the long chains at half speed."""
     import subprocess
@@ -624,3 +624,24 @@ def test_batch_ingest_reports_a_status_per_proof(gpv):
     nulls = (ctypes.c_char_p * 1)(None)
     assert L.gpv_proof_pack_json_batch_status(ctypes.c_void_p(circuit.h), nulls, lens, 1, gpv._lib.ptr(out), 1, gpv._lib.ptr(st)) == gpv._lib.GPV_OK
     assert st[0] == gpv._lib.GPV_EINVAL and not out.any()
+
+
+def test_no_kernel_uses_a_dynamic_stack():
+    """Every kernel of the shipped translation units has a FIXED private segment (no recursion, no indirect calls: `.uses_dynamic_stack: false`). The runtime sizes
+    scratch for such kernels from the code object alone; the sanitizer build's instrumented k_plonk does use a dynamic stack and overflows the default per-lane limit
+    from 33 workgroups on (tools/asan/run_asan.py raises hipLimitStackSize) -- the shipped kernels must not depend on that limit."""
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    csrc = T.ROOT / "gnark-plonky2-verifier_amd" / "csrc"
+    total = 0
+    for obj in ("gpv_k_prim.o", "gpv_k_bn254.o", "gpv_k_crown.o", "gpv_k_transcript.o", "gpv_k_plonk.o", "gpv_k_fri.o", "gpv_k_witness.o"):
+        with tempfile.TemporaryDirectory() as tmp:
+            subprocess.run([llvm + "llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", str(csrc / obj), tmp + "/fat.bin"], check=True)
+            listing = subprocess.run([llvm + "clang-offload-bundler", "--list", "--type=o", "--input=" + tmp + "/fat.bin"], capture_output=True, text=True, check=True).stdout
+            target = next(t for t in listing.split() if "gfx950" in t)
+            subprocess.run([llvm + "clang-offload-bundler", "--type=o", "--targets=" + target, "--input=" + tmp + "/fat.bin", "--output=" + tmp + "/dev.co", "--unbundle"], check=True)
+            notes = subprocess.run([llvm + "llvm-readelf", "--notes", tmp + "/dev.co"], capture_output=True, text=True, check=True).stdout
+        assert notes.count(".symbol:") > 0 and "uses_dynamic_stack: true" not in notes, obj
+        total += notes.count(".symbol:")
+    assert total >= 60

@@ -296,50 +296,50 @@ def test_longest_leaf_class_alone_is_identical(gpv, api, orc, name):
 @pytest.mark.gpu
 def test_batches_in_flight_get_their_own_verdicts(gpv, api, orc):
     """VerifierChipsInFlight (round 5): a stream of device-resident batches, three in flight on three contexts -- sizes from every launch-shape
-    regime (four lanes per permutation, the mixed shapes, one launch per phase), each with its own tamper pattern, submitted back to back
+    regime (four lanes per permutation, operand scanning, one launch per phase), each with its own tamper pattern, submitted back to back
     without waiting. Every batch's accept vector == its own tamper mask == what one context gives for the same records, and the first 24
-    records of every batch == the oracle."""
-    import torch
+    records of every batch == the oracle. (Device buffers without torch, so that the test also runs on the sanitizer build.)"""
     common, vo, circuit, proofs = _load(gpv, "step")
     ci, packed, _ = T.load_fixture("step")
     oc = orc.circuit(ci)
-    dev = torch.device("cuda", 0)
-    sizes = (1, 130, 300, 40, 600, 1100, 7, 450, 256, 2100)
+    sizes = (1, 130, 300, 40, 600, 1100, 7, 450, 256, 2000)   # (<= 2048: the sanitizer build's k_plonk overflows its default dynamic stack beyond)
     flight = gpv.verifier.VerifierChipsInFlight(common, k=3)
     vchip = gpv.verifier.NewVerifierChip(api, common)
+    dev = T.DeviceBuffers()
     try:
-        batches, accepts, masks = [], [], []
+        hosts, batches, accepts, masks = [], [], [], []
         for b, n in enumerate(sizes):
             batch, tampered = T.synthetic_batch(ci, packed, n, seed=900 + b, tamper_every=3 + b % 4)
-            batches.append(torch.from_numpy(batch.view(np.int64).copy()).to(dev))
-            accepts.append(torch.full((n,), 7, dtype=torch.uint8, device=dev))
+            hosts.append(batch)
+            batches.append(dev.upload(batch))
+            accepts.append(dev.alloc(n, fill=7))
             masks.append(tampered)
-        torch.cuda.synchronize()
-        tickets = [flight.VerifyDevice(circuit, batches[b].data_ptr(), n, accepts[b].data_ptr()) for b, n in enumerate(sizes)]
+        tickets = [flight.VerifyDevice(circuit, batches[b], n, accepts[b]) for b, n in enumerate(sizes)]
         assert tickets == [b % 3 for b in range(len(sizes))]
         flight.wait()
+        alone = dev.alloc(max(sizes), fill=7)
         for b, n in enumerate(sizes):
-            got = accepts[b].cpu().numpy()
+            got = dev.download(accepts[b], n)
             assert (got == (~masks[b]).astype(np.uint8)).all(), (b, n)
-            alone = torch.full((n,), 7, dtype=torch.uint8, device=dev)
-            vchip.VerifyDevice(circuit, batches[b].data_ptr(), n, alone.data_ptr())
+            dev.fill(alone, n, 7)
+            vchip.VerifyDevice(circuit, batches[b], n, alone)
             api.synchronize()
-            assert (alone.cpu().numpy() == got).all(), (b, n)
+            assert (dev.download(alone, n) == got).all(), (b, n)
             head = min(n, 24)
-            oacc, _, _ = orc.verify(oc, batches[b][:head].cpu().numpy().tobytes(), n_threads=8)
+            oacc, _, _ = orc.verify(oc, hosts[b][:head].tobytes(), n_threads=8)
             assert got[:head].tolist() == oacc.tolist(), (b, n)
         # a second round on the same contexts, other buffers in another order: nothing of a context's previous batch leaks into its next
         order = [9, 0, 5, 2, 7]
         for b in order:
-            accepts[b].fill_(7)
-        torch.cuda.synchronize()
+            dev.fill(accepts[b], sizes[b], 7)
         for b in order:
-            flight.VerifyDevice(circuit, batches[b].data_ptr(), sizes[b], accepts[b].data_ptr())
+            flight.VerifyDevice(circuit, batches[b], sizes[b], accepts[b])
         flight.wait()
         for b in order:
-            assert (accepts[b].cpu().numpy() == (~masks[b]).astype(np.uint8)).all(), b
+            assert (dev.download(accepts[b], sizes[b]) == (~masks[b]).astype(np.uint8)).all(), b
     finally:
         flight.close()
+        dev.free_all()
 
 
 # ---------------------------------------------------------------- gates (plonk/gates/gates_test.go:712-768)

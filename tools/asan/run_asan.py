@@ -14,5 +14,7 @@ gpv = importlib.import_module("gnark-plonky2-verifier_amd")
 gpv._lib.LIB_PATH = ROOT / "tools" / "asan" / "libgpv_asan.so"
 gpv._lib.SHARE_TORCH_RUNTIME = False  # the system ROCm runtime: ASan's HSA interceptors fail inside the torch wheel's bundled one
 print("# library:", gpv._lib.LIB_PATH, flush=True)
+import gpv_testlib
+gpv_testlib.raise_hip_stack_limit()  # only when GPV_ASAN_STACK_BYTES is set (probe_in_flight_cases.sh: batches beyond 2048 proofs)
 sys.argv = sys.argv[1:]
 runpy.run_path(sys.argv[0], run_name="__main__")

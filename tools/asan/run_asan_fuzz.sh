@@ -35,3 +35,5 @@ echo "== the colliding-query, shared-level, random-record, beyond-the-reference,
 LD_PRELOAD="$PRE" timeout 3000 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider --libgpv tools/asan/libgpv_asan.so \
   -k "(colliding or shared_merkle_levels_are_exact or merkle_and_fri or random_records_differential or shapes_beyond_the_reference or longest_leaf or batches_in_flight) and not witness" -v 2>&1 | grep -E "PASSED|FAILED|ERROR|passed|failed|Fatal|Hostcall|fault|SUMMARY|ERROR: AddressSanitizer" | cut -c1-200 | tail -60
 echo "   exit status ${PIPESTATUS[0]}"
+echo "== batch sizes the fuzz does not reach (2048 .. 4096 proofs on one context) and batches in flight on three / four contexts (tools/asan/probe_in_flight_cases.sh)"
+bash tools/asan/probe_in_flight_cases.sh 2>&1
