@@ -103,7 +103,7 @@ func (c *VerifierChip) VerifyWithChallengesDevice(circuit *gpv.Circuit, proofsDe
 
 // VerifierChipsInFlight: a stream of device-resident batches with up to k of them in flight, each on a VerifierChip / context (= three streams)
 // of its own, so that the idle SIMDs of one batch's dependent hand-offs (leaf digests -> sibling walk -> three shared levels) are filled by the
-// next batch's kernels: batches of 1024 `step` proofs run at 87 000 proofs/s one at a time, 104 300 with two in flight, 111 700 with three (profiles/r05_in_flight.txt).
+// next batch's kernels: batches of 1024 `step` proofs run at 87 000 proofs/s one at a time, 101 400 with two in flight, 112 100 with three (profiles/r05_in_flight.txt).
 // No counterpart in the reference; the verdicts are VerifyDevice's. With more than two in flight export GPU_MAX_HW_QUEUES=8 before the process
 // first touches HIP. Same type as the Python and C++ mirrors' (verifier.py, host/gpv.hpp).
 type VerifierChipsInFlight struct {

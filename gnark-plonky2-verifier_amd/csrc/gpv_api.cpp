@@ -443,10 +443,14 @@ static int circuit_on_device(gpv_ctx* ctx, const gpv_circuit* c, const DevCircui
 // The shared upper levels pay from ~500 proofs up: below that the level kernels are too small to fill the GPU and the extra launches cost more than
 // the saved hashes (round 1 measured ~1000, profiles/r01k_batch_sweep.txt; re-measured with the round-5 leaf launch: +1.7 .. 3.5 % at 512 - 896,
 // -2.7 % at 384, profiles/r05_shared_levels_sweep.txt).
+// With other batches in flight on the device (GPV_OPT_BATCHES_IN_FLIGHT > 1) the three dependent level launches cost more and the per-path walk's extra
+// hashes less (another batch fills the SIMDs either way): 512-proof batches, three in flight, 100 700 proofs/s per path against 90 100 shared; equal at
+// 768 - 1024; shared ahead from 1536 (profiles/r05_in_flight.txt part 4).
 #define GPV_MERKLE_SHARED_FROM 512
+#define GPV_MERKLE_SHARED_FROM_IN_FLIGHT 768
 static bool merkle_shared_for(const gpv_ctx* ctx, const gpv_circuit* c, size_t n) {
   if (ctx->merkle_shared == 0 || !gpvk_crown_supported(c->dc, n)) return false;
-  return ctx->merkle_shared == 2 || n >= GPV_MERKLE_SHARED_FROM;
+  return ctx->merkle_shared == 2 || n >= (size_t)(ctx->in_flight > 1 ? GPV_MERKLE_SHARED_FROM_IN_FLIGHT : GPV_MERKLE_SHARED_FROM);
 }
 // ---- fail-closed verdict plumbing (gpv_launch.h)
 static Verdict verdict_of(gpv_ctx* ctx) { return Verdict{ctx->fail, ctx->fail + ctx->fail_n}; }

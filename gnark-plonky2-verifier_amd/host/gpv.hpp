@@ -558,7 +558,7 @@ class VerifierChip {
 };
 // A stream of device-resident batches with up to k of them in flight, each on a context (= three streams) of its own: the idle SIMDs of one
 // batch's dependent hand-offs (leaf digests -> sibling walk -> three shared levels) are filled by the next batch's kernels -- batches of 1024
-// `step` proofs: 87 000 proofs/s one at a time, 104 300 with two in flight, 111 700 with three (profiles/r05_in_flight.txt). No counterpart in the reference; the
+// `step` proofs: 87 000 proofs/s one at a time, 101 400 with two in flight, 112 100 with three (profiles/r05_in_flight.txt). No counterpart in the reference; the
 // verdicts are VerifierChip::VerifyDevice's. With more than two in flight export GPU_MAX_HW_QUEUES=8 before the process first touches HIP
 // (streams that share a hardware queue run in order; the runtime's default is 4 queues).
 class VerifierChipsInFlight {

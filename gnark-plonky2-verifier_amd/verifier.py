@@ -136,7 +136,7 @@ class VerifierChipsInFlight:
     """A stream of device-resident batches with up to `k` of them in flight, each on a VerifierChip / context (= three streams) of its own.
     One batch is a chain of dependent launches -- leaf digests, sibling walk, three shared levels -- and each hand-off leaves SIMDs idle while
     its last waves finish; the next batch's kernels fill them. One MI355X, `step` proofs, batches of 1024: 87 000 proofs/s one at a time,
-    104 300 with two in flight, 111 700 with three (2048: 102 600 / 109 700 / 112 700; profiles/r05_in_flight.txt). The reference has no
+    101 400 with two in flight, 112 100 with three (2048: 102 500 / 110 600 / 113 100; profiles/r05_in_flight.txt). The reference has no
     counterpart (it verifies one proof inside one circuit); same verdicts as VerifierChip.VerifyDevice, batch for batch.
     The HIP runtime spreads streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and streams on one queue run in order: with more
     than two batches in flight export GPU_MAX_HW_QUEUES=8 before the process first touches HIP."""

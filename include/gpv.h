@@ -154,8 +154,9 @@ int gpv_ctx_synchronize(gpv_ctx* ctx);
  * phase); 2 = the longest tree alone whenever the operand-scanning kernels run. Identical verdicts.
  * GPV_OPT_BATCHES_IN_FLIGHT (default 1; 1 .. 64): how many similar batches the caller keeps in flight on this device, each on a context of its own
  * (a service that receives mid-size batches: the next batch's kernels fill the SIMDs one batch's dependent hand-offs leave idle -- batches of 1024
- * `step` proofs: 87 000 proofs/s one at a time, 111 700 with three in flight). The launch shapes then assume a shared device: no SIMD-per-wave shapes
- * (GPV_OPT_MERKLE_LONGEST_ALONE = 0 behaves as 1), and four lanes per permutation only while k batches together leave most of the chip idle.
+ * `step` proofs: 87 000 proofs/s one at a time, 112 100 with three in flight). The launch shapes then assume a shared device: no SIMD-per-wave shapes
+ * (GPV_OPT_MERKLE_LONGEST_ALONE = 0 behaves as 1), four lanes per permutation only while k batches together leave most of the chip idle, and the shared
+ * upper Merkle levels (GPV_OPT_MERKLE_SHARED_LEVELS = 1) from 768 proofs per batch instead of 512.
  * Identical verdicts. The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and streams on one queue run
  * in order: with more than two batches in flight export GPU_MAX_HW_QUEUES=8 before the process first touches HIP.
  * GPV_OPT_HOST_CHUNK_FIRST / GPV_OPT_HOST_CHUNK_MAX: gpv_verify uploads a host batch in chunks of first, first, 2 first, 4 first, ...
