@@ -645,3 +645,12 @@ def test_no_kernel_uses_a_dynamic_stack():
         assert notes.count(".symbol:") > 0 and "uses_dynamic_stack: true" not in notes, obj
         total += notes.count(".symbol:")
     assert total >= 60
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a GPU")
+def test_batches_in_flight_need_a_gpu_and_a_positive_count(gpv):
+    """VerifierChipsInFlight is k contexts: a bad k is refused before anything is created, and without a GPU the first context fails loudly (no CPU fallback)."""
+    with pytest.raises(ValueError):
+        gpv.verifier.VerifierChipsInFlight(None, k=0)
+    with pytest.raises(gpv.DeviceError):
+        gpv.verifier.VerifierChipsInFlight(None, k=2)
