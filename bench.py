@@ -28,6 +28,9 @@ The same line carries
                     in its own order (distinct records and Merkle work lists, all valid; verified with supplied challenges),
                     (b) both fixture circuits back to back, (c) an all-invalid batch in which no two query paths can share a
                     Merkle node.
+  mid_size_batches / batches_in_flight -- a service's operating points, neither of them `value`: one batch of 512 .. 4096 proofs at a time
+                    (every call synchronised), and a stream of such batches with k = 1 / 2 / 3 in flight on contexts of their own
+                    (gpv.verifier.VerifierChipsInFlight, GPV_OPT_BATCHES_IN_FLIGHT).
 """
 import argparse
 import importlib
