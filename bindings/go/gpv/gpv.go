@@ -482,6 +482,43 @@ func (c *Circuit) Describe() []uint64 {
 	return blob
 }
 
+// Dims: the numbers of a circuit that the host-side mirrors need to address a packed record (gpv_circuit_describe; record layout:
+// csrc/gpv_ingest.cpp finish_layout = types/deserialize.go:26-72 flattened -- NGl Goldilocks words, the public inputs last, then NFr BN254
+// elements of four words each: the three commitment caps, one cap per reduction step, the sibling hashes of every query).
+type Dims struct {
+	NumWires, NumRouted, NumConstants, NumChallenges, NumPartialProducts, QuotientDegreeFactor int
+	NumGateConstraints, NumPublicInputs, DegreeBits, RateBits, CapHeight, NumQueryRounds       int
+	ArityBits                                                                                  []int
+	Salted                                                                                     bool
+	HashKind                                                                                   int
+	NFr, NGl, OffPublicInputs                                                                  int
+	SigmasCap                                                                                  []uint64 // [1 << CapHeight][4]
+}
+
+func (c *Circuit) Dims() Dims {
+	b := c.Describe()
+	d := Dims{
+		NumWires: int(b[1]), NumRouted: int(b[2]), NumConstants: int(b[3]), NumChallenges: int(b[4]), NumPartialProducts: int(b[5]),
+		QuotientDegreeFactor: int(b[6]), NumGateConstraints: int(b[7]), NumPublicInputs: int(b[8]), DegreeBits: int(b[9]), RateBits: int(b[10]),
+		CapHeight: int(b[11]), NumQueryRounds: int(b[13]), Salted: b[0]&0x100 != 0, HashKind: int(b[0] & 0xff),
+	}
+	for s := 0; s < int(b[14]); s++ {
+		d.ArityBits = append(d.ArityBits, int(b[15+s]))
+	}
+	d.SigmasCap = append([]uint64(nil), b[b[29]:b[30]]...)
+	// BN254 elements per record (the same count as fri.py _n_fr): caps, then per query 4 full paths and one shorter path per reduction step
+	capLen, sib := 1<<uint(d.CapHeight), d.DegreeBits+d.RateBits-d.CapHeight
+	perQuery, bits := 4*sib, sib
+	for _, a := range d.ArityBits {
+		bits -= a
+		perQuery += bits
+	}
+	d.NFr = (3+len(d.ArityBits))*capLen + d.NumQueryRounds*perQuery
+	d.NGl = (c.ProofNBytes() - 32*d.NFr) / 8
+	d.OffPublicInputs = d.NGl - d.NumPublicInputs
+	return d
+}
+
 func (ctx *Context) SetStream(hipStream unsafe.Pointer) { check(C.gpv_ctx_set_stream(ctx.h, hipStream), ctx.h) }
 
 // RangeCheck (goldilocks/base.go:362-400): true where a[i] < p.

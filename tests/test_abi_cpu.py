@@ -108,6 +108,21 @@ def test_go_shim_call_sites_match_the_header(tmp_path):
         (d / "gpv" / "gpv.go").write_text(mutated)
         problems, _ = G.check(go_dir=d)
         assert any(expect in p for p in problems), (new, problems)
+    # what a compiler would reject before type checking (round 5: three packages called Circuit.Dims(), which nobody had defined)
+    assert G.lexical_problems() == []
+    lexical_seeds = [
+        ("func (c *Circuit) Dims() Dims {", "func (c *Circuit) dimsOf() Dims {", ".Dims(): no type of the shim declares such a method"),
+        ("type Dims struct {", "type dims struct {", "gpv.Dims is not declared in package gpv"),
+        ("func (c *Circuit) Close()                 { C.gpv_circuit_destroy(c.h) }", "func (c *Circuit) Close()                 { C.gpv_circuit_destroy(c.h) ", "never closed"),
+        ('import (\n', 'import (\n\t"strings"\n', 'imports "strings" and never uses strings.'),
+    ]
+    for k, (old, new, expect) in enumerate(lexical_seeds):
+        assert src.count(old) >= 1, old
+        d = tmp_path / ("lex%d" % k)
+        shutil.copytree(T.ROOT / "bindings" / "go", d)
+        (d / "gpv" / "gpv.go").write_text(src.replace(old, new, 1))
+        problems = G.lexical_problems(go_dir=d)
+        assert any(expect in p for p in problems), (new, problems)
 
 
 def test_option_ids_agree_across_the_mirrors():

@@ -7,6 +7,9 @@ with a small type inference over the Go source (conversions `C.T(x)`, pointer ca
 it with the type cgo assigns to that parameter of the prototype in include/gpv.h (`const T*` -> `*C.T`, `void*` -> `unsafe.Pointer`,
 `const void* const*` -> `*unsafe.Pointer`, `size_t` -> `C.size_t`, ...). It also checks the generic helper `ptr[T any](s []T)` is only
 ever handed a slice (the round-4 regression), and that every header function is called somewhere.
+Since round 5 also what a compiler rejects before type checking (`lexical_problems`): unbalanced brackets, imports that are never used, exported
+names `pkg.Name` of the shim's own packages that the package does not declare, and exported methods / fields that no type of the shim declares
+(receiver types are not resolved) -- that is how `Circuit.Dims()`, called by three packages and defined by none, was found.
 
     python tools/check_go_shim.py            # prints a summary, exit status 1 on any mismatch
 
@@ -339,7 +342,93 @@ def check(verbose=False, go_dir=None):
     return problems, {"header_functions": len(protos), "call_sites": n_sites, "arguments_checked": n_args}
 
 
+# ---------------------------------------------------------------- lexical / cross-package checks (round 5)
+def lexical_problems(go_dir=None):
+    """What a Go compiler would reject before type checking, as far as it can be seen without one: unbalanced brackets, an imported package that is
+    never used, and an exported name `pkg.Name` of one of the shim's own packages that the package does not declare (functions, types, constants,
+    variables; methods and fields are not resolved)."""
+    go_dir = Path(go_dir) if go_dir else GO_DIR
+    problems = []
+    files = {p: strip_go_comments(p.read_text()) for p in sorted(go_dir.rglob("*.go"))}
+    declared = {}
+    for path, src in files.items():
+        names = declared.setdefault(path.parent.name, set())
+        names.update(re.findall(r"^func (\w+)\s*[\[(]", src, re.M))
+        names.update(re.findall(r"^type (\w+)", src, re.M))
+        names.update(re.findall(r"^(?:const|var) (\w+)", src, re.M))
+        for block in re.findall(r"^(?:const|var|type) \((.*?)^\)", src, re.M | re.S):
+            names.update(re.findall(r"^\s+(\w+)", block, re.M))
+    for path, src in files.items():
+        rel = path.relative_to(go_dir)
+        stack = []
+        pairs = {")": "(", "]": "[", "}": "{"}
+        for i, ch in enumerate(src):
+            if ch in "([{":
+                stack.append((ch, i))
+            elif ch in ")]}":
+                if not stack or stack[-1][0] != pairs[ch]:
+                    problems.append("%s:%d: unbalanced `%s`" % (rel, src.count("\n", 0, i) + 1, ch))
+                    stack = None
+                    break
+                stack.pop()
+        if stack:
+            problems.append("%s:%d: `%s` is never closed" % (rel, src.count("\n", 0, stack[-1][1]) + 1, stack[-1][0]))
+        raw = path.read_text()
+        imports = re.findall(r'^\s*(?:(\w+)\s+)?"([^"]+)"\s*$', "\n".join(re.findall(r"^import \((.*?)^\)", raw, re.M | re.S)), re.M)
+        imports += [(a, q) for a, q in re.findall(r'^import (?:(\w+)\s+)?"([^"]+)"', raw, re.M)]
+        for alias, ipath in imports:
+            name = alias or ipath.rsplit("/", 1)[-1]
+            if name in ("_", "C"):
+                continue
+            if not re.search(r"\b%s\." % re.escape(name), src):
+                problems.append("%s: imports \"%s\" and never uses %s." % (rel, ipath, name))
+            own = ipath.rsplit("/", 1)[-1]
+            if "bindings/go/" in ipath and own in declared:
+                for m in re.finditer(r"\b%s\.([A-Z]\w*)" % re.escape(name), src):
+                    if m.group(1) not in declared[own]:
+                        problems.append("%s:%d: %s.%s is not declared in package %s" % (rel, src.count("\n", 0, m.start()) + 1, name, m.group(1), own))
+    # exported METHODS and FIELDS: `x.Name(` / `x.Name` on a value must be a method or a field that some type of the shim declares (receiver types are
+    # not resolved), unless x is an imported package. Catches a helper that several packages call and nobody defined.
+    methods, fields = set(), set()
+    for src in files.values():
+        methods.update(re.findall(r"^func \([^)]*\) (\w+)\s*\(", src, re.M))
+        for body in re.findall(r"^type \w+ struct\s*\{(.*?)^\}", src, re.M | re.S) + re.findall(r"^type \w+ struct\s*\{([^\n}]*)\}", src, re.M):
+            for line in body.replace(";", "\n").split("\n"):
+                m = re.match(r"\s*((?:\w+\s*,\s*)*\w+)\s+[\w\[\]*.(){}]", line)
+                if m:
+                    fields.update(x.strip() for x in m.group(1).split(","))
+                else:
+                    m = re.match(r"\s*\*?(?:\w+\.)?(\w+)\s*$", line)   # embedded type
+                    if m:
+                        fields.add(m.group(1))
+        for block in re.findall(r"interface\s*\{(.*?)\}", src, re.S):
+            methods.update(re.findall(r"^\s*(\w+)\s*\(", block, re.M))
+    STD_METHODS = {"Error", "String", "Add", "Done", "Wait", "Lock", "Unlock", "Unmarshal", "Decode", "Token", "Len", "Bytes", "Write", "WriteString", "Seconds",
+                   "Pointer", "Slice", "SliceData", "Sizeof", "Cmp", "SetString", "Uint64", "IsUint64", "Int64", "Text", "Fatalf", "Errorf", "Helper", "Run", "Skip", "Logf",
+                   "Fatal", "SetUint64", "Lsh", "Or", "Sign", "Mod", "Set",                                     # testing.T, math/big.Int
+                   "Instructions", "Levels", "Blueprints", "BlueprintID", "DecompressHint", "HintID"}           # gnark v0.9.1 constraint.System (witness/adapter_gnark_v0_9.go)
+    for path, src in files.items():
+        rel = path.relative_to(go_dir)
+        raw = path.read_text()
+        aliases = {a or q.rsplit("/", 1)[-1] for a, q in re.findall(r'^\s*(?:(\w+)\s+)?"([^"]+)"\s*$', "\n".join(re.findall(r"^import \((.*?)^\)", raw, re.M | re.S)), re.M)}
+        aliases |= {a or q.rsplit("/", 1)[-1] for a, q in re.findall(r'^import (?:(\w+)\s+)?"([^"]+)"', raw, re.M)} | {"C"}
+        for m in re.finditer(r"(\w+|\)|\])\.([A-Z]\w*)(\s*\()?", src):
+            recv, name, call = m.group(1), m.group(2), m.group(3)
+            if recv in aliases:
+                continue
+            if name in methods or name in fields or name in STD_METHODS:
+                continue
+            problems.append("%s:%d: .%s%s: no type of the shim declares such a %s" % (rel, src.count("\n", 0, m.start()) + 1, name, "()" if call else "", "method" if call else "field"))
+    return problems
+
+
 def main():
+    lex = lexical_problems()
+    for p in lex:
+        print(p)
+    if lex:
+        print("check_go_shim: %d lexical / cross-package problem(s)" % len(lex))
+        return 1
     problems, stats = check(verbose="-v" in sys.argv)
     for p in problems:
         print(p)
