@@ -123,6 +123,20 @@ def test_go_shim_call_sites_match_the_header(tmp_path):
         (d / "gpv" / "gpv.go").write_text(src.replace(old, new, 1))
         problems = G.lexical_problems(go_dir=d)
         assert any(expect in p for p in problems), (new, problems)
+    # argument counts of calls to the shim's own functions and methods, across packages
+    count_seeds = [
+        ("verifier/verifier.go", "NewVerifierChip(ctx, commonCircuitData))", "NewVerifierChip(ctx))", "NewVerifierChip() called with 1 argument(s), its declaration takes 2"),
+        ("verifier/verifier.go", "f.chips[j].VerifyDevice(circuit, proofsDev, n, acceptDev)", "f.chips[j].VerifyDevice(circuit, proofsDev, n)", "VerifyDevice() called with 3 argument(s), its declaration takes 4"),
+        ("verifier/verifier.go", "gpv.NewContext(device)", "gpv.NewContext(device, 1)", "gpv.NewContext() called with 2 argument(s), its declaration takes 1"),
+    ]
+    for k, (rel, old, new, expect) in enumerate(count_seeds):
+        d = tmp_path / ("cnt%d" % k)
+        shutil.copytree(T.ROOT / "bindings" / "go", d)
+        text = (d / rel).read_text()
+        assert text.count(old) >= 1, old
+        (d / rel).write_text(text.replace(old, new, 1))
+        problems = G.lexical_problems(go_dir=d)
+        assert any(expect in p for p in problems), (new, problems)
 
 
 def test_option_ids_agree_across_the_mirrors():

@@ -10,6 +10,7 @@ ever handed a slice (the round-4 regression), and that every header function is 
 Since round 5 also what a compiler rejects before type checking (`lexical_problems`): unbalanced brackets, imports that are never used, exported
 names `pkg.Name` of the shim's own packages that the package does not declare, and exported methods / fields that no type of the shim declares
 (receiver types are not resolved) -- that is how `Circuit.Dims()`, called by three packages and defined by none, was found.
+And the argument COUNT of every call to one of the shim's own functions or methods (a method name only when all its declarations agree).
 
     python tools/check_go_shim.py            # prints a summary, exit status 1 on any mismatch
 
@@ -419,6 +420,50 @@ def lexical_problems(go_dir=None):
             if name in methods or name in fields or name in STD_METHODS:
                 continue
             problems.append("%s:%d: .%s%s: no type of the shim declares such a %s" % (rel, src.count("\n", 0, m.start()) + 1, name, "()" if call else "", "method" if call else "field"))
+    # argument COUNTS of calls to the shim's own functions and methods (a method name is checked only when every type that declares it takes the same number)
+    def n_params(text):
+        ps = split_args(text)
+        return len(ps), bool(ps) and "..." in ps[-1]
+
+    pkg_funcs, method_sigs = {}, {}
+    for path, src in files.items():
+        for m in re.finditer(r"(?m)^func\s*(\([^)]*\))?\s*(\w+)(?:\[[^\]]*\])?\s*\(", src):
+            close = matching_paren(src, m.end() - 1)
+            sig = n_params(src[m.end():close])
+            if m.group(1):
+                method_sigs.setdefault(m.group(2), set()).add(sig)
+            else:
+                pkg_funcs.setdefault(path.parent.name, {})[m.group(2)] = sig
+    for path, src in files.items():
+        rel = path.relative_to(go_dir)
+        raw = path.read_text()
+        own = {}
+        for a, q in re.findall(r'^\s*(?:(\w+)\s+)?"([^"]+)"\s*$', "\n".join(re.findall(r"^import \((.*?)^\)", raw, re.M | re.S)), re.M):
+            if "bindings/go/" in q:
+                own[a or q.rsplit("/", 1)[-1]] = q.rsplit("/", 1)[-1]
+        for m in re.finditer(r"(?:(\w+|\)|\])\.)?\b([A-Za-z_]\w*)\(", src):
+            recv, name = m.group(1), m.group(2)
+            line_start = src.rfind("\n", 0, m.start()) + 1
+            if re.match(r"\s*func\b", src[line_start:m.start()]) :   # a declaration, not a call
+                continue
+            if recv is None:
+                sig = pkg_funcs.get(path.parent.name, {}).get(name)
+                if src[max(0, m.start() - 1)] == ".":
+                    continue
+            elif recv in own:
+                sig = pkg_funcs.get(own[recv], {}).get(name)
+            else:
+                sigs = method_sigs.get(name, set())
+                sig = next(iter(sigs)) if len(sigs) == 1 and name[0].isupper() else None
+            if sig is None:
+                continue
+            close = matching_paren(src, m.end() - 1)
+            args = split_args(src[m.end():close])
+            if len(args) == 1 and args[0].endswith(")") and sig[0] > 1:   # f(g()) with a multi-value g
+                continue
+            want, variadic = sig
+            if (variadic and len(args) < want - 1) or (not variadic and len(args) != want):
+                problems.append("%s:%d: %s%s() called with %d argument(s), its declaration takes %d" % (rel, src.count("\n", 0, m.start()) + 1, (recv + ".") if recv else "", name, len(args), want))
     return problems
 
 
