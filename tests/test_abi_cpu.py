@@ -129,6 +129,10 @@ def test_go_shim_call_sites_match_the_header(tmp_path):
         ("verifier/verifier.go", "f.chips[j].VerifyDevice(circuit, proofsDev, n, acceptDev)", "f.chips[j].VerifyDevice(circuit, proofsDev, n)", "VerifyDevice() called with 3 argument(s), its declaration takes 4"),
         ("verifier/verifier.go", "gpv.NewContext(device)", "gpv.NewContext(device, 1)", "gpv.NewContext() called with 2 argument(s), its declaration takes 1"),
     ]
+    count_seeds += [
+        ("verifier/verifier.go", "\tj := f.next\n", "\tj := f.next\n\tunused := 3\n", "`unused` is declared and never used"),
+        ("gpv/gpv.go", "\tb := c.Describe()\n\td := Dims{", "\tb, extra := c.Describe()\n\td := Dims{", "2 value(s) assigned from c.Describe(), which returns 1"),
+    ]
     for k, (rel, old, new, expect) in enumerate(count_seeds):
         d = tmp_path / ("cnt%d" % k)
         shutil.copytree(T.ROOT / "bindings" / "go", d)

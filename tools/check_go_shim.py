@@ -10,7 +10,8 @@ ever handed a slice (the round-4 regression), and that every header function is 
 Since round 5 also what a compiler rejects before type checking (`lexical_problems`): unbalanced brackets, imports that are never used, exported
 names `pkg.Name` of the shim's own packages that the package does not declare, and exported methods / fields that no type of the shim declares
 (receiver types are not resolved) -- that is how `Circuit.Dims()`, called by three packages and defined by none, was found.
-And the argument COUNT of every call to one of the shim's own functions or methods (a method name only when all its declarations agree).
+And the argument COUNT of every call to one of the shim's own functions or methods (a method name only when all its declarations agree), the number
+of values assigned from such a call, and variables declared with := that their function never mentions again.
 
     python tools/check_go_shim.py            # prints a summary, exit status 1 on any mismatch
 
@@ -464,6 +465,55 @@ def lexical_problems(go_dir=None):
             want, variadic = sig
             if (variadic and len(args) < want - 1) or (not variadic and len(args) != want):
                 problems.append("%s:%d: %s%s() called with %d argument(s), its declaration takes %d" % (rel, src.count("\n", 0, m.start()) + 1, (recv + ".") if recv else "", name, len(args), want))
+    # RESULT counts: `a, b := f(...)` against the declaration of f (own functions; methods when all declarations agree), and variables that are
+    # declared with := and never mentioned again in their function (Go rejects both)
+    def n_results(text):
+        return len(result_types(text))
+
+    fn_results, method_results = {}, {}
+    for path, src in files.items():
+        gf = GoFile(path)
+        for m in re.finditer(r"(?m)^func\s*(\([^)]*\))?\s*(\w+)(?:\[[^\]]*\])?\s*\(", src):
+            res = n_results(gf.funcs[m.group(2)][1]) if m.group(2) in gf.funcs else None
+            if res is None:
+                continue
+            if m.group(1):
+                method_results.setdefault(m.group(2), set()).add(res)
+            else:
+                fn_results.setdefault(path.parent.name, {})[m.group(2)] = res
+    for path, src in files.items():
+        rel = path.relative_to(go_dir)
+        raw = path.read_text()
+        own = {}
+        for a, q in re.findall(r'^\s*(?:(\w+)\s+)?"([^"]+)"\s*$', "\n".join(re.findall(r"^import \((.*?)^\)", raw, re.M | re.S)), re.M):
+            if "bindings/go/" in q:
+                own[a or q.rsplit("/", 1)[-1]] = q.rsplit("/", 1)[-1]
+        for m in re.finditer(r"(?m)^\s*((?:[\w.\[\]]+\s*,\s*)*[\w.\[\]]+)\s*:?=\s*(?:(\w+)\.)?(\w+)\(", src):
+            lhs = [x.strip() for x in m.group(1).split(",")]
+            recv, name = m.group(2), m.group(3)
+            close = matching_paren(src, m.end() - 1)
+            if src[close + 1:close + 2] not in ("\n", "", " ", "\t", "}") or src[close + 1:].lstrip(" \t").startswith((".", "[", "+", "-", "*", "/", "&", "|", "<", ">", "=", "!", "%")):
+                continue   # the call is only part of the right-hand side
+            if recv is None:
+                want = fn_results.get(path.parent.name, {}).get(name)
+            elif recv in own:
+                want = fn_results.get(own[recv], {}).get(name)
+            else:
+                rs = method_results.get(name, set())
+                want = next(iter(rs)) if len(rs) == 1 and name[0].isupper() else None
+            if want is not None and want != len(lhs) and not (want == 0):
+                problems.append("%s:%d: %d value(s) assigned from %s%s(), which returns %d" % (rel, src.count("\n", 0, m.start()) + 1, len(lhs), (recv + ".") if recv else "", name, want))
+        gf = GoFile(path)
+        spans = sorted(st for st, _, _ in gf.func_spans) + [len(src)]
+        for a, b in zip(spans, spans[1:]):
+            body = src[a:b]
+            for m in re.finditer(r"(?m)(?:^|[;{]|\bif\s|\bfor\s|\bswitch\s)\s*((?:\w+\s*,\s*)*\w+)\s*:=", body):
+                for nm in [x.strip() for x in m.group(1).split(",")]:
+                    if nm == "_":
+                        continue
+                    uses = len(re.findall(r"\b%s\b" % re.escape(nm), body))
+                    if uses < 2:
+                        problems.append("%s:%d: `%s` is declared and never used" % (rel, src.count("\n", 0, a + m.start(1)) + 1, nm))
     return problems
 
 
