@@ -514,6 +514,31 @@ def lexical_problems(go_dir=None):
                     uses = len(re.findall(r"\b%s\b" % re.escape(nm), body))
                     if uses < 2:
                         problems.append("%s:%d: `%s` is declared and never used" % (rel, src.count("\n", 0, a + m.start(1)) + 1, nm))
+    # bare calls `name(...)`: a function or type of the package, a builtin, or something local to the function (:=, var, a parameter, a closure)
+    builtin = set("len cap make new append copy delete panic recover print println min max close complex real imag int uint uint8 uint16 uint32 uint64 int8 int16 "
+                  "int32 int64 uintptr float32 float64 string bool byte rune error func if for switch return go defer select case var type const range else chan "
+                  "map struct interface".split())
+    for path, src in files.items():
+        rel = path.relative_to(go_dir)
+        gf = GoFile(path)
+        no_iface = re.sub(r"interface\s*\{.*?\}", lambda m: " " * len(m.group(0)) if "\n" not in m.group(0) else re.sub(r"[^\n]", " ", m.group(0)), src, flags=re.S)
+        spans = sorted((st, params) for st, _, params in gf.func_spans) + [(len(src), "")]
+        for (a, params), (b, _) in zip(spans, spans[1:]):
+            body = no_iface[a:b]
+            local = set(param_types(params))
+            for m in re.finditer(r"((?:\w+\s*,\s*)*\w+)\s*:=", body):
+                local.update(x.strip() for x in m.group(1).split(","))
+            local |= set(re.findall(r"\bvar\s+(\w+)", body)) | set(re.findall(r"(\w+)\s+func\(", body[:max(0, body.find("{"))]))
+            for m in re.finditer(r"\bfunc\s*\(([^)]*)\)", body):   # parameters of closures
+                local |= set(param_types(m.group(1)))
+            for m in re.finditer(r"(?<![\w.\])])\b([A-Za-z_]\w*)\(", body):
+                name = m.group(1)
+                ls = body.rfind("\n", 0, m.start()) + 1
+                if re.match(r"\s*func\b", body[ls:m.start()]) and "{" not in body[ls:m.start()]:
+                    continue
+                if name in builtin or name in declared.get(path.parent.name, ()) or name in local:
+                    continue
+                problems.append("%s:%d: %s() is neither declared in package %s nor local to the function" % (rel, src.count("\n", 0, a + m.start()) + 1, name, path.parent.name))
     return problems
 
 
