@@ -133,6 +133,8 @@ def test_go_shim_call_sites_match_the_header(tmp_path):
         ("verifier/verifier.go", "\tj := f.next\n", "\tj := f.next\n\tunused := 3\n", "`unused` is declared and never used"),
         ("gpv/gpv.go", "\tb := c.Describe()\n\td := Dims{", "\tb, extra := c.Describe()\n\td := Dims{", "2 value(s) assigned from c.Describe(), which returns 1"),
     ]
+    count_seeds.append(("fri/fri.go", "return &Chip{ctx, circuit, circuit.Dims()}", "return &Chip{ctx, circuit}", "Chip{...} lists 2 value(s), the struct has 3 field(s)"))
+    count_seeds.append(("gpv/gpv.go", "NumWires: int(b[1]),", "NumWire: int(b[1]),", "names the field NumWire, which the struct does not have"))
     count_seeds.append(("fri/fri.go", "reduce128(hi, lo)", "reduce129(hi, lo)", "reduce129() is neither declared in package fri nor local to the function"))
     for k, (rel, old, new, expect) in enumerate(count_seeds):
         d = tmp_path / ("cnt%d" % k)

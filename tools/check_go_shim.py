@@ -539,6 +539,39 @@ def lexical_problems(go_dir=None):
                 if name in builtin or name in declared.get(path.parent.name, ()) or name in local:
                     continue
                 problems.append("%s:%d: %s() is neither declared in package %s nor local to the function" % (rel, src.count("\n", 0, a + m.start()) + 1, name, path.parent.name))
+    # composite literals of the shim's struct types: a positional literal names every field, a keyed one only fields that exist
+    struct_fields = {}
+    for path, src in files.items():
+        for m in re.finditer(r"(?ms)^type (\w+) struct\s*\{(.*?)\}", src):
+            fl = []
+            for line in m.group(2).replace(";", "\n").split("\n"):
+                line = line.strip()
+                if not line:
+                    continue
+                fm = re.match(r"((?:\w+\s*,\s*)*\w+)\s+\S", line)
+                fl += [x.strip() for x in fm.group(1).split(",")] if fm else [line.lstrip("*").split(".")[-1]]
+            struct_fields[(path.parent.name, m.group(1))] = fl
+    for path, src in files.items():
+        rel = path.relative_to(go_dir)
+        for m in re.finditer(r"(?:(\w+)\.)?\b(\w+)\{", src):
+            key = (m.group(1) or path.parent.name, m.group(2))
+            ls = src.rfind("\n", 0, m.start()) + 1
+            if key not in struct_fields or re.match(r"\s*type\b", src[ls:m.start()]) or src[:m.start()].rstrip().endswith("]"):
+                continue   # (`[]T{{a}, {b}}` is a slice literal with elided element types)
+            depth, j = 0, m.end() - 1
+            for j in range(m.end() - 1, len(src)):
+                depth += src[j] == "{"
+                depth -= src[j] == "}"
+                if depth == 0:
+                    break
+            args = split_args(src[m.end():j])
+            keyed = [a for a in args if re.match(r"^\w+\s*:", a)]
+            line = src.count("\n", 0, m.start()) + 1
+            if args and not keyed and len(args) != len(struct_fields[key]):
+                problems.append("%s:%d: %s{...} lists %d value(s), the struct has %d field(s)" % (rel, line, m.group(2), len(args), len(struct_fields[key])))
+            for a in keyed:
+                if a.split(":")[0].strip() not in struct_fields[key]:
+                    problems.append("%s:%d: %s{...} names the field %s, which the struct does not have" % (rel, line, m.group(2), a.split(":")[0].strip()))
     return problems
 
 
