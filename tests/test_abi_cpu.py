@@ -690,3 +690,23 @@ def test_batches_in_flight_need_a_gpu_and_a_positive_count(gpv):
         gpv.verifier.VerifierChipsInFlight(None, k=0)
     with pytest.raises(gpv.DeviceError):
         gpv.verifier.VerifierChipsInFlight(None, k=2)
+
+
+def test_big_batch_kernels_fit_the_instruction_cache():
+    """The column-scanning kernels of the big-batch step keep ONE copy of the full-round code so that each fits the 64 KB instruction cache (105 KB cost
+    4 % in round 2; EXPERIMENTS.md section B), and stay at four waves per SIMD (<= 128 registers). A property of the compiled kernels: checked on the code
+    objects of the built translation units, so that a toolchain or source change that crosses either line fails here and not as a slower bench."""
+    import subprocess
+    csrc = T.ROOT / "gnark-plonky2-verifier_amd" / "csrc"
+    want = {"gpv_k_bn254.o": ("k_merkle_leavesP", "k_merkle_climbP", "k_merkle_climb_lowerP"), "gpv_k_crown.o": ("k_crown_levelP",)}
+    seen = 0
+    for obj, names in want.items():
+        out = subprocess.run(["bash", str(T.ROOT / "tools" / "kernel_info.sh"), str(csrc / obj)], capture_output=True, text=True, check=True).stdout
+        for line in set(out.splitlines()):
+            f = line.split()
+            if any(n in f[0] for n in names):
+                info = dict(x.split("=") for x in f[1:])
+                assert int(info["code_bytes"]) < 64 * 1024, line
+                assert int(info["vgpr"]) <= 136 and int(info["scratch"]) <= 32, line   # k_crown_level: 134 registers (three waves per SIMD), the others <= 128
+                seen += 1
+    assert seen == 4
