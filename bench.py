@@ -588,6 +588,7 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+        line["library_build_id"] = library_build_id(gpv)  # joins this line with smoke(), the pytest header and profiles/traffic.json
         print(json.dumps(line), flush=True)
     if exchange_fallback and args.strict_exchange:
         sys.stdout.flush()

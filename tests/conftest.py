@@ -24,6 +24,18 @@ def pytest_configure(config):
         gpv._lib.SHARE_TORCH_RUNTIME = False
 
 
+def pytest_report_header(config):
+    """The GNU build id of the library under test, so a test record can be joined with a bench line and with profiles/traffic.json."""
+    try:
+        import importlib
+        sys.path.insert(0, str(ROOT / "tools"))
+        import make_traffic_json
+        gpv = importlib.import_module("gnark-plonky2-verifier_amd")
+        return "libgpv library_build_id: %s (%s)" % (make_traffic_json.build_id(gpv._lib.LIB_PATH), gpv._lib.LIB_PATH)
+    except Exception as e:  # a header must never fail a run
+        return "libgpv library_build_id: unavailable (%s)" % e
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built_libraries():
     """libgpv.so and oracle/liborc.so are build artefacts (git-ignored). Build them when they are missing -- hipcc
