@@ -587,11 +587,13 @@ def test_probe_library_reports(gpv):
 
 
 # ---------------------------------------------------------------- full-size configurations (BASELINE.json configs 3 and 5)
-def test_fri_full_size_config3(gpv, api, orc):
-    """fri.VerifyFriProof, 28 queries x 4096 `step` proofs (114 688 query rounds): the accept vector must equal the tamper
-    mask (size-independent property) and a 48-proof sample must match the oracle's failure masks bit for bit."""
-    common, vo, circuit, proofs = _load(gpv, "step")
-    ci, packed, _ = T.load_fixture("step")
+@pytest.mark.parametrize("name", ["step", "decode_block"])
+def test_fri_full_size_config3(gpv, api, orc, name):
+    """fri.VerifyFriProof, 28 queries x 4096 proofs (114 688 query rounds), on `step` (BASELINE config 3 as worded) and separately on
+    `decode_block` (the fixture of fri_test.go:106-133): the accept vector must equal the tamper mask (size-independent
+    property) and a 48-proof sample must match the oracle's failure masks bit for bit."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
     oc = orc.circuit(ci)
     n = 4096
     batch, tampered = T.synthetic_batch(ci, packed, n, seed=7, tamper_every=16)
@@ -605,10 +607,12 @@ def test_fri_full_size_config3(gpv, api, orc):
     assert mask[idx].tolist() == [int(x) for x in exp]
 
 
-def test_merkle_full_size_config5(gpv, api, orc):
-    """Poseidon-BN254 Merkle paths only, 4096 `decode_block` proofs x 168 chains (688 128 chains, 10.7 M permutations)."""
-    common, vo, circuit, proofs = _load(gpv, "decode_block")
-    ci, packed, _ = T.load_fixture("decode_block")
+@pytest.mark.parametrize("name", ["decode_block", "step"])
+def test_merkle_full_size_config5(gpv, api, orc, name):
+    """Poseidon-BN254 Merkle paths only, 4096 proofs x 168 chains (688 128 chains; `decode_block`: 10.7 M permutations, `step`: 10.9 M --
+    the two circuits differ in leaf lengths, i.e. in the permutation count per leaf class: SURVEY 8d, "both perm counts")."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
     oc = orc.circuit(ci)
     n = 4096
     batch, tampered = T.synthetic_batch(ci, packed, n, seed=9, tamper_every=16)
@@ -1490,13 +1494,15 @@ def test_gl_hint_functions(gpv, api, orc):
     assert (inv[g] == gl.Inverse(np.array(single, dtype=np.uint64)[g])[0]).all()
 
 
-def test_config4_whole_batch_65536_on_one_gpu(gpv, api):
+@pytest.mark.parametrize("name", ["step", "decode_block"])
+def test_config4_whole_batch_65536_on_one_gpu(gpv, api, name):
     """BASELINE config 4 is 65 536 `step` proofs; sharded it is 8 x 8192 (test above). Here the WHOLE batch sits on one GPU (8.7 GB of
-    288 GB) and goes through one gpv_verify_dev call -- the largest size the configs name: accept == tamper mask for all 65 536,
-    and the verdict of the first 8192 equals what the 8192-proof call gives for the same records (no dependence on batch size)."""
+    288 GB; `decode_block`: 8.3 GB) and goes through one gpv_verify_dev call -- the largest size the configs name: accept == tamper mask
+    for all 65 536, and the verdict of the first 8192 equals what the 8192-proof call gives for the same records (no dependence on
+    batch size). Both circuits."""
     torch = pytest.importorskip("torch")
-    common, vo, circuit, proofs = _load(gpv, "step")
-    ci, packed, _ = T.load_fixture("step")
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
     n = 65536
     dev = torch.device("cuda:0")
     rec = torch.from_numpy(np.frombuffer(packed, dtype=np.int64).copy()).to(dev)
@@ -1570,13 +1576,14 @@ def test_verify_given_challenges_on_permuted_query_rounds(gpv, api, orc, name):
 
 
 # ---------------------------------------------------------------- BASELINE config 4: the 8192-proof per-GPU shard at size
-def test_config4_shard_8192_step_proofs(gpv, api, orc):
+@pytest.mark.parametrize("name", ["step", "decode_block"])
+def test_config4_shard_8192_proofs(gpv, api, orc, name):
     """BASELINE.json config 4 shards 65 536 `step` proofs 8 x 8192; this is one rank's shard at full size with the default
     options (shared upper Merkle levels on, one-lane transcript hidden under the leaf hashing): accept == tamper mask for
     all 8192, and accept / failure mask / challenges == oracle on a 96-proof sample that contains every tampered proof of the
-    first 1024 plus untampered neighbours."""
-    common, vo, circuit, proofs = _load(gpv, "step")
-    ci, packed, _ = T.load_fixture("step")
+    first 1024 plus untampered neighbours. Run on `step` (verifier_test.go:13-41) and on `decode_block` ("both circuits")."""
+    common, vo, circuit, proofs = _load(gpv, name)
+    ci, packed, _ = T.load_fixture(name)
     n = 8192
     batch, tampered = T.synthetic_batch(ci, packed, n, seed=1, tamper_every=16)
     assert 400 < tampered.sum() < 650
