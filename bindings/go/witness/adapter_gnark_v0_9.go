@@ -2,8 +2,10 @@
 //
 // UNCOMPILED here like the rest of bindings/go, and -- unlike the rest, which only needs this repository's own header -- written against
 // the constraint package of gnark v0.9.1 (go.mod:5 of the reference) WITHOUT the module at hand (not vendored, no network): the field and
-// method names below (System.Instructions / Blueprints / Levels, PackedInstruction.BlueprintID, System.GetInstruction,
-// BlueprintHint.DecompressHint, HintMapping.HintID) are that version's as the author remembers them. A maintainer with the module checks
+// method names below (System.Instructions / Blueprints / Levels, PackedInstruction.BlueprintID, PackedInstruction.Unpack,
+// BlueprintHint.DecompressHint, HintMapping.HintID) are that version's as the author remembers them. The blueprint id lives on the
+// PACKED instruction (System.Instructions[i]); the unpacked constraint.Instruction carries only ConstraintOffset / WireOffset / Calldata,
+// which is why the interface is indexed by instruction number (ADVICE r5). A maintainer with the module checks
 // them with `go vet ./bindings/go/...`; if a name differs, this file is the only place to touch. Nothing here can produce a wrong witness:
 // Bind only computes an ORDER, every served record is cross-checked against the call's inputs (replay.go: fits), and Bind compares the
 // number of hint calls it finds with the trace layout and fails loudly on any difference.
@@ -21,17 +23,16 @@ func FromSystem(sys *constraint.System) HintSystem { return systemAdapter{sys} }
 
 func (a systemAdapter) GetNbInstructions() int { return len(a.sys.Instructions) }
 
-func (a systemAdapter) GetInstruction(i int) constraint.Instruction { return a.sys.GetInstruction(i) }
-
 func (a systemAdapter) GetLevels() [][]int { return a.sys.Levels }
 
-// GetHintIDOf: a hint call is an instruction whose blueprint is the generic hint blueprint; its calldata decompresses to a HintMapping.
-func (a systemAdapter) GetHintIDOf(inst constraint.Instruction) (solver.HintID, bool) {
-	bp, ok := a.sys.Blueprints[inst.BlueprintID].(constraint.BlueprintHint)
+// GetHintIDAt: instruction i is a hint call when its blueprint is the generic hint blueprint; its calldata decompresses to a HintMapping.
+func (a systemAdapter) GetHintIDAt(i int) (solver.HintID, bool) {
+	pi := a.sys.Instructions[i]
+	bp, ok := a.sys.Blueprints[pi.BlueprintID].(constraint.BlueprintHint)
 	if !ok {
 		return 0, false
 	}
 	var hm constraint.HintMapping
-	bp.DecompressHint(&hm, inst)
+	bp.DecompressHint(&hm, pi.Unpack(a.sys))
 	return hm.HintID, true
 }

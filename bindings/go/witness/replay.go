@@ -29,7 +29,6 @@ import (
 	"math/big"
 	"sync"
 
-	"github.com/consensys/gnark/constraint"
 	"github.com/consensys/gnark/constraint/solver"
 	gl "github.com/succinctlabs/gnark-plonky2-verifier/goldilocks"
 )
@@ -77,8 +76,7 @@ func NewReplay(trace []uint64, kinds []uint8) *Replay {
 // (adapter_gnark_v0_9.go) wraps gnark v0.9.1's *constraint.System -- r.Bind(witness.FromSystem(&ccs.(*cs_bn254.R1CS).System)).
 type HintSystem interface {
 	GetNbInstructions() int
-	GetInstruction(int) constraint.Instruction
-	GetHintIDOf(constraint.Instruction) (solver.HintID, bool) // the instruction's hint id when it is a hint call
+	GetHintIDAt(i int) (solver.HintID, bool) // instruction i's hint id when it is a hint call (the blueprint id is a field of the PACKED instruction)
 	GetLevels() [][]int
 }
 
@@ -93,7 +91,7 @@ func (r *Replay) Bind(sys HintSystem) error {
 	progNumber := make(map[int]int) // instruction index -> hint number in program order
 	n := 0
 	for i := 0; i < sys.GetNbInstructions(); i++ {
-		if id, isHint := sys.GetHintIDOf(sys.GetInstruction(i)); isHint && ours[id] {
+		if id, isHint := sys.GetHintIDAt(i); isHint && ours[id] {
 			progNumber[i] = n
 			n++
 		}

@@ -408,7 +408,7 @@ def lexical_problems(go_dir=None):
     STD_METHODS = {"Error", "String", "Add", "Done", "Wait", "Lock", "Unlock", "Unmarshal", "Decode", "Token", "Len", "Bytes", "Write", "WriteString", "Seconds",
                    "Pointer", "Slice", "SliceData", "Sizeof", "Cmp", "SetString", "Uint64", "IsUint64", "Int64", "Text", "Fatalf", "Errorf", "Helper", "Run", "Skip", "Logf",
                    "Fatal", "SetUint64", "Lsh", "Or", "Sign", "Mod", "Set",                                     # testing.T, math/big.Int
-                   "Instructions", "Levels", "Blueprints", "BlueprintID", "DecompressHint", "HintID"}           # gnark v0.9.1 constraint.System (witness/adapter_gnark_v0_9.go)
+                   "Instructions", "Levels", "Blueprints", "BlueprintID", "DecompressHint", "HintID", "Unpack"}           # gnark v0.9.1 constraint.System (witness/adapter_gnark_v0_9.go)
     for path, src in files.items():
         rel = path.relative_to(go_dir)
         raw = path.read_text()
