@@ -565,6 +565,7 @@ def main():
             line["full_batch_65536"] = bench_full_batch(gpv, T, ctx, dev, args.fixture)
             line["single_proof"] = bench_single_proof(gpv, T, ctx, dev)
             line["mid_size_batches"] = bench_mid_size(gpv, T, ctx, wl, dev)
+            line["launch_shapes_regressed"] = line["mid_size_batches"]["launch_shapes_regressed"]  # top level: a regression must not hide in a leg
             line["batches_in_flight"] = bench_in_flight(gpv, T, wl, dev)
             line["witness_verify_1024"] = bench_witness(gpv, T, ctx, dev)
             line["witness_verify_4096"] = bench_witness(gpv, T, ctx, dev, 4096)  # 44 GB of trace: the store-bound regime (docs/DESIGN_HISTORY.md section 3, "the trace cursor")
@@ -756,6 +757,13 @@ def bench_mid_size(gpv, T, ctx, wl, dev, sizes=(512, 1024, 2048, 4096)):
             row[label + "_proofs_per_s"] = n / ms * 1e3
         ctx.set_option(gpv._lib.OPT_MERKLE_LONGEST_ALONE, 0)
         out[str(n)] = row
+    # The shaped launches below ~1600 proofs rest on how the dispatcher places waves: a runtime / firmware change can make them
+    # LOSE against one launch per phase. The line says so itself instead of leaving it to a reader of two columns.
+    lost = [str(n) for n in sizes if out[str(n)]["default_ms"] > out[str(n)]["one_launch_ms"] * 1.02]
+    out["launch_shapes_regressed"] = bool(lost)
+    if lost:
+        out["launch_shapes_regressed_at"] = lost
+        out["launch_shapes_remedy"] = "ctx.set_option(GPV_OPT_MERKLE_LONGEST_ALONE, 1) restores one launch per phase; verdicts do not depend on it"
     out["entry_point"] = "gpv_verify_dev, records resident in HBM, every call synchronised; accept == tamper mask"
     return out
 

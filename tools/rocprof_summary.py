@@ -39,11 +39,14 @@ def main():
             if r[0].startswith("k_") or "gpv" in r[0]:
                 print("%-40s %5d %5d %5d %7d %8d %10d %6d %5d" % ((r[0].split("(")[0][:40],) + tuple(r[1:])))
     else:
-        rows = db.execute("select name, counter_name, count(*), sum(counter_value), avg(counter_value), avg(duration) from pmc_events "
-                          "group by name, counter_name order by 4 desc").fetchall()
-        print("%-56s %-12s %6s %18s %18s %14s" % ("kernel", "counter", "n", "sum", "avg_per_dispatch", "avg_dur_us"))
-        for name, ctr, n, total, avg, dur in rows:
-            print("%-56s %-12s %6d %18.3f %18.3f %14.3f" % (str(name).split("(")[0][-56:], ctr, n, total, avg, dur / 1e3))
+        # min / max over the rows of one (kernel, counter): a row is one dispatch on one XCD (GRBM_*, TCC_*) or shader engine (SQ_*), so for a
+        # kernel launched the same way every time the spread IS the imbalance between XCDs / shader engines (round 6; appended columns --
+        # tools/make_traffic_json.py reads the first six only)
+        rows = db.execute("select name, counter_name, count(*), sum(counter_value), avg(counter_value), avg(duration), min(counter_value), max(counter_value) "
+                          "from pmc_events group by name, counter_name order by 4 desc").fetchall()
+        print("%-56s %-12s %6s %18s %18s %14s %18s %18s" % ("kernel", "counter", "n", "sum", "avg_per_dispatch", "avg_dur_us", "min_row", "max_row"))
+        for name, ctr, n, total, avg, dur, lo, hi in rows:
+            print("%-56s %-12s %6d %18.3f %18.3f %14.3f %18.3f %18.3f" % (str(name).split("(")[0][-56:], ctr, n, total, avg, dur / 1e3, lo, hi))
 
 
 if __name__ == "__main__":
