@@ -728,6 +728,11 @@ def bench_single_proof(gpv, T, ctx, dev):
     return out
 
 
+def launch_shapes_lost(rows, sizes):
+    """Batch sizes at which the shaped launches (GPV_OPT_MERKLE_LONGEST_ALONE = 0) are more than 2 % SLOWER than one launch per phase (= 1)."""
+    return [str(n) for n in sizes if rows[str(n)]["default_ms"] > rows[str(n)]["one_launch_ms"] * 1.02]
+
+
 def bench_mid_size(gpv, T, ctx, wl, dev, sizes=(512, 1024, 2048, 4096)):
     """The operating point of a service rather than of a benchmark: gpv_verify_dev on batches of a few hundred to a few thousand proofs of the
     line's fixture (1 in 16 tampered, accept vector checked), every call synchronised before the next. Below ~1 600 proofs the longest tree class is
@@ -759,7 +764,7 @@ def bench_mid_size(gpv, T, ctx, wl, dev, sizes=(512, 1024, 2048, 4096)):
         out[str(n)] = row
     # The shaped launches below ~1600 proofs rest on how the dispatcher places waves: a runtime / firmware change can make them
     # LOSE against one launch per phase. The line says so itself instead of leaving it to a reader of two columns.
-    lost = [str(n) for n in sizes if out[str(n)]["default_ms"] > out[str(n)]["one_launch_ms"] * 1.02]
+    lost = launch_shapes_lost(out, sizes)
     out["launch_shapes_regressed"] = bool(lost)
     if lost:
         out["launch_shapes_regressed_at"] = lost

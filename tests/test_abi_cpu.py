@@ -710,3 +710,37 @@ def test_big_batch_kernels_fit_the_instruction_cache():
                 assert int(info["vgpr"]) <= 136 and int(info["scratch"]) <= 32, line   # k_crown_level: 134 registers (three waves per SIMD), the others <= 128
                 seen += 1
     assert seen == 4
+
+
+def test_kernel_clock_table_reproduces_the_design_numbers():
+    """DESIGN.md section 5's "leaves against lower walk, cause by cause" table is a re-reading of committed rocprofv3 PMC passes
+    (profiles/r05_pmc_sq.txt): tools/kernel_clock_table.py must give those numbers from those files -- same instruction mix, same
+    multiply-adds per cycle, different shader clock."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, str(T.ROOT / "tools" / "kernel_clock_table.py"), str(T.ROOT / "profiles" / "r05_pmc_sq.txt")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = {ln.split()[0]: ln.split() for ln in out.stdout.splitlines() if ln.startswith("k_merkle")}
+    leaves, lower = rows["k_merkle_leaves"], rows["k_merkle_climb_lower"]
+    # columns: kernel dur_ms Mcycles/XCD clock_GHz VALU/perm non-perm% MAD/cyc/SIMD frac@clock spread
+    assert abs(float(leaves[3]) - 2.129) < 0.002 and abs(float(lower[3]) - 2.312) < 0.002          # each kernel's own clock
+    assert abs(float(leaves[7]) - 0.793) < 0.002 and abs(float(lower[7]) - 0.787) < 0.002          # cycle for cycle: equal
+    assert abs(float(leaves[4]) - 121568) < 2 and abs(float(lower[4]) - 118048) < 2                # VALU per permutation
+    assert abs(float(leaves[5]) - 0.84) < 0.01                                                     # HashNoPad packing share
+
+
+def test_bench_flags_a_launch_shape_regression():
+    """bench.py's mid_size_batches leg says by itself when the shaped launches LOSE against one launch per phase:
+    the rule, on synthetic timings."""
+    sys_path = str(T.ROOT)
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import bench
+    ok = {"512": {"default_ms": 8.3, "one_launch_ms": 9.4}, "1024": {"default_ms": 11.7, "one_launch_ms": 13.1}, "2048": {"default_ms": 20.0, "one_launch_ms": 20.0}}
+    assert bench.launch_shapes_lost(ok, (512, 1024, 2048)) == []
+    bad = dict(ok, **{"1024": {"default_ms": 13.5, "one_launch_ms": 13.1}})
+    assert bench.launch_shapes_lost(bad, (512, 1024, 2048)) == ["1024"]
+    within = dict(ok, **{"2048": {"default_ms": 20.3, "one_launch_ms": 20.0}})   # 1.5 %: inside the 2 % band
+    assert bench.launch_shapes_lost(within, (512, 1024, 2048)) == []
