@@ -22,6 +22,8 @@ def pytest_configure(config):
         gpv = importlib.import_module("gnark-plonky2-verifier_amd")
         gpv._lib.LIB_PATH = Path(alt).resolve()
         gpv._lib.SHARE_TORCH_RUNTIME = False
+        if gpv._lib.LIB_PATH.name.startswith("libgpv_hostemu"):  # tests/hostemu: its own build with the fault hook beside it
+            gpv._lib.TEST_LIB_PATH = gpv._lib.LIB_PATH.with_name("libgpv_hostemu_test.so")
 
 
 def pytest_report_header(config):

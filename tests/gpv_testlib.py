@@ -1728,6 +1728,13 @@ class DeviceBuffers:
     """hipMalloc / hipMemcpy through the HIP runtime the process has already loaded (libgpv's), without torch: the device-AddressSanitizer runs
     (tools/asan/) preload ROCm's runtime, and torch's bundled one cannot initialise beside it. Create it after the first gpv.Context."""
 
+    def __new__(cls):
+        import importlib
+        lib_path = importlib.import_module("gnark-plonky2-verifier_amd")._lib.LIB_PATH
+        if cls is DeviceBuffers and lib_path.name.startswith("libgpv_hostemu"):
+            return object.__new__(HostEmuBuffers)  # tests/hostemu: "device" memory is host memory
+        return object.__new__(cls)
+
     def __init__(self):
         import ctypes
         import os
@@ -1773,6 +1780,38 @@ class DeviceBuffers:
     def free_all(self):
         for p in self.ptrs:
             self.hip.hipFree(p)
+        self.ptrs = []
+
+
+class HostEmuBuffers(DeviceBuffers):
+    """DeviceBuffers for the host-emulation build of the library (tests/hostemu): its hipMalloc is host memory, so a buffer is a numpy array
+    kept alive here and its address."""
+
+    def __init__(self):
+        self.ptrs = []
+
+    def alloc(self, nbytes, fill=0):
+        a = np.full(max(1, nbytes), fill, dtype=np.uint8)
+        self.ptrs.append(a)
+        return a.ctypes.data
+
+    def _view(self, ptr, nbytes):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr))
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        ptr = self.alloc(a.nbytes)
+        self._view(ptr, a.nbytes)[:] = a.view(np.uint8).reshape(-1)
+        return ptr
+
+    def download(self, ptr, nbytes):
+        return self._view(ptr, nbytes).copy()
+
+    def fill(self, ptr, nbytes, value):
+        self._view(ptr, nbytes)[:] = value
+
+    def free_all(self):
         self.ptrs = []
 
 

@@ -69,6 +69,10 @@ def rewrite(name, t):
     if name == "gpv_witness.cuh":
         t = sub(t, 'asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");', 'asm volatile("" ::: "memory");', 1, "wt s_waitcnt")
         t = sub(t, 'asm volatile("" ::"v"(v[i]));', 'asm volatile("" ::"r"(v[i]));', 1, "wt keep-alive pin")
+        # the one place where the product leans on LOCKSTEP without a cross-lane instruction: every lane's ring reads of a flush event precede any
+        # lane's next ring write (in-order LDS of one wave). Fibers run one after the other between collectives, so the point becomes a wave barrier.
+        t = sub(t, 'asm volatile("" ::: "memory");  // the ring reads above stay ahead of the writes that follow (in-order LDS)',
+                '(void)__ballot(true);  // [hostemu] lockstep point: the ring reads above stay ahead of the writes that follow', 1, "wt flush lockstep point")
     if name == "gpv_k_bn254.hip":
         t, n = re.subn(r'  asm volatile\("v_accvgpr_write_b32 a\d+, 0" ::: "a\d+"\);[^\n]*\n', "", t)
         assert n == 4, "solo kernels: %d register-inflation lines, expected 4" % n

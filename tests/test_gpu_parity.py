@@ -1790,7 +1790,7 @@ def _set_fault(gpv, stage, nth=-1, num=0, den=1):
     """Arms the hook of csrc/gpv_testhooks.h. Only libgpv_test.so has it (the product library neither defines nor exports it), so this
     must run inside `with gpv._lib.test_library():`."""
     L = gpv._lib.lib()
-    assert L._name.endswith("libgpv_test.so")
+    assert L._name.endswith("_test.so")  # libgpv_test.so (tests/hostemu: libgpv_hostemu_test.so)
     assert L.gpvi_test_set_fault(stage, nth, num, den) == 0
 
 
