@@ -84,3 +84,35 @@ def test_verify_pipeline_under_emulation(emu_lib):
 def test_every_emulable_gpu_test(emu_lib):
     n = run_gpu_tests_on(emu_lib, " and ".join("not " + t for t in NEEDS_HARDWARE), timeout=4 * 3600)
     assert n >= 100
+
+
+def _run_group_check(args, env, timeout=600):
+    return subprocess.Popen([sys.executable, str(EMU / "group_check.py")] + args, env=dict(os.environ, **env), cwd=str(ROOT), stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, text=True)
+
+
+def test_group_with_four_ranks_in_one_process_under_emulation(emu_lib):
+    """csrc/gpv_group.cpp with world = 4 (no reference counterpart): four "devices", a worker thread each, the RCCL branch -- ncclCommInitAll and
+    the in-place ncclAllGather of the packed accept bits, served by tests/hostemu/fake_rccl.cpp -- then the peer-copy exchange, fewer proofs than ranks,
+    and a rank that fails (GPV_EPEER on the others, the next call clean). Every rank ends with the whole verdict == the oracle's tamper mask."""
+    p = _run_group_check(["clique"], {"HOSTEMU_DEVICES": "4"})
+    out, _ = p.communicate(timeout=900)
+    assert p.returncode == 0 and "clique ok: 4 ranks" in out, out[-3000:]
+
+
+def test_group_one_process_per_rank_under_emulation(emu_lib, tmp_path):
+    """The shape the multi-GPU bench runs in (one process per GPU, gpv_group_create_rank + ncclCommInitRank over a distributed unique id): three PROCESSES,
+    each verifies its own block and the all-gather hands every one of them the whole verdict -- world > 1 in rank mode, which no one-GPU box can run."""
+    uid = tmp_path / "uid.bin"
+    procs = [_run_group_check(["rank", str(r), "3", str(uid)], {"HOSTEMU_DEVICES": "3", "HOSTEMU_THREADS": "2"}) for r in range(3)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d of 3 ok" % r) in o, o[-3000:]
