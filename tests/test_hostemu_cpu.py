@@ -4,8 +4,8 @@ MI355X run uses, through the C ABI, against the oracle -- run on that library vi
 reachable from the package (tests/hostemu/README.md); it checks the LOGIC of the source that ships in a container without a GPU, not the hardware.
 
 The selection below is sized for the CPU suite (about two minutes on 8 cores). GPV_HOSTEMU_ALL=1 runs every GPU test that can run without a GPU
-(round 6: 116 of 134 pass -- everything except the tests that need torch.cuda buffers, RCCL, the probe library or a subprocess on libgpv.so;
-that takes about an hour)."""
+(round 6: 113 of the 134 GPU tests pass under emulation -- every one that does not need torch.cuda buffers, RCCL, the probe library, a subprocess on
+libgpv.so or hours of CPU; about an hour on 8 cores)."""
 import os
 import re
 import subprocess
@@ -30,7 +30,9 @@ PRIMITIVES = ["test_gl_base_ops", "test_gl_extension_ops", "test_gl_extension_th
 PIPELINE = ["test_verify_end_to_end", "test_fr_evaluation_orders_are_identical", "test_shared_merkle_levels_with_colliding_queries", "test_merkle_and_fri"]
 # cannot run without a GPU box: torch.cuda buffers, RCCL, the probe library, subprocesses that load libgpv.so, or sizes a CPU cannot do in minutes
 NEEDS_HARDWARE = ["test_verify_device_resident", "test_poseidon_gl_full_size_properties", "test_probe_library_reports", "test_verify_json_tool_on_the_reference_files",
-                  "test_bench_collective_path_single_rank", "test_group_", "test_config4_", "test_fresh_contexts_started_concurrently", "test_cpp_host_mirror_on_gpu"]
+                  "test_bench_collective_path_single_rank", "test_group_", "test_config4_", "test_fresh_contexts_started_concurrently", "test_cpp_host_mirror_on_gpu",
+                  "test_witness_verify_is_the_four_slices_in_order", "test_verify_json_two_threads_one_context", "test_batches_in_flight_get_their_own_verdicts",
+                  "test_verdict_is_fail_closed"]  # (the last two pass under emulation -- 13 and 7 + 6 minutes on 8 cores -- and are left to a deliberate run)
 
 
 @pytest.fixture(scope="module")
