@@ -60,6 +60,22 @@ hostemu_switch:
 .size hostemu_switch,.-hostemu_switch
 )");
 
+// AddressSanitizer must be told about stack switches it did not make (make SAN=1: the device code's indexing under the host sanitizers)
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HOSTEMU_ASAN 1
+#endif
+#endif
+#ifdef HOSTEMU_ASAN
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+#define SAN_START(save, bottom, size) __sanitizer_start_switch_fiber(save, bottom, size)
+#define SAN_FINISH(fake, bottom_old, size_old) __sanitizer_finish_switch_fiber(fake, bottom_old, size_old)
+#else
+#define SAN_START(save, bottom, size) ((void)0)
+#define SAN_FINISH(fake, bottom_old, size_old) ((void)0)
+#endif
+
 enum { WAIT_NONE = 0, WAIT_BALLOT, WAIT_READ, WAIT_BLOCK };
 struct Fiber {
   Lane lane;
@@ -71,6 +87,7 @@ struct Fiber {
   uint32_t value = 0;  // WAIT_BALLOT: the predicate; WAIT_READ: this lane's value
   int src = 0;         // WAIT_READ: lane of the wave to read from
   uint64_t result = 0;
+  void* san_fake = nullptr;
 };
 static const size_t STACK_BYTES = 1u << 20;  // per lane; pages are touched only as far as the code goes
 struct Block {
@@ -82,14 +99,19 @@ struct Block {
   std::vector<char> dyn_lds;
   std::map<const void*, uint64_t> first_seen;  // call site -> order of first arrival (per block)
   uint64_t seen_seq = 0;
+  void* san_sched_fake = nullptr;  // the scheduler's side of the sanitizer's fiber bookkeeping
+  const void* san_sched_bottom = nullptr;
+  size_t san_sched_size = 0;
 };
 static thread_local Block* g_blk = nullptr;
 
 static void fiber_entry() {
   Block* b = g_blk;
+  SAN_FINISH(nullptr, &b->san_sched_bottom, &b->san_sched_size);
   b->fn(b->closure);
   b->cur->done = true;
   void* dummy;
+  SAN_START(nullptr, b->san_sched_bottom, b->san_sched_size);  // this fiber's stack is done with
   hostemu_switch(&dummy, b->sched_sp);  // never comes back
   abort();
 }
@@ -112,7 +134,9 @@ static void fiber_prepare(Fiber& f) {
 static void yield_to_scheduler() {
   Block* b = g_blk;
   Fiber* me = b->cur;
+  SAN_START(&me->san_fake, b->san_sched_bottom, b->san_sched_size);
   hostemu_switch(&me->sp, b->sched_sp);
+  SAN_FINISH(me->san_fake, nullptr, nullptr);
   g_lane = &me->lane;  // (the scheduler sets it too; kept for clarity)
 }
 static void note_site(Block* b, const void* site) {
@@ -197,7 +221,9 @@ static void run_block(Block* b, size_t n_lanes) {
       if (f.wait != WAIT_NONE) continue;
       b->cur = &f;
       g_lane = &f.lane;
+      SAN_START(&b->san_sched_fake, f.stack, STACK_BYTES);
       hostemu_switch(&b->sched_sp, f.sp);
+      SAN_FINISH(b->san_sched_fake, nullptr, nullptr);
       ran = true;
     }
     if (!live) return;
