@@ -31,9 +31,10 @@ PRIMITIVES = ["test_gl_base_ops", "test_gl_extension_ops", "test_gl_extension_th
 PIPELINE = ["test_verify_end_to_end", "(test_fr_evaluation_orders_are_identical and not 3)", "test_shared_merkle_levels_with_colliding_queries"]
 # cannot run without a GPU box: torch.cuda buffers, RCCL, the probe library, subprocesses that load libgpv.so, or sizes a CPU cannot do in minutes
 NEEDS_HARDWARE = ["test_verify_device_resident", "test_poseidon_gl_full_size_properties", "test_probe_library_reports", "test_verify_json_tool_on_the_reference_files",
-                  "test_bench_collective_path_single_rank", "test_group_", "test_config4_", "test_fresh_contexts_started_concurrently", "test_cpp_host_mirror_on_gpu",
+                  "test_bench_collective_path_single_rank", "test_group_", "test_config4_whole_batch", "test_fresh_contexts_started_concurrently", "test_cpp_host_mirror_on_gpu",
                   "test_witness_verify_is_the_four_slices_in_order", "test_verify_json_two_threads_one_context", "test_batches_in_flight_get_their_own_verdicts",
-                  "test_verdict_is_fail_closed"]  # (the last two pass under emulation -- 13 and 7 + 6 minutes on 8 cores -- and are left to a deliberate run)
+                  "test_verdict_is_fail_closed", "test_config4_shard_8192_proofs"]  # (the last three pass under emulation -- 13, 7 + 6 and 2 x ~10 minutes on 8 cores: BASELINE config 4's
+                  # 8192-proof shard at FULL size on both circuits -- and are left to a deliberate run: profiles/r06_hostemu_*.txt)
 
 
 @pytest.fixture(scope="module")
