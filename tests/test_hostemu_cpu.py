@@ -120,3 +120,20 @@ def test_group_one_process_per_rank_under_emulation(emu_lib, tmp_path):
         outs.append(o)
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("rank %d of 3 ok" % r) in o, o[-3000:]
+
+
+def test_cpp_host_mirror_under_emulation(emu_lib):
+    """The header-only C++ mirror (gnark-plonky2-verifier_amd/host/gpv.hpp) end to end: tests/cpp/host_mirror_test.cpp -- the driver of the `-m gpu` test
+    test_cpp_host_mirror_on_gpu -- linked against the emulation build (a symlink libgpv.so -> libgpv_hostemu.so beside it, the three HIP memory calls
+    it makes from hipmem_stub.c, the stand-in RCCL preloaded for its world-1 group with the collective forced)."""
+    b = emu_lib.parent
+    link = b / "libgpv.so"
+    if not link.exists():
+        link.symlink_to("libgpv_hostemu.so")
+    subprocess.check_call(["gcc", "-O1", "-c", "-o", str(b / "hipmem_stub.o"), str(EMU / "hipmem_stub.c")])
+    exe = b / "host_mirror_test"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", str(exe), str(ROOT / "tests" / "cpp" / "host_mirror_test.cpp"), str(b / "hipmem_stub.o"),
+                           "-L" + str(b), "-lgpv", "-Wl,-rpath," + str(b)])
+    env = dict(os.environ, LD_PRELOAD=str(b / "fake_rccl" / "librccl.so.1"))
+    out = subprocess.run([str(exe), str(ROOT / "tests" / "golden" / "step")], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "host mirror ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
