@@ -4,8 +4,8 @@ MI355X run uses, through the C ABI, against the oracle -- run on that library vi
 reachable from the package (tests/hostemu/README.md); it checks the LOGIC of the source that ships in a container without a GPU, not the hardware.
 
 The selection below is sized for the CPU suite (about two minutes on 8 cores, build included). GPV_HOSTEMU_ALL=1 runs every GPU test that can run without a GPU
-(round 6: 113 of the 134 GPU tests pass under emulation -- every one that does not need torch.cuda buffers, RCCL, the probe library, a subprocess on
-libgpv.so or hours of CPU; about an hour on 8 cores)."""
+(round 6: 113 of the 133 tests of tests/test_gpu_parity.py pass under emulation -- every one that does not need torch.cuda buffers, RCCL, the probe
+library or a subprocess on libgpv.so; profiles/r06_hostemu_gpu_suite.txt, 1 h 09 min on 8 cores; this switch leaves the five slowest out: about 40 minutes)."""
 import os
 import re
 import subprocess
